@@ -1,0 +1,505 @@
+"""ORACLE — CPU restatement of the Pix2Poly / FFL encoder-fusion-decoder hot path.
+
+THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import it; the product package (pixelspointspolygons_amd) never does.
+
+Every function is a plain fp32 PyTorch-CPU (or numpy / C) restatement of what the reference
+computes, keyed by the reference's own state_dict names so that one seeded weight set drives the
+reference import, the oracle and the HIP path.  Citations are relative to /root/reference.
+
+Pinning status:
+  * decoder / create_mask / ScoreNet / log_optimal_transport / EncoderDecoder.forward /
+    EarlyFusionViT.forward glue / Tokenizer  -> PINNED: tests/golden/*.npz were produced by
+    importing the reference's own modules in the build container (tests/golden/make_golden.py)
+    and tests/test_oracle_golden.py checks this file against them.
+  * timm VisionTransformer body (third-party, un-pinned `timm` in pyproject.toml:31; call sites
+    models/vision_transformer/vit.py:29-35, models/fusion_layers/early_fusion_vit.py:58-72):
+    restated from the published timm algorithm; cross-checked against the independent
+    `transformers.ViTModel` implementation (golden fixture vit_hf_*.npz).  PARITY UNPINNED vs timm.
+  * Open3D-ML 0.19.0 PointPillars stem (pyproject.toml:23; call site
+    models/pointpillars/pointpillars_o3d.py:92-95): restated from the published algorithm
+    (oracle/pillarize.c + pfn/scatter below).  PARITY UNPINNED vs open3d.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# ----------------------------------------------------------------------------------------------
+# constants of the reference configs (config/encoder/early_fusion_vit.yaml, config/model/pix2poly.yaml)
+# ----------------------------------------------------------------------------------------------
+VIT_S8 = dict(dim=384, depth=12, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
+VIT_B16 = dict(dim=768, depth=12, heads=12, mlp=3072, patch=16, img=224, eps=1e-6)
+NUM_BINS, BOS, EOS, PAD, VOCAB = 224, 224, 225, 226, 227   # models/pix2poly/tokenizer.py:13-23
+MAX_VERTS = 192                                            # config/model/pix2poly.yaml:13
+MAX_LEN = MAX_VERTS * 2 + 2                                # tokenizer.py:17 -> 386
+
+
+# ----------------------------------------------------------------------------------------------
+# C part: pillarize
+# ----------------------------------------------------------------------------------------------
+_LIB = None
+
+
+def _oracle_lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "_build", "libp3oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _LIB = ctypes.CDLL(so)
+        _LIB.p3o_pillarize.restype = ctypes.c_int
+    return _LIB
+
+
+def pillarize(values: torch.Tensor, offsets: torch.Tensor, voxel_size, range_min, range_max,
+              max_points: int, max_voxels: int):
+    """Open3D `PointPillars.voxelize` (hard voxelisation); see oracle/pillarize.c header.
+
+    values [sumN,3] f32, offsets [B+1] int64 (the jagged layout built at
+    datasets/collate_funcs.py:108).  Returns voxels [V,max_points,3] f32 (zero padded),
+    num_points [V] int64, coors [V,4] int64 = (b, z, y, x), point_idx [V,max_points] (sample-local).
+    """
+    lib = _oracle_lib()
+    pts = np.ascontiguousarray(values.detach().cpu().numpy(), dtype=np.float32)
+    off = np.ascontiguousarray(offsets.detach().cpu().numpy(), dtype=np.int64)
+    B = off.shape[0] - 1
+    cap = max(1, B * max_voxels)
+    coors = np.zeros((cap, 4), np.int32)
+    npts = np.zeros((cap,), np.int32)
+    pidx = np.full((cap, max_points), -1, np.int32)
+    f3 = lambda v: np.asarray(v, np.float32)
+    vs, rmin, rmax = f3(voxel_size), f3(range_min), f3(range_max)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    V = lib.p3o_pillarize(P(pts), P(off), ctypes.c_int(B), P(vs), P(rmin), P(rmax),
+                          ctypes.c_int(max_points), ctypes.c_int(max_voxels), P(coors), P(npts), P(pidx))
+    coors, npts, pidx = coors[:V], npts[:V], pidx[:V]
+    # ragged_to_dense(..., -1) + 1 then gather from cat(zeros(1,3), points): padded slots are exact zeros
+    glob = pidx.astype(np.int64) + off[coors[:, 0].astype(np.int64)][:, None]
+    padded = np.concatenate([np.zeros((1, 3), np.float32), pts], 0)
+    voxels = padded[np.where(pidx >= 0, glob + 1, 0)]
+    return (torch.from_numpy(voxels), torch.from_numpy(npts.astype(np.int64)),
+            torch.from_numpy(coors.astype(np.int64)), torch.from_numpy(pidx.astype(np.int64)))
+
+
+# ----------------------------------------------------------------------------------------------
+# PointPillars stem: PillarFeatureNet + scatter  (Open3D-ML point_pillars.py, restated)
+# ----------------------------------------------------------------------------------------------
+def _bn(x, sd, pre, training, eps, momentum, dims):
+    """BatchNorm over `dims` with channel on the remaining axis; updates running stats like torch."""
+    w, b = sd[pre + ".weight"], sd[pre + ".bias"]
+    shape = [1] * x.dim()
+    cdim = [d for d in range(x.dim()) if d not in dims][0]
+    shape[cdim] = -1
+    if training:
+        mean = x.mean(dims)
+        var = x.var(dims, unbiased=False)
+        n = x.numel() // x.shape[cdim]
+        with torch.no_grad():
+            if pre + ".running_mean" in sd:
+                sd[pre + ".running_mean"].mul_(1 - momentum).add_(momentum * mean.detach())
+                sd[pre + ".running_var"].mul_(1 - momentum).add_(momentum * var.detach() * n / max(n - 1, 1))
+                sd[pre + ".num_batches_tracked"] += 1
+    else:
+        mean, var = sd[pre + ".running_mean"], sd[pre + ".running_var"]
+    return (x - mean.view(shape)) / torch.sqrt(var.view(shape) + eps) * w.view(shape) + b.view(shape)
+
+
+def pfn(voxels, num_points, coors, sd, prefix, voxel_xy=(8.0, 8.0), range_min_xy=(0.0, 0.0), training=False):
+    """PillarFeatureNet.forward with feat_channels [64, C]: decorate -> mask -> 2 PFN layers -> [V,C].
+
+    BN eps 1e-3, momentum 0.01; BN statistics include the zero padded slots; the max runs over
+    all `max_points` slots including padded ones.
+    """
+    V, P, _ = voxels.shape
+    mean = voxels.sum(1, keepdim=True) / num_points.to(voxels.dtype).view(-1, 1, 1)
+    f_cluster = voxels - mean
+    f_center = voxels[:, :, :2].clone()
+    vx, vy = voxel_xy
+    f_center[:, :, 0] -= (coors[:, 3].to(voxels.dtype).unsqueeze(1) * vx + (vx / 2 + range_min_xy[0]))
+    f_center[:, :, 1] -= (coors[:, 2].to(voxels.dtype).unsqueeze(1) * vy + (vy / 2 + range_min_xy[1]))
+    feats = torch.cat([voxels, f_cluster, f_center], -1)                      # [V,P,8]
+    mask = (torch.arange(P).view(1, -1) < num_points.view(-1, 1)).to(voxels.dtype).unsqueeze(-1)
+    feats = feats * mask
+    n_layers = len([k for k in sd if k.startswith(prefix + "pfn_layers.") and k.endswith("linear.weight")])
+    x = feats
+    for li in range(n_layers):
+        pre = f"{prefix}pfn_layers.{li}"
+        x = x @ sd[pre + ".linear.weight"].t()
+        x = _bn(x, sd, pre + ".norm", training, 1e-3, 0.01, dims=(0, 1))
+        x = F.relu(x)
+        xmax = x.max(dim=1, keepdim=True)[0]
+        if li == n_layers - 1:
+            x = xmax
+        else:
+            x = torch.cat([x, xmax.expand(-1, P, -1)], dim=2)
+    return x.squeeze(1)
+
+
+def scatter(feats, coors, batch, ny, nx):
+    """PointPillarsScatter.forward: canvas[:, y*nx+x] = feat (later duplicates overwrite)."""
+    C = feats.shape[1]
+    out = feats.new_zeros(batch, C, ny * nx)
+    for b in range(batch):
+        m = coors[:, 0] == b
+        idx = coors[m, 2] * nx + coors[m, 3]
+        fb = feats[m]
+        for k in range(idx.shape[0]):            # explicit order: last write wins
+            out[b, :, idx[k]] = fb[k]
+    return out.view(batch, C, ny, nx)
+
+
+def pillar_stem(values, offsets, sd, prefix, grid=(28, 28), voxel=(8.0, 8.0, 100.0), zmax=100.0,
+                max_points=64, max_voxels=784, training=False):
+    """PointPillarsEncoder.forward(..., return_flattened=False)  (pointpillars_o3d.py:85-107) -> [B,C,ny,nx]."""
+    nx, ny = grid
+    B = offsets.shape[0] - 1
+    voxels, npts, coors, _ = pillarize(values, offsets, voxel, (0, 0, 0), (nx * voxel[0], ny * voxel[1], zmax),
+                                       max_points, max_voxels)
+    feats = pfn(voxels, npts, coors, sd, prefix + "voxel_encoder.", voxel[:2], (0.0, 0.0), training)
+    return scatter(feats, coors, B, ny, nx)
+
+
+# ----------------------------------------------------------------------------------------------
+# timm VisionTransformer body (vit_small_patch8_224.dino), restated
+# ----------------------------------------------------------------------------------------------
+def patch_embed(img, sd, prefix, patch):
+    """timm PatchEmbed.proj: Conv2d(3, dim, k=patch, s=patch) -> NCHW map (flatten=False)."""
+    return F.conv2d(img, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"], stride=patch)
+
+
+def vit_blocks(x, sd, prefix, depth, heads, eps=1e-6):
+    """timm: _pos_embed (cat CLS, + pos_embed) -> Block x depth -> norm.  x: [B,N,dim] patch tokens."""
+    B, N, D = x.shape
+    x = torch.cat([sd[prefix + "cls_token"].expand(B, -1, -1), x], 1) + sd[prefix + "pos_embed"]
+    hd = D // heads
+    for i in range(depth):
+        p = f"{prefix}blocks.{i}."
+        h = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+        qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+        qkv = qkv.reshape(B, N + 1, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        a = torch.softmax((q @ k.transpose(-2, -1)) * (hd ** -0.5), dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, N + 1, D)
+        x = x + F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        h = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+        h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        x = x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return F.layer_norm(x, (D,), sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], eps)
+
+
+def pool_channels(x, out_dim):
+    """nn.AdaptiveAvgPool1d(out_dim) over the channel axis (vit.py:41,49): 384->256 = pairs {0,1},{1,2},{3,4}.."""
+    return F.adaptive_avg_pool1d(x, out_dim)
+
+
+def encoder_vit(img, sd, cfg=VIT_S8, out_dim=256, prefix="encoder."):
+    """ViT.forward (models/vision_transformer/vit.py:45-50), bottleneck=True."""
+    x = patch_embed(img, sd, prefix + "vit.patch_embed.", cfg["patch"]).flatten(2).transpose(1, 2)
+    x = vit_blocks(x, sd, prefix + "vit.", cfg["depth"], cfg["heads"], cfg["eps"])
+    return pool_channels(x[:, 1:, :], out_dim)
+
+
+def encoder_lidar(values, offsets, sd, cfg=VIT_S8, out_dim=256, prefix="encoder.", training=False, **kw):
+    """PointPillarsViT.forward (models/pointpillars/pointpillars_vit.py:71-76): pillar stem is the ViT patch_embed."""
+    x = pillar_stem(values, offsets, sd, prefix + "vit.patch_embed.", training=training, **kw)
+    x = x.flatten(2).transpose(1, 2)
+    x = vit_blocks(x, sd, prefix + "vit.", cfg["depth"], cfg["heads"], cfg["eps"])
+    return pool_channels(x[:, 1:, :], out_dim)
+
+
+def fusion_stem(img, values, offsets, sd, cfg=VIT_S8, prefix="encoder.", training=False, lidar_scale=1.0, **kw):
+    """EarlyFusionViT.forward up to the ViT (early_fusion_vit.py:99-123): cat(image, lidar) -> conv3x3+BN+ReLU."""
+    xi = patch_embed(img, sd, prefix + "image_embed.", cfg["patch"])
+    xl = pillar_stem(values, offsets, sd, prefix + "lidar_embed.", training=training, **kw) * lidar_scale
+    x = torch.cat([xi, xl], 1)
+    x = F.conv2d(x, sd[prefix + "fusion_layer.0.weight"], sd[prefix + "fusion_layer.0.bias"], padding=1)
+    x = _bn(x, sd, prefix + "fusion_layer.1", training, 1e-5, 0.1, dims=(0, 2, 3))
+    return F.relu(x)
+
+
+def encoder_fusion(img, values, offsets, sd, cfg=VIT_S8, out_dim=256, prefix="encoder.", training=False, **kw):
+    """EarlyFusionViT.forward (models/fusion_layers/early_fusion_vit.py:96-127)."""
+    x = fusion_stem(img, values, offsets, sd, cfg, prefix, training, **kw).flatten(2).transpose(1, 2)
+    x = vit_blocks(x, sd, prefix + "vit.", cfg["depth"], cfg["heads"], cfg["eps"])
+    return pool_channels(x[:, 1:, :], out_dim)
+
+
+# ----------------------------------------------------------------------------------------------
+# Pix2Poly decoder (models/pix2poly/model_pix2poly.py:116-219), nn.TransformerDecoder restated
+# ----------------------------------------------------------------------------------------------
+def create_mask(tgt, pad_idx=PAD):
+    """model_pix2poly.py:12-31: causal 0/-inf float mask + *float* key padding mask (additive +1.0 on PAD keys)."""
+    L = tgt.shape[1]
+    causal = torch.full((L, L), float("-inf")).triu(1)
+    return causal, (tgt == pad_idx).to(torch.float32)
+
+
+def _mha(xq, xkv, sd, pre, heads, bias=None):
+    """nn.MultiheadAttention (packed in_proj), batch-first here.  bias: additive [B,1|H,Lq,Lk] or None."""
+    B, Lq, D = xq.shape
+    Lk = xkv.shape[1]
+    W, b = sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"]
+    q = F.linear(xq, W[:D], b[:D])
+    k = F.linear(xkv, W[D:2 * D], b[D:2 * D])
+    v = F.linear(xkv, W[2 * D:], b[2 * D:])
+    hd = D // heads
+    sp = lambda t, L: t.reshape(B, L, heads, hd).transpose(1, 2)
+    s = (sp(q, Lq) @ sp(k, Lk).transpose(-2, -1)) / math.sqrt(hd)
+    if bias is not None:
+        s = s + bias
+    a = torch.softmax(s, -1) @ sp(v, Lk)
+    a = a.transpose(1, 2).reshape(B, Lq, D)
+    return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+
+
+def decoder_forward(enc, tgt, sd, prefix="decoder.", heads=8, layers=6, pad_idx=PAD, eps=1e-5):
+    """Decoder.forward (model_pix2poly.py:158-185), eval / dropout-free.  Returns (logits, feats)."""
+    causal, kpm = create_mask(tgt, pad_idx)
+    L = tgt.shape[1]
+    x = sd[prefix + "embedding.weight"][tgt] + sd[prefix + "decoder_pos_embed"][:, :L]
+    mem = enc + sd[prefix + "encoder_pos_embed"]
+    bias = causal.view(1, 1, L, L) + kpm.view(-1, 1, 1, L)           # float kpm => additive (+1.0)
+    D = x.shape[-1]
+    for i in range(layers):
+        p = f"{prefix}decoder.layers.{i}."
+        x = F.layer_norm(x + _mha(x, x, sd, p + "self_attn.", heads, bias), (D,),
+                         sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+        x = F.layer_norm(x + _mha(x, mem, sd, p + "multihead_attn.", heads), (D,),
+                         sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+        h = F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
+                     sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        x = F.layer_norm(x + h, (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], eps)
+    return F.linear(x, sd[prefix + "output.weight"], sd[prefix + "output.bias"]), x
+
+
+def decoder_predict(enc, tgt, sd, prefix="decoder.", max_len=MAX_LEN, pad_idx=PAD, **kw):
+    """Decoder.predict (model_pix2poly.py:187-219): right-pad to max_len-1 with PAD, full re-run."""
+    length = tgt.shape[1]
+    pad = torch.full((tgt.shape[0], max_len - length - 1), pad_idx, dtype=torch.long)
+    logits, feats = decoder_forward(enc, torch.cat([tgt, pad], 1), sd, prefix, pad_idx=pad_idx, **kw)
+    return logits[:, length - 1, :], feats
+
+
+# ----------------------------------------------------------------------------------------------
+# ScoreNet + Sinkhorn (model_pix2poly.py:35-112)
+# ----------------------------------------------------------------------------------------------
+def scorenet(feats, sd, prefix, n_vertices=MAX_VERTS, training=False):
+    """ScoreNet.forward (model_pix2poly.py:86-112), dense formulation (materialises [B,512,N,N]: small B only)."""
+    f = feats[:, 1:]
+    B = f.shape[0]
+    f = f.reshape(B, f.shape[1] // 2, 2, f.shape[2]).mean(2)                    # [B,N,256]
+    x = f.transpose(1, 2).unsqueeze(-1).repeat(1, 1, 1, n_vertices)             # [B,256,N(i),N(j)]
+    x = torch.cat([x, x.transpose(2, 3)], 1)
+    for li, last in ((1, False), (2, False), (3, False), (4, True)):
+        x = F.conv2d(x, sd[f"{prefix}conv{li}.weight"], sd[f"{prefix}conv{li}.bias"])
+        if not last:
+            x = F.relu(_bn(x, sd, f"{prefix}bn{li}", training, 1e-5, 0.1, dims=(0, 2, 3)))
+    return x[:, 0]
+
+
+def log_optimal_transport(scores, alpha, iters):
+    """model_pix2poly.py:35-66 (SuperGlue log-Sinkhorn with dustbin row/col = alpha)."""
+    b, m, n = scores.shape
+    ms, ns = scores.new_tensor(float(m)), scores.new_tensor(float(n))
+    bins0, bins1, a = alpha.expand(b, m, 1), alpha.expand(b, 1, n), alpha.expand(b, 1, 1)
+    Z = torch.cat([torch.cat([scores, bins0], -1), torch.cat([bins1, a], -1)], 1)
+    norm = -(ms + ns).log()
+    log_mu = torch.cat([norm.expand(m), ns.log()[None] + norm])[None].expand(b, -1)
+    log_nu = torch.cat([norm.expand(n), ms.log()[None] + norm])[None].expand(b, -1)
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1) - norm
+
+
+def perm_head(feats, sd, iters=100, training=False):
+    """EncoderDecoder.forward tail (model_pix2poly.py:256-264)."""
+    s = scorenet(feats, sd, "scorenet1.", training=training) + scorenet(feats, sd, "scorenet2.", training=training).transpose(1, 2)
+    z = log_optimal_transport(s, sd["bin_score"], iters)[:, :s.shape[1], :s.shape[2]]
+    return torch.softmax(z, -1), s
+
+
+def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, training=False):
+    """EncoderDecoder.forward (model_pix2poly.py:245-266).  lidar = (values, offsets)."""
+    if img is not None and lidar is not None:
+        enc = encoder_fusion(img, lidar[0], lidar[1], sd, cfg, training=training)
+    elif img is not None:
+        enc = encoder_vit(img, sd, cfg)
+    else:
+        enc = encoder_lidar(lidar[0], lidar[1], sd, cfg, training=training)
+    logits, feats = decoder_forward(enc, y, sd)
+    perm, _ = perm_head(feats, sd, iters, training)
+    return logits, perm
+
+
+def pix2poly_loss(logits, perm, y_expected, y_perm, w_vertex=1.0, w_perm=10.0, pad_idx=PAD):
+    """trainer_pix2poly.py:318-323: 1.0*CE(ignore_index=PAD) + 10.0*BCE."""
+    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), y_expected.reshape(-1), ignore_index=pad_idx)
+    bce = F.binary_cross_entropy(perm, y_perm)
+    return w_vertex * ce + w_perm * bce, ce, bce
+
+
+def greedy_generate(enc, sd, steps=MAX_LEN - 1, bos=BOS):
+    """Pix2PolyPredictor.test_generate loop (predict/predictor_pix2poly.py:188-207): softmax->argmax, full re-run."""
+    B = enc.shape[0]
+    preds = torch.full((B, 1), bos, dtype=torch.long)
+    feats = None
+    for _ in range(steps):
+        logits, feats = decoder_predict(enc, preds, sd)
+        nxt = torch.softmax(logits, -1).argmax(-1, keepdim=True)
+        preds = torch.cat([preds, nxt], 1)
+    return preds, feats
+
+
+# ----------------------------------------------------------------------------------------------
+# FFL heads (models/ffl/model_ffl.py:28-104) + the *CNN encoder tails
+# ----------------------------------------------------------------------------------------------
+def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
+    x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
+    return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))
+
+
+def vitcnn_tail(tokens, sd, prefix="encoder.", size=224, training=False):
+    """EarlyFusionViTCNN.forward tail (early_fusion_vit_cnn.py:96-104): tokens -> map -> bilinear -> conv3x3+BN+ReLU."""
+    x = tokens[:, 1:, :]
+    B, N, C = x.shape
+    H = W = int(N ** 0.5)
+    x = x.permute(0, 2, 1).reshape(B, C, H, W)
+    x = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    return conv_bn_relu(x, sd, prefix + "proj.1", prefix + "proj.2", training)
+
+
+def ffl_heads(features, sd, training=False):
+    """ffl EncoderDecoder.inference (model_ffl.py:71-96): seg (sigmoid) then crossfield = 2*tanh on cat(features, seg.detach())."""
+    s = conv_bn_relu(features, sd, "seg_module.0", "seg_module.1", training)
+    seg = torch.sigmoid(F.conv2d(s, sd["seg_module.3.weight"], sd["seg_module.3.bias"]))
+    c = conv_bn_relu(torch.cat([features, seg.detach()], 1), sd, "crossfield_module.0", "crossfield_module.1", training)
+    cross = 2 * torch.tanh(F.conv2d(c, sd["crossfield_module.3.weight"], sd["crossfield_module.3.bias"]))
+    return {"seg": seg, "crossfield": cross}
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded weights + synthetic inputs; shared by tests, bench and the product's init
+# ----------------------------------------------------------------------------------------------
+def make_state_dict(kind="fusion", cfg=VIT_S8, seed=42, n_vertices=MAX_VERTS, dec_dim=256, dec_layers=6,
+                    dec_ffn=2048, pfn_mid=64):
+    """Random-init weights with the reference's key names/shapes (SURVEY §8b state_dict contract)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std=0.02: torch.randn(*s, generator=g) * std
+    sd = {}
+    D, depth, mlp, P = cfg["dim"], cfg["depth"], cfg["mlp"], cfg["patch"]
+    N = (cfg["img"] // P) ** 2
+
+    def bn(pre, c):
+        sd[pre + ".weight"] = 1 + rn(c, std=0.1)
+        sd[pre + ".bias"] = rn(c, std=0.1)
+        sd[pre + ".running_mean"] = rn(c, std=0.1)
+        sd[pre + ".running_var"] = 1 + rn(c, std=0.1).abs()
+        sd[pre + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def pfn_w(pre):
+        sd[pre + "voxel_encoder.pfn_layers.0.linear.weight"] = rn(pfn_mid // 2, 8, std=0.1)
+        bn(pre + "voxel_encoder.pfn_layers.0.norm", pfn_mid // 2)
+        sd[pre + "voxel_encoder.pfn_layers.1.linear.weight"] = rn(D, pfn_mid, std=0.1)
+        bn(pre + "voxel_encoder.pfn_layers.1.norm", D)
+
+    v = "encoder.vit."
+    sd[v + "cls_token"] = rn(1, 1, D)
+    sd[v + "pos_embed"] = rn(1, N + 1, D)
+    if kind == "image":
+        sd[v + "patch_embed.proj.weight"] = rn(D, 3, P, P, std=0.05)
+        sd[v + "patch_embed.proj.bias"] = rn(D)
+    elif kind == "lidar":
+        pfn_w(v + "patch_embed.")
+    else:
+        sd["encoder.image_embed.proj.weight"] = rn(D, 3, P, P, std=0.05)
+        sd["encoder.image_embed.proj.bias"] = rn(D)
+        pfn_w("encoder.lidar_embed.")
+        sd["encoder.fusion_layer.0.weight"] = rn(D, 2 * D, 3, 3, std=0.02)
+        sd["encoder.fusion_layer.0.bias"] = rn(D)
+        bn("encoder.fusion_layer.1", D)
+    for i in range(depth):
+        p = f"{v}blocks.{i}."
+        for n_ in ("norm1", "norm2"):
+            sd[p + n_ + ".weight"] = 1 + rn(D, std=0.05)
+            sd[p + n_ + ".bias"] = rn(D, std=0.05)
+        sd[p + "attn.qkv.weight"] = rn(3 * D, D, std=0.04)
+        sd[p + "attn.qkv.bias"] = rn(3 * D)
+        sd[p + "attn.proj.weight"] = rn(D, D, std=0.04)
+        sd[p + "attn.proj.bias"] = rn(D)
+        sd[p + "mlp.fc1.weight"] = rn(mlp, D, std=0.04)
+        sd[p + "mlp.fc1.bias"] = rn(mlp)
+        sd[p + "mlp.fc2.weight"] = rn(D, mlp, std=0.03)
+        sd[p + "mlp.fc2.bias"] = rn(D)
+    sd[v + "norm.weight"] = 1 + rn(D, std=0.05)
+    sd[v + "norm.bias"] = rn(D, std=0.05)
+    # decoder (model_pix2poly.py:116-156)
+    d = "decoder."
+    L = 2 * n_vertices + 1
+    sd[d + "decoder_pos_embed"] = rn(1, L, dec_dim)
+    sd[d + "encoder_pos_embed"] = rn(1, N, dec_dim)
+    sd[d + "embedding.weight"] = rn(VOCAB, dec_dim, std=0.1)
+    for i in range(dec_layers):
+        p = f"{d}decoder.layers.{i}."
+        for a in ("self_attn.", "multihead_attn."):
+            sd[p + a + "in_proj_weight"] = rn(3 * dec_dim, dec_dim, std=0.06)
+            sd[p + a + "in_proj_bias"] = rn(3 * dec_dim)
+            sd[p + a + "out_proj.weight"] = rn(dec_dim, dec_dim, std=0.06)
+            sd[p + a + "out_proj.bias"] = rn(dec_dim)
+        sd[p + "linear1.weight"] = rn(dec_ffn, dec_dim, std=0.05)
+        sd[p + "linear1.bias"] = rn(dec_ffn)
+        sd[p + "linear2.weight"] = rn(dec_dim, dec_ffn, std=0.03)
+        sd[p + "linear2.bias"] = rn(dec_dim)
+        for n_ in ("norm1", "norm2", "norm3"):
+            sd[p + n_ + ".weight"] = 1 + rn(dec_dim, std=0.05)
+            sd[p + n_ + ".bias"] = rn(dec_dim, std=0.05)
+    sd[d + "output.weight"] = rn(VOCAB, dec_dim, std=0.08)
+    sd[d + "output.bias"] = rn(VOCAB)
+    for s in ("scorenet1.", "scorenet2."):
+        for li, (ci, co) in enumerate(((2 * dec_dim, 256), (256, 128), (128, 64), (64, 1)), 1):
+            sd[f"{s}conv{li}.weight"] = rn(co, ci, 1, 1, std=1.0 / math.sqrt(ci))
+            sd[f"{s}conv{li}.bias"] = rn(co)
+            if li < 4:
+                bn(f"{s}bn{li}", co)
+    sd["bin_score"] = torch.tensor(1.0)
+    return sd
+
+
+def make_inputs(batch, seed=1234, n_points=3000, jitter=300, n_vertices=MAX_VERTS, img_size=224, min_verts=8,
+                zmax=99.99):
+    """Synthetic inputs of SURVEY §8d: image U[0,1), jagged lidar, token sequence, GT permutation."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(batch, 3, img_size, img_size, generator=g)
+    counts = torch.randint(n_points - jitter, n_points + jitter + 1, (batch,), generator=g)
+    offsets = torch.zeros(batch + 1, dtype=torch.long)
+    offsets[1:] = counts.cumsum(0)
+    tot = int(offsets[-1])
+    vals = torch.rand(tot, 3, generator=g) * torch.tensor([img_size - 0.01, img_size - 0.01, zmax])
+    L = 2 * n_vertices + 2
+    y = torch.full((batch, L), PAD, dtype=torch.long)
+    perm = torch.zeros(batch, n_vertices, n_vertices)
+    for b in range(batch):
+        n = int(torch.randint(min_verts, n_vertices + 1, (1,), generator=g))
+        y[b, 0] = BOS
+        y[b, 1:1 + 2 * n] = torch.randint(0, NUM_BINS, (2 * n,), generator=g)
+        y[b, 1 + 2 * n] = EOS
+        # random union of cycles over the first n vertices, identity on the rest (p3_coco.py:389-414)
+        i = 0
+        while i < n:
+            ln = min(int(torch.randint(3, 9, (1,), generator=g)), n - i)
+            for k in range(ln):
+                perm[b, i + k, i + (k + 1) % ln] = 1.0
+            i += ln
+        for k in range(n, n_vertices):
+            perm[b, k, k] = 1.0
+    return dict(image=img, lidar_values=vals, lidar_offsets=offsets, y=y, y_perm=perm)

@@ -1,0 +1,25 @@
+"""Shared helpers for the parity tests (oracle side only: fixtures + tolerances)."""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLD, name), allow_pickle=False)
+    data, weights = {}, {}
+    for k in z.files:
+        t = torch.from_numpy(z[k])
+        if k.startswith("w::"):
+            weights[k[3:]] = t
+        else:
+            data[k] = t
+    return data, weights
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b|  (the 'within 1e-3 rel' metric of BASELINE.json north_star)."""
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
