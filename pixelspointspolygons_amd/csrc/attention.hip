@@ -1,0 +1,321 @@
+// p3hip fused attention forward (flash style, online softmax, MFMA 32x32).
+//
+// Work split: grid = (ceil(Lq/128), H, B); a 256-thread workgroup = 4 waves, each wave owns 32 query rows
+// and walks the key/value sequence in tiles of KT keys (64 for bf16, 32 for f32) staged in LDS.
+//
+// Formulation (chosen so that every per-query quantity is lane-local, wave = 64):
+//   S^T[kv, q] = K[kv, :] . Q[q, :]      A = K rows from LDS, B = Q rows held in registers for the whole kernel
+//       -> lane (q = lane&31, hi = lane>>5) holds the scores of ONE query for 16 keys per 32-key sub-tile
+//          (keys crow32(r, hi)); row max / sum need only one exchange with lane^32.
+//   O^T[d, q] += V^T[d, kv] . P^T[kv, q]  A = V^T from LDS, B = P of the lane's own query, fed straight from the
+//       score registers: the MFMA k-slots are *assigned* to the keys the lane already holds (a sum over keys is
+//       order independent), so no cross-lane shuffle of P is needed; the V^T fragment is read with the same key order.
+//   bf16: v_mfma_f32_32x32x16_bf16, V is transposed while it is staged (pairs of keys packed per dword);
+//   f32 : v_mfma_f32_32x32x2_f32 (exact fp32), V stays row-major.
+// Masks: keys >= Lk, causal (key > query) -> -inf; key_bias[b, key] is ADDED (reference's float padding mask).
+#include "p3_common.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct AttnArgs {
+    const void* Q; const void* K; const void* V; void* O;
+    p3_attn_desc d;
+};
+
+template <typename T, int D> struct ATr;
+template <int D> struct ATr<bf16_t, D> {
+    static constexpr int KT = 64, PK = D + 8, PV = KT + 4;  // K [KT][PK] ; V^T [D][PV]
+    static constexpr int K_ELEMS = KT * PK, V_ELEMS = D * PV;
+};
+template <int D> struct ATr<float, D> {
+    static constexpr int KT = 32, PK = D + 1, PV = D;       // K [KT][PK] ; V [KT][PV]
+    static constexpr int K_ELEMS = KT * PK, V_ELEMS = KT * PV;
+};
+
+template <typename T, int D, int KPT, int VPT>
+__device__ __forceinline__ void attn_load_tile(int t, int tid, const p3_attn_desc& d, const T* Kp, const T* Vp,
+                                               u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT]) {
+    using TR = ATr<T, D>;
+    constexpr int KT = TR::KT;
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KV16 = KT * D * (int)sizeof(T) / 16;
+    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;
+
+        const int kv0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int item = tid + 256 * i;
+            if (KV16 % 256 == 0 || item < KV16) {
+                constexpr int VPR = D * (int)sizeof(T) / 16;  // vectors per row
+                int row = item / VPR, cv = item % VPR;
+                int kv = kv0 + row; if (kv >= d.Lk) kv = d.Lk - 1;
+                kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (int64_t)kv * d.k_rs + cv * (16 / (int)sizeof(T)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int item = tid + 256 * i;
+            if (VITEMS % 256 == 0 || item < VITEMS) {
+                if constexpr (BF) {
+                    int dg = item % (D / 4), kp = item / (D / 4);
+                    int kva = kv0 + 2 * kp, kvb = kva + 1;
+                    if (kva >= d.Lk) kva = d.Lk - 1;
+                    if (kvb >= d.Lk) kvb = d.Lk - 1;
+                    uint2 ra = *reinterpret_cast<const uint2*>(Vp + (int64_t)kva * d.v_rs + dg * 4);
+                    uint2 rb = *reinterpret_cast<const uint2*>(Vp + (int64_t)kvb * d.v_rs + dg * 4);
+                    vreg[i] = u32x4{ra.x, ra.y, rb.x, rb.y};
+                } else {
+                    int row = item / (D / 4), cv = item % (D / 4);
+                    int kv = kv0 + row; if (kv >= d.Lk) kv = d.Lk - 1;
+                    vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (int64_t)kv * d.v_rs + cv * 4);
+                }
+            }
+        }
+}
+
+template <typename T, int D, int KPT, int VPT>
+__device__ __forceinline__ void attn_store_tile(int tid, T* Ks, T* Vs, const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT]) {
+    using TR = ATr<T, D>;
+    constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV;
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KV16 = KT * D * (int)sizeof(T) / 16;
+    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;
+
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int item = tid + 256 * i;
+            if (KV16 % 256 == 0 || item < KV16) {
+                constexpr int VPR = D * (int)sizeof(T) / 16;
+                int row = item / VPR, cv = item % VPR;
+                if constexpr (BF) {
+                    *reinterpret_cast<u32x4*>(Ks + row * PK + cv * 8) = kreg[i];
+                } else {
+                    float* p = reinterpret_cast<float*>(Ks) + row * PK + cv * 4;
+                    p[0] = __uint_as_float(kreg[i].x); p[1] = __uint_as_float(kreg[i].y);
+                    p[2] = __uint_as_float(kreg[i].z); p[3] = __uint_as_float(kreg[i].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int item = tid + 256 * i;
+            if (VITEMS % 256 == 0 || item < VITEMS) {
+                if constexpr (BF) {
+                    int dg = item % (D / 4), kp = item / (D / 4);
+                    // V^T[d][2kp..2kp+1] as one dword: low half = key 2kp, high half = key 2kp+1
+                    uint32_t* p = reinterpret_cast<uint32_t*>(Vs);
+                    const uint32_t a0 = vreg[i].x, a1 = vreg[i].y, b0 = vreg[i].z, b1 = vreg[i].w;
+                    p[((dg * 4 + 0) * PV) / 2 + kp] = (a0 & 0xffffu) | (b0 << 16);
+                    p[((dg * 4 + 1) * PV) / 2 + kp] = (a0 >> 16) | (b0 & 0xffff0000u);
+                    p[((dg * 4 + 2) * PV) / 2 + kp] = (a1 & 0xffffu) | (b1 << 16);
+                    p[((dg * 4 + 3) * PV) / 2 + kp] = (a1 >> 16) | (b1 & 0xffff0000u);
+                } else {
+                    int row = item / (D / 4), cv = item % (D / 4);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(Vs) + row * PV + cv * 4) = vreg[i];
+                }
+            }
+        }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    using TR = ATr<T, D>;
+    constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV, NH2 = KT / 32, NDJ = D / 32;
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) T Ks[TR::K_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Vs[TR::V_ELEMS];
+
+    const p3_attn_desc& d = a.d;
+    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
+    const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
+    const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
+    T* Op = reinterpret_cast<T*>(a.O) + (int64_t)b * d.o_bs + h * D;
+
+    const int q = qblk + wave * 32 + l31;          // this lane's query row
+    const int qc = q < d.Lq ? q : d.Lq - 1;        // clamped for loads
+
+    // ---- Q fragments (B operand of S^T) ----
+    s16x8 qb[BF ? D / 16 : 1];
+    float qf[BF ? 1 : D / 2];
+    if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+            qb[ks] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qc * d.q_rs + ks * 16 + 8 * hi);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < D / 2; ++ks) qf[ks] = Qp[(int64_t)qc * d.q_rs + 2 * ks + hi];
+    }
+
+    f32x16 oacc[NDJ];
+#pragma unroll
+    for (int j = 0; j < NDJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kv_end = d.Lk;
+    if (d.causal) { int lim = qblk + 128; if (lim < kv_end) kv_end = lim; }  // keys beyond the block's last query are masked
+    const int ntiles = (kv_end + KT - 1) / KT;
+    const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
+
+    // staging registers
+    constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
+    constexpr int KPT = (KV16 + 255) / 256;                 // per thread
+    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;  // bf16: (key pair, 4 dims) items ; f32: float4 items
+    constexpr int VPT = (VITEMS + 255) / 256;
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT];  // bf16: {row kv: 8 B, row kv+1: 8 B} ; f32: float4
+
+    if (ntiles > 0) attn_load_tile<T, D, KPT, VPT>(0, tid, d, Kp, Vp, kreg, vreg);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();  // previous tile's LDS reads are done
+        attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
+        __syncthreads();
+        if (t + 1 < ntiles) attn_load_tile<T, D, KPT, VPT>(t + 1, tid, d, Kp, Vp, kreg, vreg);
+        const int kv0 = t * KT;
+
+        // ---- S^T = K . Q^T ----
+        f32x16 sacc[NH2];
+#pragma unroll
+        for (int h2 = 0; h2 < NH2; ++h2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[h2][r] = 0.f;
+            if constexpr (BF) {
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    s16x8 kf = *reinterpret_cast<const s16x8*>(Ks + (h2 * 32 + l31) * PK + ks * 16 + 8 * hi);
+                    sacc[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), kf),
+                        __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), qb[ks]), sacc[h2], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < D / 2; ++ks) {
+                    float kf = reinterpret_cast<const float*>(Ks)[(h2 * 32 + l31) * PK + 2 * ks + hi];
+                    sacc[h2] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[ks], sacc[h2], 0, 0, 0);
+                }
+            }
+        }
+        // ---- scale, bias, masks, online softmax ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + h2 * 32 + crow32(r, hi);
+                float s = sacc[h2][r] * d.scale;
+                if (kbias) s += kbias[kv < d.Lk ? kv : d.Lk - 1];
+                if (kv >= d.Lk || (d.causal && kv > q)) s = -INFINITY;
+                sacc[h2][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(sacc[h2][r] - m_use);
+                sacc[h2][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int j = 0; j < NDJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ----
+        if constexpr (BF) {
+#pragma unroll
+            for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pw[i] = pack_bf2(sacc[h2][8 * c2 + 2 * i], sacc[h2][8 * c2 + 2 * i + 1]);
+                    s16x8 pb = __builtin_bit_cast(s16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+                    const int kvb = h2 * 32 + 16 * c2 + 4 * hi;
+#pragma unroll
+                    for (int j = 0; j < NDJ; ++j) {
+                        const T* vrow = Vs + (j * 32 + l31) * PV + kvb;
+                        uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+                        uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+                        s16x8 vf = __builtin_bit_cast(s16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), vf),
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), pb), oacc[j], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = sacc[h2][r];
+                    const int kvl = h2 * 32 + crow32(r, hi);
+#pragma unroll
+                    for (int j = 0; j < NDJ; ++j) {
+                        float vf = reinterpret_cast<const float*>(Vs)[kvl * PV + j * 32 + l31];
+                        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pv, oacc[j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- finalize ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (q < d.Lq) {
+#pragma unroll
+        for (int j = 0; j < NDJ; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int dd = j * 32 + 8 * rg + 4 * hi;
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = oacc[j][4 * rg + i] * inv;
+                T* dst = Op + (int64_t)q * d.o_rs + dd;
+                if constexpr (BF) {
+                    uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        if (d.lse && hi == 0) d.lse[((int64_t)b * d.H + h) * d.Lq + q] = m_run + __logf(l_tot);
+    }
+}
+
+}  // namespace
+
+extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream) {
+    P3_CHECK(Q && K && V && O && d, P3_EINVAL, "p3_attention: null pointer");
+    P3_CHECK(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0, P3_ESHAPE, "p3_attention: empty problem");
+    P3_CHECK(d->head_dim == 32 || d->head_dim == 64, P3_EUNSUP, "p3_attention: head_dim must be 32 or 64");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention: dtype");
+    const int al = d->dtype == P3_BF16 ? 8 : 4;
+    P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % 4 == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
+    P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % 4 == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
+    P3_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, P3_EALIGN, "p3_attention: 16-byte base alignment");
+    AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d;
+    dim3 grid(p3_ceil_div(d->Lq, 128), d->H, d->B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == P3_BF16) {
+        if (d->head_dim == 64) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 64>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 32>), grid, block, 0, s, a);
+    } else {
+        if (d->head_dim == 64) hipLaunchKernelGGL((attn_fwd_kernel<float, 64>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<float, 32>), grid, block, 0, s, a);
+    }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -1,0 +1,298 @@
+// p3hip GEMM:  C[M,N] = act(A'[M,K] * W[N,K]^T + bias) + residual     (gfx950 MFMA, LDS-tiled)
+//
+// One 256-thread workgroup (4 waves, 2x2) computes a 128x128 tile; every wave owns 64x64 = 2x2
+// MFMA 32x32 accumulators (64 AGPR/VGPR per lane).  Operands are staged global -> VGPR -> LDS with
+// the next K-slice's global loads issued before the MFMAs of the current slice (register-staged
+// double buffering, guide T14 form), two LDS buffers, one barrier per K-slice.
+//   bf16: v_mfma_f32_32x32x16_bf16, BK = 64, LDS rows padded to 72 elements (ds_read_b128, conflict free)
+//   f32 : v_mfma_f32_32x32x2_f32 (exact fp32, = fmaf chain), BK = 16, LDS k-major [16][132]
+// The A operand can be generated on the fly (implicit 3x3 conv gather, BN+ReLU fold, ScoreNet pair sum).
+#include "p3_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const void* A; const void* W; void* C;
+    p3_gemm_desc d;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16_t> { static constexpr int BK = 64, PITCH = 72, VEC = 8, LDS_ELEMS = BM * 72; };
+template <> struct Tr<float> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
+
+// ---- per-thread A-row descriptor (fixed over the K loop) -------------------------------------
+struct RowSrc {
+    int64_t off;   // element offset of the row start (plain / affine) or U row (pair)
+    int64_t off2;  // pair: V row offset
+    int y, x;      // conv: pixel coordinates
+    int64_t img;   // conv: element offset of the image (b*H*W*lda)
+};
+
+template <int AMODE>
+__device__ __forceinline__ RowSrc make_row(const p3_gemm_desc& d, int gm) {
+    RowSrc r; r.off = 0; r.off2 = 0; r.y = 0; r.x = 0; r.img = 0;
+    if (gm >= d.M) gm = d.M - 1;
+    if (AMODE == P3_A_CONV3X3) {
+        int hw = d.conv_H * d.conv_W;
+        int b = gm / hw, p = gm - b * hw;
+        r.y = p / d.conv_W; r.x = p - r.y * d.conv_W;
+        r.img = (int64_t)b * hw * d.lda;
+    } else if (AMODE == P3_A_PAIR_AFFINE_RELU) {
+        int n = d.pair_n, nn = n * n;
+        int b = gm / nn, p = gm - b * nn;
+        int i = p / n, j = p - i * n;
+        r.off = (int64_t)(b * n + i) * d.lda;
+        r.off2 = (int64_t)(b * n + j) * d.lda;
+    } else {
+        r.off = (int64_t)gm * d.lda;
+    }
+    return r;
+}
+
+// ---- 16-byte staged vectors: 8 bf16 or 4 f32 -------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void unpack(const uint4& raw, float (&v)[Tr<T>::VEC]) {
+    if constexpr (sizeof(T) == 2) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+        v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+    }
+}
+template <typename T>
+__device__ __forceinline__ uint4 repack(const float (&v)[Tr<T>::VEC]) {
+    uint4 p;
+    if constexpr (sizeof(T) == 2) {
+        p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); p.z = pack_bf2(v[4], v[5]); p.w = pack_bf2(v[6], v[7]);
+    } else {
+        p.x = __float_as_uint(v[0]); p.y = __float_as_uint(v[1]); p.z = __float_as_uint(v[2]); p.w = __float_as_uint(v[3]);
+    }
+    return p;
+}
+
+// load VEC consecutive k-elements of one A row starting at global k index `k`
+template <typename T, int AMODE>
+__device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const RowSrc& r, int k) {
+    constexpr int VEC = Tr<T>::VEC;
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    if (AMODE == P3_A_CONV3X3) {
+        int tap = k / d.conv_C, c = k - tap * d.conv_C;
+        int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
+        if ((yy >= 0) && (yy < d.conv_H) && (xx >= 0) && (xx < d.conv_W))
+            raw = *reinterpret_cast<const uint4*>(A + r.img + (int64_t)(yy * d.conv_W + xx) * d.lda + c);
+        return raw;
+    }
+    raw = *reinterpret_cast<const uint4*>(A + r.off + k);
+    if (AMODE == P3_A_AFFINE_RELU || AMODE == P3_A_PAIR_AFFINE_RELU) {
+        float v[VEC];
+        unpack<T>(raw, v);
+        if (AMODE == P3_A_PAIR_AFFINE_RELU) {
+            float v2[VEC];
+            unpack<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(d.pair_V) + r.off2 + k), v2);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] += v2[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i] * d.a_scale[k + i] + d.a_shift[k + i], 0.f);
+        raw = repack<T>(v);
+    }
+    return raw;
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 load_w(const T* W, int64_t rowoff, int k) {
+    return *reinterpret_cast<const uint4*>(W + rowoff + k);
+}
+
+// store one thread's staged vector into LDS.  bf16: row-major [row][PITCH]; f32: k-major [k][PITCH]
+template <typename T>
+__device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v) {
+    if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(buf + row * Tr<T>::PITCH + kq) = v;
+    } else {
+        buf[(kq + 0) * Tr<T>::PITCH + row] = __uint_as_float(v.x);
+        buf[(kq + 1) * Tr<T>::PITCH + row] = __uint_as_float(v.y);
+        buf[(kq + 2) * Tr<T>::PITCH + row] = __uint_as_float(v.z);
+        buf[(kq + 3) * Tr<T>::PITCH + row] = __uint_as_float(v.w);
+    }
+}
+
+template <typename T, typename TO, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int BK = Tr<T>::BK, PITCH = Tr<T>::PITCH, VEC = Tr<T>::VEC, LDSE = Tr<T>::LDS_ELEMS;
+    // rows handled per thread per operand per stage
+    constexpr int ROWS_PER_PASS = 256 / (BK / VEC);  // bf16: 32, f32: 64
+    constexpr int NPASS = BM / ROWS_PER_PASS;        // bf16: 4,  f32: 2
+    __shared__ __attribute__((aligned(16))) T lds[4 * LDSE];
+
+    const p3_gemm_desc& d = g.d;
+    const T* A = reinterpret_cast<const T*>(g.A);
+    const T* W = reinterpret_cast<const T*>(g.W);
+
+    // XCD-aware bijective remap: consecutive logical tiles (same A row-panel) share one XCD's L2
+    int nwg = gridDim.x, bid = blockIdx.x;
+    {
+        int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+
+    const int kq = (tid % (BK / VEC)) * VEC;
+    const int r0 = tid / (BK / VEC);
+    RowSrc arow[NPASS];
+    int64_t wrow[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        arow[p] = make_row<AMODE>(d, tm * BM + r0 + p * ROWS_PER_PASS);
+        int gn = tn * BN + r0 + p * ROWS_PER_PASS;
+        wrow[p] = (int64_t)(gn < d.N ? gn : d.N - 1) * d.ldb;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[NPASS], rb[NPASS];
+    const int nk = d.K / BK;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) { ra[p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[p] = load_w<T>(W, wrow[p], kq); }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) { lds_put<T>(lds, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) {
+            const int k = (t + 1) * BK + kq;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) { ra[p] = load_a<T, AMODE>(d, A, arow[p], k); rb[p] = load_w<T>(W, wrow[p], k); }
+        }
+        const T* as = lds + cur * LDSE;
+        const T* bs = lds + (2 + cur) * LDSE;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                s16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const s16x8*>(as + (wm * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
+                    bf[i] = *reinterpret_cast<const s16x8*>(bs + (wn * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), af[i]),
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), bf[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = as[(kk * 2 + hi) * PITCH + wm * 64 + i * 32 + l31];
+                    bf[i] = bs[(kk * 2 + hi) * PITCH + wn * 64 + i * 32 + l31];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nk) {
+            T* an = lds + (cur ^ 1) * LDSE;
+            T* bn = lds + (2 + (cur ^ 1)) * LDSE;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) { lds_put<T>(an, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T>(bn, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------
+    TO* C = reinterpret_cast<TO*>(g.C);
+    TO* aux = reinterpret_cast<TO*>(d.aux);
+    const TO* res = reinterpret_cast<const TO*>(d.residual);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = tn * BN + wn * 64 + j * 32 + l31;
+        const bool cok = col < d.N;
+        const float bias = (d.bias && cok) ? d.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * BM + wm * 64 + i * 32 + crow32(r, hi);
+                if (row < d.M && cok) {
+                    float v = acc[i][j][r] + bias;
+                    s1 += v; s2 += v * v;
+                    if (aux) aux[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
+                    if (d.act == P3_ACT_GELU) v = gelu_erf(v);
+                    else if (d.act == P3_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (res) v += Cvt<TO>::to_f(res[(int64_t)row * d.ldr + col]);
+                    C[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
+                }
+            }
+        }
+        if (d.colsum) {
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (hi == 0 && cok) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+        }
+    }
+}
+
+template <typename T, typename TO>
+int launch_mode(const GemmArgs& g, hipStream_t s) {
+    dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    switch (g.d.a_mode) {
+        case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3>), grid, block, 0, s, g); break;
+        case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU>), grid, block, 0, s, g); break;
+        case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU>), grid, block, 0, s, g); break;
+        default: p3_set_error("p3_gemm: bad a_mode"); return P3_EINVAL;
+    }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+}  // namespace
+
+extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
+    P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm: null pointer");
+    P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm: empty problem");
+    const int bk = d->dtype_in == P3_BF16 ? 64 : 16;
+    const int vec = d->dtype_in == P3_BF16 ? 8 : 4;
+    P3_CHECK(d->dtype_in == P3_BF16 || d->dtype_in == P3_F32, P3_EUNSUP, "p3_gemm: dtype_in");
+    P3_CHECK(d->dtype_out == P3_BF16 || d->dtype_out == P3_F32, P3_EUNSUP, "p3_gemm: dtype_out");
+    P3_CHECK(d->K % bk == 0, P3_ESHAPE, "p3_gemm: K must be a multiple of 64 (bf16) / 16 (f32)");
+    P3_CHECK(d->lda % vec == 0 && d->ldb % vec == 0, P3_EALIGN, "p3_gemm: lda/ldb must keep 16-byte row alignment");
+    P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, P3_EALIGN, "p3_gemm: A/W must be 16-byte aligned");
+    if (d->a_mode == P3_A_CONV3X3) {
+        P3_CHECK(d->conv_C > 0 && d->conv_C % bk == 0 && d->K == 9 * d->conv_C, P3_ESHAPE, "p3_gemm: conv3x3 needs K == 9*C, C % BK == 0");
+        P3_CHECK(d->M % (d->conv_H * d->conv_W) == 0, P3_ESHAPE, "p3_gemm: conv3x3 needs M == B*H*W");
+    }
+    if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU)
+        P3_CHECK(d->a_scale && d->a_shift, P3_EINVAL, "p3_gemm: affine mode needs a_scale/a_shift");
+    if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
+        P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");
+    P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.d = *d;
+    g.tiles_m = p3_ceil_div(d->M, BM);
+    g.tiles_n = p3_ceil_div(d->N, BN);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype_in == P3_BF16) return d->dtype_out == P3_BF16 ? launch_mode<bf16_t, bf16_t>(g, s) : launch_mode<bf16_t, float>(g, s);
+    return d->dtype_out == P3_BF16 ? launch_mode<float, bf16_t>(g, s) : launch_mode<float, float>(g, s);
+}

@@ -1,0 +1,185 @@
+// p3hip LayerNorm forward / backward (HBM-bound; one wave per row, 4 rows per 256-thread block).
+// cols <= 1024 and cols % 4 == 0 (the path uses 384, 768 and 256).
+#include "p3_common.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // up to 4 float4-chunks per lane -> cols <= 1024
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+        uint2 raw = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        float4 raw = *reinterpret_cast<const float4*>(p);
+        v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+        uint2 raw; raw.x = pack_bf2(v[0], v[1]); raw.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = raw;
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TO* __restrict__ y, int64_t rows,
+                                                     int cols, int ldx, int ldy, float eps, float* __restrict__ smean,
+                                                     float* __restrict__ srstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = cols >> 2;
+    float v[MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            load4<TI>(x + row * ldx + ci * 4, v[c]);
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float dlt = v[c][i] - mean; q += dlt * dlt; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            float g[4], b[4], o[4];
+            load4<float>(gamma + ci * 4, g);
+            load4<float>(beta + ci * 4, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+            store4<TO>(y + row * ldy + ci * 4, o);
+        }
+    }
+    if (lane == 0 && smean) { smean[row] = mean; srstd[row] = rstd; }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma/dbeta accumulated with one atomic per block-column
+template <typename TDY, typename TX, typename TDX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, TDX* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
+                                                     int cols, int rows_per_block) {
+    __shared__ float sg[4][1024], sb[4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchunk = cols >> 2;
+    float ag[MAXV][4], ab[MAXV][4];
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    int64_t rend = rbeg + rows_per_block;
+    if (rend > rows) rend = rows;
+    for (int64_t row = rbeg + w; row < rend; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[MAXV][4], xh[MAXV][4], d[MAXV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                float xv[4];
+                load4<TX>(x + row * cols + ci * 4, xv);
+                load4<TDY>(dy + row * cols + ci * 4, d[c]);
+                load4<float>(gamma + ci * 4, g[c]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[c][i] = (xv[i] - mu) * rs;
+                    const float gd = g[c][i] * d[c][i];
+                    s1 += gd; s2 += gd * xh[c][i];
+                    ag[c][i] += d[c][i] * xh[c][i];
+                    ab[c][i] += d[c][i];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rs * (g[c][i] * d[c][i] - s1 - xh[c][i] * s2);
+                store4<TDX>(dx + row * cols + ci * 4, o);
+            }
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int ci = lane + 64 * c;
+            if (ci < nchunk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sg[w][ci * 4 + i] = ag[c][i]; sb[w][ci * 4 + i] = ab[c][i]; }
+        }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < cols; cidx += 256) {
+            atomicAdd(dgamma + cidx, (sg[0][cidx] + sg[1][cidx]) + (sg[2][cidx] + sg[3][cidx]));
+            atomicAdd(dbeta + cidx, (sb[0][cidx] + sb[1][cidx]) + (sb[2][cidx] + sb[3][cidx]));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int p3_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int cols, int ldx,
+                            int ldy, float eps, int dtype_in, int dtype_out, float* save_mean, float* save_rstd, void* stream) {
+    P3_CHECK(x && gamma && beta && y, P3_EINVAL, "p3_layernorm: null pointer");
+    P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, P3_ESHAPE, "p3_layernorm: cols must be <=1024 and %4");
+    if (rows <= 0) return P3_OK;
+    dim3 grid(p3_ceil_div(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(TI, TO) \
+    hipLaunchKernelGGL((ln_fwd_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, gamma, beta, (TO*)y, rows, cols, ldx, ldy, eps, save_mean, save_rstd)
+    if (dtype_in == P3_F32 && dtype_out == P3_F32) LN_LAUNCH(float, float);
+    else if (dtype_in == P3_F32 && dtype_out == P3_BF16) LN_LAUNCH(float, bf16_t);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_BF16) LN_LAUNCH(bf16_t, bf16_t);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_F32) LN_LAUNCH(bf16_t, float);
+    else { p3_set_error("p3_layernorm: dtype"); return P3_EUNSUP; }
+#undef LN_LAUNCH
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
+                                int dtype_dx, void* stream) {
+    P3_CHECK(dy && x && gamma && mean && rstd && dx, P3_EINVAL, "p3_layernorm_bwd: null pointer");
+    P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
+    P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
+    if (rows <= 0) return P3_OK;
+    const int rpb = 64;
+    dim3 grid(p3_ceil_div(rows, rpb)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LNB(TDY, TX, TDX) \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
+    if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(float, float, float);
+    else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(bf16_t, float, float);
+    else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNB(bf16_t, bf16_t, bf16_t);
+    else if (dtype_dy == P3_F32 && dtype_x == P3_BF16 && dtype_dx == P3_F32) LNB(float, bf16_t, float);
+    else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
+#undef LNB
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -1,0 +1,152 @@
+"""Thin tensor-level bindings of the C-ABI in include/p3hip.h (PyTorch = device memory + streams only)."""
+import ctypes
+from ctypes import POINTER, Structure, byref, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+from ._lib import P3Error, check, lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+A_PLAIN, A_CONV3X3, A_AFFINE_RELU, A_PAIR_AFFINE_RELU = 0, 1, 2, 3
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise P3Error(f"unsupported dtype {t.dtype}")
+
+
+def tdtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise P3Error("p3hip ops need device tensors (there is no CPU path)")
+
+
+class GemmDesc(Structure):
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
+                ("dtype_in", c_int), ("dtype_out", c_int), ("act", c_int), ("a_mode", c_int),
+                ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("aux", c_void_p),
+                ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
+                ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
+                ("colsum", c_void_p), ("colsumsq", c_void_p)]
+
+
+def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
+         a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
+         lda=None, ldc=None):
+    """C[M,N] = act(A'[M,K] @ W[N,K]^T + bias) + residual.  a: [..., K] (2-D view), w: [N, K]."""
+    _dev(a)
+    N, K = w.shape
+    if a_mode == A_CONV3X3:
+        B, H, W_, C = conv
+        M_ = B * H * W_
+        lda_ = lda if lda is not None else a.stride(-2)
+    elif a_mode == A_PAIR_AFFINE_RELU:
+        M_ = M
+        lda_ = a.stride(-2)
+    else:
+        a2 = a.reshape(-1, a.shape[-1]) if a.dim() != 2 else a
+        M_ = a2.shape[0] if M is None else M
+        lda_ = a2.stride(0) if lda is None else lda
+    odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else a.dtype)
+    if out is None:
+        out = torch.empty((M_, N), dtype=odt, device=a.device)
+    d = GemmDesc()
+    d.M, d.N, d.K = M_, N, K
+    d.lda, d.ldb, d.ldc = lda_, w.stride(0), (out.stride(-2) if ldc is None else ldc)
+    d.dtype_in, d.dtype_out, d.act, d.a_mode = dt(a), dt(out), act, a_mode
+    if w.dtype != a.dtype:
+        raise P3Error("gemm: A and W dtypes differ")
+    d.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        if residual.dtype != out.dtype:
+            raise P3Error("gemm: residual dtype must equal output dtype")
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(-2)
+    if aux is not None:
+        d.aux = aux.data_ptr()
+    if conv is not None:
+        d.conv_H, d.conv_W, d.conv_C = conv[1], conv[2], conv[3]
+    if a_scale is not None:
+        d.a_scale, d.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
+    if pair_v is not None:
+        d.pair_V, d.pair_n = pair_v.data_ptr(), pair_n
+    if colsum is not None:
+        d.colsum, d.colsumsq = colsum.data_ptr(), colsumsq.data_ptr()
+    check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
+    _dev(x)
+    cols = x.shape[-1]
+    x2 = x.reshape(-1, cols)
+    rows = x2.shape[0]
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    o2 = out.view(-1, cols)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().p3_layernorm(ptr(x2), ptr(gamma), ptr(beta), ptr(o2), c_int64(rows), c_int(cols), c_int(x2.stride(0)),
+                             c_int(o2.stride(0)), c_float(eps), c_int(dt(x)), c_int(dt(out)), ptr(mean), ptr(rstd),
+                             stream()), "p3_layernorm")
+    return (out, mean, rstd) if save_stats else out
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None):
+    cols = x.shape[-1]
+    dy2, x2 = dy.reshape(-1, cols).contiguous(), x.reshape(-1, cols).contiguous()
+    rows = x2.shape[0]
+    dx = torch.empty(x.shape, dtype=dx_dtype or x.dtype, device=x.device)
+    check(lib().p3_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                 c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
+          "p3_layernorm_bwd")
+    return dx
+
+
+class AttnDesc(Structure):
+    _fields_ = [("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("head_dim", c_int),
+                ("q_bs", c_int64), ("k_bs", c_int64), ("v_bs", c_int64), ("o_bs", c_int64),
+                ("q_rs", c_int), ("k_rs", c_int), ("v_rs", c_int), ("o_rs", c_int),
+                ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p)]
+
+
+def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse):
+    B, Lq, Dm = q.shape
+    Lk = k.shape[1]
+    d = AttnDesc()
+    d.B, d.H, d.Lq, d.Lk, d.head_dim = B, heads, Lq, Lk, Dm // heads
+    d.q_bs, d.k_bs, d.v_bs, d.o_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    d.scale, d.causal, d.dtype = scale, int(causal), dt(q)
+    d.key_bias = key_bias.data_ptr() if key_bias is not None else None
+    d.lse = lse.data_ptr() if lse is not None else None
+    return d
+
+
+def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False):
+    """q [B,Lq,H*D], k/v [B,Lk,H*D] (arbitrary batch/row strides, unit inner stride) -> o [B,Lq,H*D]."""
+    _dev(q)
+    for t in (q, k, v):
+        if t.stride(2) != 1:
+            raise P3Error("attention: inner stride must be 1")
+    o = torch.empty((q.shape[0], q.shape[1], q.shape[2]), dtype=q.dtype, device=q.device)
+    lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if need_lse else None
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse)
+    check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
+    return (o, lse) if need_lse else o

@@ -1,0 +1,159 @@
+"""Per-kernel parity: HIP C-ABI ops vs plain fp32 CPU math on identical seeded inputs (GPU box only)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _h():
+    import pixelspointspolygons_amd.hip as h
+    return h
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 227, 256), (785 * 2, 1152, 384), (1000, 384, 1536)])
+def test_gemm_f32_exact_path(M, N, K):
+    h = _h()
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(N, seed=3)
+    ref = a @ w.t() + b
+    out = h.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV)).cpu()
+    assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_f32_epilogues(act):
+    h = _h()
+    M, N, K = 260, 200, 128
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2), _rand(N, seed=3), _rand(M, N, seed=4)
+    pre = a @ w.t() + b
+    ref = {0: pre, 1: F.gelu(pre), 2: F.relu(pre)}[act] + r
+    aux = torch.empty(M, N, device=DEV)
+    cs, cq = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    out = h.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), act=act, residual=r.to(DEV), aux=aux, colsum=cs, colsumsq=cq).cpu()
+    assert rel_err(out, ref) < 3e-6
+    assert rel_err(aux.cpu(), pre) < 3e-6
+    assert rel_err(cs.cpu(), pre.sum(0)) < 1e-5 and rel_err(cq.cpu(), (pre * pre).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 227, 256), (785 * 2, 1152, 384), (1000, 384, 1536)])
+def test_gemm_bf16(M, N, K):
+    h = _h()
+    a = _rand(M, K, seed=1).bfloat16()
+    w = _rand(N, K, seed=2, scale=0.1).bfloat16()
+    b = _rand(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out32 = h.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), out_dtype=torch.float32).cpu()
+    assert rel_err(out32, ref) < 1e-5            # fp32 accumulate of exact bf16 products
+    out16 = h.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV)).cpu()
+    assert out16.dtype == torch.bfloat16 and rel_err(out16.float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_conv3x3_implicit(dtype):
+    h = _h()
+    B, H, W, C, Co = 3, 28, 28, 128, 192
+    x = _rand(B, C, H, W, seed=5).to(dtype)
+    wt = _rand(Co, C, 3, 3, seed=6, scale=0.05).to(dtype)
+    b = _rand(Co, seed=7)
+    ref = F.conv2d(x.float(), wt.float(), b, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Co)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(DEV)                    # [B,H,W,C]
+    w2 = wt.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous().to(DEV)    # [Co,(ky,kx,ci)]
+    out = h.gemm(x_nhwc.view(-1, C), w2, bias=b.to(DEV), a_mode=h.A_CONV3X3, conv=(B, H, W, C), lda=C,
+                 out_dtype=torch.float32).cpu()
+    assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else 2e-5)
+
+
+def test_gemm_affine_and_pair_modes():
+    h = _h()
+    Bn, n, K, N = 2, 12, 64, 96
+    U, V = _rand(Bn * n, K, seed=1), _rand(Bn * n, K, seed=2)
+    sc, sh = _rand(K, seed=3).abs() + 0.5, _rand(K, seed=4)
+    w = _rand(N, K, seed=5, scale=0.2)
+    pair = (U.view(Bn, n, 1, K) + V.view(Bn, 1, n, K)).reshape(-1, K)
+    ref = F.relu(pair * sc + sh) @ w.t()
+    out = h.gemm(U.to(DEV), w.to(DEV), a_mode=h.A_PAIR_AFFINE_RELU, M=Bn * n * n, pair_v=V.to(DEV), pair_n=n,
+                 a_scale=sc.to(DEV), a_shift=sh.to(DEV)).cpu()
+    assert rel_err(out, ref) < 3e-6
+    ref2 = F.relu(U * sc + sh) @ w.t()
+    out2 = h.gemm(U.to(DEV), w.to(DEV), a_mode=h.A_AFFINE_RELU, a_scale=sc.to(DEV), a_shift=sh.to(DEV)).cpu()
+    assert rel_err(out2, ref2) < 3e-6
+
+
+def test_gemm_rejects_bad_shapes():
+    h = _h()
+    from pixelspointspolygons_amd._lib import P3Error
+    with pytest.raises(P3Error):
+        h.gemm(torch.zeros(8, 24, device=DEV), torch.zeros(8, 24, device=DEV))      # K % 16 != 0
+    with pytest.raises(P3Error):
+        h.gemm(torch.zeros(8, 32), torch.zeros(8, 32))                               # host tensors
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("cols,eps", [(384, 1e-6), (256, 1e-5), (768, 1e-6)])
+def test_layernorm_fwd_bwd(cols, eps):
+    h = _h()
+    x = _rand(777, cols, seed=1, scale=2.0).requires_grad_(True)
+    g, b = (1 + _rand(cols, seed=2, scale=0.1)).requires_grad_(True), _rand(cols, seed=3, scale=0.1).requires_grad_(True)
+    y = F.layer_norm(x, (cols,), g, b, eps)
+    dy = _rand(777, cols, seed=4)
+    y.backward(dy)
+    out, mean, rstd = h.layernorm(x.detach().to(DEV), g.detach().to(DEV), b.detach().to(DEV), eps, save_stats=True)
+    assert rel_err(out.cpu(), y.detach()) < 2e-6
+    dg, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    dx = h.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), g.detach().to(DEV), mean, rstd, dgamma=dg, dbeta=db)
+    assert rel_err(dx.cpu(), x.grad) < 1e-5
+    assert rel_err(dg.cpu(), g.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
+    o16 = h.layernorm(x.detach().to(DEV), g.detach().to(DEV), b.detach().to(DEV), eps, out_dtype=torch.bfloat16)
+    assert rel_err(o16.float().cpu(), y.detach()) < 5e-3
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, heads, scale, causal, kb):
+    B, Lq, Dm = q.shape
+    Lk, hd = k.shape[1], Dm // heads
+    sp = lambda t, L: t.float().reshape(B, L, heads, hd).transpose(1, 2)
+    s = sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) * scale
+    if kb is not None:
+        s = s + kb.view(B, 1, 1, Lk)
+    if causal:
+        s = s + torch.full((Lq, Lk), float("-inf")).triu(1)
+    p = torch.softmax(s, -1)
+    return (p @ sp(v, Lk)).transpose(1, 2).reshape(B, Lq, Dm), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,bias", [
+    (2, 6, 785, 785, 64, False, False),      # ViT-S/8 block attention (timm Attention)
+    (2, 8, 385, 385, 32, True, True),        # decoder self-attention: causal + additive +1.0 PAD bias
+    (2, 8, 385, 784, 32, False, False),      # decoder cross-attention
+    (1, 2, 37, 50, 64, False, True),         # ragged small
+    (1, 1, 1, 1, 32, True, False),           # degenerate
+])
+def test_attention_forward(dtype, B, H, Lq, Lk, hd, causal, bias):
+    h = _h()
+    Dm = H * hd
+    qkv = _rand(B, max(Lq, Lk), 3 * Dm, seed=1).to(dtype)
+    q, k, v = qkv[:, :Lq, :Dm], qkv[:, :Lk, Dm:2 * Dm], qkv[:, :Lk, 2 * Dm:]       # strided views like the packed qkv GEMM output
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk)
+        kb[:, Lk // 2:] = 1.0
+    scale = 1.0 / math.sqrt(hd)
+    ref, lse_ref = _attn_ref(q, k, v, H, scale, causal, kb)
+    qd = qkv.to(DEV)
+    o, lse = h.attention(qd[:, :Lq, :Dm], qd[:, :Lk, Dm:2 * Dm], qd[:, :Lk, 2 * Dm:], H, scale, causal=causal,
+                         key_bias=kb.to(DEV) if kb is not None else None, need_lse=True)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(o.float().cpu(), ref) < tol
+    assert rel_err(lse.cpu(), lse_ref) < (1e-5 if dtype == torch.float32 else 1e-4)
