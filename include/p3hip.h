@@ -60,12 +60,13 @@ typedef struct {
     int M, N, K;
     int lda, ldb, ldc;
     int dtype_in;  /* dtype of A and W */
-    int dtype_out; /* dtype of C, aux and residual */
+    int dtype_out; /* dtype of C and aux */
     int act;
     int a_mode;
     const float* bias;    /* [N] or NULL */
     const void* residual; /* [M,N] (ldr) or NULL; added after the activation */
     int ldr;
+    int dtype_res;        /* dtype of residual (may differ from dtype_out: bf16 stream + fp32 pre-LayerNorm sum) */
     void* aux;            /* optional [M,N] (ldc): pre-activation values (for backward) */
     int conv_H, conv_W, conv_C; /* P3_A_CONV3X3 */
     const float* a_scale; /* [K] for the AFFINE modes */
@@ -111,9 +112,81 @@ typedef struct {
     float* lse;            /* [B,H,Lq] or NULL */
 } p3_attn_desc;
 int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream);
-/* backward: dQ,dK,dV given dO, O, lse (same addressing as forward; dq/dk/dv strides = q/k/v strides) */
-int p3_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK,
-                     void* dV, float* delta_ws, const p3_attn_desc* d, void* stream);
+
+
+
+/* ------------------------------------------------------------------------------------------
+ * LiDAR pillar stem = PointPillarsEncoder.forward (models/pointpillars/pointpillars_o3d.py:85-107):
+ * Open3D-ML PointPillars.voxelize (hard voxelisation: inclusive range test, <= max_points lowest point
+ * indices per pillar, <= max_voxels pillars per sample in ascending hash order) -> PillarFeatureNet
+ * (decorate to 8 ch; Linear(8,32,no bias)+BatchNorm1d(eps 1e-3, momentum 0.01)+ReLU+max+concat;
+ * Linear(64,C)+BN+ReLU+max; padded slots are zeros and take part in BN statistics and in the max) ->
+ * PointPillarsScatter.  Input is the jagged layout of datasets/collate_funcs.py:108:
+ * values [sumN,3] f32 + offsets [B+1] int64.  Output: token-major canvas out[b, y*nx+x, col_off + c]
+ * (row stride out_ld) = NHWC of the reference's [B,C,ny,nx]; empty pillars are exact zeros.
+ * training != 0: BatchNorm batch statistics + running-stat update, else running statistics.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B;
+    int64_t total_points; /* offsets[B] (rows of `values`) */
+    int nx, ny;           /* pillar grid (patch_feature_width/height) */
+    float vx, vy, vz;     /* in_voxel_size */
+    float zmax;           /* point_cloud_range z max (range min is 0) */
+    int max_points;       /* max_num_points_per_voxel (<= 64) */
+    int max_voxels;       /* max_num_voxels.{train,test} */
+    int C;                /* patch_feature_dim */
+    int training;
+    float bn_eps, bn_momentum;
+    int dtype;            /* dtype of w2, of the internal X2/H2 matrices and of `out` */
+    int out_ld, out_col_off;
+} p3_pillar_desc;
+int64_t p3_pillar_stem_workspace_bytes(const p3_pillar_desc* d);
+int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
+                   const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
+                   const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
+                   const p3_pillar_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HBM-bound glue of the encoders / decoder (each replaces a chain of ATen elementwise kernels)
+ * ------------------------------------------------------------------------------------------ */
+/* im2col of timm PatchEmbed.proj (Conv2d k=P, s=P): img NCHW f32 -> rows [B*(H/P)*(W/P), Cin*P*P], k = c*P*P + py*P + px */
+int p3_patchify(const float* img, void* out, int B, int Cin, int H, int W, int P, int dtype_out, void* stream);
+/* timm VisionTransformer._pos_embed (+ fusion BN2d+ReLU, early_fusion_vit.py:75-79,123 when scale/shift given):
+ *   x[b,0,:] = cls + pos[0];  x[b,1+p,:] = f(src[b,p,:]) + pos[1+p];  x is the fp32 residual stream [B, np+1, D] */
+int p3_tokens_assemble(const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* cls,
+                       const float* pos, float* x, int B, int np, int D, void* stream);
+/* drop CLS + nn.AdaptiveAvgPool1d(Dout) over channels (vit.py:41,49; early_fusion_vit.py:94,125) (+ Decoder's
+ * `encoder_out + encoder_pos_embed`, model_pix2poly.py:171-173, when pos != NULL).  y: [B, np+1, Din] */
+int p3_pool_pos(const void* y, int dtype_in, const float* pos, void* out, void* out_nopos, int dtype_out, int B, int np, int Din,
+                int Dout, void* stream);
+/* Decoder.forward head (model_pix2poly.py:164-168 + create_mask :21-31): x = embedding[tgt] + decoder_pos_embed,
+ * key_bias = (tgt == pad).float() */
+int p3_embed_tokens(const int64_t* tokens, const float* emb, const float* pos, void* x, float* key_bias, int B, int L, int D,
+                    int pad_idx, int dtype_out, void* stream);
+/* ScoreNet.forward (model_pix2poly.py:86-112), never materialising the [B,512,N,N] pair tensor:
+ *   p3_pair_mean   feats[:,1:] -> mean of token pairs [B,N,D]
+ *   p3_gemm x2     U = F W1[:, :D]^T + b1, V = F W1[:, D:]^T              (conv1 is separable over (i, j))
+ *   p3_pair_stats  closed-form BatchNorm2d batch statistics of U_i + V_j  (sums[0:C] = sum, sums[C:2C] = sum of squares)
+ *   p3_bn_finalize scale/shift (+ running stats update, torch momentum semantics)
+ *   p3_gemm        conv2 with P3_A_PAIR_AFFINE_RELU, conv3 with P3_A_AFFINE_RELU (colsum -> next BN)
+ *   p3_score_out   BN3+ReLU+conv4 -> scores [B,N,N]; transpose_accumulate adds s2^T (perm = s1 + s2^T, :257-259) */
+int p3_pair_mean(const void* feats, void* out, int B, int L, int N, int D, int dtype, void* stream);
+int p3_pair_stats(const void* U, const void* V, int B, int N, int C, int dtype, float* sums, void* stream);
+int p3_bn_finalize(const float* sums, int C, float count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float eps, float momentum, int training, float* scale, float* shift, float* save_mean,
+                   float* save_rstd, void* stream);
+int p3_score_out(const void* H3, int dtype, const float* scale, const float* shift, const float* w4, const float* b4, float* out,
+                 int B, int N, int C, int transpose_accumulate, void* stream);
+/* log_optimal_transport (model_pix2poly.py:44-66) + [:, :m, :n] + softmax(-1) (:261-264) in one launch.
+ * perm [B,m,n] (may be NULL), z_full [B,m+1,n+1] = log_optimal_transport's return value (may be NULL),
+ * uv_hist [B,iters,(m+1)+(n+1)] optional dual iterates for the backward pass. */
+int p3_sinkhorn(const float* scores, const float* alpha, int B, int m, int n, int iters, float* perm, float* z_full,
+                float* uv_hist, void* stream);
+/* greedy decode step (predictor_pix2poly.py:165,196-197): argmax over the last dim, first maximum wins */
+int p3_argmax(const float* x, int64_t* out, int rows, int cols, int ld, void* stream);
+int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* stream);
+/* out[b,t,:] = x[b,t,:] + pos[t,:]  (Decoder: encoder_out + encoder_pos_embed, model_pix2poly.py:171-173) */
+int p3_add_pos(const void* x, const float* pos, void* out, int B, int L, int D, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

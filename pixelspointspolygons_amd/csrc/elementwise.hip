@@ -1,0 +1,302 @@
+// p3hip HBM-bound glue kernels (coalesced, vectorised where the layout allows; grid-stride, <= 2048 blocks).
+#include "p3_common.h"
+
+namespace {
+
+inline int grid_for(int64_t work, int per_block = 256) {
+    int64_t g = (work + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// ---- patchify: NCHW f32 image -> [B*np, 3*P*P] rows (k = c*P*P + py*P + px), the im2col of a stride-P conv ----
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int Cin, int H, int W, int P) {
+    const int gw = W / P, gh = H / P, K = Cin * P * P;
+    const int64_t total = (int64_t)B * gh * gw * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t row = i / K;
+        const int px = k % P, py = (k / P) % P, c = k / (P * P);
+        const int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gw * gh));
+        out[i] = Cvt<T>::from_f(img[(((int64_t)b * Cin + c) * H + gy * P + py) * W + gx * P + px]);
+    }
+}
+
+// ---- tokens_assemble: x[b,0,:] = cls + pos[0]; x[b,1+p,:] = f(src[b,p,:]) + pos[1+p]  (f = BN+ReLU affine or identity) ----
+template <typename TS>
+__global__ void tokens_assemble_kernel(const TS* __restrict__ src, int src_ld, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const float* __restrict__ cls, const float* __restrict__ pos,
+                                       float* __restrict__ x, int B, int np, int D) {
+    const int64_t total = (int64_t)B * (np + 1) * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int t = (int)((i / D) % (np + 1));
+        const int b = (int)(i / ((int64_t)D * (np + 1)));
+        float v;
+        if (t == 0) v = cls[c];
+        else {
+            v = Cvt<TS>::to_f(src[((int64_t)b * np + (t - 1)) * src_ld + c]);
+            if (scale) v = fmaxf(v * scale[c] + shift[c], 0.f);
+        }
+        x[i] = v + pos[(int64_t)t * D + c];
+    }
+}
+
+// ---- pool_pos: AdaptiveAvgPool1d(Din -> Dout) over channels of tokens 1..np (CLS dropped) + encoder pos embed ----
+template <typename TI, typename TO>
+__global__ void pool_pos_kernel(const TI* __restrict__ y, const float* __restrict__ pos, TO* __restrict__ out, TO* __restrict__ out_nopos,
+                                int B, int np, int Din, int Dout) {
+    const int64_t total = (int64_t)B * np * Dout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Dout);
+        const int p = (int)((i / Dout) % np);
+        const int b = (int)(i / ((int64_t)Dout * np));
+        const int s = (int)(((int64_t)c * Din) / Dout), e = (int)((((int64_t)(c + 1)) * Din + Dout - 1) / Dout);
+        const TI* row = y + ((int64_t)b * (np + 1) + 1 + p) * Din;
+        float a = 0.f;
+        for (int k = s; k < e; ++k) a += Cvt<TI>::to_f(row[k]);
+        a /= (float)(e - s);
+        if (out_nopos) out_nopos[i] = Cvt<TO>::from_f(a);
+        out[i] = Cvt<TO>::from_f(pos ? a + pos[(int64_t)p * Dout + c] : a);
+    }
+}
+
+// ---- embed_tokens: x[b,t,:] = emb[tok[b,t]] + pos[t]; key_bias[b,t] = (tok == pad) ? 1 : 0 ----
+template <typename TO>
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pos,
+                                    TO* __restrict__ x, float* __restrict__ key_bias, int B, int L, int D, int pad_idx) {
+    const int64_t total = (int64_t)B * L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int64_t bt = i / D;
+        const int t = (int)(bt % L);
+        const int64_t id = tok[bt];
+        x[i] = Cvt<TO>::from_f(emb[id * D + c] + pos[(int64_t)t * D + c]);
+        if (c == 0 && key_bias) key_bias[bt] = id == pad_idx ? 1.f : 0.f;
+    }
+}
+
+// ---- pair_mean: F[b,v,:] = 0.5*(feats[b,1+2v,:] + feats[b,2+2v,:])  (ScoreNet.forward, model_pix2poly.py:87-90) ----
+template <typename T>
+__global__ void pair_mean_kernel(const T* __restrict__ feats, T* __restrict__ out, int B, int L, int N, int D) {
+    const int64_t total = (int64_t)B * N * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int v = (int)((i / D) % N);
+        const int b = (int)(i / ((int64_t)D * N));
+        const T* r = feats + ((int64_t)b * L + 1 + 2 * v) * D + c;
+        out[i] = Cvt<T>::from_f((Cvt<T>::to_f(r[0]) + Cvt<T>::to_f(r[D])) / 2.f);
+    }
+}
+
+// ---- ScoreNet BN1 batch statistics in closed form: h[b,i,j,c] = U[b,i,c] + V[b,j,c] ----
+template <typename T>
+__global__ void pair_stats_kernel(const T* __restrict__ U, const T* __restrict__ V, int N, int C, float* __restrict__ sums) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float su = 0.f, sv = 0.f, su2 = 0.f, sv2 = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const float u = Cvt<T>::to_f(U[((int64_t)b * N + i) * C + c]), v = Cvt<T>::to_f(V[((int64_t)b * N + i) * C + c]);
+            su += u; sv += v; su2 += u * u; sv2 += v * v;
+        }
+        atomicAdd(sums + c, (float)N * (su + sv));
+        atomicAdd(sums + C + c, (float)N * (su2 + sv2) + 2.f * su * sv);
+    }
+}
+
+// ---- ScoreNet tail: score[b,i,j] (+)= sum_c w4[c]*relu(H3[(b,i,j),c]*sc[c]+sh[c]) + b4 ; transposed accumulate for scorenet2 ----
+template <typename T>
+__global__ void score_out_kernel(const T* __restrict__ H3, const float* __restrict__ sc, const float* __restrict__ sh,
+                                 const float* __restrict__ w4, const float* __restrict__ b4, float* __restrict__ out, int B, int N, int C,
+                                 int transpose_acc) {
+    const int64_t total = (int64_t)B * N * N;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (int64_t)gridDim.x * blockDim.x) {
+        const T* row = H3 + r * C;
+        float a = b4[0];
+        for (int c = 0; c < C; ++c) a += w4[c] * fmaxf(Cvt<T>::to_f(row[c]) * sc[c] + sh[c], 0.f);
+        if (transpose_acc) {
+            const int j = (int)(r % N), i = (int)((r / N) % N);
+            const int64_t b = r / ((int64_t)N * N);
+            out[(b * N + j) * N + i] += a;
+        } else {
+            out[r] = a;
+        }
+    }
+}
+
+__global__ void bn_finalize2_kernel(const float* __restrict__ sums, int C, float count, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float eps,
+                                    float momentum, int training, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        mean = sums[c] / count;
+        var = fmaxf(sums[C + c] / count - mean * mean, 0.f);
+        if (rmean) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        }
+    } else { mean = rmean[c]; var = rvar[c]; }
+    const float rstd = rsqrtf(var + eps), s = gamma[c] * rstd;
+    scale[c] = s; shift[c] = beta[c] - mean * s;
+    if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
+}
+
+// ---- argmax over the last dim (greedy decode: softmax -> argmax == argmax of logits; first max wins like torch) ----
+__global__ void argmax_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int rows, int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = x[(int64_t)row * ld + c];
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) out[row] = bi;
+}
+
+// ---- add_pos: out[b,t,:] = x[b,t,:] + pos[t,:] ----
+template <typename T>
+__global__ void add_pos_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ out, int64_t total, int64_t LD) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = Cvt<T>::from_f(Cvt<T>::to_f(x[i]) + pos[i % LD]);
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        b[i] = Cvt<TO>::from_f(Cvt<TI>::to_f(a[i]));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32, name)                 \
+    if ((dtype) == P3_BF16) { CALL_BF; }                           \
+    else if ((dtype) == P3_F32) { CALL_F32; }                      \
+    else { p3_set_error(name ": dtype"); return P3_EUNSUP; }
+
+extern "C" int p3_patchify(const float* img, void* out, int B, int Cin, int H, int W, int P, int dtype_out, void* stream) {
+    P3_CHECK(img && out && B > 0 && H % P == 0 && W % P == 0, P3_ESHAPE, "p3_patchify: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * Cin * H * W;
+    DISPATCH_T(dtype_out, hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, img, (bf16_t*)out, B, Cin, H, W, P),
+               hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, img, (float*)out, B, Cin, H, W, P), "p3_patchify");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_tokens_assemble(const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* cls,
+                                  const float* pos, float* x, int B, int np, int D, void* stream) {
+    P3_CHECK(src && cls && pos && x && B > 0, P3_EINVAL, "p3_tokens_assemble: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * (np + 1) * D;
+    DISPATCH_T(dtype_src, hipLaunchKernelGGL((tokens_assemble_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, src_ld, scale, shift, cls, pos, x, B, np, D),
+               hipLaunchKernelGGL((tokens_assemble_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, src_ld, scale, shift, cls, pos, x, B, np, D), "p3_tokens_assemble");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pool_pos(const void* y, int dtype_in, const float* pos, void* out, void* out_nopos, int dtype_out, int B, int np, int Din,
+                           int Dout, void* stream) {
+    P3_CHECK(y && out && B > 0 && Dout > 0 && Din >= Dout, P3_EINVAL, "p3_pool_pos: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * np * Dout;
+    dim3 g(grid_for(total)), b(256);
+    if (dtype_in == P3_F32 && dtype_out == P3_F32) hipLaunchKernelGGL((pool_pos_kernel<float, float>), g, b, 0, s, (const float*)y, pos, (float*)out, (float*)out_nopos, B, np, Din, Dout);
+    else if (dtype_in == P3_F32 && dtype_out == P3_BF16) hipLaunchKernelGGL((pool_pos_kernel<float, bf16_t>), g, b, 0, s, (const float*)y, pos, (bf16_t*)out, (bf16_t*)out_nopos, B, np, Din, Dout);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_BF16) hipLaunchKernelGGL((pool_pos_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)y, pos, (bf16_t*)out, (bf16_t*)out_nopos, B, np, Din, Dout);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_F32) hipLaunchKernelGGL((pool_pos_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)y, pos, (float*)out, (float*)out_nopos, B, np, Din, Dout);
+    else { p3_set_error("p3_pool_pos: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_embed_tokens(const int64_t* tokens, const float* emb, const float* pos, void* x, float* key_bias, int B, int L, int D,
+                               int pad_idx, int dtype_out, void* stream) {
+    P3_CHECK(tokens && emb && pos && x && B > 0, P3_EINVAL, "p3_embed_tokens: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * L * D;
+    DISPATCH_T(dtype_out, hipLaunchKernelGGL((embed_tokens_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, tokens, emb, pos, (bf16_t*)x, key_bias, B, L, D, pad_idx),
+               hipLaunchKernelGGL((embed_tokens_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, tokens, emb, pos, (float*)x, key_bias, B, L, D, pad_idx), "p3_embed_tokens");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pair_mean(const void* feats, void* out, int B, int L, int N, int D, int dtype, void* stream) {
+    P3_CHECK(feats && out && B > 0 && L >= 2 * N + 1, P3_ESHAPE, "p3_pair_mean: need L >= 2N+1");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * N * D;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pair_mean_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)feats, (bf16_t*)out, B, L, N, D),
+               hipLaunchKernelGGL((pair_mean_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)feats, (float*)out, B, L, N, D), "p3_pair_mean");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pair_stats(const void* U, const void* V, int B, int N, int C, int dtype, float* sums, void* stream) {
+    P3_CHECK(U && V && sums && B > 0, P3_EINVAL, "p3_pair_stats: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pair_stats_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, N, C, sums),
+               hipLaunchKernelGGL((pair_stats_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)U, (const float*)V, N, C, sums), "p3_pair_stats");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_bn_finalize(const float* sums, int C, float count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float eps, float momentum, int training, float* scale, float* shift, float* save_mean,
+                              float* save_rstd, void* stream) {
+    P3_CHECK(gamma && beta && scale && shift && C > 0, P3_EINVAL, "p3_bn_finalize: bad arguments");
+    P3_CHECK(training ? sums != nullptr : (running_mean && running_var), P3_EINVAL, "p3_bn_finalize: missing statistics");
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, count, gamma, beta, running_mean,
+                       running_var, eps, momentum, training, scale, shift, save_mean, save_rstd);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_score_out(const void* H3, int dtype, const float* scale, const float* shift, const float* w4, const float* b4, float* out,
+                            int B, int N, int C, int transpose_accumulate, void* stream) {
+    P3_CHECK(H3 && scale && shift && w4 && b4 && out && B > 0, P3_EINVAL, "p3_score_out: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * N * N;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((score_out_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)H3, scale, shift, w4, b4, out, B, N, C, transpose_accumulate),
+               hipLaunchKernelGGL((score_out_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)H3, scale, shift, w4, b4, out, B, N, C, transpose_accumulate), "p3_score_out");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_argmax(const float* x, int64_t* out, int rows, int cols, int ld, void* stream) {
+    P3_CHECK(x && out && rows > 0 && cols > 0, P3_EINVAL, "p3_argmax: bad arguments");
+    hipLaunchKernelGGL(argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols, ld);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* stream) {
+    P3_CHECK(a && b && n >= 0, P3_EINVAL, "p3_cast: bad arguments");
+    if (n == 0) return P3_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for(n)), blk(256);
+    if (dtype_a == P3_F32 && dtype_b == P3_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, blk, 0, s, (const float*)a, (bf16_t*)b, n);
+    else if (dtype_a == P3_BF16 && dtype_b == P3_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, blk, 0, s, (const bf16_t*)a, (float*)b, n);
+    else if (dtype_a == P3_F32 && dtype_b == P3_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, blk, 0, s, (const float*)a, (float*)b, n);
+    else if (dtype_a == P3_BF16 && dtype_b == P3_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, blk, 0, s, (const bf16_t*)a, (bf16_t*)b, n);
+    else { p3_set_error("p3_cast: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_add_pos(const void* x, const float* pos, void* out, int B, int L, int D, int dtype, void* stream) {
+    P3_CHECK(x && pos && out && B > 0, P3_EINVAL, "p3_add_pos: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * L * D, LD = (int64_t)L * D;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_pos_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, pos, (bf16_t*)out, total, LD),
+               hipLaunchKernelGGL((add_pos_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, pos, (float*)out, total, LD), "p3_add_pos");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // ---- epilogue -------------------------------------------------------------------------
     TO* C = reinterpret_cast<TO*>(g.C);
     TO* aux = reinterpret_cast<TO*>(d.aux);
-    const TO* res = reinterpret_cast<const TO*>(d.residual);
+    const bool has_res = d.residual != nullptr;
+    const bool res_bf = d.dtype_res == P3_BF16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = tn * BN + wn * 64 + j * 32 + l31;
@@ -241,7 +242,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     if (aux) aux[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
                     if (d.act == P3_ACT_GELU) v = gelu_erf(v);
                     else if (d.act == P3_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (res) v += Cvt<TO>::to_f(res[(int64_t)row * d.ldr + col]);
+                    if (has_res) {
+                        const int64_t ri = (int64_t)row * d.ldr + col;
+                        v += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
+                    }
                     C[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
                 }
             }

@@ -1,0 +1,431 @@
+// p3hip LiDAR pillar stem: pillarize -> PillarFeatureNet (2 PFN layers, BatchNorm1d, max) -> scatter.
+// Replaces PointPillarsEncoder.forward (models/pointpillars/pointpillars_o3d.py:85-107), i.e. Open3D-ML
+// PointPillars.voxelize / PillarFeatureNet / PointPillarsScatter, including the reference's per-sample python loops.
+//
+// Pipeline (one launch each, all samples at once, no host sync):
+//   1 pillar_sort      one workgroup per sample: stable counting sort of the points by pillar hash in LDS
+//                      (16 per-wave histograms -> cross-wave prefix -> in-order fill), so that the first
+//                      max_points of each pillar are the LOWEST point indices (Open3D keeps those), bit-exact.
+//   2 pfn_l1_stats     (train) BatchNorm1d(32) batch statistics over all V*max_points slots (padded slots are zeros)
+//   3 pfn_l1_apply     decorate (xyz, xyz - pillar mean, xy - pillar centre) -> Linear(8,32) -> BN -> ReLU -> max;
+//                      writes the layer-2 input rows [x | xmax] for the real points + ONE representative padded slot
+//   4 p3_gemm          H2 = X2 . W2^T   (MFMA; K = 64)
+//   5 pfn_l2_reduce    per pillar max / min over its rows (+ BN statistics, padded slot weighted by its multiplicity)
+//   6 bn_finalize      scale / shift (+ running statistics update)
+//   7 pfn_scatter      relu(scale * (scale > 0 ? hmax : hmin) + shift) -> token-major canvas (empty pillars = 0)
+#include "p3_common.h"
+
+namespace {
+
+constexpr int C1 = 32;      // PFN layer-0 units (feat_channels[0] / 2)
+constexpr int K2 = 64;      // layer-1 input = [x | xmax]
+constexpr int SORT_THREADS = 1024, SORT_WAVES = 16;
+constexpr int MAX_CELLS = 1900;   // (16 + 5) * nc * 4 B of LDS must stay below 160 KB
+
+struct PillarGeom {
+    int nx, ny, ncx, ncy, nc;  // ncx = nx+1 (cell nx holds x == xmax), nc = ncx*ncy*2
+    float invx, invy, invz, xmax, ymax, zmax, vx, vy;
+};
+
+__device__ __forceinline__ int cell_of(const PillarGeom& g, float x, float y, float z) {
+    if (!(x >= 0.f && x <= g.xmax && y >= 0.f && y <= g.ymax && z >= 0.f && z <= g.zmax)) return -1;
+    int cx = (int)(x * g.invx), cy = (int)(y * g.invy), cz = (int)(z * g.invz);
+    return cx + cy * g.ncx + cz * g.ncx * g.ncy;
+}
+
+// exclusive scan of arr[0..n) in LDS by the whole 1024-thread block; returns total. tmp: >= 17 words
+__device__ unsigned block_scan_excl(unsigned* arr, int n, unsigned* tmp) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (n + SORT_THREADS - 1) / SORT_THREADS;
+    unsigned loc[4];
+    unsigned s = 0;
+    for (int i = 0; i < per; ++i) { int idx = tid * per + i; loc[i] = idx < n ? arr[idx] : 0u; s += loc[i]; }
+    unsigned incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    if (tid == 0) { unsigned r = 0; for (int i = 0; i < SORT_WAVES; ++i) { unsigned t = tmp[i]; tmp[i] = r; r += t; } tmp[SORT_WAVES] = r; }
+    __syncthreads();
+    unsigned run = tmp[w] + incl - s;
+    for (int i = 0; i < per; ++i) { int idx = tid * per + i; if (idx < n) arr[idx] = run; run += loc[i]; }
+    unsigned total = tmp[SORT_WAVES];
+    __syncthreads();
+    return total;
+}
+
+struct SortOut {
+    int* sorted;      // [total_points] global point index, grouped by pillar hash, ascending index inside a pillar
+    int* vox_xy;      // [B*MV] cy*nx+cx of kept pillar, bit 30 = "skip in scatter" (overwritten by the top-z pillar)
+    int* vox_start;   // [B*MV] position of the pillar's first point in `sorted`
+    int* vox_cnt;     // [B*MV] min(count, max_points)
+    int* vox_row;     // [B*MV] first row in X2/H2
+    int* nvox;        // [B]
+    int* totals;      // [0] = kept pillars over the batch
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void pillar_sort_kernel(const float* __restrict__ pts, const int64_t* __restrict__ offs,
+                                                                   PillarGeom g, int max_points, int max_voxels, SortOut o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    const int nc = g.nc;
+    unsigned* hist = sm;                      // [16][nc] per-wave histograms -> per-wave bases
+    unsigned* tot = sm + SORT_WAVES * nc;     // [nc] points per cell
+    unsigned* start = tot + nc;               // [nc] first position in the sorted list
+    unsigned* kept = start + nc;              // [nc] 1 if the pillar is emitted
+    unsigned* slot = kept + nc;               // [nc] output slot of a kept pillar
+    unsigned* rows = slot + nc;               // [nc] first X2 row (sample local)
+    unsigned* tmp = rows + nc;                // [32]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t p0 = offs[b];
+    const int n = (int)(offs[b + 1] - p0);
+    for (int i = tid; i < SORT_WAVES * nc; i += SORT_THREADS) hist[i] = 0;
+    __syncthreads();
+    int chunk = (n + SORT_WAVES - 1) / SORT_WAVES;
+    chunk = (chunk + 63) / 64 * 64;
+    const int beg = w * chunk, end = min(n, beg + chunk);
+    for (int i = beg + lane; i < end; i += 64) {
+        const float* p = pts + 3 * (p0 + i);
+        int c = cell_of(g, p[0], p[1], p[2]);
+        if (c >= 0) atomicAdd(&hist[w * nc + c], 1u);
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        unsigned run = 0;
+        for (int k = 0; k < SORT_WAVES; ++k) { unsigned t = hist[k * nc + c]; hist[k * nc + c] = run; run += t; }
+        tot[c] = run; start[c] = run; slot[c] = run > 0 ? 1u : 0u;
+    }
+    __syncthreads();
+    block_scan_excl(start, nc, tmp);
+    block_scan_excl(slot, nc, tmp);   // rank among non-empty cells in hash order: max_voxels counts BEFORE the bounds filter
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy;
+        kept[c] = (tot[c] > 0 && slot[c] < (unsigned)max_voxels && cx < g.nx && cy < g.ny) ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        slot[c] = kept[c];
+        const unsigned cnt = min(tot[c], (unsigned)max_points);
+        rows[c] = kept[c] ? cnt + (cnt < (unsigned)max_points ? 1u : 0u) : 0u;
+    }
+    __syncthreads();
+    const unsigned nkept = block_scan_excl(slot, nc, tmp);
+    block_scan_excl(rows, nc, tmp);
+    const int plane = g.ncx * g.ncy;
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        if (kept[c]) {
+            const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / plane;
+            // PointPillarsScatter writes pillars in order; a top-z pillar (z == zmax) at the same (x,y) comes later and wins
+            const bool overwritten = (cz == 0) && kept[c + plane];
+            const int idx = b * max_voxels + (int)slot[c];
+            o.vox_xy[idx] = (cy * g.nx + cx) | (overwritten ? (1 << 30) : 0);
+            o.vox_start[idx] = (int)(p0 + start[c]);
+            o.vox_cnt[idx] = (int)min(tot[c], (unsigned)max_points);
+            o.vox_row[idx] = (int)(p0 + (int64_t)b * max_voxels + rows[c]);
+        }
+    }
+    if (tid == 0) { o.nvox[b] = (int)nkept; atomicAdd(o.totals, (int)nkept); }
+    // ---- in-order fill: every wave walks its range again; rank inside a 64-point chunk by a match loop ----
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        int c = -1;
+        if (i < end) { const float* p = pts + 3 * (p0 + i); c = cell_of(g, p[0], p[1], p[2]); }
+        unsigned long long active = __ballot(c >= 0);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int lc = __shfl(c, leader, 64);
+            const unsigned long long m = __ballot(c == lc);
+            if (c == lc) {
+                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                o.sorted[p0 + start[lc] + hist[w * nc + lc] + rank] = (int)(p0 + i);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) hist[w * nc + lc] += (unsigned)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            active &= ~m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PFN layer 0
+// ------------------------------------------------------------------------------------------------
+struct VoxTab { const int* sorted; const int* xy; const int* start; const int* cnt; const int* row; const int* nvox; };
+
+// decorated features of slot `lane` of a pillar (valid iff lane < cnt); h = W1 . f
+__device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxTab& t, int v, int lane, const PillarGeom& g,
+                                       const float* __restrict__ w1s, float (&h)[C1], int& cnt_out, bool& valid_out) {
+    const int cnt = t.cnt[v];
+    const bool valid = lane < cnt;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) { const float* p = pts + 3 * (int64_t)t.sorted[t.start[v] + lane]; x = p[0]; y = p[1]; z = p[2]; }
+    const float inv = 1.f / (float)cnt;
+    // same operation order as the reference: sum over slots, then divide
+    const float mx = wave_sum(x) / (float)cnt, my = wave_sum(y) / (float)cnt, mz = wave_sum(z) / (float)cnt;
+    (void)inv;
+    const int xy = t.xy[v] & 0xffffff;
+    const int cx = xy % g.nx, cy = xy / g.nx;
+    float f[8] = {x, y, z, x - mx, y - my, z - mz, x - ((float)cx * g.vx + 0.5f * g.vx), y - ((float)cy * g.vy + 0.5f * g.vy)};
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += w1s[c * 8 + k] * f[k];
+        h[c] = valid ? a : 0.f;
+    }
+    cnt_out = cnt; valid_out = valid;
+}
+
+__global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
+                                                           int nslots, const float* __restrict__ w1, float* __restrict__ sums /*[2*C1]*/) {
+    __shared__ float w1s[C1 * 8];
+    for (int i = threadIdx.x; i < C1 * 8; i += 256) w1s[i] = w1[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float s1[C1], s2[C1];
+#pragma unroll
+    for (int c = 0; c < C1; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        float h[C1]; int cnt; bool valid;
+        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid);
+#pragma unroll
+        for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+        const float a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+        if (lane == 0) { atomicAdd(sums + c, a); atomicAdd(sums + C1 + c, b2); }
+    }
+}
+
+// scale/shift from batch statistics (train) or running statistics (eval); updates running stats like torch BatchNorm
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, const int* __restrict__ count_ptr, float count_mul,
+                                   float count_fixed, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float eps, float momentum, int training,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        const float n = count_ptr ? (float)(*count_ptr) * count_mul : count_fixed;
+        mean = sums[c] / n;
+        var = fmaxf(sums[C + c] / n - mean * mean, 0.f);
+        if (rmean) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+        }
+    } else {
+        mean = rmean[c]; var = rvar[c];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc; shift[c] = beta[c] - mean * sc;
+    if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
+                                                           int max_points, int nslots, const float* __restrict__ w1,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           T* __restrict__ X2) {
+    __shared__ float w1s[C1 * 8];
+    __shared__ float ss[2 * C1];
+    for (int i = threadIdx.x; i < C1 * 8; i += 256) w1s[i] = w1[i];
+    if (threadIdx.x < C1) { ss[threadIdx.x] = scale[threadIdx.x]; ss[C1 + threadIdx.x] = shift[threadIdx.x]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        float h[C1]; int cnt; bool valid;
+        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid);
+        const bool has_pad = cnt < max_points;
+        float xm[C1];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) {
+            h[c] = fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f);          // padded slots: relu(shift)
+            float m = wave_max(valid ? h[c] : -INFINITY);
+            if (has_pad) m = fmaxf(m, fmaxf(ss[C1 + c], 0.f));
+            xm[c] = m;
+        }
+        // rows: lane < cnt -> real slot; lane == cnt (if has_pad) -> the representative padded slot
+        if (valid || (has_pad && lane == cnt)) {
+            T* dst = X2 + (int64_t)(t.row[v] + lane) * K2;
+#pragma unroll
+            for (int c = 0; c < C1; ++c) { dst[c] = Cvt<T>::from_f(h[c]); dst[C1 + c] = Cvt<T>::from_f(xm[c]); }
+        }
+    }
+}
+
+// per pillar: max / min over its H2 rows and BN statistics (padded representative weighted by its multiplicity)
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict__ H2, VoxTab t, int max_voxels, int max_points, int nslots,
+                                                            int C, float* __restrict__ hmax, float* __restrict__ hmin,
+                                                            float* __restrict__ sums /*[2C] or null*/) {
+    const int lane = threadIdx.x & 63;
+    constexpr int MAXJ = 12;
+    float s1[MAXJ], s2[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int nj = C / 64;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        const int cnt = t.cnt[v];
+        const int nrow = cnt + (cnt < max_points ? 1 : 0);
+        const T* base = H2 + (int64_t)t.row[v] * C;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (j < nj) {
+                float mx = -INFINITY, mn = INFINITY;
+                for (int r = 0; r < nrow; ++r) {
+                    const float val = Cvt<T>::to_f(base[(int64_t)r * C + lane + 64 * j]);
+                    const float wgt = r < cnt ? 1.f : (float)(max_points - cnt);
+                    mx = fmaxf(mx, val); mn = fminf(mn, val);
+                    s1[j] += wgt * val; s2[j] += wgt * val * val;
+                }
+                hmax[(int64_t)v * C + lane + 64 * j] = mx;
+                hmin[(int64_t)v * C + lane + 64 * j] = mn;
+            }
+        }
+    }
+    if (sums) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (j < nj) { atomicAdd(sums + lane + 64 * j, s1[j]); atomicAdd(sums + C + lane + 64 * j, s2[j]); }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_scatter_kernel(VoxTab t, int max_voxels, int nslots, int C, int ncell,
+                                                          const float* __restrict__ hmax, const float* __restrict__ hmin,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          T* __restrict__ out, int out_ld) {
+    const int lane = threadIdx.x & 63;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        const int b = v / max_voxels;
+        if ((v % max_voxels) >= t.nvox[b]) continue;
+        const int xyf = t.xy[v];
+        if (xyf & (1 << 30)) continue;
+        const int xy = xyf & 0xffffff;
+        T* dst = out + ((int64_t)b * ncell + xy) * out_ld;
+        for (int c = lane; c < C; c += 64) {
+            const float sc = scale[c];
+            const float hv = sc > 0.f ? hmax[(int64_t)v * C + c] : hmin[(int64_t)v * C + c];
+            dst[c] = Cvt<T>::from_f(fmaxf(sc * hv + shift[c], 0.f));
+        }
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Ws {
+    int* sorted; int* vox_xy; int* vox_start; int* vox_cnt; int* vox_row; int* nvox; int* totals;
+    float* sums1; float* sums2; float* sc1; float* sh1; float* sc2; float* sh2; float* hmax; float* hmin;
+    void* X2; void* H2;
+    size_t bytes;
+};
+
+Ws carve(void* base, const p3_pillar_desc* d) {
+    Ws w; char* p = (char*)base; size_t off = 0;
+    const size_t nv = (size_t)d->B * d->max_voxels;
+    const size_t rows = (size_t)d->total_points + nv;
+    const size_t es = d->dtype == P3_BF16 ? 2 : 4;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align256(bytes); return r; };
+    w.totals = (int*)take(256);
+    w.sums1 = (float*)take(2 * C1 * 4);
+    w.sums2 = (float*)take(2 * (size_t)d->C * 4);
+    const size_t zero_end = off;   // [0, zero_end) is cleared every call
+    w.sc1 = (float*)take(C1 * 4); w.sh1 = (float*)take(C1 * 4);
+    w.sc2 = (float*)take((size_t)d->C * 4); w.sh2 = (float*)take((size_t)d->C * 4);
+    w.sorted = (int*)take((size_t)(d->total_points > 0 ? d->total_points : 1) * 4);
+    w.vox_xy = (int*)take(nv * 4); w.vox_start = (int*)take(nv * 4); w.vox_cnt = (int*)take(nv * 4); w.vox_row = (int*)take(nv * 4);
+    w.nvox = (int*)take((size_t)d->B * 4);
+    w.hmax = (float*)take(nv * d->C * 4); w.hmin = (float*)take(nv * d->C * 4);
+    w.X2 = take(rows * K2 * es);
+    w.H2 = take(rows * (size_t)d->C * es);
+    w.bytes = off;
+    (void)zero_end;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int64_t p3_pillar_stem_workspace_bytes(const p3_pillar_desc* d) {
+    if (!d) return -1;
+    return (int64_t)carve(nullptr, d).bytes;
+}
+
+extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
+                              const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
+                              const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
+                              const p3_pillar_desc* d, void* stream) {
+    P3_CHECK(values && offsets && w1 && w2 && out && workspace && d, P3_EINVAL, "p3_pillar_stem: null pointer");
+    P3_CHECK(d->B > 0 && d->nx > 0 && d->ny > 0 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem: max_points must be 1..64");
+    P3_CHECK(d->C % 64 == 0 && d->C <= 768, P3_ESHAPE, "p3_pillar_stem: C must be a multiple of 64, <= 768");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_pillar_stem: dtype");
+    P3_CHECK(d->vz >= d->zmax, P3_EUNSUP, "p3_pillar_stem: only one z cell (voxel z size == z range) is supported");
+    PillarGeom g;
+    g.nx = d->nx; g.ny = d->ny; g.ncx = d->nx + 1; g.ncy = d->ny + 1; g.nc = g.ncx * g.ncy * 2;
+    P3_CHECK(g.nc <= MAX_CELLS, P3_EUNSUP, "p3_pillar_stem: pillar grid too large for the LDS counting sort");
+    g.invx = 1.0f / d->vx; g.invy = 1.0f / d->vy; g.invz = 1.0f / d->vz;
+    g.xmax = d->nx * d->vx; g.ymax = d->ny * d->vy; g.zmax = d->zmax; g.vx = d->vx; g.vy = d->vy;
+    hipStream_t s = (hipStream_t)stream;
+    Ws w = carve(workspace, d);
+    const int nslots = d->B * d->max_voxels;
+    const size_t es = d->dtype == P3_BF16 ? 2 : 4;
+    const size_t rows = (size_t)d->total_points + (size_t)nslots;
+    hipError_t e;
+    e = hipMemsetAsync(w.totals, 0, (char*)w.sc1 - (char*)w.totals, s);
+    if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+    e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
+    if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+    // zero canvas columns [col_off, col_off + C) of every token row (empty pillars stay exactly 0)
+    e = hipMemset2DAsync((char*)out + (size_t)d->out_col_off * es, (size_t)d->out_ld * es, 0, (size_t)d->C * es,
+                         (size_t)d->B * d->nx * d->ny, s);
+    if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+
+    SortOut so{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox, w.totals};
+    const size_t lds = (size_t)(SORT_WAVES + 5) * g.nc * 4 + 32 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pillar_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
+    P3_LAUNCH_CHECK();
+    VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
+    const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
+    if (d->training) {
+        hipLaunchKernelGGL(pfn_l1_stats_kernel, dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
+        P3_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, w.sums1, C1, w.totals, (float)d->max_points, 0.f, bn1_gamma, bn1_beta,
+                       bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, (float*)nullptr, (float*)nullptr);
+    P3_LAUNCH_CHECK();
+    if (d->dtype == P3_BF16)
+        hipLaunchKernelGGL((pfn_l1_apply_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (bf16_t*)w.X2);
+    else
+        hipLaunchKernelGGL((pfn_l1_apply_kernel<float>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (float*)w.X2);
+    P3_LAUNCH_CHECK();
+    p3_gemm_desc gd;
+    memset(&gd, 0, sizeof(gd));
+    gd.M = (int)rows; gd.N = d->C; gd.K = K2; gd.lda = K2; gd.ldb = K2; gd.ldc = d->C;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    int rc = p3_gemm(w.X2, w2, w.H2, &gd, stream);
+    if (rc != P3_OK) return rc;
+    float* sums2 = d->training ? w.sums2 : nullptr;
+    if (d->dtype == P3_BF16)
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+    else
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+    P3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, s, w.sums2, d->C, w.totals, (float)d->max_points, 0.f, bn2_gamma,
+                       bn2_beta, bn2_rmean, bn2_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc2, w.sh2, (float*)nullptr, (float*)nullptr);
+    P3_LAUNCH_CHECK();
+    if (d->dtype == P3_BF16)
+        hipLaunchKernelGGL((pfn_scatter_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, nslots, d->C, d->nx * d->ny, w.hmax, w.hmin, w.sc2, w.sh2, (bf16_t*)out + d->out_col_off, d->out_ld);
+    else
+        hipLaunchKernelGGL((pfn_scatter_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, nslots, d->C, d->nx * d->ny, w.hmax, w.hmin, w.sc2, w.sh2, (float*)out + d->out_col_off, d->out_ld);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -1,0 +1,89 @@
+"""Early fusion encoder — mirror of pixelspointspolygons/models/fusion_layers/early_fusion_vit.py.
+
+Reference forward (early_fusion_vit.py:96-127): image patch-embed map (+) pillar map -> channel concat ->
+Conv3x3(2D -> D) + BatchNorm2d + ReLU -> flatten -> timm blocks (patch_embed = Identity) -> drop CLS -> AdaptiveAvgPool1d.
+HIP data flow: both stems write straight into one token-major (NHWC) canvas [B, 28*28, 2D] (the concat is free), the 3x3
+conv is an implicit-GEMM gather over that canvas with the BN batch statistics accumulated in the GEMM epilogue, and
+BN + ReLU + CLS + pos_embed are applied by one assemble kernel that produces the fp32 residual stream.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+from .pointpillars import PointPillarsEncoder, jagged_parts
+from .vision_transformer import VisionTransformer, compute_dtype, parse_timm_name, pool
+
+
+class EarlyFusionViT(nn.Module):
+    def __init__(self, cfg, local_rank=0):
+        super().__init__()
+        self.cfg = cfg
+        enc = cfg.experiment.encoder
+        D = enc.patch_feature_dim
+        self.cd = compute_dtype(cfg)
+        self.lidar_embed = PointPillarsEncoder(cfg, voxel_encoder={"in_channels": 3, "feat_channels": [64, D]},
+                                               scatter={"in_channels": D, "output_shape": [enc.patch_feature_width, enc.patch_feature_height]},
+                                               local_rank=local_rank)
+        shp = parse_timm_name(enc.vit.type)
+        self.vit = VisionTransformer(enc.in_size, enc.patch_size, D, getattr(enc.vit, "depth", shp["depth"]),
+                                     getattr(enc.vit, "num_heads", shp["heads"]), getattr(enc.vit, "mlp_dim", None), cd=self.cd)
+        if getattr(enc.vit, "pretrained", False):
+            self.vit.load_state_dict(torch.load(enc.vit.checkpoint_file, map_location="cpu"), strict=False)
+        self.image_embed = self.vit.patch_embed
+        self.image_embed.flatten = False
+        self.vit.patch_embed = nn.Identity()
+        self.fusion_layer = nn.Sequential(nn.Conv2d(D * 2, D, kernel_size=3, padding=1), nn.BatchNorm2d(D), nn.ReLU(inplace=True))
+        self.bottleneck = nn.AdaptiveAvgPool1d(enc.out_feature_dim)
+        self.D, self.g = D, enc.patch_feature_size
+
+    def fused_tokens(self, x_image, x_lidar):
+        """-> LN'd ViT tokens [B, np+1, D] (compute dtype)."""
+        B, D, g, cd = x_image.shape[0], self.D, self.g, self.cd
+        canvas = torch.empty((B, g * g, 2 * D), dtype=cd, device=x_image.device)
+        self.image_embed.tokens(x_image, cd, out=canvas.view(B * g * g, 2 * D)[:, :D])
+        canvas = self.lidar_embed.scatter_into(x_lidar, canvas, D)
+        p = self.cfg.experiment.lidar_dropout
+        if p is not None:
+            # one draw for the whole batch (early_fusion_vit.py:113-119); host-side RNG like the reference's .item()
+            if torch.rand(1).item() <= p:
+                canvas = _zero_lidar(canvas, D)
+        conv, bn = self.fusion_layer[0], self.fusion_layer[1]
+        pre, scale, shift = _FusionConvBN.apply(canvas, conv.weight, conv.bias, bn.weight, bn.bias, self, B)
+        return self.vit.forward_tokens(pre, B, scale=scale, shift=shift)
+
+    def forward(self, x_image, x_lidar):
+        y = self.fused_tokens(x_image, x_lidar)
+        return pool(y, self.cfg.experiment.encoder.out_feature_dim)
+
+
+def _zero_lidar(canvas, D):
+    canvas = canvas.clone()
+    canvas[..., D:] = 0
+    return canvas
+
+
+class _FusionConvBN(torch.autograd.Function):
+    """Conv3x3 (implicit GEMM, stats in the epilogue) + BatchNorm2d scale/shift (applied later by tokens_assemble)."""
+
+    @staticmethod
+    def forward(ctx, canvas, w, b, gamma, beta, mod, B):
+        cd, g, D = mod.cd, mod.g, mod.D
+        bn = mod.fusion_layer[1]
+        training = mod.training
+        # [Co, Ci, 3, 3] -> [Co, (ky, kx, ci)] to match the NHWC gather order
+        w2 = ops.shadow(w, cd, key="khwc", fn=lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))
+        sums = torch.zeros(2 * D, dtype=torch.float32, device=canvas.device) if training else None
+        pre = hip.gemm(canvas.view(B * g * g, 2 * D), w2, bias=b.detach(), a_mode=hip.A_CONV3X3, conv=(B, g, g, 2 * D), lda=2 * D,
+                       out_dtype=cd, colsum=sums[:D] if training else None, colsumsq=sums[D:] if training else None)
+        scale, shift, mean, rstd = hip.bn_finalize(sums, float(B * g * g), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
+                                                   bn.eps, bn.momentum, training, save=True)
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(canvas, pre, w, gamma, mean, rstd)
+        ctx.mod, ctx.B = mod, B
+        ctx.mark_non_differentiable()
+        return pre, scale, shift
+
+    @staticmethod
+    def backward(ctx, dpre, dscale, dshift):
+        raise NotImplementedError("fusion conv backward is provided by pixelspointspolygons_amd.backward (training path)")

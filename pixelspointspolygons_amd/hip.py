@@ -39,7 +39,7 @@ def _dev(t):
 class GemmDesc(Structure):
     _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype_in", c_int), ("dtype_out", c_int), ("act", c_int), ("a_mode", c_int),
-                ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("aux", c_void_p),
+                ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("dtype_res", c_int), ("aux", c_void_p),
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
                 ("colsum", c_void_p), ("colsumsq", c_void_p)]
@@ -73,9 +73,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         raise P3Error("gemm: A and W dtypes differ")
     d.bias = bias.data_ptr() if bias is not None else None
     if residual is not None:
-        if residual.dtype != out.dtype:
-            raise P3Error("gemm: residual dtype must equal output dtype")
-        d.residual, d.ldr = residual.data_ptr(), residual.stride(-2)
+        d.residual, d.ldr, d.dtype_res = residual.data_ptr(), residual.stride(-2), dt(residual)
     if aux is not None:
         d.aux = aux.data_ptr()
     if conv is not None:
@@ -150,3 +148,148 @@ def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False
     d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse)
     check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
     return (o, lse) if need_lse else o
+
+
+# ------------------------------------------------------------------------------------------ pillar stem
+class PillarDesc(Structure):
+    _fields_ = [("B", c_int), ("total_points", c_int64), ("nx", c_int), ("ny", c_int), ("vx", c_float), ("vy", c_float),
+                ("vz", c_float), ("zmax", c_float), ("max_points", c_int), ("max_voxels", c_int), ("C", c_int),
+                ("training", c_int), ("bn_eps", c_float), ("bn_momentum", c_float), ("dtype", c_int), ("out_ld", c_int),
+                ("out_col_off", c_int)]
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag): avoids allocator traffic inside the step / graph capture."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax, max_points, max_voxels, training,
+                col_off=0, total_points=None):
+    """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas."""
+    _dev(values)
+    d = PillarDesc()
+    d.B = B
+    d.total_points = values.shape[0] if total_points is None else total_points
+    d.nx, d.ny = grid
+    d.vx, d.vy, d.vz = voxel
+    d.zmax = zmax
+    d.max_points, d.max_voxels, d.C = max_points, max_voxels, w2.shape[0]
+    d.training, d.bn_eps, d.bn_momentum = int(training), 1e-3, 0.01
+    d.dtype, d.out_ld, d.out_col_off = dt(out), out.stride(-2), col_off
+    if w2.dtype != out.dtype:
+        raise P3Error("pillar_stem: w2 dtype must equal the canvas dtype")
+    L = lib()
+    L.p3_pillar_stem_workspace_bytes.restype = c_int64
+    nbytes = L.p3_pillar_stem_workspace_bytes(byref(d))
+    ws = workspace(nbytes, values.device, "pillar")
+    check(L.p3_pillar_stem(ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
+                           ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d), stream()),
+          "p3_pillar_stem")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ glue ops
+def patchify(img, P, dtype):
+    _dev(img)
+    B, Cin, H, W = img.shape
+    out = torch.empty((B * (H // P) * (W // P), Cin * P * P), dtype=dtype, device=img.device)
+    check(lib().p3_patchify(ptr(img), ptr(out), c_int(B), c_int(Cin), c_int(H), c_int(W), c_int(P), c_int(dt(out)), stream()),
+          "p3_patchify")
+    return out
+
+
+def tokens_assemble(src, cls, pos, B, np_, D, scale=None, shift=None, src_ld=None):
+    x = torch.empty((B, np_ + 1, D), dtype=torch.float32, device=src.device)
+    check(lib().p3_tokens_assemble(ptr(src), c_int(src.stride(-2) if src_ld is None else src_ld), c_int(dt(src)), ptr(scale),
+                                   ptr(shift), ptr(cls), ptr(pos), ptr(x), c_int(B), c_int(np_), c_int(D), stream()),
+          "p3_tokens_assemble")
+    return x
+
+
+def pool_pos(y, pos, Dout, out_dtype, want_nopos=False):
+    B, L, Din = y.shape
+    out = torch.empty((B, L - 1, Dout), dtype=out_dtype, device=y.device)
+    nop = torch.empty_like(out) if want_nopos else None
+    check(lib().p3_pool_pos(ptr(y), c_int(dt(y)), ptr(pos), ptr(out), ptr(nop), c_int(dt(out)), c_int(B), c_int(L - 1),
+                            c_int(Din), c_int(Dout), stream()), "p3_pool_pos")
+    return (out, nop) if want_nopos else out
+
+
+def embed_tokens(tokens, emb, pos, pad_idx, dtype):
+    B, L = tokens.shape
+    D = emb.shape[1]
+    x = torch.empty((B, L, D), dtype=dtype, device=tokens.device)
+    kb = torch.empty((B, L), dtype=torch.float32, device=tokens.device)
+    check(lib().p3_embed_tokens(ptr(tokens), ptr(emb), ptr(pos), ptr(x), ptr(kb), c_int(B), c_int(L), c_int(D), c_int(pad_idx),
+                                c_int(dt(x)), stream()), "p3_embed_tokens")
+    return x, kb
+
+
+def pair_mean(feats, N):
+    B, L, D = feats.shape
+    out = torch.empty((B, N, D), dtype=feats.dtype, device=feats.device)
+    check(lib().p3_pair_mean(ptr(feats), ptr(out), c_int(B), c_int(L), c_int(N), c_int(D), c_int(dt(feats)), stream()),
+          "p3_pair_mean")
+    return out
+
+
+def pair_stats(U, V, B, N, sums):
+    check(lib().p3_pair_stats(ptr(U), ptr(V), c_int(B), c_int(N), c_int(U.shape[-1]), c_int(dt(U)), ptr(sums), stream()),
+          "p3_pair_stats")
+
+
+def bn_finalize(sums, count, gamma, beta, rmean, rvar, eps, momentum, training, save=False):
+    C = gamma.shape[0]
+    scale = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    sm = torch.empty_like(scale) if save else None
+    sr = torch.empty_like(scale) if save else None
+    check(lib().p3_bn_finalize(ptr(sums), c_int(C), c_float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), c_float(eps),
+                               c_float(momentum), c_int(int(training)), ptr(scale), ptr(shift), ptr(sm), ptr(sr), stream()),
+          "p3_bn_finalize")
+    return (scale, shift, sm, sr) if save else (scale, shift)
+
+
+def score_out(H3, scale, shift, w4, b4, out, B, N, transpose_acc):
+    check(lib().p3_score_out(ptr(H3), c_int(dt(H3)), ptr(scale), ptr(shift), ptr(w4), ptr(b4), ptr(out), c_int(B), c_int(N),
+                             c_int(H3.shape[-1]), c_int(int(transpose_acc)), stream()), "p3_score_out")
+    return out
+
+
+def sinkhorn(scores, alpha, iters, want_perm=True, want_z=False, want_hist=False):
+    B, m, n = scores.shape
+    dev = scores.device
+    perm = torch.empty((B, m, n), dtype=torch.float32, device=dev) if want_perm else None
+    z = torch.empty((B, m + 1, n + 1), dtype=torch.float32, device=dev) if want_z else None
+    hist = torch.empty((B, iters, m + n + 2), dtype=torch.float32, device=dev) if want_hist else None
+    check(lib().p3_sinkhorn(ptr(scores), ptr(alpha), c_int(B), c_int(m), c_int(n), c_int(iters), ptr(perm), ptr(z), ptr(hist),
+                            stream()), "p3_sinkhorn")
+    return perm, z, hist
+
+
+def argmax(x):
+    rows, cols = x.shape
+    out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    check(lib().p3_argmax(ptr(x), ptr(out), c_int(rows), c_int(cols), c_int(x.stride(0)), stream()), "p3_argmax")
+    return out
+
+
+def cast(a, dtype):
+    out = torch.empty(a.shape, dtype=dtype, device=a.device)
+    check(lib().p3_cast(ptr(a.contiguous()), c_int(dt(a)), ptr(out), c_int(dt(out)), c_int64(a.numel()), stream()), "p3_cast")
+    return out
+
+
+def add_pos(x, pos):
+    B, L, D = x.shape
+    out = torch.empty_like(x)
+    check(lib().p3_add_pos(ptr(x), ptr(pos), ptr(out), c_int(B), c_int(L), c_int(D), c_int(dt(x)), stream()), "p3_add_pos")
+    return out

@@ -1,0 +1,344 @@
+"""Pix2Poly head — mirror of pixelspointspolygons/models/pix2poly/{model_pix2poly.py,tokenizer.py}.
+
+Same classes, constructor / forward signatures and state_dict keys as the reference (Decoder, ScoreNet, EncoderDecoder,
+Pix2PolyModel, Tokenizer); every forward runs on the HIP library.  torch.nn modules are used as *parameter containers*
+only (nn.TransformerDecoder, nn.Conv2d, nn.BatchNorm2d: identical key names and initialisation), never called.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from . import hip, ops
+from .fusion_layers import EarlyFusionViT
+from .pointpillars import PointPillarsViT
+from .vision_transformer import ViT, compute_dtype
+
+
+# ------------------------------------------------------------------------------------------------ Tokenizer
+class Tokenizer:
+    """models/pix2poly/tokenizer.py:4-97 (host-side integer bookkeeping; identical constants and behaviour)."""
+
+    def __init__(self, cfg, num_classes=1):
+        self.num_classes = num_classes
+        self.cfg = cfg
+        self.token_mode = 2
+        self.num_bins = self.cfg.experiment.model.tokenizer.num_bins
+        self.width = self.cfg.experiment.encoder.in_width
+        self.height = self.cfg.experiment.encoder.in_height
+        self.max_len = self.cfg.experiment.model.tokenizer.max_num_vertices * self.token_mode + 2
+        self.BOS_code = self.num_bins
+        self.EOS_code = self.BOS_code + 1
+        self.PAD_code = self.EOS_code + 1
+        self.vocab_size = self.num_bins + 3
+        self.cfg.experiment.model.tokenizer.pad_idx = self.PAD_code
+        self.cfg.experiment.model.tokenizer.max_len = self.max_len
+        self.cfg.experiment.model.tokenizer.generation_steps = self.cfg.experiment.model.tokenizer.max_num_vertices * self.token_mode + 1
+
+    def quantize(self, x):
+        return (x * (self.num_bins - 1)).round(0).astype("int")
+
+    def dequantize(self, x):
+        return x.astype("float32") / (self.num_bins - 1)
+
+    def __call__(self, coords, shuffle=True):
+        if len(coords) > 0:
+            coords[:, 0] = coords[:, 0] / self.width
+            coords[:, 1] = coords[:, 1] / self.height
+        coords = self.quantize(coords)[: self.max_len]
+        rand_idxs = np.arange(0, len(coords))
+        if shuffle:
+            rand_idxs = np.arange(0, len(coords))
+            if self.cfg.run_type.name == "debug":
+                rand_idxs = rand_idxs[::-1]
+            else:
+                np.random.shuffle(rand_idxs)
+            coords = coords[rand_idxs]
+        tokenized = [self.BOS_code]
+        for coord in coords:
+            tokenized.extend(list(map(int, list(coord))))
+        tokenized.append(self.EOS_code)
+        return tokenized, rand_idxs
+
+    def decode(self, tokens):
+        mask = tokens != self.PAD_code
+        tokens = tokens[mask]
+        tokens = tokens[1:-1]
+        assert len(tokens) % self.token_mode == 0, "Invalid tokens!"
+        coords = np.array(tokens).reshape(-1, self.token_mode)[:, :2]
+        coords = self.dequantize(coords)
+        if len(coords) > 0:
+            coords[:, 0] = coords[:, 0] * self.width
+            coords[:, 1] = coords[:, 1] * self.height
+        return coords
+
+
+# ------------------------------------------------------------------------------------------------ mask helpers (API parity)
+def generate_square_subsequent_mask(sz, device):
+    mask = (torch.triu(torch.ones((sz, sz), device=device)) == 1).transpose(0, 1)
+    return mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, float(0.0))
+
+
+def create_mask(tgt, pad_idx):
+    """model_pix2poly.py:21-31.  The HIP attention kernel applies exactly these two masks (causal -inf, +1.0 on PAD keys)."""
+    tgt_mask = generate_square_subsequent_mask(tgt.size(1), device=tgt.device)
+    return tgt_mask, (tgt == pad_idx).to(dtype=tgt_mask.dtype)
+
+
+def log_optimal_transport(scores, alpha, iters):
+    """model_pix2poly.py:44-66 -> [B, m+1, n+1]; single fused HIP launch (forward only; training uses `perm_from_scores`)."""
+    _, z, _ = hip.sinkhorn(scores.contiguous().float(), alpha.reshape(1).float(), iters, want_perm=False, want_z=True)
+    return z
+
+
+# ------------------------------------------------------------------------------------------------ ScoreNet
+class ScoreNet(nn.Module):
+    def __init__(self, n_vertices, in_channels=512, token_mode=2):
+        super().__init__()
+        self.n_vertices = n_vertices
+        self.in_channels = in_channels
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(in_channels, 256, kernel_size=1, stride=1, padding=0, bias=True)
+        self.bn1 = nn.BatchNorm2d(256)
+        self.conv2 = nn.Conv2d(256, 128, kernel_size=1, stride=1, padding=0, bias=True)
+        self.bn2 = nn.BatchNorm2d(128)
+        self.conv3 = nn.Conv2d(128, 64, kernel_size=1, stride=1, padding=0, bias=True)
+        self.bn3 = nn.BatchNorm2d(64)
+        self.conv4 = nn.Conv2d(64, 1, kernel_size=1, stride=1, padding=0, bias=True)
+        self.token_mode = token_mode
+        self.cd = torch.bfloat16
+
+    def scores_into(self, feats, out, transpose_acc):
+        """Fused ScoreNet.forward: never materialises the [B, 2D, N, N] pair tensor (conv1 is separable over (i, j))."""
+        if self.token_mode != 2:
+            raise NotImplementedError("token_mode 2 only (reference default)")
+        return _ScoreNetFn.apply(feats, self, out, transpose_acc, *[p for p in self.parameters()])
+
+    def forward(self, feats):
+        B, N = feats.shape[0], self.n_vertices
+        out = torch.empty((B, N, N), dtype=torch.float32, device=feats.device)
+        return self.scores_into(feats if feats.dtype == self.cd else hip.cast(feats.contiguous(), self.cd), out, False)
+
+
+def _bn_scale_shift(sums, count, bn, training, save=False):
+    r = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                        training, save=save)
+    if training:
+        bn.num_batches_tracked += 1
+    return r
+
+
+def scorenet_forward(net, feats, out, transpose_acc, keep=None):
+    """feats [B, L, D] (compute dtype) -> raw scores written / transposed-accumulated into `out` [B, N, N]."""
+    cd, N, training = net.cd, net.n_vertices, net.training
+    B, L, D = feats.shape
+    dev = feats.device
+    F = hip.pair_mean(feats.contiguous(), N)                                              # [B,N,D]
+    w1 = ops.shadow(net.conv1.weight, cd, key="2d", fn=lambda t: t.reshape(t.shape[0], -1))  # [256, 2D]
+    U = hip.gemm(F.view(B * N, D), w1[:, :D], bias=net.conv1.bias.detach(), out_dtype=cd)
+    V = hip.gemm(F.view(B * N, D), w1[:, D:], out_dtype=cd)
+    cnt = float(B * N * N)
+    s1 = None
+    if training:
+        s1 = torch.zeros(512, dtype=torch.float32, device=dev)
+        hip.pair_stats(U, V, B, N, s1)
+    sc1, sh1, m1, r1 = _bn_scale_shift(s1, cnt, net.bn1, training, save=True)
+    w2 = ops.shadow(net.conv2.weight, cd, key="2d", fn=lambda t: t.reshape(t.shape[0], -1))
+    s2 = torch.zeros(256, dtype=torch.float32, device=dev) if training else None
+    H2 = hip.gemm(U, w2, bias=net.conv2.bias.detach(), a_mode=hip.A_PAIR_AFFINE_RELU, M=B * N * N, pair_v=V, pair_n=N, a_scale=sc1,
+                  a_shift=sh1, out_dtype=cd, colsum=s2[:128] if training else None, colsumsq=s2[128:] if training else None)
+    sc2, sh2, m2, r2 = _bn_scale_shift(s2, cnt, net.bn2, training, save=True)
+    w3 = ops.shadow(net.conv3.weight, cd, key="2d", fn=lambda t: t.reshape(t.shape[0], -1))
+    s3 = torch.zeros(128, dtype=torch.float32, device=dev) if training else None
+    H3 = hip.gemm(H2, w3, bias=net.conv3.bias.detach(), a_mode=hip.A_AFFINE_RELU, a_scale=sc2, a_shift=sh2, out_dtype=cd,
+                  colsum=s3[:64] if training else None, colsumsq=s3[64:] if training else None)
+    sc3, sh3, m3, r3 = _bn_scale_shift(s3, cnt, net.bn3, training, save=True)
+    hip.score_out(H3, sc3, sh3, net.conv4.weight.detach().reshape(-1), net.conv4.bias.detach(), out, B, N, transpose_acc)
+    if keep is not None:
+        keep.update(F=F, U=U, V=V, H2=H2, H3=H3, bn=((sc1, sh1, m1, r1), (sc2, sh2, m2, r2), (sc3, sh3, m3, r3)))
+    return out
+
+
+class _ScoreNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, net, out, transpose_acc, *params):
+        keep = {} if ops._needs_grad(feats, *params) else None
+        scorenet_forward(net, feats, out, transpose_acc, keep)
+        ctx.net, ctx.keep, ctx.transpose_acc = net, keep, transpose_acc
+        ctx.save_for_backward(feats)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .backward import scorenet_backward
+        (feats,) = ctx.saved_tensors
+        dfeats, dparams = scorenet_backward(ctx.net, feats, ctx.keep, dout, ctx.transpose_acc)
+        return (dfeats, None, None, None, *dparams)
+
+
+# ------------------------------------------------------------------------------------------------ Decoder
+class Decoder(nn.Module):
+    def __init__(self, vocab_size, encoder_len, dim, num_heads, num_layers, max_len, pad_idx):
+        super().__init__()
+        self.dim, self.max_len, self.pad_idx, self.num_heads = dim, max_len, pad_idx, num_heads
+        self.embedding = nn.Embedding(vocab_size, dim)
+        self.decoder_pos_embed = nn.Parameter(torch.randn(1, self.max_len - 1, dim) * 0.02)
+        self.decoder_pos_drop = nn.Dropout(p=0.05)
+        decoder_layer = nn.TransformerDecoderLayer(d_model=dim, nhead=num_heads)
+        self.decoder = nn.TransformerDecoder(decoder_layer=decoder_layer, num_layers=num_layers)   # parameter container only
+        self.output = nn.Linear(dim, vocab_size)
+        self.encoder_pos_embed = nn.Parameter(torch.randn(1, encoder_len, dim) * 0.02)
+        self.encoder_pos_drop = nn.Dropout(p=0.05)
+        self.cd = torch.bfloat16
+        self.init_weights()
+
+    def init_weights(self):
+        for name, p in self.named_parameters():
+            if "encoder_pos_embed" in name or "decoder_pos_embed" in name:
+                continue
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        nn.init.trunc_normal_(self.encoder_pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.decoder_pos_embed, std=0.02)
+
+    def _check_dropout(self):
+        if self.training and (self.decoder_pos_drop.p > 0 or self.decoder.layers[0].dropout.p > 0):
+            raise NotImplementedError(
+                "HIP decoder runs dropout-free; call set_dropout(0.0) (parity is asserted in eval() or with p = 0, SURVEY §8b)")
+
+    def set_dropout(self, p):
+        for m in self.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = p
+
+    def _run(self, encoder_out, tgt):
+        cd, D, H = self.cd, self.dim, self.num_heads
+        B, L = tgt.shape
+        x, kb = ops.embed_tokens(tgt, self.embedding.weight, self.decoder_pos_embed, self.pad_idx, cd)
+        enc = encoder_out if encoder_out.dtype == cd else ops.cast(encoder_out, cd)
+        mem = ops.add_pos(enc, self.encoder_pos_embed)
+        for lyr in self.decoder.layers:
+            sa, ca = lyr.self_attn, lyr.multihead_attn
+            qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)
+            a = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H, causal=True, key_bias=kb)
+            y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
+            q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
+            kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D))
+            a = ops.attention(q, kv[..., :D], kv[..., D:], H)
+            y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
+            h = ops.linear(x, lyr.linear1.weight, lyr.linear1.bias, act=hip.ACT_RELU, cd=cd)
+            y = ops.linear(h, lyr.linear2.weight, lyr.linear2.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
+        return x
+
+    def forward(self, encoder_out, tgt):
+        """encoder_out (N, L_enc, D), tgt (N, L) -> (logits fp32 (N, L, vocab), pre-logit features (N, L, D))."""
+        self._check_dropout()
+        x = self._run(encoder_out, tgt)
+        logits = ops.linear(x, self.output.weight, self.output.bias, out_dtype=torch.float32, cd=self.cd)
+        return logits, x
+
+    def predict(self, encoder_out, tgt):
+        """model_pix2poly.py:187-219: right-pad with PAD to max_len-1, full pass, logits of position len-1."""
+        length = tgt.size(1)
+        padding = torch.ones((tgt.size(0), self.max_len - length - 1), device=tgt.device).fill_(self.pad_idx).long()
+        tgt = torch.cat([tgt, padding], dim=1)
+        x = self._run(encoder_out, tgt)
+        logits = ops.linear(x[:, length - 1, :], self.output.weight, self.output.bias, out_dtype=torch.float32, cd=self.cd)
+        return logits, x
+
+
+# ------------------------------------------------------------------------------------------------ EncoderDecoder
+class EncoderDecoder(nn.Module):
+    def __init__(self, encoder, decoder, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.token_mode = 2
+        self.encoder = encoder
+        self.decoder = decoder
+        self.max_num_vertices = cfg.experiment.model.tokenizer.max_num_vertices
+        self.sinkhorn_iterations = cfg.experiment.model.sinkhorn_iterations
+        self.scorenet1 = ScoreNet(self.max_num_vertices, in_channels=2 * decoder.dim, token_mode=self.token_mode)
+        self.scorenet2 = ScoreNet(self.max_num_vertices, in_channels=2 * decoder.dim, token_mode=self.token_mode)
+        self.bin_score = torch.nn.Parameter(torch.tensor(1.0))
+        self.bottleneck = nn.AdaptiveAvgPool1d(cfg.experiment.encoder.out_feature_dim)
+        cd = compute_dtype(cfg)
+        for m in (self.decoder, self.scorenet1, self.scorenet2):
+            m.cd = cd
+
+    def perm_scores(self, features):
+        """scorenet1(f) + scorenet2(f)^T (model_pix2poly.py:257-259), accumulated in place by the second ScoreNet's tail kernel."""
+        B, N = features.shape[0], self.max_num_vertices
+        out = torch.empty((B, N, N), dtype=torch.float32, device=features.device)
+        out = self.scorenet1.scores_into(features, out, False)
+        return self.scorenet2.scores_into(features, out, True)
+
+    def forward(self, x_images, x_lidar, y):
+        enc = self.cfg.experiment.encoder
+        if enc.use_images and not enc.use_lidar:
+            features = self.encoder(x_images)
+        elif not enc.use_images and enc.use_lidar:
+            features = self.encoder(x_lidar)
+        elif enc.use_images and enc.use_lidar:
+            features = self.encoder(x_images, x_lidar)
+        else:
+            raise ValueError("At least one of use_images or use_lidar must be True")
+        seq_pred, features = self.decoder(features, y)
+        perm_mat = self.perm_scores(features)
+        perm_mat = ops.sinkhorn_softmax(perm_mat, self.bin_score, self.sinkhorn_iterations)
+        return seq_pred, perm_mat
+
+    def predict(self, encoded_image, tgt):
+        return self.decoder.predict(encoded_image, tgt)
+
+    @torch.no_grad()
+    def generate(self, encoded, steps=None, bos=None):
+        """Greedy decode (predictor_pix2poly.py:188-207 contract: softmax -> argmax, full pass per step)."""
+        tk = self.cfg.experiment.model.tokenizer
+        steps = steps if steps is not None else (tk.generation_steps or 2 * tk.max_num_vertices + 1)
+        bos = bos if bos is not None else tk.num_bins
+        B = encoded.shape[0]
+        preds = torch.full((B, 1), bos, dtype=torch.long, device=encoded.device)
+        feats = None
+        for _ in range(steps):
+            logits, feats = self.decoder.predict(encoded, preds)
+            preds = torch.cat([preds, hip.argmax(logits).view(B, 1)], dim=1)
+        return preds, feats
+
+
+class Pix2PolyModel(torch.nn.Module):
+    """Factory with the reference's signature (model_pix2poly.py:278-330): returns EncoderDecoder (DDP-wrapped if multi_gpu)."""
+
+    def __new__(cls, cfg, vocab_size, local_rank=0):
+        enc = cfg.experiment.encoder
+        if enc.use_images and enc.use_lidar:
+            if enc.name == "early_fusion_vit":
+                encoder = EarlyFusionViT(cfg, local_rank=local_rank)
+            else:
+                raise NotImplementedError(f"Encoder {enc.name} not implemented for Pix2PolyModel")
+        elif enc.use_images:
+            if enc.name == "vit":
+                encoder = ViT(cfg, bottleneck=True, local_rank=local_rank)
+            else:
+                raise NotImplementedError(f"Encoder {enc.name} not implemented for Pix2PolyModel")
+        elif enc.use_lidar:
+            if enc.name == "pointpillars_vit":
+                encoder = PointPillarsViT(cfg, bottleneck=True, local_rank=local_rank)
+            else:
+                raise NotImplementedError(f"Encoder {enc.name} not implemented for Pix2PolyModel")
+        else:
+            raise ValueError("Please specify either and image or lidar encoder with encoder=<name>.")
+        tk = cfg.experiment.model.tokenizer
+        if tk.max_len is None or tk.pad_idx is None:
+            Tokenizer(cfg)   # writes max_len / pad_idx / generation_steps back into cfg like the reference's trainer does
+        decoder = Decoder(vocab_size=vocab_size, encoder_len=enc.num_patches, dim=enc.out_feature_dim, num_heads=8, num_layers=6,
+                          max_len=tk.max_len, pad_idx=tk.pad_idx)
+        model = EncoderDecoder(encoder=encoder, decoder=decoder, cfg=cfg)
+        model.to(cfg.host.device)
+        if cfg.host.multi_gpu:
+            model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            model = DDP(model, device_ids=[local_rank], find_unused_parameters=cfg.run_type.name == "debug")
+        return model

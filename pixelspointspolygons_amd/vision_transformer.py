@@ -1,0 +1,228 @@
+"""Image encoders — mirror of pixelspointspolygons/models/vision_transformer/{vit.py,vit_cnn.py}.
+
+`VisionTransformer` restates the timm model the reference instantiates with
+`timm.create_model("vit_small_patch8_224.dino", num_classes=0, global_pool='')` (vit.py:29-35): same attribute tree
+(cls_token, pos_embed, patch_embed.proj, blocks.{i}.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}, norm) so that
+DINO / reference checkpoints load by name; its forward runs on the HIP kernels only.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+
+
+def compute_dtype(cfg):
+    p = getattr(cfg, "precision", "bf16")
+    return torch.float32 if p in ("fp32", "float32", "exact") else torch.bfloat16
+
+
+class PatchEmbed(nn.Module):
+    """timm PatchEmbed: Conv2d(3, D, k=P, s=P).  HIP: p3_patchify (im2col) + MFMA GEMM with bias epilogue."""
+
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size, self.grid = patch_size, img_size // patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.flatten = True
+
+    def tokens(self, x, cd, out=None):
+        """-> [B*np, D] token-major (== NHWC of the conv output); `out` may be a strided view (fusion canvas)."""
+        B = x.shape[0]
+        patches = hip.patchify(x.contiguous(), self.patch_size, cd)
+        w = self.proj.weight
+        w2 = ops.shadow(w, cd, key="flat", fn=lambda t: t.reshape(t.shape[0], -1))
+        return _PatchGemm.apply(patches, w, self.proj.bias, w2, out, cd)
+
+    def forward(self, x):
+        cd = torch.bfloat16 if getattr(self, "cd", None) is None else self.cd
+        B = x.shape[0]
+        t = self.tokens(x, cd).view(B, self.grid * self.grid, -1)
+        if self.flatten:
+            return t
+        return t.transpose(1, 2).reshape(B, -1, self.grid, self.grid)
+
+
+class _PatchGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, patches, weight, bias, w2, out, cd):
+        y = hip.gemm(patches, w2, bias=bias, out=out, out_dtype=cd)
+        ctx.save_for_backward(patches)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dw = hip.gemm_tn(dyc, patches).view(ctx.wshape)
+        db = hip.colsum(dyc)
+        return None, dw, db, None, None, None
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Block(nn.Module):
+    """timm Block (pre-norm, no LayerScale, no drop-path): x += proj(SDPA(qkv(LN1 x))); x += fc2(GELU(fc1(LN2 x)))."""
+
+    def __init__(self, dim, num_heads, mlp_dim, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, mlp_dim)
+
+    def run(self, x, cd):
+        """x: fp32 residual stream [B, L, D]."""
+        D = x.shape[-1]
+        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
+        qkv = ops.linear(h, self.attn.qkv.weight, self.attn.qkv.bias, cd=cd)
+        a = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], self.attn.num_heads)
+        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
+        h = ops.linear(h, self.mlp.fc1.weight, self.mlp.fc1.bias, act=hip.ACT_GELU, cd=cd)
+        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, out_dtype=torch.float32, cd=cd)
+
+
+_TIMM_SHAPES = {  # model_name prefix -> (dim, depth, heads)
+    "vit_tiny": (192, 12, 3), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12), "vit_large": (1024, 24, 16),
+}
+
+
+def parse_timm_name(name):
+    """'vit_small_patch8_224.dino' -> dict(dim, depth, heads, patch, img)."""
+    base = name.split(".")[0]
+    parts = base.split("_")
+    dim, depth, heads = _TIMM_SHAPES["_".join(parts[:2])]
+    patch = int(parts[2].replace("patch", ""))
+    img = int(parts[3])
+    return dict(dim=dim, depth=depth, heads=heads, patch=patch, img=img)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=8, embed_dim=384, depth=12, num_heads=6, mlp_dim=None, eps=1e-6, cd=torch.bfloat16):
+        super().__init__()
+        self.embed_dim, self.cd = embed_dim, cd
+        self.patch_embed = PatchEmbed(img_size, patch_size, 3, embed_dim)
+        n = (img_size // patch_size) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, n + 1, embed_dim) * 0.02)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_dim or 4 * embed_dim, eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def forward_tokens(self, tok, B, scale=None, shift=None, src_ld=None):
+        """tok: [B*np, D] patch/pillar/fused tokens (any dtype) -> LN'd tokens [B, np+1, D] in compute dtype.
+
+        timm `_pos_embed` (cat CLS, + pos_embed) is fused with the optional BN+ReLU affine of the fusion layer."""
+        np_ = self.pos_embed.shape[1] - 1
+        x = _Assemble.apply(tok, self.cls_token, self.pos_embed, scale, shift, B, np_, self.embed_dim, src_ld)
+        for blk in self.blocks:
+            x = blk.run(x, self.cd)
+        return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=self.cd)
+
+    def forward(self, x):
+        pe = self.patch_embed
+        if isinstance(pe, PatchEmbed):
+            B = x.shape[0]
+            tok = pe.tokens(x, self.cd)
+        elif isinstance(pe, nn.Identity):
+            B = x.shape[0]
+            tok = x.reshape(-1, x.shape[-1])
+        else:  # PointPillarsEncoder plugged in as patch_embed (pointpillars_vit.py:64)
+            B = x.shape[0]
+            tok = pe(x, return_flattened=True).reshape(-1, self.embed_dim)
+        return self.forward_tokens(tok, B)
+
+
+class _Assemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, cls, pos, scale, shift, B, np_, D, src_ld):
+        x = hip.tokens_assemble(tok, cls.reshape(-1), pos.reshape(-1), B, np_, D, scale=scale, shift=shift, src_ld=src_ld)
+        ctx.save_for_backward(tok, scale, shift)
+        ctx.meta = (B, np_, D, src_ld, tok.dtype)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        tok, scale, shift = ctx.saved_tensors
+        B, np_, D, src_ld, tdt = ctx.meta
+        dcls = dx[:, 0, :].sum(0).view(1, 1, D)
+        dpos = dx.sum(0, keepdim=True)
+        dtok, dscale, dshift = hip.tokens_assemble_bwd(dx, tok, scale, shift, B, np_, D, src_ld)
+        return dtok, dcls, dpos, dscale, dshift, None, None, None, None
+
+
+class ViT(nn.Module):
+    """models/vision_transformer/vit.py:14-50."""
+
+    def __init__(self, cfg, bottleneck=False, local_rank=0):
+        super().__init__()
+        self.cfg = cfg
+        enc = cfg.experiment.encoder
+        ckpt = getattr(enc, "checkpoint_file", None)
+        vitc = getattr(enc, "vit", None)
+        pretrained = bool(getattr(vitc, "pretrained", False)) if vitc is not None else bool(getattr(enc, "pretrained", False))
+        if pretrained and (ckpt is None or not os.path.isfile(ckpt)):
+            ckpt2 = getattr(vitc, "checkpoint_file", None) if vitc is not None else None
+            if ckpt2 is None or not os.path.isfile(ckpt2):
+                raise FileNotFoundError(f"Checkpoint file {ckpt} not found.")
+            ckpt = ckpt2
+        shp = parse_timm_name(getattr(enc, "type", None) or enc.vit.type)
+        cd = compute_dtype(cfg)
+        self.cd = cd
+        depth = getattr(vitc, "depth", shp["depth"]) if vitc is not None else shp["depth"]
+        heads = getattr(vitc, "num_heads", shp["heads"]) if vitc is not None else shp["heads"]
+        self.vit = VisionTransformer(enc.in_size, enc.patch_size, enc.patch_feature_dim, depth, heads,
+                                     getattr(vitc, "mlp_dim", None) if vitc is not None else None, cd=cd)
+        if pretrained:
+            self.vit.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)
+        self.out_dim = enc.out_feature_dim if bottleneck else None
+        self.bottleneck = nn.AdaptiveAvgPool1d(enc.out_feature_dim) if bottleneck else nn.Identity()
+
+    def forward(self, x):
+        y = self.vit(x)
+        return pool(y, self.out_dim)
+
+
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, pos, Dout, out_dtype):
+        ctx.meta = (y.shape, y.dtype, Dout, pos is not None)
+        return hip.pool_pos(y, pos.reshape(-1) if pos is not None else None, Dout, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        yshape, ydt, Dout, has_pos = ctx.meta
+        dy = hip.pool_pos_bwd(dout.contiguous(), yshape, ydt)
+        dpos = dout.float().sum(0, keepdim=True) if has_pos else None
+        return dy, dpos, None, None
+
+
+def pool(y, out_dim, pos=None, out_dtype=None):
+    """drop CLS + AdaptiveAvgPool1d over channels (identity pooling when out_dim is None) (+ positional embedding)."""
+    return _Pool.apply(y, pos, out_dim or y.shape[-1], out_dtype or y.dtype)

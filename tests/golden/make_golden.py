@@ -82,6 +82,23 @@ for i in range(2 * 10 + 1):
     preds = torch.cat([preds, nxt], 1)
 npz("greedy_small.npz", enc=enc, tokens=preds, feats=feats)
 
+
+# ---------------------------------------------------------------- 2b. greedy decode at head_dim 32 (dim 256, 2 layers): bit-exact tokens
+sd_g = O.make_state_dict("image", dict(small_cfg(), img=32), seed=77, n_vertices=10, dec_dim=256, dec_layers=2)
+dec_g = ref.Decoder(vocab_size=O.VOCAB, encoder_len=16, dim=256, num_heads=8, num_layers=2, max_len=22, pad_idx=O.PAD)
+dec_g.load_state_dict(sub(sd_g, "decoder."), strict=True)
+dec_g.eval()
+g = torch.Generator().manual_seed(78)
+enc = torch.randn(3, 16, 256, generator=g)
+preds = torch.full((3, 1), O.BOS, dtype=torch.long)
+for i in range(21):
+    lg, feats = dec_g.predict(enc, preds)
+    preds = torch.cat([preds, torch.softmax(lg, -1).argmax(-1, keepdim=True)], 1)
+yg = tokens(3, 10, g)
+lgf, ftf = dec_g(enc, yg)
+npz("greedy_d256.npz", enc=enc, tokens=preds, feats=feats, y=yg, logits=lgf, fwd_feats=ftf,
+    wsum=np.array([float(sum(v.double().sum() for k, v in sd_g.items() if k.startswith("decoder.")))]))
+
 # ---------------------------------------------------------------- 3. ScoreNet (reduced dims + full, eval and train BN)
 for tag, dim, nv, B, seed in (("small", 64, 10, 3, 7), ("full", 256, 192, 1, 42)):
     sd = sd_s if tag == "small" else sd_f
