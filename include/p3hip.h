@@ -188,6 +188,36 @@ int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* s
 /* out[b,t,:] = x[b,t,:] + pos[t,:]  (Decoder: encoder_out + encoder_pos_embed, model_pix2poly.py:171-173) */
 int p3_add_pos(const void* x, const float* pos, void* out, int B, int L, int D, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step (a-11: trainer_pix2poly.py:284-351 = forward, CE + 10*BCE, backward, AdamW)
+ * ------------------------------------------------------------------------------------------ */
+/* attention backward (recompute, no atomics): delta_ws float [B,H,Lq] scratch; dQ/dK/dV use the q/k/v strides, dO the o strides */
+int p3_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, void* dQ,
+                     void* dK, void* dV, float* delta_ws, const p3_attn_desc* d, void* stream);
+/* weight gradient: C[N,K] += A[M,N]^T B[M,K] (fp32 C, split over M with fp32 atomics) ; column sums (bias gradients) */
+int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream);
+int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream);
+/* dpre = dy * act'(.)  (GELU: saved = pre-activation; ReLU: saved = output) */
+int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act, void* stream);
+int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream);
+int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift,
+                           void* dsrc, float* dscale, float* dshift, int B, int np, int D, void* stream);
+int p3_pool_pos_bwd(const void* dout, int dtype_dout, void* dy, int dtype_dy, int B, int np, int Din, int Dout, void* stream);
+int p3_pair_mean_bwd(const float* dF, void* dfeats, int dtype, int B, int L, int N, int D, int accumulate, void* stream);
+/* reverse-mode through all Sinkhorn iterations + slice + softmax in one launch (uv_hist from p3_sinkhorn) */
+int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
+                    const float* uv_hist, const float* dperm, float* dscores, float* dalpha, void* stream);
+/* nn.CrossEntropyLoss(ignore_index) / nn.BCELoss (trainer_pix2poly.py:91-93): acc[0] = loss sum, acc[1] = #valid rows;
+ * backward kernels read the upstream gradient x loss weight from the device scalar `gscale` (no host sync) */
+int p3_ce_loss_fwd(const float* logits, int ld, const int64_t* targets, int R, int V, int ignore_index, float* row_lse, float* acc, void* stream);
+int p3_ce_loss_bwd(const float* logits, int ld, const int64_t* targets, int R, int V, int ignore_index, const float* row_lse,
+                   const float* acc, const float* gscale, void* dlogits, int dtype_out, int ld_out, int Vpad, void* stream);
+int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float* acc, void* stream);
+int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gscale, float* dp, void* stream);
+/* torch.optim.AdamW step over a flat parameter arena; hyper = {lr, 1-beta1^t, 1-beta2^t} on the device; optional bf16 shadow */
+int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1,
+             float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,333 @@
+// p3hip fused attention backward (flash style, recompute; MFMA 32x32), no atomics:
+//   attn_delta_kernel : delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+//   attn_bwd_dq_kernel: one workgroup per 128-query block, walks the key tiles  -> dQ
+//   attn_bwd_dkv_kernel: one workgroup per 128-key block, walks the query tiles  -> dK, dV
+// Both reuse the forward's lane-local formulation: a lane owns ONE query (dQ kernel) or ONE key (dK/dV kernel), the
+// score-like products (K.Q^T, V.dO^T / Q.K^T, dO.V^T) put that index on the MFMA column, and the accumulate products
+// (K^T.dS^T / dO^T.P, Q^T.dS) feed P / dS straight from the score registers with the k-slots assigned to the rows the
+// lane already holds.  bf16: transposed LDS images are built while staging (row pairs packed per dword).
+#include "p3_common.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct BwdArgs {
+    const void* Q; const void* K; const void* V; const void* O; const void* dO;
+    void* dQ; void* dK; void* dV;
+    const float* lse; float* delta;
+    p3_attn_desc d;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(BwdArgs a, int D) {
+    const p3_attn_desc& d = a.d;
+    const int64_t total = (int64_t)d.B * d.H * d.Lq;
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < total; row += (int64_t)gridDim.x * 4) {
+        const int q = (int)(row % d.Lq), h = (int)((row / d.Lq) % d.H), b = (int)(row / ((int64_t)d.Lq * d.H));
+        const T* o = reinterpret_cast<const T*>(a.O) + (int64_t)b * d.o_bs + (int64_t)q * d.o_rs + h * D;
+        const T* g = reinterpret_cast<const T*>(a.dO) + (int64_t)b * d.o_bs + (int64_t)q * d.o_rs + h * D;
+        float s = lane < D ? Cvt<T>::to_f(o[lane]) * Cvt<T>::to_f(g[lane]) : 0.f;
+        s = wave_sum(s);
+        if (lane == 0) a.delta[row] = s;
+    }
+}
+
+// ---- LDS tile: R rows x D.  Row image [R][PR] (+ bf16 only: transposed image [D][PT], row pairs packed) -------------
+template <typename T, int D, int R> struct Tile {
+    static constexpr bool BF = sizeof(T) == 2;
+    static constexpr int PR = BF ? D + 8 : D + 1;
+    static constexpr int PT = R + 4;
+    static constexpr int ROW_ELEMS = R * PR;
+    static constexpr int TR_ELEMS = BF ? D * PT : 0;
+};
+
+// stage R rows (row0.., clamped to nvalid-1) of a [*, row_stride] tensor into LDS; WANT_ROW / WANT_TR select the images
+template <typename T, int D, int R, bool WANT_ROW, bool WANT_TR>
+__device__ __forceinline__ void stage(const T* __restrict__ src, int row0, int nvalid, int row_stride, T* rowimg, T* trimg, int tid) {
+    using TL = Tile<T, D, R>;
+    if constexpr (TL::BF) {
+        // items: (row pair, 4 dims)
+        constexpr int ITEMS = (R / 2) * (D / 4);
+#pragma unroll
+        for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
+            const int item = tid + 256 * it;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                const int dg = item % (D / 4), rp = item / (D / 4);
+                int ra = row0 + 2 * rp, rb = ra + 1;
+                if (ra >= nvalid) ra = nvalid - 1;
+                if (rb >= nvalid) rb = nvalid - 1;
+                const uint2 va = *reinterpret_cast<const uint2*>(src + (int64_t)ra * row_stride + dg * 4);
+                const uint2 vb = *reinterpret_cast<const uint2*>(src + (int64_t)rb * row_stride + dg * 4);
+                if constexpr (WANT_ROW) {
+                    *reinterpret_cast<uint2*>(rowimg + (2 * rp) * TL::PR + dg * 4) = va;
+                    *reinterpret_cast<uint2*>(rowimg + (2 * rp + 1) * TL::PR + dg * 4) = vb;
+                }
+                if constexpr (WANT_TR) {
+                    uint32_t* p = reinterpret_cast<uint32_t*>(trimg);
+                    p[((dg * 4 + 0) * TL::PT) / 2 + rp] = (va.x & 0xffffu) | (vb.x << 16);
+                    p[((dg * 4 + 1) * TL::PT) / 2 + rp] = (va.x >> 16) | (vb.x & 0xffff0000u);
+                    p[((dg * 4 + 2) * TL::PT) / 2 + rp] = (va.y & 0xffffu) | (vb.y << 16);
+                    p[((dg * 4 + 3) * TL::PT) / 2 + rp] = (va.y >> 16) | (vb.y & 0xffff0000u);
+                }
+            }
+        }
+    } else {
+        constexpr int ITEMS = R * (D / 4);
+#pragma unroll
+        for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
+            const int item = tid + 256 * it;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                const int cv = item % (D / 4), r = item / (D / 4);
+                int rr = row0 + r; if (rr >= nvalid) rr = nvalid - 1;
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)rr * row_stride + cv * 4);
+                float* p = reinterpret_cast<float*>(rowimg) + r * TL::PR + cv * 4;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            }
+        }
+    }
+}
+
+// score-like product: acc[rows32 x cols32] = X[rows from LDS row image] . Y[cols held in regs]^T   (contract over D)
+template <typename T, int D, int R>
+__device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], const float (&yf)[D / 2],
+                                            int l31, int hi) {
+    using TL = Tile<T, D, R>;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (TL::BF) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            s16x8 xf = *reinterpret_cast<const s16x8*>(rowimg + (sub * 32 + l31) * TL::PR + ks * 16 + 8 * hi);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), xf),
+                                                          __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), yb[ks]), acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < D / 2; ++ks) {
+            const float xf = reinterpret_cast<const float*>(rowimg)[(sub * 32 + l31) * TL::PR + 2 * ks + hi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf, yf[ks], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// accumulate product: out[dj][d32 x cols32] += X^T[d, rows(sub)] . W[rows(sub), cols]   with W lane-local (f32x16 of sub-tile `sub`)
+template <typename T, int D, int R>
+__device__ __forceinline__ void accum_mma(const T* rowimg, const T* trimg, int sub, const f32x16& w, f32x16 (&out)[D / 32], int l31, int hi) {
+    using TL = Tile<T, D, R>;
+    if constexpr (TL::BF) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            uint32_t pw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pw[i] = pack_bf2(w[8 * c2 + 2 * i], w[8 * c2 + 2 * i + 1]);
+            const s16x8 wb = __builtin_bit_cast(s16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            const int rb = sub * 32 + 16 * c2 + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < D / 32; ++j) {
+                const T* xr = trimg + (j * 32 + l31) * TL::PT + rb;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(xr);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(xr + 8);
+                const s16x8 xf = __builtin_bit_cast(s16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
+                out[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), xf),
+                                                                 __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), wb), out[j], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = sub * 32 + crow32(r, hi);
+#pragma unroll
+            for (int j = 0; j < D / 32; ++j) {
+                const float xf = reinterpret_cast<const float*>(rowimg)[row * TL::PR + j * 32 + l31];
+                out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf, w[r], out[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void load_rowfrags(const T* base, int64_t row, int row_stride, s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], float (&yf)[D / 2], int hi) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) yb[ks] = *reinterpret_cast<const s16x8*>(base + row * row_stride + ks * 16 + 8 * hi);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < D / 2; ++ks) yf[ks] = base[row * row_stride + 2 * ks + hi];
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 32], float mul, int hi) {
+    // acc[j][r] holds element d = j*32 + crow32(r, hi) of this lane's row
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int dd = j * 32 + 8 * rg + 4 * hi;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = acc[j][4 * rg + i] * mul;
+            if constexpr (sizeof(T) == 2) {
+                uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(dst_row + dd) = pk;
+            } else {
+                *reinterpret_cast<float4*>(dst_row + dd) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KT = BF ? 64 : 32;
+    using TK = Tile<T, D, KT>;
+    __shared__ __attribute__((aligned(16))) T Krow[TK::ROW_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Vrow[TK::ROW_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Ktr[BF ? TK::TR_ELEMS : 8];
+    const p3_attn_desc& d = a.d;
+    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
+    const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
+    const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
+    const T* dOp = reinterpret_cast<const T*>(a.dO) + (int64_t)b * d.o_bs + h * D;
+    T* dQp = reinterpret_cast<T*>(a.dQ) + (int64_t)b * d.q_bs + h * D;
+    const int q = qblk + wave * 32 + l31;
+    const int qc = q < d.Lq ? q : d.Lq - 1;
+    s16x8 qb[D / 16], gb[D / 16];
+    float qf[D / 2], gf[D / 2];
+    load_rowfrags<T, D>(Qp, qc, d.q_rs, qb, qf, hi);
+    load_rowfrags<T, D>(dOp, qc, d.o_rs, gb, gf, hi);
+    const float lse = a.lse[((int64_t)b * d.H + h) * d.Lq + qc];
+    const float dlt = a.delta[((int64_t)b * d.H + h) * d.Lq + qc];
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
+    int kv_end = d.Lk;
+    if (d.causal) { const int lim = qblk + 128; if (lim < kv_end) kv_end = lim; }
+    const int ntiles = (kv_end + KT - 1) / KT;
+    const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * KT;
+        __syncthreads();
+        stage<T, D, KT, true, true>(Kp, kv0, d.Lk, d.k_rs, Krow, Ktr, tid);
+        stage<T, D, KT, true, false>(Vp, kv0, d.Lk, d.v_rs, Vrow, nullptr, tid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, l31, hi);       // S^T[kv, q]
+            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, l31, hi);      // dP^T[kv, q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + sub * 32 + crow32(r, hi);
+                float sv = s[r] * d.scale;
+                if (kbias) sv += kbias[kv < d.Lk ? kv : d.Lk - 1];
+                const bool masked = kv >= d.Lk || (d.causal && kv > q);
+                const float p = masked ? 0.f : __expf(sv - lse);
+                s[r] = p * (dp[r] - dlt);                                     // dS^T
+            }
+            accum_mma<T, D, KT>(Krow, Ktr, sub, s, dq, l31, hi);              // dQ^T[d, q] += K^T . dS^T
+        }
+    }
+    if (q < d.Lq) store_T_acc<T, D>(dQp + (int64_t)q * d.q_rs, dq, d.scale, hi);
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int QT = BF ? 64 : 32;
+    using TQ = Tile<T, D, QT>;
+    __shared__ __attribute__((aligned(16))) T Qrow[TQ::ROW_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Grow[TQ::ROW_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Qtr[BF ? TQ::TR_ELEMS : 8];
+    __shared__ __attribute__((aligned(16))) T Gtr[BF ? TQ::TR_ELEMS : 8];
+    __shared__ float Ls[QT], Ds[QT];
+    const p3_attn_desc& d = a.d;
+    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
+    const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
+    const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
+    const T* dOp = reinterpret_cast<const T*>(a.dO) + (int64_t)b * d.o_bs + h * D;
+    T* dKp = reinterpret_cast<T*>(a.dK) + (int64_t)b * d.k_bs + h * D;
+    T* dVp = reinterpret_cast<T*>(a.dV) + (int64_t)b * d.v_bs + h * D;
+    const int kv = kblk + wave * 32 + l31;
+    const int kvc = kv < d.Lk ? kv : d.Lk - 1;
+    s16x8 kb[D / 16], vb[D / 16];
+    float kf[D / 2], vf[D / 2];
+    load_rowfrags<T, D>(Kp, kvc, d.k_rs, kb, kf, hi);
+    load_rowfrags<T, D>(Vp, kvc, d.v_rs, vb, vf, hi);
+    const float bias = d.key_bias ? d.key_bias[(int64_t)b * d.Lk + kvc] : 0.f;
+    f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
+    const int q_begin = d.causal ? (kblk / QT) * QT : 0;   // queries before the block's first key never see it
+    const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
+    for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
+        __syncthreads();
+        stage<T, D, QT, true, true>(Qp, q0, d.Lq, d.q_rs, Qrow, Qtr, tid);
+        stage<T, D, QT, true, true>(dOp, q0, d.Lq, d.o_rs, Grow, Gtr, tid);
+        if (tid < QT) {
+            const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
+            Ls[tid] = a.lse[stat_base + qq]; Ds[tid] = a.delta[stat_base + qq];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < QT / 32; ++sub) {
+            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, l31, hi);       // S[q, kv]
+            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, l31, hi);      // dP[q, kv]
+            f32x16 ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = sub * 32 + crow32(r, hi), qq = q0 + ql;
+                const bool masked = qq >= d.Lq || kv >= d.Lk || (d.causal && kv > qq);
+                const float p = masked ? 0.f : __expf(s[r] * d.scale + bias - Ls[ql]);
+                s[r] = p;
+                ds[r] = p * (dp[r] - Ds[ql]);
+            }
+            accum_mma<T, D, QT>(Grow, Gtr, sub, s, dv, l31, hi);              // dV^T[d, kv] += dO^T . P
+            accum_mma<T, D, QT>(Qrow, Qtr, sub, ds, dk, l31, hi);             // dK^T[d, kv] += Q^T . dS
+        }
+    }
+    if (kv < d.Lk) {
+        store_T_acc<T, D>(dKp + (int64_t)kv * d.k_rs, dk, d.scale, hi);
+        store_T_acc<T, D>(dVp + (int64_t)kv * d.v_rs, dv, 1.f, hi);
+    }
+}
+
+template <typename T, int D>
+int launch_bwd(const BwdArgs& a, hipStream_t s) {
+    const p3_attn_desc& d = a.d;
+    const int64_t rows = (int64_t)d.B * d.H * d.Lq;
+    int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(g), dim3(256), 0, s, a, D);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+}  // namespace
+
+extern "C" int p3_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, void* dQ,
+                                void* dK, void* dV, float* delta_ws, const p3_attn_desc* d, void* stream) {
+    P3_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws && d, P3_EINVAL, "p3_attention_bwd: null pointer");
+    P3_CHECK(d->head_dim == 32 || d->head_dim == 64, P3_EUNSUP, "p3_attention_bwd: head_dim must be 32 or 64");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention_bwd: dtype");
+    const int al = d->dtype == P3_BF16 ? 8 : 4;
+    P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % al == 0, P3_EALIGN, "p3_attention_bwd: row strides");
+    BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == P3_BF16) return d->head_dim == 64 ? launch_bwd<bf16_t, 64>(a, s) : launch_bwd<bf16_t, 32>(a, s);
+    return d->head_dim == 64 ? launch_bwd<float, 64>(a, s) : launch_bwd<float, 32>(a, s);
+}

@@ -1,0 +1,178 @@
+// p3hip backward glue (HBM-bound elementwise / gather-scatter kernels of the training step).
+#include "p3_common.h"
+
+namespace {
+
+inline int grid_for(int64_t work) {
+    int64_t g = (work + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// dpre = dy * act'(.) ; GELU: saved = pre-activation ; ReLU: saved = output
+template <typename TDY, typename TS, typename TO>
+__global__ void act_bwd_kernel(const TDY* __restrict__ dy, const TS* __restrict__ saved, TO* __restrict__ out, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = Cvt<TDY>::to_f(dy[i]), x = Cvt<TS>::to_f(saved[i]);
+        float d;
+        if (act == P3_ACT_GELU) {
+            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+            d = g * (cdf + x * pdf);
+        } else {
+            d = x > 0.f ? g : 0.f;
+        }
+        out[i] = Cvt<TO>::from_f(d);
+    }
+}
+
+// embedding + positional gradients: demb[tok[b,t], :] += dx[b,t,:] ; dpos[t,:] += dx[b,t,:]
+template <typename T>
+__global__ void embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ tok, float* __restrict__ demb, float* __restrict__ dpos,
+                                 int B, int L, int D) {
+    const int64_t total = (int64_t)B * L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int64_t bt = i / D;
+        const int t = (int)(bt % L);
+        const float g = Cvt<T>::to_f(dx[i]);
+        atomicAdd(demb + tok[bt] * D + c, g);
+        atomicAdd(dpos + (int64_t)t * D + c, g);
+    }
+}
+
+// backward of tokens_assemble: dsrc = dz * scale (or dx), dscale += sum dz*src, dshift += sum dz, with dz = dx * (src*scale+shift > 0)
+template <typename TS>
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const TS* __restrict__ src, int src_ld,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           TS* __restrict__ dsrc, float* __restrict__ dscale, float* __restrict__ dshift,
+                                                           int B, int np, int D, int rows_per_block) {
+    const int64_t rows = (int64_t)B * np;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        float a1 = 0.f, a2 = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t b = r / np, p = r - b * np;
+            float g = dx[(b * (np + 1) + 1 + p) * D + c];
+            if (scale) {
+                const float s = Cvt<TS>::to_f(src[r * src_ld + c]);
+                if (s * sc + sh <= 0.f) g = 0.f;
+                a1 += g * s; a2 += g;
+                g *= sc;
+            }
+            dsrc[r * D + c] = Cvt<TS>::from_f(g);
+        }
+        if (scale) { atomicAdd(dscale + c, a1); atomicAdd(dshift + c, a2); }
+    }
+}
+
+// backward of pool_pos (drop CLS + adaptive average pool over channels)
+template <typename TG, typename TY>
+__global__ void pool_bwd_kernel(const TG* __restrict__ dout, TY* __restrict__ dy, int B, int np, int Din, int Dout) {
+    const int64_t total = (int64_t)B * (np + 1) * Din;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Din);
+        const int t = (int)((i / Din) % (np + 1));
+        const int64_t b = i / ((int64_t)Din * (np + 1));
+        float g = 0.f;
+        if (t > 0) {
+            int c0 = (int)(((int64_t)k * Dout) / Din) - 1; if (c0 < 0) c0 = 0;
+            for (int c = c0; c < Dout && c <= c0 + 3; ++c) {
+                const int s = (int)(((int64_t)c * Din) / Dout), e = (int)((((int64_t)(c + 1)) * Din + Dout - 1) / Dout);
+                if (k >= s && k < e) g += Cvt<TG>::to_f(dout[(b * np + (t - 1)) * Dout + c]) / (float)(e - s);
+            }
+        }
+        dy[i] = Cvt<TY>::from_f(g);
+    }
+}
+
+// d(pair_mean): dfeats[b, 1+2v+{0,1}, :] += 0.5 * dF[b, v, :] ; position 0 gets nothing from this path
+template <typename T>
+__global__ void pair_mean_bwd_kernel(const float* __restrict__ dF, T* __restrict__ dfeats, int B, int L, int N, int D, int accumulate) {
+    const int64_t total = (int64_t)B * L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int t = (int)((i / D) % L);
+        const int64_t b = i / ((int64_t)D * L);
+        float g = 0.f;
+        if (t >= 1 && t <= 2 * N) g = 0.5f * dF[(b * N + (t - 1) / 2) * D + c];
+        dfeats[i] = Cvt<T>::from_f(accumulate ? Cvt<T>::to_f(dfeats[i]) + g : g);
+    }
+}
+
+}  // namespace
+
+extern "C" int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act,
+                          void* stream) {
+    P3_CHECK(dy && saved && out && (act == P3_ACT_GELU || act == P3_ACT_RELU), P3_EINVAL, "p3_act_bwd: bad arguments");
+    if (n <= 0) return P3_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for(n)), b(256);
+#define AB(TDY, TS, TO) hipLaunchKernelGGL((act_bwd_kernel<TDY, TS, TO>), g, b, 0, s, (const TDY*)dy, (const TS*)saved, (TO*)out, n, act)
+    const int key = dtype_dy * 4 + dtype_saved * 2 + dtype_out;
+    switch (key) {
+        case 0: AB(float, float, float); break;
+        case 1: AB(float, float, bf16_t); break;
+        case 2: AB(float, bf16_t, float); break;
+        case 3: AB(float, bf16_t, bf16_t); break;
+        case 4: AB(bf16_t, float, float); break;
+        case 5: AB(bf16_t, float, bf16_t); break;
+        case 6: AB(bf16_t, bf16_t, float); break;
+        case 7: AB(bf16_t, bf16_t, bf16_t); break;
+        default: p3_set_error("p3_act_bwd: dtype"); return P3_EUNSUP;
+    }
+#undef AB
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream) {
+    P3_CHECK(dx && tokens && demb && dpos && B > 0, P3_EINVAL, "p3_embed_tokens_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * L * D;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dx, tokens, demb, dpos, B, L, D);
+    else if (dtype == P3_F32) hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)dx, tokens, demb, dpos, B, L, D);
+    else { p3_set_error("p3_embed_tokens_bwd: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift,
+                                      void* dsrc, float* dscale, float* dshift, int B, int np, int D, void* stream) {
+    P3_CHECK(dx && src && dsrc && B > 0, P3_EINVAL, "p3_tokens_assemble_bwd: bad arguments");
+    P3_CHECK(!scale || (shift && dscale && dshift), P3_EINVAL, "p3_tokens_assemble_bwd: scale needs shift/dscale/dshift");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 64;
+    dim3 g(p3_ceil_div((int64_t)B * np, rpb)), b(256);
+    if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb);
+    else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, (float*)dsrc, dscale, dshift, B, np, D, rpb);
+    else { p3_set_error("p3_tokens_assemble_bwd: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pool_pos_bwd(const void* dout, int dtype_dout, void* dy, int dtype_dy, int B, int np, int Din, int Dout, void* stream) {
+    P3_CHECK(dout && dy && B > 0, P3_EINVAL, "p3_pool_pos_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * (np + 1) * Din;
+    dim3 g(grid_for(total)), b(256);
+    if (dtype_dout == P3_BF16 && dtype_dy == P3_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)dout, (bf16_t*)dy, B, np, Din, Dout);
+    else if (dtype_dout == P3_F32 && dtype_dy == P3_F32) hipLaunchKernelGGL((pool_bwd_kernel<float, float>), g, b, 0, s, (const float*)dout, (float*)dy, B, np, Din, Dout);
+    else if (dtype_dout == P3_F32 && dtype_dy == P3_BF16) hipLaunchKernelGGL((pool_bwd_kernel<float, bf16_t>), g, b, 0, s, (const float*)dout, (bf16_t*)dy, B, np, Din, Dout);
+    else if (dtype_dout == P3_BF16 && dtype_dy == P3_F32) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)dout, (float*)dy, B, np, Din, Dout);
+    else { p3_set_error("p3_pool_pos_bwd: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pair_mean_bwd(const float* dF, void* dfeats, int dtype, int B, int L, int N, int D, int accumulate, void* stream) {
+    P3_CHECK(dF && dfeats && B > 0, P3_EINVAL, "p3_pair_mean_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * L * D;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_mean_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, dF, (bf16_t*)dfeats, B, L, N, D, accumulate);
+    else if (dtype == P3_F32) hipLaunchKernelGGL((pair_mean_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, dF, (float*)dfeats, B, L, N, D, accumulate);
+    else { p3_set_error("p3_pair_mean_bwd: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

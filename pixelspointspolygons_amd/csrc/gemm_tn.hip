@@ -1,0 +1,202 @@
+// p3hip weight-gradient GEMM:  C[N,K] += A[M,N]^T * B[M,K]   (reduction over the M rows; fp32 output, split over M)
+//
+// dW = dY^T X of every Linear / conv on the path.  Both operands are "k-strided" for MFMA (the reduction index is the
+// row index), so for bf16 the staging pass transposes while writing to LDS: each thread loads two consecutive rows and
+// packs the row pair of every column into one dword ([col][m, m+1]) -> fragments are then plain ds_read_b128 like in
+// the NT kernel.  f32 (v_mfma_f32_32x32x2_f32 takes one element per lane) needs no transpose.
+// Grid = tiles_n x tiles_k x splits; every split adds its partial tile with fp32 atomics (C must be zero-filled or hold
+// the gradient being accumulated).  Rows >= M contribute zeros.
+#include "p3_common.h"
+
+namespace {
+
+constexpr int TN = 128, TK = 128;
+
+struct TnArgs {
+    const void* A; const void* B; float* C;
+    int M, N, K, lda, ldb, ldc, rows_per_split, tiles_k;
+};
+
+template <typename T> struct TTr;
+template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 72, ELEMS = TN * 72; };   // [col][m]  (transposed)
+template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS = 16 * 132; };  // [m][col]
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
+    constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
+    const int m_beg = split * g.rows_per_split;
+    const int m_end = min(g.M, m_beg + g.rows_per_split);
+    const T* A = reinterpret_cast<const T*>(g.A);
+    const T* B = reinterpret_cast<const T*>(g.B);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging geometry
+    constexpr int VEC = BF ? 8 : 4;                 // elements per 16-byte load
+    constexpr int TPR = TN / VEC;                   // threads per row: 16 (bf16) / 32 (f32)
+    const int cv = (tid % TPR) * VEC;               // column offset inside the tile
+    const int rt = tid / TPR;                       // bf16: row-pair index 0..15 ; f32: row 0..7
+    constexpr int NLOAD = BF ? 4 : 2;               // 16-byte loads per operand per step
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NLOAD], rb[NLOAD];
+    const int coln = tn * TN + cv, colk = tk * TK + cv;
+    const bool okn = coln < g.N, okk = colk < g.K;  // N, K are multiples of VEC (checked on the host)
+
+    auto load_step = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            int row;
+            if constexpr (BF) row = m0 + 2 * rt + 32 * (i >> 1) + (i & 1);
+            else row = m0 + rt + 8 * i;
+            const bool okr = row < m_end;
+            ra[i] = (okr && okn) ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * g.lda + coln) : u32x4{0, 0, 0, 0};
+            rb[i] = (okr && okk) ? *reinterpret_cast<const u32x4*>(B + (int64_t)row * g.ldb + colk) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        T* as = lds + buf * ELEMS;
+        T* bs = lds + (2 + buf) * ELEMS;
+        if constexpr (BF) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int mloc = 2 * rt + 32 * pp;   // even row of the pair
+                uint32_t* pa = reinterpret_cast<uint32_t*>(as);
+                uint32_t* pb = reinterpret_cast<uint32_t*>(bs);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a0 = ra[2 * pp][j], a1 = ra[2 * pp + 1][j], b0 = rb[2 * pp][j], b1 = rb[2 * pp + 1][j];
+                    pa[((cv + 2 * j) * PITCH + mloc) / 2] = (a0 & 0xffffu) | (a1 << 16);
+                    pa[((cv + 2 * j + 1) * PITCH + mloc) / 2] = (a0 >> 16) | (a1 & 0xffff0000u);
+                    pb[((cv + 2 * j) * PITCH + mloc) / 2] = (b0 & 0xffffu) | (b1 << 16);
+                    pb[((cv + 2 * j + 1) * PITCH + mloc) / 2] = (b0 >> 16) | (b1 & 0xffff0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(as) + (rt + 8 * i) * PITCH + cv) = ra[i];
+                *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(bs) + (rt + 8 * i) * PITCH + cv) = rb[i];
+            }
+        }
+    };
+
+    const int nsteps = (m_end - m_beg + BM - 1) / BM;
+    if (nsteps > 0) { load_step(m_beg); store_step(0); }
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nsteps) load_step(m_beg + (t + 1) * BM);
+        const T* as = lds + cur * ELEMS;
+        const T* bs = lds + (2 + cur) * ELEMS;
+        if constexpr (BF) {
+#pragma unroll
+            for (int kk = 0; kk < BM / 16; ++kk) {
+                s16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const s16x8*>(as + (wm * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
+                    bf[i] = *reinterpret_cast<const s16x8*>(bs + (wn * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), af[i]),
+                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), bf[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BM / 2; ++kk) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = reinterpret_cast<const float*>(as)[(kk * 2 + hi) * PITCH + wm * 64 + i * 32 + l31];
+                    bf[i] = reinterpret_cast<const float*>(bs)[(kk * 2 + hi) * PITCH + wn * 64 + i * 32 + l31];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nsteps) store_step(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = tk * TK + wn * 64 + j * 32 + l31;
+        if (col >= g.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tn * TN + wm * 64 + i * 32 + crow32(r, hi);
+                if (row < g.N) atomicAdd(g.C + (int64_t)row * g.ldc + col, acc[i][j][r]);
+            }
+    }
+}
+
+// column sums of a [M, N] matrix (bias gradients, positional-embedding gradients): out[c] += sum_m x[m, c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int c = threadIdx.x + blockIdx.y * 256; c < N; c += 256 * gridDim.y) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += Cvt<T>::to_f(x[r * ld + c]);
+        atomicAdd(out + c, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
+    P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
+    P3_CHECK(dtype == P3_F32 || dtype == P3_BF16, P3_EUNSUP, "p3_gemm_tn: dtype");
+    const int vec = dtype == P3_BF16 ? 8 : 4;
+    P3_CHECK(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0, P3_EALIGN, "p3_gemm_tn: N, K, lda, ldb must be multiples of 8 (bf16) / 4 (f32)");
+    P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, P3_EALIGN, "p3_gemm_tn: 16-byte base alignment");
+    TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    const int tiles_n = p3_ceil_div(N, TN);
+    g.tiles_k = p3_ceil_div(K, TK);
+    const int tiles = tiles_n * g.tiles_k;
+    const int bm = dtype == P3_BF16 ? 64 : 16;
+    int splits = p3_ceil_div(1024, tiles);
+    int max_splits = p3_ceil_div(M, 4 * bm);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    g.rows_per_split = p3_ceil_div(p3_ceil_div(M, splits), bm) * bm;
+    splits = p3_ceil_div(M, g.rows_per_split);
+    dim3 grid(tiles, splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 0, s, g);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream) {
+    P3_CHECK(x && out && M >= 0 && N > 0, P3_EINVAL, "p3_colsum: bad arguments");
+    if (M == 0) return P3_OK;
+    const int rpb = M > 65536 ? 256 : (M > 4096 ? 64 : 16);
+    dim3 grid(p3_ceil_div(M, rpb), N > 1024 ? 4 : 1), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
+    else if (dtype == P3_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
+    else { p3_set_error("p3_colsum: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -429,3 +429,14 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
+
+// byte offsets of the workspace sections (for the training path, which re-reads the pillar tables in backward)
+extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[10]*/) {
+    P3_CHECK(d && off, P3_EINVAL, "p3_pillar_stem_layout: null pointer");
+    char* base = (char*)256;   // any non-null base: only differences are used
+    Ws w = carve(base, d);
+    off[0] = (char*)w.sorted - base; off[1] = (char*)w.vox_xy - base; off[2] = (char*)w.vox_start - base;
+    off[3] = (char*)w.vox_cnt - base; off[4] = (char*)w.vox_row - base; off[5] = (char*)w.nvox - base;
+    off[6] = (char*)w.X2 - base; off[7] = (char*)w.H2 - base; off[8] = (char*)w.hmax - base; off[9] = (char*)w.hmin - base;
+    return P3_OK;
+}

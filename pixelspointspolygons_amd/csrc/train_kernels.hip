@@ -1,0 +1,271 @@
+// p3hip training-step kernels: Sinkhorn backward (single launch), CE / BCE losses (forward + backward), fused AdamW.
+#include "p3_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ Sinkhorn backward
+// Reverse-mode through all `iters` log-Sinkhorn iterations + slice + row softmax (what autograd does over ~1200 launches in
+// the reference, model_pix2poly.py:35-66,261-264).  One 1024-thread workgroup per sample: Z stays in LDS, the gradient dZ
+// lives in registers with a fixed (row = wave + 16k, col = lane + 64c) ownership; the LSE terms are recovered from the saved
+// dual iterates (u_t, v_t):  softmax_i(Z + u_t)[i,j] = exp(Z_ij + u_t[i] + v_t[j] - log_nu[j]), etc. - no re-reduction.
+constexpr int SK_MAXK = 13, SK_MAXC = 4;   // rows <= 16*13 = 208, cols <= 256  (reference: 193 x 193)
+
+__global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
+                                                            int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
+                                                            const float* __restrict__ dperm, float* __restrict__ dscores,
+                                                            float* __restrict__ dalpha) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int M1 = m + 1, N1 = n + 1;
+    float* Z = sm;                   // [M1][N1]
+    float* ut = sm + M1 * N1;        // [M1] u_t
+    float* vt = ut + M1;             // [N1] v_t
+    float* vp = vt + N1;             // [N1] v_{t-1}
+    float* du = vp + N1;             // [M1]
+    float* dv = du + M1;             // [N1]
+    float* dvn = dv + N1;            // [N1] next dv (accumulated with LDS atomics)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float alpha = alpha_p[0];
+    for (int i = tid; i < M1 * N1; i += 1024) {
+        const int r = i / N1, c = i - r * N1;
+        Z[i] = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
+    }
+    for (int i = tid; i < N1; i += 1024) { dv[i] = 0.f; dvn[i] = 0.f; }
+    for (int i = tid; i < M1; i += 1024) du[i] = 0.f;
+    const float norm = -logf((float)(m + n));
+    const float a_last = logf((float)n) + norm, b_last = logf((float)m) + norm;
+    float dZ[SK_MAXK][SK_MAXC];
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k)
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) dZ[k][c] = 0.f;
+    __syncthreads();
+    // ---- softmax backward: G = perm * (dperm - rowdot); dZ += G; dv[j] = sum_i G ----
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k) {
+        const int i = w + 16 * k;
+        float pv[SK_MAXC], gv[SK_MAXC];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = i < m && j < n;
+            pv[c] = ok ? perm[((int64_t)b * m + i) * n + j] : 0.f;
+            gv[c] = ok ? dperm[((int64_t)b * m + i) * n + j] : 0.f;
+            dot += pv[c] * gv[c];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const float G = pv[c] * (gv[c] - dot);
+            dZ[k][c] += G;
+            if (i < m && j < n && G != 0.f) atomicAdd(&dv[j], G);
+        }
+    }
+    __syncthreads();
+    for (int t = iters; t >= 1; --t) {
+        const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
+        const float* hp = t > 1 ? h - (M1 + N1) : nullptr;
+        for (int i = tid; i < M1; i += 1024) ut[i] = h[i];
+        for (int i = tid; i < N1; i += 1024) { vt[i] = h[M1 + i]; vp[i] = hp ? hp[M1 + i] : 0.f; }
+        __syncthreads();
+        // pass A: v_t = log_nu - LSE_i(Z + u_t):  q = softmax_i * dv[j];  dZ -= q;  du[i] = -sum_j q
+#pragma unroll
+        for (int k = 0; k < SK_MAXK; ++k) {
+            const int i = w + 16 * k;
+            float acc = 0.f;
+            if (i < M1) {
+                const float ui = ut[i];
+#pragma unroll
+                for (int c = 0; c < SK_MAXC; ++c) {
+                    const int j = lane + 64 * c;
+                    if (j < N1) {
+                        const float q = expf(Z[i * N1 + j] + ui + vt[j] - (j < n ? norm : b_last)) * dv[j];
+                        dZ[k][c] -= q; acc += q;
+                    }
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && i < M1) du[i] = -acc;
+        }
+        __syncthreads();
+        // pass B: u_t = log_mu - LSE_j(Z + v_{t-1}):  r = softmax_j * du[i];  dZ -= r;  dv_{t-1}[j] = -sum_i r
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            float acc = 0.f;
+            if (j < N1) {
+                const float vj = vp[j];
+#pragma unroll
+                for (int k = 0; k < SK_MAXK; ++k) {
+                    const int i = w + 16 * k;
+                    if (i < M1) {
+                        const float r = expf(Z[i * N1 + j] + vj + ut[i] - (i < m ? norm : a_last)) * du[i];
+                        dZ[k][c] -= r; acc += r;
+                    }
+                }
+                atomicAdd(&dvn[j], -acc);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < N1; i += 1024) { dv[i] = dvn[i]; dvn[i] = 0.f; }
+        __syncthreads();
+    }
+    float da = 0.f;
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k) {
+        const int i = w + 16 * k;
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            if (i < m && j < n) dscores[((int64_t)b * m + i) * n + j] = dZ[k][c];
+            else if (i < M1 && j < N1) da += dZ[k][c];
+        }
+    }
+    da = wave_sum(da);
+    if (lane == 0 && da != 0.f) atomicAdd(dalpha, da);
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+// CrossEntropyLoss(ignore_index) over rows: acc[0] += sum(lse - logit[target]), acc[1] += #valid rows; row_lse saved
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ tgt, int R, int V,
+                                                     int ignore, float* __restrict__ row_lse, float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* x = logits + (int64_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(x[c] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    if (lane == 0) {
+        row_lse[row] = lse;
+        const int64_t t = tgt[row];
+        if (t != ignore) { atomicAdd(acc, lse - x[t]); atomicAdd(acc + 1, 1.f); }
+    }
+}
+
+template <typename TO>
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ tgt, int R, int V, int ignore,
+                              const float* __restrict__ row_lse, const float* __restrict__ acc, const float* __restrict__ gscale,
+                              TO* __restrict__ dlogits, int ld_out, int Vpad) {
+    const int64_t total = (int64_t)R * Vpad;
+    const float g = gscale[0] / fmaxf(acc[1], 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Vpad);
+        const int64_t r = i / Vpad;
+        float d = 0.f;
+        const int64_t t = tgt[r];
+        if (c < V && t != ignore) d = g * (expf(logits[r * ld + c] - row_lse[r]) - (c == t ? 1.f : 0.f));
+        dlogits[r * ld_out + c] = Cvt<TO>::from_f(d);
+    }
+}
+
+// BCELoss (mean): acc[0] += sum -(y*max(log p,-100) + (1-y)*max(log(1-p),-100))
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float* __restrict__ acc) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i], yi = y[i];
+        s -= yi * fmaxf(logf(pi), -100.f) + (1.f - yi) * fmaxf(logf(1.f - pi), -100.f);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, const float* __restrict__ gscale,
+                               float* __restrict__ dp) {
+    const float g = gscale[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        dp[i] = g * (pi - y[i]) / fmaxf((1.f - pi) * pi, 1e-12f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW (torch semantics)
+// hyper = {lr, 1 - beta1^t, 1 - beta2^t} in device memory so that one captured graph serves every step
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd, float grad_scale,
+                             bf16_t* __restrict__ shadow) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
+    const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (shadow) shadow[i] = f2bf(pi);
+    }
+}
+
+inline int grid_for(int64_t work) {
+    int64_t g = (work + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
+                               const float* uv_hist, const float* dperm, float* dscores, float* dalpha, void* stream) {
+    P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
+    P3_CHECK(m + 1 <= 16 * SK_MAXK && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
+    const size_t lds = ((size_t)(m + 1) * (n + 1) + 2 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
+    P3_CHECK(lds <= 160 * 1024, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, alpha, m, n, iters, perm, uv_hist, dperm,
+                       dscores, dalpha);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_ce_loss_fwd(const float* logits, int ld, const int64_t* targets, int R, int V, int ignore_index, float* row_lse, float* acc,
+                              void* stream) {
+    P3_CHECK(logits && targets && row_lse && acc && R > 0 && V > 0, P3_EINVAL, "p3_ce_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, R, V, ignore_index, row_lse, acc);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_ce_loss_bwd(const float* logits, int ld, const int64_t* targets, int R, int V, int ignore_index, const float* row_lse,
+                              const float* acc, const float* gscale, void* dlogits, int dtype_out, int ld_out, int Vpad, void* stream) {
+    P3_CHECK(logits && targets && row_lse && acc && gscale && dlogits && Vpad >= V && ld_out >= Vpad, P3_EINVAL, "p3_ce_loss_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)R * Vpad;
+    if (dtype_out == P3_BF16) hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, logits, ld, targets, R, V, ignore_index, row_lse, acc, gscale, (bf16_t*)dlogits, ld_out, Vpad);
+    else if (dtype_out == P3_F32) hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, logits, ld, targets, R, V, ignore_index, row_lse, acc, gscale, (float*)dlogits, ld_out, Vpad);
+    else { p3_set_error("p3_ce_loss_bwd: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float* acc, void* stream) {
+    P3_CHECK(p && y && acc && n > 0, P3_EINVAL, "p3_bce_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, acc);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gscale, float* dp, void* stream) {
+    P3_CHECK(p && y && gscale && dp && n > 0, P3_EINVAL, "p3_bce_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, gscale, dp);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow, void* stream) {
+    P3_CHECK(params && grads && exp_avg && exp_avg_sq && hyper && n > 0, P3_EINVAL, "p3_adamw: bad arguments");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, hyper, beta1,
+                       beta2, eps, weight_decay, grad_scale, (bf16_t*)bf16_shadow);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -40,7 +40,7 @@ class EarlyFusionViT(nn.Module):
         """-> LN'd ViT tokens [B, np+1, D] (compute dtype)."""
         B, D, g, cd = x_image.shape[0], self.D, self.g, self.cd
         canvas = torch.empty((B, g * g, 2 * D), dtype=cd, device=x_image.device)
-        self.image_embed.tokens(x_image, cd, out=canvas.view(B * g * g, 2 * D)[:, :D])
+        canvas = self.image_embed.tokens(x_image, cd, canvas=canvas)
         canvas = self.lidar_embed.scatter_into(x_lidar, canvas, D)
         p = self.cfg.experiment.lidar_dropout
         if p is not None:
@@ -79,11 +79,13 @@ class _FusionConvBN(torch.autograd.Function):
                                                    bn.eps, bn.momentum, training, save=True)
         if training:
             bn.num_batches_tracked += 1
-        ctx.save_for_backward(canvas, pre, w, gamma, mean, rstd)
+        ctx.save_for_backward(canvas, w, b, gamma, beta)
         ctx.mod, ctx.B = mod, B
-        ctx.mark_non_differentiable()
         return pre, scale, shift
 
     @staticmethod
     def backward(ctx, dpre, dscale, dshift):
-        raise NotImplementedError("fusion conv backward is provided by pixelspointspolygons_amd.backward (training path)")
+        from .backward import fusion_conv_bn_backward
+        canvas, w, b, gamma, beta = ctx.saved_tensors
+        dc, dw, db, dg, dbt = fusion_conv_bn_backward(ctx.mod, canvas, w, b, gamma, beta, ctx.B, dpre, dscale, dshift)
+        return dc, dw, db, dg, dbt, None, None

@@ -172,7 +172,7 @@ def workspace(nbytes, device, tag="default"):
 
 
 def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax, max_points, max_voxels, training,
-                col_off=0, total_points=None):
+                col_off=0, total_points=None, want_tables=False):
     """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas."""
     _dev(values)
     d = PillarDesc()
@@ -193,7 +193,18 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     check(L.p3_pillar_stem(ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
                            ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d), stream()),
           "p3_pillar_stem")
-    return out
+    if not want_tables:
+        return out
+    off = (c_int64 * 10)()
+    check(L.p3_pillar_stem_layout(byref(d), off), "p3_pillar_stem_layout")
+    nv, npts = B * max_voxels, int(d.total_points)
+
+    def i32(o, n):
+        return ws[o:o + 4 * n].view(torch.int32).clone()
+
+    tables = dict(sorted=i32(off[0], max(npts, 1)), xy=i32(off[1], nv), start=i32(off[2], nv), cnt=i32(off[3], nv), nvox=i32(off[5], B),
+                  MV=max_voxels)
+    return out, tables
 
 
 # ------------------------------------------------------------------------------------------ glue ops
@@ -293,3 +304,132 @@ def add_pos(x, pos):
     out = torch.empty_like(x)
     check(lib().p3_add_pos(ptr(x), ptr(pos), ptr(out), c_int(B), c_int(L), c_int(D), c_int(dt(x)), stream()), "p3_add_pos")
     return out
+
+
+# ------------------------------------------------------------------------------------------ backward / training ops
+def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None):
+    """dq/dk/dv get the same batch/row strides as q/k/v (pass views of a packed buffer to get a packed gradient)."""
+    dq = torch.empty_like(q) if dq is None else dq
+    dk = torch.empty_like(k) if dk is None else dk
+    dv = torch.empty_like(v) if dv is None else dv
+    for a, b_ in ((q, dq), (k, dk), (v, dv)):
+        if a.stride() != b_.stride():
+            raise P3Error("attention_bwd: gradient strides must equal input strides")
+    if do.stride() != o.stride():
+        raise P3Error("attention_bwd: dO strides must equal O strides")
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None)
+    delta = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
+    check(lib().p3_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta), byref(d),
+                                 stream()), "p3_attention_bwd")
+    return dq, dk, dv
+
+
+def gemm_tn(a, b, out=None):
+    """out[N,K] (+)= a[M,N]^T @ b[M,K]  (fp32 out; zero-filled when not given)."""
+    M, N = a.shape
+    K = b.shape[1]
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
+    check(lib().p3_gemm_tn(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
+                           c_int(out.stride(0)), c_int(dt(a)), stream()), "p3_gemm_tn")
+    return out
+
+
+def colsum(x, out=None):
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    check(lib().p3_colsum(ptr(x), ptr(out), c_int64(M), c_int(N), c_int(x.stride(0)), c_int(dt(x)), stream()), "p3_colsum")
+    return out
+
+
+def batch_sum(x):
+    """sum over the leading dim of a contiguous [B, ...] tensor -> fp32 [...]."""
+    B = x.shape[0]
+    return colsum(x.reshape(B, -1)).view(x.shape[1:])
+
+
+def act_bwd(dy, saved, act, out_dtype):
+    out = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
+    dyc, sc = dy.contiguous(), saved.contiguous()
+    check(lib().p3_act_bwd(ptr(dyc), c_int(dt(dyc)), ptr(sc), c_int(dt(sc)), ptr(out), c_int(dt(out)), c_int64(dy.numel()), c_int(act),
+                           stream()), "p3_act_bwd")
+    return out
+
+
+def embed_tokens_bwd(dx, tokens, emb_shape, pos_shape):
+    B, L, D = dx.shape
+    demb = torch.zeros(emb_shape, dtype=torch.float32, device=dx.device)
+    dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dx.device)
+    check(lib().p3_embed_tokens_bwd(ptr(dx), c_int(dt(dx)), ptr(tokens), ptr(demb), ptr(dpos), c_int(B), c_int(L), c_int(D), stream()),
+          "p3_embed_tokens_bwd")
+    return demb, dpos
+
+
+def tokens_assemble_bwd(dx, tok, scale, shift, B, np_, D, src_ld):
+    dsrc = torch.empty((B * np_, D), dtype=tok.dtype, device=dx.device)
+    dscale = torch.zeros(D, dtype=torch.float32, device=dx.device) if scale is not None else None
+    dshift = torch.zeros(D, dtype=torch.float32, device=dx.device) if scale is not None else None
+    check(lib().p3_tokens_assemble_bwd(ptr(dx.contiguous()), ptr(tok), c_int(tok.stride(-2) if src_ld is None else src_ld), c_int(dt(tok)),
+                                       ptr(scale), ptr(shift), ptr(dsrc), ptr(dscale), ptr(dshift), c_int(B), c_int(np_), c_int(D), stream()),
+          "p3_tokens_assemble_bwd")
+    return dsrc, dscale, dshift
+
+
+def pool_pos_bwd(dout, yshape, ydtype):
+    B, L, Din = yshape
+    dy = torch.empty(yshape, dtype=ydtype, device=dout.device)
+    check(lib().p3_pool_pos_bwd(ptr(dout), c_int(dt(dout)), ptr(dy), c_int(dt(dy)), c_int(B), c_int(L - 1), c_int(Din), c_int(dout.shape[-1]),
+                                stream()), "p3_pool_pos_bwd")
+    return dy
+
+
+def pair_mean_bwd(dF, B, L, N, D, dtype, accumulate_into=None):
+    out = accumulate_into if accumulate_into is not None else torch.empty((B, L, D), dtype=dtype, device=dF.device)
+    check(lib().p3_pair_mean_bwd(ptr(dF.contiguous()), ptr(out), c_int(dt(out)), c_int(B), c_int(L), c_int(N), c_int(D),
+                                 c_int(int(accumulate_into is not None)), stream()), "p3_pair_mean_bwd")
+    return out
+
+
+def sinkhorn_bwd(scores, alpha, perm, hist, dperm, iters):
+    B, m, n = scores.shape
+    dscores = torch.empty_like(scores)
+    dalpha = torch.zeros(1, dtype=torch.float32, device=scores.device)
+    check(lib().p3_sinkhorn_bwd(ptr(scores), ptr(alpha), c_int(B), c_int(m), c_int(n), c_int(iters), ptr(perm), ptr(hist), ptr(dperm),
+                                ptr(dscores), ptr(dalpha), stream()), "p3_sinkhorn_bwd")
+    return dscores, dalpha
+
+
+def ce_loss_fwd(logits2d, targets, ignore_index):
+    R, V = logits2d.shape
+    lse = torch.empty(R, dtype=torch.float32, device=logits2d.device)
+    acc = torch.zeros(2, dtype=torch.float32, device=logits2d.device)
+    check(lib().p3_ce_loss_fwd(ptr(logits2d), c_int(logits2d.stride(0)), ptr(targets), c_int(R), c_int(V), c_int(ignore_index), ptr(lse),
+                               ptr(acc), stream()), "p3_ce_loss_fwd")
+    return lse, acc
+
+
+def ce_loss_bwd(logits2d, targets, ignore_index, lse, acc, gscale, out_dtype=torch.float32, vpad=None):
+    R, V = logits2d.shape
+    vpad = vpad or V
+    out = torch.empty((R, vpad), dtype=out_dtype, device=logits2d.device)
+    check(lib().p3_ce_loss_bwd(ptr(logits2d), c_int(logits2d.stride(0)), ptr(targets), c_int(R), c_int(V), c_int(ignore_index), ptr(lse),
+                               ptr(acc), ptr(gscale), ptr(out), c_int(dt(out)), c_int(vpad), c_int(vpad), stream()), "p3_ce_loss_bwd")
+    return out
+
+
+def bce_loss_fwd(p, y):
+    acc = torch.zeros(1, dtype=torch.float32, device=p.device)
+    check(lib().p3_bce_loss_fwd(ptr(p), ptr(y), c_int64(p.numel()), ptr(acc), stream()), "p3_bce_loss_fwd")
+    return acc
+
+
+def bce_loss_bwd(p, y, gscale):
+    dp = torch.empty_like(p)
+    check(lib().p3_bce_loss_bwd(ptr(p), ptr(y), c_int64(p.numel()), ptr(gscale), ptr(dp), stream()), "p3_bce_loss_bwd")
+    return dp
+
+
+def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, shadow=None):
+    check(lib().p3_adamw(ptr(params), ptr(grads), ptr(m), ptr(v), c_int64(params.numel()), ptr(hyper), c_float(beta1), c_float(beta2),
+                         c_float(eps), c_float(wd), c_float(grad_scale), ptr(shadow), stream()), "p3_adamw")

@@ -12,21 +12,48 @@ import torch
 from . import hip
 
 _shadow_cache = {}
+_registered = {}     # id(param) -> (param, bf16 view of the optimizer's shadow arena; refreshed by the AdamW kernel itself)
+_epoch = [0]         # bumped by the optimizer: parameters changed behind autograd's back (flat arena update)
+
+
+def register_shadow(p, view):
+    _registered[id(p)] = (p, view)
+
+
+def invalidate_derived():
+    _epoch[0] += 1
 
 
 def shadow(p, dtype, key=None, fn=None):
-    """compute-dtype (and optionally re-laid-out) copy of parameter `p`, cached until p._version changes."""
+    """compute-dtype (and optionally re-laid-out) copy of parameter `p`, cached until the parameter changes."""
     if dtype == torch.float32 and fn is None:
         return p.detach()
+    reg = _registered.get(id(p))
+    if reg is not None and reg[0] is p and dtype == torch.bfloat16:
+        if fn is None:
+            return reg[1]
+        base = reg[1]            # derive re-laid-out copies from the bf16 arena (no fp32 -> bf16 cast pass)
+    else:
+        base = None
     k = (id(p), dtype, key)
     ent = _shadow_cache.get(k)
-    if ent is not None and ent[0] == p._version and ent[2] is p:
+    ver = (p._version, _epoch[0])
+    if ent is not None and ent[0] == ver and ent[2] is p:
         return ent[1]
-    src = p.detach()
+    src = base if base is not None else p.detach()
     if fn is not None:
         src = fn(src)
     out = hip.cast(src, dtype) if src.dtype != dtype else src.contiguous()
-    _shadow_cache[k] = (p._version, out, p)
+    _shadow_cache[k] = (ver, out, p)
+    return out
+
+
+def _pad_cols(t, n):
+    t = t.contiguous()
+    if t.shape[1] == n:
+        return t
+    out = torch.zeros((t.shape[0], n), dtype=t.dtype, device=t.device)
+    out[:, :t.shape[1]] = t
     return out
 
 
@@ -50,7 +77,7 @@ class _Linear(torch.autograd.Function):
             bias = bias[rows[0]:rows[1]] if bias is not None else None
         ctx.rows = rows
         x2 = x.reshape(-1, x.shape[-1])
-        need = _needs_grad(x, weight, bias, residual)
+        need = any(ctx.needs_input_grad)
         aux = None
         if need and act == hip.ACT_GELU:
             aux = torch.empty((x2.shape[0], w.shape[0]), dtype=out_dtype, device=x.device)
@@ -75,19 +102,26 @@ class _Linear(torch.autograd.Function):
             dpre = hip.act_bwd(dy2, saved, ctx.act, cd)
         dx = dw = db = None
         rows = ctx.rows
+        n_true = dpre.shape[1]
+        if n_true % 64 != 0 and (n_true % 8 != 0 or ctx.needs_input_grad[0]):
+            # e.g. the 227-wide vocabulary layer: zero-pad N so that 16-byte rows / K % 64 hold for the gradient GEMMs
+            npad = (n_true + 63) // 64 * 64
+            dpad = torch.zeros((dpre.shape[0], npad), dtype=dpre.dtype, device=dpre.device)
+            dpad[:, :n_true] = dpre
+            dpre = dpad
         if ctx.needs_input_grad[0]:
-            wt = shadow(weight, cd, key="T", fn=lambda t: t.t().contiguous())      # [K, N_full]
-            if rows is not None:
-                wt = wt[:, rows[0]:rows[1]]
+            nfull = (weight.shape[0] + 63) // 64 * 64
+            wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
+            wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
             dx = hip.gemm(dpre, wt, out_dtype=cd).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = hip.gemm_tn(dpre, x2)                                               # [N, K] fp32
+            dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
             if rows is not None:
                 full = torch.zeros_like(weight)
                 full[rows[0]:rows[1]] = dw
                 dw = full
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = hip.colsum(dpre)
+            db = hip.colsum(dpre)[:n_true]
             if rows is not None:
                 full = torch.zeros(weight.shape[0], dtype=torch.float32, device=db.device)
                 full[rows[0]:rows[1]] = db
@@ -104,7 +138,7 @@ def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=N
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, out_dtype):
-        need = _needs_grad(x, gamma, beta)
+        need = any(ctx.needs_input_grad)
         if need:
             y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
             ctx.save_for_backward(x, gamma, mean, rstd)
@@ -126,29 +160,62 @@ def layernorm(x, gamma, beta, eps, out_dtype=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-class _Attention(torch.autograd.Function):
+class _SelfAttention(torch.autograd.Function):
+    """qkv [B, L, 3D] packed (output of the qkv / in_proj GEMM) -> o [B, L, D]; the gradient comes back packed."""
+
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, causal, key_bias):
-        need = _needs_grad(q, k, v)
-        if need:
+    def forward(ctx, qkv, heads, scale, causal, key_bias):
+        D = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        if any(ctx.needs_input_grad):
             o, lse = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, need_lse=True)
-            ctx.save_for_backward(q, k, v, o, lse, key_bias)
-            ctx.cfg = (heads, scale, causal)
+            ctx.save_for_backward(qkv, o, lse, key_bias)
+            ctx.cfg = (heads, scale, causal, D)
         else:
             o = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, key_bias = ctx.saved_tensors
-        heads, scale, causal = ctx.cfg
-        dq, dk, dv = hip.attention_bwd(q, k, v, o, lse, do.contiguous(), heads, scale, causal=causal, key_bias=key_bias)
-        return dq, dk, dv, None, None, None, None
+        qkv, o, lse, key_bias = ctx.saved_tensors
+        heads, scale, causal, D = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        hip.attention_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), heads, scale, causal=causal,
+                          key_bias=key_bias, dq=dqkv[..., :D], dk=dqkv[..., D:2 * D], dv=dqkv[..., 2 * D:])
+        return dqkv, None, None, None, None
 
 
-def attention(q, k, v, heads, scale=None, causal=False, key_bias=None):
-    hd = q.shape[-1] // heads
-    return _Attention.apply(q, k, v, heads, scale if scale is not None else 1.0 / math.sqrt(hd), causal, key_bias)
+class _CrossAttention(torch.autograd.Function):
+    """q [B, Lq, D], kv [B, Lk, 2D] packed -> o [B, Lq, D]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        D = q.shape[-1]
+        k, v = kv[..., :D], kv[..., D:]
+        if any(ctx.needs_input_grad):
+            o, lse = hip.attention(q, k, v, heads, scale, need_lse=True)
+            ctx.save_for_backward(q, kv, o, lse)
+            ctx.cfg = (heads, scale, D)
+        else:
+            o = hip.attention(q, k, v, heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        heads, scale, D = ctx.cfg
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        hip.attention_bwd(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), heads, scale, dq=dq, dk=dkv[..., :D], dv=dkv[..., D:])
+        return dq, dkv, None, None
+
+
+def self_attention(qkv, heads, causal=False, key_bias=None):
+    hd = qkv.shape[-1] // 3 // heads
+    return _SelfAttention.apply(qkv, heads, 1.0 / math.sqrt(hd), causal, key_bias)
+
+
+def cross_attention(q, kv, heads):
+    return _CrossAttention.apply(q, kv, heads, 1.0 / math.sqrt(q.shape[-1] // heads))
 
 
 # ---------------------------------------------------------------------------------------------- glue with autograd
@@ -171,7 +238,8 @@ class _EmbedTokens(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, emb, pos, pad_idx, cd):
         L = tokens.shape[1]
-        x, kb = hip.embed_tokens(tokens.contiguous(), emb.detach(), pos.detach().reshape(-1, pos.shape[-1])[:L].contiguous(), pad_idx, cd)
+        tokens = tokens.contiguous()          # y[:, :-1] is a strided view: the kernels index [B, L] densely
+        x, kb = hip.embed_tokens(tokens, emb.detach(), pos.detach().reshape(-1, pos.shape[-1])[:L].contiguous(), pad_idx, cd)
         ctx.save_for_backward(tokens)
         ctx.meta = (emb.shape, pos.shape)
         ctx.mark_non_differentiable(kb)
@@ -208,7 +276,7 @@ def add_pos(x, pos):
 class _SinkhornSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, alpha, iters):
-        need = _needs_grad(scores, alpha)
+        need = any(ctx.needs_input_grad)
         perm, _, hist = hip.sinkhorn(scores.contiguous(), alpha.detach().reshape(1), iters, want_perm=True, want_hist=need)
         if need:
             ctx.save_for_backward(scores, alpha, perm, hist)

@@ -162,7 +162,7 @@ def scorenet_forward(net, feats, out, transpose_acc, keep=None):
 class _ScoreNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, net, out, transpose_acc, *params):
-        keep = {} if ops._needs_grad(feats, *params) else None
+        keep = {} if any(ctx.needs_input_grad) else None
         scorenet_forward(net, feats, out, transpose_acc, keep)
         ctx.net, ctx.keep, ctx.transpose_acc = net, keep, transpose_acc
         ctx.save_for_backward(feats)
@@ -174,7 +174,8 @@ class _ScoreNetFn(torch.autograd.Function):
         from .backward import scorenet_backward
         (feats,) = ctx.saved_tensors
         dfeats, dparams = scorenet_backward(ctx.net, feats, ctx.keep, dout, ctx.transpose_acc)
-        return (dfeats, None, None, None, *dparams)
+        # out_new = out_old + s^T in accumulate mode: the gradient passes straight through to the first ScoreNet's output
+        return (dfeats, None, dout if ctx.transpose_acc else None, None, *dparams)
 
 
 # ------------------------------------------------------------------------------------------------ Decoder
@@ -221,12 +222,12 @@ class Decoder(nn.Module):
         for lyr in self.decoder.layers:
             sa, ca = lyr.self_attn, lyr.multihead_attn
             qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)
-            a = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H, causal=True, key_bias=kb)
+            a = ops.self_attention(qkv, H, causal=True, key_bias=kb)
             y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
             x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
             q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
             kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D))
-            a = ops.attention(q, kv[..., :D], kv[..., D:], H)
+            a = ops.cross_attention(q, kv, H)
             y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
             x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
             h = ops.linear(x, lyr.linear1.weight, lyr.linear1.bias, act=hip.ACT_RELU, cd=cd)

@@ -85,20 +85,28 @@ class _PillarStem(torch.autograd.Function):
         l0, l1 = mod.voxel_encoder.pfn_layers
         training = mod.training
         w2c = ops.shadow(w2, mod.cd)
-        saved = hip.pillar_stem(values, offsets, w1.detach(), (g1.detach(), b1.detach(), l0.norm.running_mean, l0.norm.running_var), w2c,
-                                (g2.detach(), b2.detach(), l1.norm.running_mean, l1.norm.running_var), canvas, B=B, grid=(mod.nx, mod.ny),
-                                voxel=mod.voxel, zmax=mod.zmax, max_points=mod.max_points,
-                                max_voxels=mod.max_voxels[0] if training else mod.max_voxels[1], training=training, col_off=col_off)
+        need = any(ctx.needs_input_grad)
+        r = hip.pillar_stem(values, offsets, w1.detach(), (g1.detach(), b1.detach(), l0.norm.running_mean, l0.norm.running_var), w2c,
+                            (g2.detach(), b2.detach(), l1.norm.running_mean, l1.norm.running_var), canvas, B=B, grid=(mod.nx, mod.ny),
+                            voxel=mod.voxel, zmax=mod.zmax, max_points=mod.max_points,
+                            max_voxels=mod.max_voxels[0] if training else mod.max_voxels[1], training=training, col_off=col_off,
+                            want_tables=need)
         if training:
             l0.norm.num_batches_tracked += 1
             l1.norm.num_batches_tracked += 1
         ctx.mark_dirty(canvas)
-        ctx.mod = mod
+        if need:
+            ctx.tables = r[1]
+            ctx.save_for_backward(values)
+        ctx.mod, ctx.B, ctx.col_off = mod, B, col_off
         return canvas
 
     @staticmethod
     def backward(ctx, dcanvas):
-        raise NotImplementedError("pillar stem backward is provided by pixelspointspolygons_amd.backward (training path)")
+        from .backward import pillar_stem_backward
+        (values,) = ctx.saved_tensors
+        g = pillar_stem_backward(ctx.mod, values, ctx.tables, ctx.B, dcanvas, ctx.col_off)
+        return None, None, g[0], g[1], g[2], g[3], g[4], g[5], dcanvas, None, None, None
 
 
 class PointPillarsViT(nn.Module):

@@ -28,13 +28,13 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.flatten = True
 
-    def tokens(self, x, cd, out=None):
-        """-> [B*np, D] token-major (== NHWC of the conv output); `out` may be a strided view (fusion canvas)."""
-        B = x.shape[0]
+    def tokens(self, x, cd, canvas=None):
+        """-> [B*np, D] token-major (== NHWC of the conv output).  With `canvas` [B*np, ld >= D] the tokens are written into
+        its first D columns (fusion: the channel concat is free) and the canvas is returned."""
         patches = hip.patchify(x.contiguous(), self.patch_size, cd)
         w = self.proj.weight
         w2 = ops.shadow(w, cd, key="flat", fn=lambda t: t.reshape(t.shape[0], -1))
-        return _PatchGemm.apply(patches, w, self.proj.bias, w2, out, cd)
+        return _PatchGemm.apply(patches, w, self.proj.bias, w2, canvas, cd)
 
     def forward(self, x):
         cd = torch.bfloat16 if getattr(self, "cd", None) is None else self.cd
@@ -47,19 +47,24 @@ class PatchEmbed(nn.Module):
 
 class _PatchGemm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, patches, weight, bias, w2, out, cd):
-        y = hip.gemm(patches, w2, bias=bias, out=out, out_dtype=cd)
+    def forward(ctx, patches, weight, bias, w2, canvas, cd):
+        D = w2.shape[0]
         ctx.save_for_backward(patches)
-        ctx.wshape = weight.shape
-        return y
+        ctx.wshape, ctx.D = weight.shape, D
+        if canvas is None:
+            return hip.gemm(patches, w2, bias=bias, out_dtype=cd)
+        hip.gemm(patches, w2, bias=bias, out=canvas[..., :D])
+        ctx.mark_dirty(canvas)
+        return canvas
 
     @staticmethod
     def backward(ctx, dy):
         (patches,) = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dw = hip.gemm_tn(dyc, patches).view(ctx.wshape)
-        db = hip.colsum(dyc)
+        dy2 = dy.reshape(-1, dy.shape[-1])[:, :ctx.D]              # strided view of the canvas gradient is fine (explicit ld)
+        if dy2.dtype != patches.dtype:
+            dy2 = hip.cast(dy2.contiguous(), patches.dtype)
+        dw = hip.gemm_tn(dy2, patches).view(ctx.wshape)
+        db = hip.colsum(dy2)
         return None, dw, db, None, None, None
 
 
@@ -93,7 +98,7 @@ class Block(nn.Module):
         D = x.shape[-1]
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
         qkv = ops.linear(h, self.attn.qkv.weight, self.attn.qkv.bias, cd=cd)
-        a = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], self.attn.num_heads)
+        a = ops.self_attention(qkv, self.attn.num_heads)
         x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
         h = ops.linear(h, self.mlp.fc1.weight, self.mlp.fc1.bias, act=hip.ACT_GELU, cd=cd)

@@ -1,0 +1,195 @@
+"""Backward / training-step parity on the GPU: HIP backward kernels vs torch autograd of the same fp32 math on the CPU."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import p3_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _h():
+    import pixelspointspolygons_amd.hip as h
+    return h
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-5)])
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 1536), (777, 1152, 384), (50, 8, 64), (4096, 256, 2048)])
+def test_gemm_tn_and_colsum(dtype, tol, M, N, K):
+    h = _h()
+    a, b = _rand(M, N, seed=1).to(dtype), _rand(M, K, seed=2).to(dtype)
+    ref = a.float().t() @ b.float()
+    out = h.gemm_tn(a.to(DEV), b.to(DEV)).cpu()
+    assert rel_err(out, ref) < tol * 10
+    assert rel_err(h.colsum(a.to(DEV)).cpu(), a.float().sum(0)) < 1e-4
+
+
+def test_gemm_tn_strided_operand_and_accumulate():
+    h = _h()
+    full = _rand(300, 512, seed=3)
+    a, b = full[:, :256], _rand(300, 64, seed=4)
+    out = torch.ones(256, 64, device=DEV)
+    h.gemm_tn(full.to(DEV)[:, :256], b.to(DEV), out=out)
+    assert rel_err(out.cpu(), 1 + a.t() @ b) < 1e-5
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_act_bwd(act):
+    h = _h()
+    x = _rand(500, 96, seed=1).requires_grad_(True)
+    y = F.gelu(x) if act == 1 else F.relu(x)
+    dy = _rand(500, 96, seed=2)
+    y.backward(dy)
+    saved = x.detach() if act == 1 else y.detach()
+    out = h.act_bwd(dy.to(DEV), saved.to(DEV), act, torch.float32).cpu()
+    assert rel_err(out, x.grad) < 1e-5
+
+
+def _attn_ref(q, k, v, heads, scale, causal, kb):
+    B, Lq, Dm = q.shape
+    Lk, hd = k.shape[1], Dm // heads
+    sp = lambda t, L: t.reshape(B, L, heads, hd).transpose(1, 2)
+    s = sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) * scale
+    if kb is not None:
+        s = s + kb.view(B, 1, 1, Lk)
+    if causal:
+        s = s + torch.full((Lq, Lk), float("-inf")).triu(1)
+    return (torch.softmax(s, -1) @ sp(v, Lk)).transpose(1, 2).reshape(B, Lq, Dm)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,bias", [
+    (2, 6, 785, 785, 64, False, False), (2, 8, 385, 385, 32, True, True), (2, 8, 385, 784, 32, False, False),
+    (1, 2, 37, 50, 64, False, True), (1, 1, 70, 70, 32, True, False)])
+def test_attention_backward(dtype, tol, B, H, Lq, Lk, hd, causal, bias):
+    h = _h()
+    Dm = H * hd
+    q = _rand(B, Lq, Dm, seed=1).to(dtype).float().requires_grad_(True)
+    k = _rand(B, Lk, Dm, seed=2).to(dtype).float().requires_grad_(True)
+    v = _rand(B, Lk, Dm, seed=3).to(dtype).float().requires_grad_(True)
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk)
+        kb[:, Lk // 2:] = 1.0
+    scale = 1 / math.sqrt(hd)
+    o = _attn_ref(q, k, v, H, scale, causal, kb)
+    do = _rand(B, Lq, Dm, seed=4).to(dtype).float()
+    o.backward(do)
+    qd, kd, vd = (t.detach().to(dtype).to(DEV) for t in (q, k, v))
+    kbd = kb.to(DEV) if kb is not None else None
+    od, lse = h.attention(qd, kd, vd, H, scale, causal=causal, key_bias=kbd, need_lse=True)
+    dq, dk, dv = h.attention_bwd(qd, kd, vd, od, lse, do.to(dtype).to(DEV), H, scale, causal=causal, key_bias=kbd)
+    for got, ref in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
+        assert rel_err(got.float().cpu(), ref) < tol
+
+
+def test_sinkhorn_backward_vs_autograd():
+    from pixelspointspolygons_amd import ops
+    for (B, m, iters, seed) in ((2, 12, 100, 1), (1, 192, 100, 2), (2, 30, 7, 3)):
+        s = (_rand(B, m, m, seed=seed) * 2).requires_grad_(True)
+        alpha = torch.tensor(0.7, requires_grad=True)
+        perm = torch.softmax(O.log_optimal_transport(s, alpha, iters)[:, :m, :m], -1)
+        g = _rand(B, m, m, seed=seed + 10)
+        perm.backward(g)
+        sd = s.detach().to(DEV).requires_grad_(True)
+        ad = alpha.detach().to(DEV).requires_grad_(True)
+        pd = ops.sinkhorn_softmax(sd, ad, iters)
+        pd.backward(g.to(DEV))
+        assert rel_err(pd.detach().cpu(), perm.detach()) < 1e-4
+        assert rel_err(sd.grad.cpu(), s.grad) < 2e-3
+        assert abs(float(ad.grad.cpu()) - float(alpha.grad)) < 2e-3 * max(1.0, abs(float(alpha.grad)))
+
+
+def test_losses_forward_backward():
+    from pixelspointspolygons_amd.training import pix2poly_loss
+    inp = O.make_inputs(3, seed=5)
+    logits = _rand(3, 385, 227, seed=1).requires_grad_(True)
+    perm = torch.rand(3, 192, 192, generator=torch.Generator().manual_seed(2)).clamp(1e-4, 1 - 1e-4).requires_grad_(True)
+    loss, ce, bce = O.pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
+    loss.backward()
+    ld, pd = logits.detach().to(DEV).requires_grad_(True), perm.detach().to(DEV).requires_grad_(True)
+    l2, ce2, bce2 = pix2poly_loss(ld, pd, inp["y"][:, 1:].to(DEV), inp["y_perm"].to(DEV))
+    l2.backward()
+    assert abs(float(l2) - float(loss)) < 1e-5 * abs(float(loss)) and abs(float(ce2) - float(ce)) < 1e-5 and abs(float(bce2) - float(bce)) < 1e-5
+    assert rel_err(ld.grad.cpu(), logits.grad) < 1e-5 and rel_err(pd.grad.cpu(), perm.grad) < 1e-5
+
+
+def test_adamw_matches_torch():
+    from pixelspointspolygons_amd.training import FlatAdamW
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5))
+    mine = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5))
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95))
+    opt = FlatAdamW(mine, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=torch.float32)
+    for step in range(5):
+        g = torch.Generator().manual_seed(step)
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad = gr.clone()
+            pm.grad.copy_(gr.to(DEV))
+        opt_ref.step()
+        opt.step()
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        assert rel_err(pm.detach().cpu(), pr.detach()) < 1e-6
+
+
+def _oracle_grads(sd, inp, kind="fusion"):
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    img = inp["image"] if kind != "lidar" else None
+    lidar = (inp["lidar_values"], inp["lidar_offsets"]) if kind != "image" else None
+    logits, perm = O.pix2poly_forward(p, inp["y"][:, :-1], img, lidar, training=True)
+    loss, ce, bce = O.pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in p.items() if v.is_floating_point() and v.requires_grad}
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-3), ("bf16", 5e-2)])
+def test_train_step_gradients_vs_oracle_autograd(precision, tol):
+    """fwd + CE + 10*BCE + backward of the whole early-fusion model: parameter gradients vs autograd of the CPU oracle."""
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import pix2poly_loss
+    sd = O.make_state_dict("fusion", seed=42)
+    inp = O.make_inputs(2, seed=321)
+    ref_loss, ref_g = _oracle_grads(sd, inp)
+    cfg = make_config("early_fusion_vit", precision=precision, device=DEV)
+    m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    m.decoder.set_dropout(0.0)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    logits, perm = m(d["image"], (d["lidar_values"], d["lidar_offsets"]), d["y"][:, :-1])
+    loss, ce, bce = pix2poly_loss(logits, perm, d["y"][:, 1:], d["y_perm"])
+    loss.backward()
+    assert abs(float(loss) - ref_loss) < (2e-3 if precision == "fp32" else 5e-2) * abs(ref_loss)
+    worst = {}
+    gmax = max(float(g.abs().max()) for g in ref_g.values())
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        # biases in front of a BatchNorm have an exactly-zero true gradient: floor the denominator
+        g, r = p.grad.float().cpu(), ref_g[k]
+        if precision == "fp32":
+            denom = max(float(r.abs().max()), 1e-3 * gmax)
+            worst[k] = float((g - r).abs().max()) / denom
+        elif float(r.abs().max()) > 1e-3 * gmax:
+            # bf16 storage: per-parameter direction must agree (1 - cosine similarity), magnitudes within tol
+            cos = float((g * r).sum() / (g.norm() * r.norm()).clamp_min(1e-30))
+            worst[k] = max(1.0 - cos, abs(float(g.norm() / r.norm()) - 1.0) * 0.25)
+        else:
+            worst[k] = float((g - r).abs().max()) / (1e-1 * gmax)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/grad_err_{precision}.json", "w") as f:
+        json.dump(sorted(worst.items(), key=lambda kv: -kv[1]), f, indent=0)
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
