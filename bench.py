@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the Pix2Poly hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one reference train step (train/trainer_pix2poly.py:305-329) on one synthetic batch that is already resident
+in HBM: forward (encoder + fusion + decoder + 2x ScoreNet + Sinkhorn) -> 1.0*CE + 10.0*BCE -> backward -> AdamW.
+Metric (BASELINE.json): training tiles/s, whole job; `fwd_ms_per_tile` is reported in the same line.
+Default workload = the configuration the metric is quoted on ("224px img + 3k-pt lidar"): early-fusion Pix2Poly
+(ViT-S/8 + PointPillars stem, mnv = 64), 64 tiles per GPU, bf16 storage / fp32 accumulate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# forward GFLOP per tile of the dense reference formulation (SURVEY §8d / BASELINE.md §2)
+GFLOP_FWD = {"fusion_s8": 85.2, "image_s8": 80.9, "image_b16": 35.13 + 10.7 + 25.4, "lidar_s8": 80.9 - 0.116 + 0.149}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fusion_s8", choices=["fusion_s8", "image_s8", "image_b16", "lidar_s8"])
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--points", type=int, default=3000)
+    ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph (single-GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
+    return ap.parse_args()
+
+
+def make_cfg(args, dev):
+    from pixelspointspolygons_amd.config import make_config
+    enc = {"fusion_s8": "early_fusion_vit", "image_s8": "vit", "image_b16": "vit", "lidar_s8": "pointpillars_vit"}[args.workload]
+    kw = {}
+    if args.workload == "image_b16":
+        kw = dict(patch_size=16, patch_feature_dim=768, vit_heads=12)
+    cfg = make_config(enc, precision=args.precision, device=dev, batch_size=args.batch, **kw)
+    if args.workload == "image_b16":
+        cfg.experiment.encoder.type = cfg.experiment.encoder.vit.type = "vit_base_patch16_224.dino"
+        cfg.experiment.model.tokenizer.max_num_vertices = 98        # 196 patches -> 98 vertex slots keep the decoder shape rules
+    return cfg
+
+
+def synth_batch(O, args, rank, step, dev, kind):
+    inp = O.make_inputs(args.batch, seed=1234 + 1000 * rank + step, n_points=args.points, jitter=args.points // 10)
+    b = {"y": inp["y"].to(dev), "y_perm": inp["y_perm"].to(dev)}
+    if kind != "lidar":
+        b["image"] = inp["image"].to(dev)
+    if kind != "image":
+        b["lidar_values"], b["lidar_offsets"] = inp["lidar_values"].to(dev), inp["lidar_offsets"].to(dev)
+    return b
+
+
+class Stepper:
+    """Static input buffers + (optionally) one captured hipGraph of forward + loss + backward + AdamW."""
+
+    def __init__(self, model, opt, reducer, pool, kind, use_graph):
+        from pixelspointspolygons_amd.training import pix2poly_loss
+        self.model, self.opt, self.reducer, self.kind = model, opt, reducer, kind
+        self.loss_fn = pix2poly_loss
+        cap = max(int(b["lidar_values"].shape[0]) for b in pool) if kind != "image" else 0
+        self.static = {k: torch.empty_like(v) for k, v in pool[0].items() if k not in ("lidar_values",)}
+        if kind != "image":
+            self.static["lidar_values"] = torch.zeros((cap, 3), dtype=torch.float32, device=pool[0]["y"].device)
+        self.graph = None
+        self.eager_done = 0
+        self.use_graph = use_graph
+        self.out = None
+
+    def load(self, b):
+        for k, v in b.items():
+            if k == "lidar_values":
+                self.static[k][: v.shape[0]].copy_(v, non_blocking=True)
+            else:
+                self.static[k].copy_(v, non_blocking=True)
+
+    def _fwd_bwd(self):
+        s = self.static
+        y = s["y"]
+        lidar = (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
+        logits, perm = self.model(s.get("image"), lidar, y[:, :-1])
+        loss, ce, bce = self.loss_fn(logits, perm, y[:, 1:], s["y_perm"], 1.0, 10.0, 226)
+        self.opt.zero_grad()
+        loss.backward()
+        return loss.detach()
+
+    def step(self, b):
+        self.load(b)
+        self.opt.prepare_step()
+        if self.use_graph and self.reducer.world == 1 and self.eager_done >= 2:
+            if self.graph is None:
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = self._fwd_bwd()
+                    self.opt.apply(1.0)
+            self.graph.replay()
+        else:
+            self.out = self._fwd_bwd()
+            self.opt.apply(self.reducer.finish())
+            self.eager_done += 1
+        return self.out
+
+    def forward_only(self, b):
+        self.load(b)
+        s = self.static
+        lidar = (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
+        with torch.no_grad():
+            return self.model(s.get("image"), lidar, s["y"][:, :-1])
+
+
+def cpu_baseline(O, args, kind):
+    """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload."""
+    import torch.nn.functional as F  # noqa: F401
+    B = 2
+    cfgv = O.VIT_S8 if args.workload != "image_b16" else O.VIT_B16
+    sd = O.make_state_dict({"fusion_s8": "fusion", "image_s8": "image", "image_b16": "image", "lidar_s8": "lidar"}[args.workload], cfgv, seed=42)
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    params = [v for v in p.values() if v.is_floating_point() and v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95))
+    inp = O.make_inputs(B, seed=1234, n_points=args.points, jitter=args.points // 10)
+    img = inp["image"] if kind != "lidar" else None
+    lidar = (inp["lidar_values"], inp["lidar_offsets"]) if kind != "image" else None
+
+    def one():
+        logits, perm = O.pix2poly_forward(p, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=True)
+        loss, _, _ = O.pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < 12 and n < 6):
+        one()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train step (fwd+CE+10*BCE+bwd+AdamW, fp32), batch {B}, {n} timed steps after 1 warm-up, host CPU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=torch.device(dev))
+    from oracle import p3_oracle as O       # synthetic-input generator + cpu_baseline leg only (never on the product path)
+    from pixelspointspolygons_amd import hip
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer
+    from pixelspointspolygons_amd.vision_transformer import compute_dtype
+
+    kind = {"fusion_s8": "fusion", "image_s8": "image", "image_b16": "image", "lidar_s8": "lidar"}[args.workload]
+    cfg = make_cfg(args, dev)
+    torch.manual_seed(42)                    # reference seed (train/trainer.py:214); random-init weights (no checkpoints offline)
+    tk = Tokenizer(cfg)
+    model = Pix2PolyModel(cfg, tk.vocab_size, local)
+    model.train()
+    model.decoder.set_dropout(0.0)           # HIP decoder is dropout-free (known gap)
+    opt = FlatAdamW(model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=compute_dtype(cfg))
+    opt.set_linear_schedule(200 * 1000)
+    reducer = GradBucketReducer(opt)
+    pool = [synth_batch(O, args, rank, s, dev, kind) for s in range(args.pool)]
+    st = Stepper(model, opt, reducer, pool, kind, bool(args.graph))
+
+    for i in range(max(args.warmup, 3 if args.graph and world == 1 else 0)):   # 2 eager steps + the capture step stay untimed
+        st.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = st.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(out)
+
+    # forward-only latency (eval of the same model state, no grad)
+    for i in range(2):
+        st.forward_only(pool[0])
+    torch.cuda.synchronize()
+    nf = max(3, min(args.steps, 10))
+    t1 = time.perf_counter()
+    for i in range(nf):
+        st.forward_only(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+
+    # dominant-kernel timing with HIP events on the launch stream (instrumented steps, after the timed region)
+    roofline = None
+    if rank == 0 and not args.no_kernel_timing:
+        hip.KTIMER.enable()
+        for i in range(3):
+            st.forward_only(pool[i % len(pool)])
+        torch.cuda.synchronize()
+        kt = hip.KTIMER.summary()
+        hip.KTIMER.disable()
+        if kt:
+            name, rec = max(kt.items(), key=lambda kv: kv[1]["ms"])
+            peak = 2500.0 if args.precision == "bf16" else 157.3
+            ach = rec["flop"] / (rec["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": None, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+                        "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3)}
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        line = {
+            "metric": "training tiles/sec (224px img + 3k-pt lidar)", "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"pix2poly_{args.workload}_bs{args.batch}x{world}", "tiles_per_gpu": args.batch, "points_per_tile": args.points,
+                       "hip_graph": bool(args.graph and world == 1), "step": "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
+            "fwd_ms_per_tile": round(fwd_ms / args.batch, 4), "fwd_ms_per_batch": round(fwd_ms, 3),
+            "fwd_mfma_frac_of_2.5PF": round(GFLOP_FWD[args.workload] * args.batch / (fwd_ms * 1e-3) / 1e3 / 2500.0, 4) if args.precision == "bf16" else None,
+            "final_loss": round(loss_val, 4),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(O, args, kind)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,9 @@ int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1,
                    const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
                    const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
                    const p3_pillar_desc* d, void* stream);
+/* byte offsets (13 int64) of the workspace sections the training path re-reads in backward: sorted, vox_xy, vox_start, vox_cnt,
+ * vox_row, nvox, X2, H2, hmax, hmin, F8 (decorated point features per X2 row), row_vox (pillar slot per row, -1 unused), row_w */
+int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* offsets);
 
 /* ------------------------------------------------------------------------------------------
  * HBM-bound glue of the encoders / decoder (each replaces a chain of ATen elementwise kernels)

@@ -76,65 +76,58 @@ def fusion_conv_bn_backward(mod, canvas, w, b, gamma, beta, B, dpre, dscale, dsh
 
 # ------------------------------------------------------------------------------------------------ PillarFeatureNet
 def pillar_stem_backward(mod, values, tables, B, dcanvas, col_off):
-    """tables: dict(sorted, xy, start, cnt, nvox) int32 device tensors cloned from the forward's workspace."""
+    """Static-shape recompute over the forward's fixed-capacity row tables (graph-capturable: no data-dependent shapes).
+
+    tables (cloned from the HIP forward's workspace): F8 [R, 8] decorated point features per X2 row (padded representative
+    rows are zeros), row_vox [R] pillar slot (-1 = unused row), row_w [R] BatchNorm weight (1 real / P - cnt padded / 0 unused),
+    xy [B*MV] scatter target (+ bit 30 = overwritten by a top-z pillar), nvox [B] pillars per sample.
+    """
     l0, l1 = mod.voxel_encoder.pfn_layers
     P, MV, C, cd = mod.max_points, tables["MV"], mod.C, mod.cd
-    dev = values.device
-    nvox = tables["nvox"].long()
-    slot = torch.arange(B * MV, device=dev)
-    keep = (slot % MV) < nvox[slot // MV]
-    vid = slot[keep]                                         # kept pillar slots
-    Vn = vid.numel()
+    dev = dcanvas.device
     params = [l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight, l1.norm.bias]
-    if Vn == 0:
-        return [torch.zeros_like(p) for p in params]
-    cnt = tables["cnt"].long()[vid]
-    start = tables["start"].long()[vid]
-    xyf = tables["xy"].long()[vid]
-    xy = xyf & 0xFFFFFF
-    skipped = (xyf >> 30) & 1
-    bidx = vid // MV
-    rep = torch.repeat_interleave(torch.arange(Vn, device=dev), cnt)
-    first = torch.cumsum(cnt, 0) - cnt
-    pos = torch.arange(rep.numel(), device=dev) - first[rep]
-    pt = tables["sorted"].long()[start[rep] + pos]
-    xyz = values[pt]
-    mean = torch.zeros(Vn, 3, device=dev).index_add_(0, rep, xyz) / cnt[:, None].float()
-    cx, cy = (xy % mod.nx).float(), (xy // mod.nx).float()
-    vx, vy = mod.voxel[0], mod.voxel[1]
-    ctr = torch.stack([cx * vx + vx / 2, cy * vy + vy / 2], 1)
-    f = torch.cat([xyz, xyz - mean[rep], xyz[:, :2] - ctr[rep]], 1)           # [S, 8]
-    n = float(Vn * P)
-    has_pad = cnt < P
-    padw = (P - cnt).float()
+    rv = tables["row_vox"].long()
+    valid = rv >= 0
+    vox = rv.clamp_min(0)
+    w_row, F8 = tables["row_w"], tables["F8"]
+    NV = B * MV
+    nvox = tables["nvox"].long()
+    n = (nvox.sum() * P).float().clamp_min(1.0)
+    slot = torch.arange(NV, device=dev)
+    used = (slot % MV) < nvox[slot // MV]
+    neg = float("-inf")
     with torch.enable_grad():
-        h1 = f @ l0.linear.weight.t()
+        h1 = F8 @ l0.linear.weight.t()                                   # padded / unused rows: exactly 0
         if mod.training:
-            sc1, sh1 = _bn_train_affine(h1, l0.norm.weight, l0.norm.bias, l0.norm.eps, count=n)
+            m1 = h1.sum(0) / n
+            v1 = ((h1 * h1).sum(0) / n - m1 * m1).clamp_min(0)
+            sc1 = l0.norm.weight * torch.rsqrt(v1 + l0.norm.eps)
+            sh1 = l0.norm.bias - m1 * sc1
         else:
             sc1 = l0.norm.weight * torch.rsqrt(l0.norm.running_var + l0.norm.eps)
             sh1 = l0.norm.bias - l0.norm.running_mean * sc1
-        x = F.relu(h1 * sc1 + sh1)
-        c0 = F.relu(sh1)
-        init = torch.where(has_pad[:, None], c0[None, :].expand(Vn, -1), torch.full((Vn, 32), float("-inf"), device=dev))
-        xmax = init.scatter_reduce(0, rep[:, None].expand(-1, 32), x, "amax", include_self=True)
-        w2 = l1.linear.weight.to(cd)
-        X2r = torch.cat([x, xmax[rep]], 1).to(cd)
-        X2p = torch.cat([c0[None, :].expand(Vn, -1), xmax], 1).to(cd)
-        h2r, h2p = (X2r @ w2.t()), (X2p @ w2.t())
+        x = F.relu(h1 * sc1 + sh1)                                       # padded rows -> relu(shift) like the reference's zero slots
+        xmax = torch.full((NV, 32), neg, device=dev).scatter_reduce(0, vox[:, None].expand(-1, 32),
+                                                                     torch.where(valid[:, None], x, torch.full_like(x, neg)), "amax", include_self=True)
+        xmr = torch.where(valid[:, None], xmax[vox], torch.zeros_like(x))
+        h2 = (torch.cat([x, xmr], 1).to(cd) @ l1.linear.weight.to(cd).t()).float()
         if mod.training:
-            allh = torch.cat([h2r, h2p], 0)
-            wts = torch.cat([torch.ones(h2r.shape[0], device=dev), padw], 0)
-            sc2, sh2 = _bn_train_affine(allh, l1.norm.weight, l1.norm.bias, l1.norm.eps, count=n, weights=wts)
+            m2 = (h2 * w_row[:, None]).sum(0) / n
+            v2 = ((h2 * h2 * w_row[:, None]).sum(0) / n - m2 * m2).clamp_min(0)
+            sc2 = l1.norm.weight * torch.rsqrt(v2 + l1.norm.eps)
+            sh2 = l1.norm.bias - m2 * sc2
         else:
             sc2 = l1.norm.weight * torch.rsqrt(l1.norm.running_var + l1.norm.eps)
             sh2 = l1.norm.bias - l1.norm.running_mean * sc2
-        zr = F.relu(h2r.float() * sc2 + sh2)
-        zp = F.relu(h2p.float() * sc2 + sh2)
-        init2 = torch.where(has_pad[:, None], zp, torch.full_like(zp, float("-inf")))
-        out = init2.scatter_reduce(0, rep[:, None].expand(-1, C), zr, "amax", include_self=True)       # [Vn, C]
+        z = F.relu(h2 * sc2 + sh2)
+        out = torch.full((NV, C), neg, device=dev).scatter_reduce(0, vox[:, None].expand(-1, C),
+                                                                   torch.where(valid[:, None], z, torch.full_like(z, neg)), "amax", include_self=True)
+        out = torch.where(used[:, None], out, torch.zeros_like(out))
+        xyf = tables["xy"].long()
+        xy = torch.where(used, xyf & 0xFFFFFF, torch.zeros_like(xyf))
+        live = used & (((xyf >> 30) & 1) == 0)
         ncell = mod.nx * mod.ny
         dcan = dcanvas.reshape(B * ncell, -1)[:, col_off:col_off + C]
-        dout = dcan[bidx * ncell + xy].float() * (1 - skipped)[:, None].float()
+        dout = dcan[(slot // MV) * ncell + xy].float() * live[:, None].float()
         grads = torch.autograd.grad(out, params, dout, allow_unused=True)
     return [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]

@@ -153,7 +153,7 @@ struct VoxTab { const int* sorted; const int* xy; const int* start; const int* c
 
 // decorated features of slot `lane` of a pillar (valid iff lane < cnt); h = W1 . f
 __device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxTab& t, int v, int lane, const PillarGeom& g,
-                                       const float* __restrict__ w1s, float (&h)[C1], int& cnt_out, bool& valid_out) {
+                                       const float* __restrict__ w1s, float (&h)[C1], int& cnt_out, bool& valid_out, float (&fo)[8]) {
     const int cnt = t.cnt[v];
     const bool valid = lane < cnt;
     float x = 0.f, y = 0.f, z = 0.f;
@@ -172,6 +172,8 @@ __device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxT
         for (int k = 0; k < 8; ++k) a += w1s[c * 8 + k] * f[k];
         h[c] = valid ? a : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fo[k] = valid ? f[k] : 0.f;
     cnt_out = cnt; valid_out = valid;
 }
 
@@ -186,8 +188,8 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
     for (int c = 0; c < C1; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
-        float h[C1]; int cnt; bool valid;
-        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid);
+        float h[C1]; int cnt; bool valid; float f8[8];
+        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
 #pragma unroll
         for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
     }
@@ -228,7 +230,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
                                                            int max_points, int nslots, const float* __restrict__ w1,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           T* __restrict__ X2) {
+                                                           T* __restrict__ X2, float* __restrict__ F8, int* __restrict__ row_vox,
+                                                           float* __restrict__ row_w) {
     __shared__ float w1s[C1 * 8];
     __shared__ float ss[2 * C1];
     for (int i = threadIdx.x; i < C1 * 8; i += 256) w1s[i] = w1[i];
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
-        float h[C1]; int cnt; bool valid;
-        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid);
+        float h[C1]; int cnt; bool valid; float f8[8];
+        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
         const bool has_pad = cnt < max_points;
         float xm[C1];
 #pragma unroll
@@ -250,7 +253,12 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
         }
         // rows: lane < cnt -> real slot; lane == cnt (if has_pad) -> the representative padded slot
         if (valid || (has_pad && lane == cnt)) {
-            T* dst = X2 + (int64_t)(t.row[v] + lane) * K2;
+            const int64_t row = (int64_t)t.row[v] + lane;
+            // training path: per-row pillar id / BN weight / decorated features (padded representative: zeros, weight P - cnt)
+            row_vox[row] = v; row_w[row] = valid ? 1.f : (float)(max_points - cnt);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) F8[row * 8 + k] = f8[k];
+            T* dst = X2 + row * K2;
 #pragma unroll
             for (int c = 0; c < C1; ++c) { dst[c] = Cvt<T>::from_f(h[c]); dst[C1 + c] = Cvt<T>::from_f(xm[c]); }
         }
@@ -321,7 +329,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Ws {
     int* sorted; int* vox_xy; int* vox_start; int* vox_cnt; int* vox_row; int* nvox; int* totals;
     float* sums1; float* sums2; float* sc1; float* sh1; float* sc2; float* sh2; float* hmax; float* hmin;
-    void* X2; void* H2;
+    void* X2; void* H2; float* F8; int* row_vox; float* row_w;
     size_t bytes;
 };
 
@@ -341,6 +349,7 @@ Ws carve(void* base, const p3_pillar_desc* d) {
     w.vox_xy = (int*)take(nv * 4); w.vox_start = (int*)take(nv * 4); w.vox_cnt = (int*)take(nv * 4); w.vox_row = (int*)take(nv * 4);
     w.nvox = (int*)take((size_t)d->B * 4);
     w.hmax = (float*)take(nv * d->C * 4); w.hmin = (float*)take(nv * d->C * 4);
+    w.F8 = (float*)take(rows * 8 * 4); w.row_w = (float*)take(rows * 4); w.row_vox = (int*)take(rows * 4);
     w.X2 = take(rows * K2 * es);
     w.H2 = take(rows * (size_t)d->C * es);
     w.bytes = off;
@@ -378,6 +387,8 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     e = hipMemsetAsync(w.totals, 0, (char*)w.sc1 - (char*)w.totals, s);
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
+    if (e == hipSuccess) e = hipMemsetAsync(w.F8, 0, (char*)w.row_vox - (char*)w.F8, s);
+    if (e == hipSuccess) e = hipMemsetAsync(w.row_vox, 0xFF, rows * 4, s);   // -1 = unused row
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     // zero canvas columns [col_off, col_off + C) of every token row (empty pillars stay exactly 0)
     e = hipMemset2DAsync((char*)out + (size_t)d->out_col_off * es, (size_t)d->out_ld * es, 0, (size_t)d->C * es,
@@ -403,9 +414,9 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
                        bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, (float*)nullptr, (float*)nullptr);
     P3_LAUNCH_CHECK();
     if (d->dtype == P3_BF16)
-        hipLaunchKernelGGL((pfn_l1_apply_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (bf16_t*)w.X2);
+        hipLaunchKernelGGL((pfn_l1_apply_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (bf16_t*)w.X2, w.F8, w.row_vox, w.row_w);
     else
-        hipLaunchKernelGGL((pfn_l1_apply_kernel<float>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (float*)w.X2);
+        hipLaunchKernelGGL((pfn_l1_apply_kernel<float>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (float*)w.X2, w.F8, w.row_vox, w.row_w);
     P3_LAUNCH_CHECK();
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
@@ -431,12 +442,13 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
 }
 
 // byte offsets of the workspace sections (for the training path, which re-reads the pillar tables in backward)
-extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[10]*/) {
+extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[13]*/) {
     P3_CHECK(d && off, P3_EINVAL, "p3_pillar_stem_layout: null pointer");
     char* base = (char*)256;   // any non-null base: only differences are used
     Ws w = carve(base, d);
     off[0] = (char*)w.sorted - base; off[1] = (char*)w.vox_xy - base; off[2] = (char*)w.vox_start - base;
     off[3] = (char*)w.vox_cnt - base; off[4] = (char*)w.vox_row - base; off[5] = (char*)w.nvox - base;
     off[6] = (char*)w.X2 - base; off[7] = (char*)w.H2 - base; off[8] = (char*)w.hmax - base; off[9] = (char*)w.hmin - base;
+    off[10] = (char*)w.F8 - base; off[11] = (char*)w.row_vox - base; off[12] = (char*)w.row_w - base;
     return P3_OK;
 }

@@ -11,6 +11,48 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 A_PLAIN, A_CONV3X3, A_AFFINE_RELU, A_PAIR_AFFINE_RELU = 0, 1, 2, 3
 
 
+class _KernelTimer:
+    """Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline object)."""
+
+    def __init__(self):
+        self.on, self.pending = False, []
+
+    def enable(self):
+        self.on, self.pending = True, []
+
+    def disable(self):
+        self.on = False
+
+    def begin(self):
+        if not self.on:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, e0, name, flop=0.0, nbytes=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream())
+        self.pending.append((name, e0, e1, flop, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, flop, nbytes in self.pending:
+            r = out.setdefault(name, {"ms": 0.0, "n": 0, "flop": 0.0, "bytes": 0.0})
+            r["ms"] += e0.elapsed_time(e1)
+            r["n"] += 1
+            r["flop"] += flop
+            r["bytes"] += nbytes
+        return out
+
+
+KTIMER = _KernelTimer()
+_AMODE_NAMES = {0: "plain", 1: "conv3x3", 2: "affine_relu", 3: "pair_affine_relu"}
+
+
 def dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -84,7 +126,9 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         d.pair_V, d.pair_n = pair_v.data_ptr(), pair_n
     if colsum is not None:
         d.colsum, d.colsumsq = colsum.data_ptr(), colsumsq.data_ptr()
+    ev = KTIMER.begin()
     check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
+    KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K)
     return out
 
 
@@ -146,7 +190,10 @@ def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False
     o = torch.empty((q.shape[0], q.shape[1], q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if need_lse else None
     d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse)
+    ev = KTIMER.begin()
     check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
+    KTIMER.end(ev, f"attn_fwd_kernel<{'bf16' if d.dtype == BF16 else 'f32'},{d.head_dim}>",
+               4.0 * d.B * d.H * d.Lq * d.Lk * d.head_dim * (0.5 if causal else 1.0))
     return (o, lse) if need_lse else o
 
 
@@ -195,15 +242,17 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
           "p3_pillar_stem")
     if not want_tables:
         return out
-    off = (c_int64 * 10)()
+    off = (c_int64 * 13)()
     check(L.p3_pillar_stem_layout(byref(d), off), "p3_pillar_stem_layout")
     nv, npts = B * max_voxels, int(d.total_points)
+    rows = npts + nv
 
-    def i32(o, n):
-        return ws[o:o + 4 * n].view(torch.int32).clone()
+    def sect(o, n, dtype):
+        return ws[o:o + 4 * n].view(dtype).clone()
 
-    tables = dict(sorted=i32(off[0], max(npts, 1)), xy=i32(off[1], nv), start=i32(off[2], nv), cnt=i32(off[3], nv), nvox=i32(off[5], B),
-                  MV=max_voxels)
+    # static-shape views of the forward's tables (fixed capacity: graph-capturable, no host sync)
+    tables = dict(xy=sect(off[1], nv, torch.int32), nvox=sect(off[5], B, torch.int32), F8=sect(off[10], rows * 8, torch.float32).view(rows, 8),
+                  row_vox=sect(off[11], rows, torch.int32), row_w=sect(off[12], rows, torch.float32), MV=max_voxels)
     return out, tables
 
 
