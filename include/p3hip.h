@@ -221,6 +221,25 @@ int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gsca
 int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1,
              float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow, void* stream);
 
+/* ScoreNet backward (model_pix2poly.py:69-112) without the [B,512,N,N] pair tensor; see csrc/scorenet_bwd.hip.
+ * p3_gemm_tn_ex: weight gradient with a generated B operand  B' = relu((B (+V)) * b_scale + b_shift)  (b_mode = P3_A_*). */
+int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
+                  const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, void* stream);
+/* tail (dS != NULL, C = 64): dS [B,N,N] (read transposed if transpose) -> dHd = dz*scale, acc = [dscale(C) | dshift(C) | dw4(C) | db4]
+ * matrix (dA != NULL, C = 128): dA [R,C] -> dHd = dA*(z>0)*scale (may alias dA), acc = [dscale(C) | dshift(C)] */
+int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean, const float* w4,
+                      void* dHd, float* acc, int64_t R, int C, int N, int transpose, int dtype, void* stream);
+/* BatchNorm backward through scale/shift and (train mode) the batch statistics: d(pre) = direct + a[c] + b[c]*pre.
+ * `dscale` is the CENTRED sum  sum dz*(pre - mean)  as accumulated by p3_row_affine_bwd / p3_pair_bwd (acc[0:C]) */
+int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd, float count,
+                     int training, int C, float* dgamma, float* dbeta, float* a, float* b, void* stream);
+int p3_affine_fix(void* dH, const void* H, const float* a, const float* b, int64_t R, int C, int dtype, void* stream);
+/* pair grid: dA [B*N*N, C] -> dU (written), dV (+=, zero-filled by the caller) [B*N, C] fp32, acc = [dscale(C) | dshift(C)] */
+int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
+                int B, int N, int C, int dtype, void* stream);
+int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,7 @@ def pfn(voxels, num_points, coors, sd, prefix, voxel_xy=(8.0, 8.0), range_min_xy
     BN eps 1e-3, momentum 0.01; BN statistics include the zero padded slots; the max runs over
     all `max_points` slots including padded ones.
     """
+    voxels = voxels.to(sd[prefix + "pfn_layers.0.linear.weight"].dtype)   # float64 weights => float64 ground-truth runs
     V, P, _ = voxels.shape
     mean = voxels.sum(1, keepdim=True) / num_points.to(voxels.dtype).view(-1, 1, 1)
     f_cluster = voxels - mean

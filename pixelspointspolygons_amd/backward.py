@@ -25,31 +25,62 @@ def _bn_train_affine(x2d, gamma, beta, eps, count=None, weights=None):
     return scale, beta - mean * scale
 
 
-# ------------------------------------------------------------------------------------------------ ScoreNet
+# ------------------------------------------------------------------------------------------------ ScoreNet (hand-written HIP)
 def scorenet_backward(net, feats, keep, dout, transpose_acc):
-    cd, N = net.cd, net.n_vertices
+    """Native backward over the tensors the forward kept (U, V, H2, H3, BN triples); see csrc/scorenet_bwd.hip."""
+    from . import hip, ops
+    cd, N, training = net.cd, net.n_vertices, net.training
     B, L, D = feats.shape
-    g = dout.transpose(1, 2) if transpose_acc else dout
-    params = list(net.parameters())
-    with torch.enable_grad():
-        f = feats.detach().requires_grad_(True)
-        Fm = f[:, 1:1 + 2 * N].reshape(B, N, 2, D).float().mean(2).to(cd)
-        w1 = net.conv1.weight.reshape(256, 2 * D).to(cd)
-        U = Fm @ w1[:, :D].t() + net.conv1.bias.to(cd)
-        V = Fm @ w1[:, D:].t()
-        h = (U[:, :, None, :] + V[:, None, :, :]).reshape(B * N * N, 256)
-        for conv, bn in ((None, net.bn1), (net.conv2, net.bn2), (net.conv3, net.bn3)):
-            if conv is not None:
-                h = h @ conv.weight.reshape(conv.weight.shape[0], -1).to(cd).t() + conv.bias.to(cd)
-            if net.training:
-                sc, sh = _bn_train_affine(h, bn.weight, bn.bias, bn.eps)
-            else:
-                sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                sh = bn.bias - bn.running_mean * sc
-            h = F.relu(h.float() * sc + sh).to(cd)
-        s = (h.float() @ net.conv4.weight.reshape(-1, 1) + net.conv4.bias).view(B, N, N)
-        grads = torch.autograd.grad(s, [f] + params, g, allow_unused=True)
-    return grads[0], grads[1:]
+    dev = feats.device
+    R = B * N * N
+    F_, U, V, H2, H3 = keep["F"], keep["U"], keep["V"], keep["H2"], keep["H3"]
+    (sc1, sh1, m1, r1), (sc2, sh2, m2, r2), (sc3, sh3, m3, r3) = keep["bn"]
+    cnt = float(R)
+    w2d = lambda conv: conv.weight.reshape(conv.weight.shape[0], -1)
+    f32 = dict(dtype=torch.float32, device=dev)
+    # ---- tail: conv4 + BN3/ReLU
+    acc3 = torch.zeros(3 * 64 + 1, **f32)
+    dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dout.contiguous(), w4=net.conv4.weight.detach().reshape(-1), N=N, transpose=transpose_acc)
+    dw4, db4 = acc3[128:192].view(1, 64, 1, 1), acc3[192:193]
+    dg3, dbt3, a3, b3 = hip.bn_bwd_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training)
+    if training:
+        hip.affine_fix(dH3, H3, a3, b3)
+    # ---- conv3 (+ BN2/ReLU in front of it)
+    dW3 = hip.gemm_tn_ex(dH3, H2, torch.zeros(64, 128, **f32), hip.A_AFFINE_RELU, sc2, sh2)
+    db3 = hip.colsum(dH3)
+    w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
+    dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
+    acc2 = torch.zeros(2 * 128, **f32)
+    dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3)
+    dg2, dbt2, a2, b2 = hip.bn_bwd_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training)
+    if training:
+        hip.affine_fix(dH2, H2, a2, b2)
+    # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
+    dW2 = hip.gemm_tn_ex(dH2, U, torch.zeros(128, 256, **f32), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
+    db2 = hip.colsum(dH2)
+    w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
+    dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
+    acc1 = torch.zeros(2 * 256, **f32)
+    dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
+    dg1, dbt1, a1, b1 = hip.bn_bwd_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training)
+    if training:
+        hip.pair_stats_bwd(U, V, a1, b1, dU, dV, B, N)
+    # ---- conv1 (separable): U = F W1a^T + b1, V = F W1b^T
+    dUc, dVc = hip.cast(dU, cd), hip.cast(dV, cd)
+    F2 = F_.view(B * N, D)
+    dW1 = torch.zeros(256, 2 * D, **f32)
+    hip.gemm_tn(dUc, F2, out=dW1[:, :D])
+    hip.gemm_tn(dVc, F2, out=dW1[:, D:])
+    db1 = hip.colsum(dU)
+    w1t = ops.shadow(net.conv1.weight, cd, key="2dT2", fn=lambda t: torch.cat([t.reshape(256, -1)[:, :D].t(), t.reshape(256, -1)[:, D:].t()], 0))  # [2D, 256]
+    dF = hip.gemm(dUc, w1t[:D], out_dtype=torch.float32)
+    dF = hip.gemm(dVc, w1t[D:], out_dtype=torch.float32, residual=dF)
+    dfeats = hip.pair_mean_bwd(dF, B, L, N, D, feats.dtype)
+    grads = {"conv1.weight": dW1.view(256, 2 * D, 1, 1), "conv1.bias": db1, "bn1.weight": dg1, "bn1.bias": dbt1,
+             "conv2.weight": dW2.view(128, 256, 1, 1), "conv2.bias": db2, "bn2.weight": dg2, "bn2.bias": dbt2,
+             "conv3.weight": dW3.view(64, 128, 1, 1), "conv3.bias": db3, "bn3.weight": dg3, "bn3.bias": dbt3,
+             "conv4.weight": dw4, "conv4.bias": db4}
+    return dfeats, [grads[n] for n, _ in net.named_parameters()]
 
 
 # ------------------------------------------------------------------------------------------------ fusion conv + BN

@@ -109,17 +109,43 @@ template <typename T>
 __global__ void score_out_kernel(const T* __restrict__ H3, const float* __restrict__ sc, const float* __restrict__ sh,
                                  const float* __restrict__ w4, const float* __restrict__ b4, float* __restrict__ out, int B, int N, int C,
                                  int transpose_acc) {
+    // 16 lanes per row (C = 64: 4 channels per lane, one 8/16-byte load), 4 rows per wave pass: fully coalesced
     const int64_t total = (int64_t)B * N * N;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (int64_t)gridDim.x * blockDim.x) {
-        const T* row = H3 + r * C;
-        float a = b4[0];
-        for (int c = 0; c < C; ++c) a += w4[c] * fmaxf(Cvt<T>::to_f(row[c]) * sc[c] + sh[c], 0.f);
-        if (transpose_acc) {
-            const int j = (int)(r % N), i = (int)((r / N) % N);
-            const int64_t b = r / ((int64_t)N * N);
-            out[(b * N + j) * N + i] += a;
-        } else {
-            out[r] = a;
+    const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
+    const int c0 = sub * 4;
+    float w[4], s[4], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w[k] = c0 + k < C ? w4[c0 + k] : 0.f; s[k] = c0 + k < C ? sc[c0 + k] : 0.f; h[k] = c0 + k < C ? sh[c0 + k] : 0.f; }
+    const float bias = b4[0];
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r0 = wave_id * 4; r0 < total; r0 += nwaves * 4) {
+        const int64_t r = r0 + rsel;
+        float a = 0.f;
+        if (r < total) {
+            const T* row = H3 + r * C + c0;
+            float v[4];
+            if constexpr (sizeof(T) == 2) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(row);
+                v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+                v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+            } else {
+                const float4 raw = *reinterpret_cast<const float4*>(row);
+                v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a += w[k] * fmaxf(v[k] * s[k] + h[k], 0.f);
+        }
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+        if (sub == 0 && r < total) {
+            a += bias;
+            if (transpose_acc) {
+                const int j = (int)(r % N), i = (int)((r / N) % N);
+                const int64_t b = r / ((int64_t)N * N);
+                out[(b * N + j) * N + i] += a;
+            } else {
+                out[r] = a;
+            }
         }
     }
 }
@@ -262,6 +288,7 @@ extern "C" int p3_bn_finalize(const float* sums, int C, float count, const float
 extern "C" int p3_score_out(const void* H3, int dtype, const float* scale, const float* shift, const float* w4, const float* b4, float* out,
                             int B, int N, int C, int transpose_accumulate, void* stream) {
     P3_CHECK(H3 && scale && shift && w4 && b4 && out && B > 0, P3_EINVAL, "p3_score_out: bad arguments");
+    P3_CHECK(C == 64, P3_EUNSUP, "p3_score_out: ScoreNet conv3 width must be 64 (model_pix2poly.py:78)");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * N * N;
     DISPATCH_T(dtype, hipLaunchKernelGGL((score_out_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)H3, scale, shift, w4, b4, out, B, N, C, transpose_accumulate),

@@ -15,6 +15,9 @@ constexpr int TN = 128, TK = 128;
 struct TnArgs {
     const void* A; const void* B; float* C;
     int M, N, K, lda, ldb, ldc, rows_per_split, tiles_k;
+    // optional generated B operand (ScoreNet backward): B'[m,k] = relu((B[m',k] (+ V[m'',k])) * b_scale[k] + b_shift[k])
+    int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j)
+    const float* b_scale; const float* b_shift; const void* pair_V; int pair_n;
 };
 
 template <typename T> struct TTr;
@@ -62,7 +65,48 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
             else row = m0 + rt + 8 * i;
             const bool okr = row < m_end;
             ra[i] = (okr && okn) ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * g.lda + coln) : u32x4{0, 0, 0, 0};
-            rb[i] = (okr && okk) ? *reinterpret_cast<const u32x4*>(B + (int64_t)row * g.ldb + colk) : u32x4{0, 0, 0, 0};
+            if (g.b_mode == 0) {
+                rb[i] = (okr && okk) ? *reinterpret_cast<const u32x4*>(B + (int64_t)row * g.ldb + colk) : u32x4{0, 0, 0, 0};
+            } else {
+                u32x4 r = u32x4{0, 0, 0, 0};
+                if (okr && okk) {
+                    int64_t r1 = row, r2 = 0;
+                    if (g.b_mode == P3_A_PAIR_AFFINE_RELU) {
+                        const int n = g.pair_n, nn = n * n;
+                        const int bb = row / nn, p = row - bb * nn, ii = p / n, jj = p - ii * n;
+                        r1 = (int64_t)bb * n + ii; r2 = (int64_t)bb * n + jj;
+                    }
+                    float v[VEC];
+                    const u32x4 x = *reinterpret_cast<const u32x4*>(B + r1 * g.ldb + colk);
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(x[q] << 16); v[2 * q + 1] = __uint_as_float(x[q] & 0xffff0000u); }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(x[q]);
+                    }
+                    if (g.b_mode == P3_A_PAIR_AFFINE_RELU) {
+                        const u32x4 y = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.pair_V) + r2 * g.ldb + colk);
+                        if constexpr (BF) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(y[q] << 16); v[2 * q + 1] += __uint_as_float(y[q] & 0xffff0000u); }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(y[q]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[q] = fmaxf(v[q] * g.b_scale[colk + q] + g.b_shift[colk + q], 0.f);
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[q] = __float_as_uint(v[q]);
+                    }
+                }
+                rb[i] = r;
+            }
         }
     };
     auto store_step = [&](int buf) __attribute__((always_inline)) {
@@ -163,13 +207,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 }  // namespace
 
-extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
+extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
+                             const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, void* stream) {
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
+    P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU, P3_EINVAL, "p3_gemm_tn: b_mode");
+    P3_CHECK(b_mode == 0 || (b_scale && b_shift), P3_EINVAL, "p3_gemm_tn: generated B operand needs b_scale / b_shift");
+    P3_CHECK(b_mode != P3_A_PAIR_AFFINE_RELU || (pair_V && pair_n > 0 && M % (pair_n * pair_n) == 0), P3_ESHAPE, "p3_gemm_tn: pair mode needs V and M == B*n*n");
     P3_CHECK(dtype == P3_F32 || dtype == P3_BF16, P3_EUNSUP, "p3_gemm_tn: dtype");
     const int vec = dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0, P3_EALIGN, "p3_gemm_tn: N, K, lda, ldb must be multiples of 8 (bf16) / 4 (f32)");
     P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, P3_EALIGN, "p3_gemm_tn: 16-byte base alignment");
     TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.b_mode = b_mode; g.b_scale = b_scale; g.b_shift = b_shift; g.pair_V = pair_V; g.pair_n = pair_n;
     const int tiles_n = p3_ceil_div(N, TN);
     g.tiles_k = p3_ceil_div(K, TK);
     const int tiles = tiles_n * g.tiles_k;
@@ -186,6 +235,10 @@ extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, 
     else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 0, s, g);
     P3_LAUNCH_CHECK();
     return P3_OK;
+}
+
+extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
+    return p3_gemm_tn_ex(A, B, C, M, N, K, lda, ldb, ldc, dtype, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream) {

@@ -193,11 +193,15 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
     }
+    // block-level reduction first: one atomic per channel per block (8k waves hammering 64 addresses cost 3 ms)
+    __shared__ float red[4][2 * C1];
 #pragma unroll
     for (int c = 0; c < C1; ++c) {
         const float a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
-        if (lane == 0) { atomicAdd(sums + c, a); atomicAdd(sums + C1 + c, b2); }
+        if (lane == 0) { red[threadIdx.x >> 6][c] = a; red[threadIdx.x >> 6][C1 + c] = b2; }
     }
+    __syncthreads();
+    if (threadIdx.x < 2 * C1) atomicAdd(sums + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // scale/shift from batch statistics (train) or running statistics (eval); updates running stats like torch BatchNorm
@@ -407,7 +411,7 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
     const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
     if (d->training) {
-        hipLaunchKernelGGL(pfn_l1_stats_kernel, dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
+        hipLaunchKernelGGL(pfn_l1_stats_kernel, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
         P3_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, w.sums1, C1, w.totals, (float)d->max_points, 0.f, bn1_gamma, bn1_beta,
@@ -426,9 +430,9 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     if (rc != P3_OK) return rc;
     float* sums2 = d->training ? w.sums2 : nullptr;
     if (d->dtype == P3_BF16)
-        hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     else
-        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     P3_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, s, w.sums2, d->C, w.totals, (float)d->max_points, 0.f, bn2_gamma,
                        bn2_beta, bn2_rmean, bn2_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc2, w.sh2, (float*)nullptr, (float*)nullptr);

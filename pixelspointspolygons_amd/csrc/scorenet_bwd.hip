@@ -1,0 +1,244 @@
+// p3hip ScoreNet backward (models/pix2poly/model_pix2poly.py:69-112), never materialising the [B,512,N,N] pair tensor.
+//
+// The forward keeps, per ScoreNet: U, V [B*N,256] (conv1 split over (i,j)), H2 [R,128], H3 [R,64] (pre-BatchNorm conv
+// outputs, R = B*N*N rows) and the BN (scale, shift, mean, rstd) triples.  Backward chain, all HBM-streaming kernels +
+// MFMA GEMMs (p3_gemm for dA = dH . W, p3_gemm_tn_ex with a generated B operand for dW = dH^T . relu(bn(prev))):
+//   row_affine_bwd<TAIL>   dS -> dH3' = dz3*sc3, d(sc3, sh3, w4, b4)
+//   bn_bwd_coeffs          d(scale, shift) -> d(gamma, beta) and the per-channel (a, b) of the statistics path
+//   affine_fix             dH = dH' + a + b*H                         (gradient through the batch mean / variance)
+//   row_affine_bwd<MAT>    dA -> dH' = dA*(z>0)*sc, d(sc, sh)          (C = 128)
+//   pair_bwd               dA2 [R,256] -> dU, dV [B*N,256], d(sc1, sh1) (sums over j / i of the pair grid)
+//   pair_stats_bwd         closed-form BN1 statistics path into dU, dV
+#include "p3_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        const float4 raw = *reinterpret_cast<const float4*>(p);
+        v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, const float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+        uint2 raw; raw.x = pack_bf2(v[0], v[1]); raw.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = raw;
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// C channels, LPR = C/4 lanes per row, 64/LPR rows per wave pass; every lane owns 4 fixed channels -> register accumulators.
+// TAIL: upstream is a per-row scalar g[r] (dS, optionally transposed) times w4[c];  else upstream is the matrix dA [R,C].
+// Writes dHd = dz * sc (may alias dA).  acc layout: [dsc(C) | dsh(C) | dw4(C) | db4(1)].
+template <typename T, int C, bool TAIL>
+__global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict__ dA, const float* __restrict__ dS, const T* __restrict__ H,
+                                                             const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
+                                                             const float* __restrict__ w4, T* __restrict__ dHd, float* __restrict__ acc,
+                                                             int64_t R, int N, int transpose) {
+    constexpr int LPR = C / 4, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, w = threadIdx.x >> 6;
+    const int c0 = sub * 4;
+    float s[4], h[4], wv[4], mu[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] = sc[c0 + k]; h[k] = sh[c0 + k]; mu[k] = mean[c0 + k]; wv[k] = TAIL ? w4[c0 + k] : 0.f; }
+    float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0}, a_w[4] = {0, 0, 0, 0}, a_b = 0.f;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave_id * RPW; r0 < R; r0 += nwaves * RPW) {
+        const int64_t r = r0 + rsel;
+        if (r < R) {
+            float hv[4], g[4];
+            ld4<T>(H + r * C + c0, hv);
+            if constexpr (TAIL) {
+                int64_t rs = r;
+                if (transpose) { const int64_t nn = (int64_t)N * N, b = r / nn, p = r - b * nn; const int i = (int)(p / N), j = (int)(p - (int64_t)i * N); rs = b * nn + (int64_t)j * N + i; }
+                const float gr = dS[rs];
+                if (sub == 0) a_b += gr;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { g[k] = gr * wv[k]; a_w[k] += gr * fmaxf(hv[k] * s[k] + h[k], 0.f); }
+            } else {
+                ld4<T>(dA + r * C + c0, g);
+            }
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dz = (hv[k] * s[k] + h[k] > 0.f) ? g[k] : 0.f;
+                a_sc[k] += dz * (hv[k] - mu[k]); a_sh[k] += dz;   // centred: sum dz*(H - mean) is what BN backward needs (no cancellation)
+                o[k] = dz * s[k];
+            }
+            st4<T>(dHd + r * C + c0, o);
+        }
+    }
+    // combine the row groups of the wave, then the 4 waves, then one atomic per value per block
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a_sc[k] += __shfl_xor(a_sc[k], o, 64); a_sh[k] += __shfl_xor(a_sh[k], o, 64); if (TAIL) a_w[k] += __shfl_xor(a_w[k], o, 64); }
+        if (TAIL) a_b += __shfl_xor(a_b, o, 64);
+    }
+    __shared__ float red[4][3 * C + 1];
+    if (rsel == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[w][c0 + k] = a_sc[k]; red[w][C + c0 + k] = a_sh[k]; red[w][2 * C + c0 + k] = a_w[k]; }
+        if (sub == 0) red[w][3 * C] = a_b;
+    }
+    __syncthreads();
+    const int nvals = TAIL ? 3 * C + 1 : 2 * C;
+    for (int i = threadIdx.x; i < nvals; i += 256) atomicAdd(acc + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+}
+
+// scale = gamma*rstd, shift = beta - mean*scale, mean = S1/n, var = S2/n - mean^2  ->  dgamma, dbeta and (a, b) such that
+// d(pre-BN value) = direct + a[c] + b[c]*value  is the full train-mode BatchNorm backward.  Eval mode: a = b = 0.
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, float count, int training, int C,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ a, float* __restrict__ b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // dscale here is the CENTRED sum  sum dz*(pre - mean)  (= dscale_raw - dshift*mean, accumulated without cancellation)
+    const float ds = dscale[c], dh = dshift[c], g = gamma[c], m = mean[c], rs = rstd[c];
+    dgamma[c] = ds * rs;
+    dbeta[c] = dh;
+    if (training) {
+        const float dmean = -dh * g * rs;
+        const float drstd = ds * g;
+        const float dvar = -0.5f * drstd * rs * rs * rs;
+        a[c] = (dmean - 2.f * m * dvar) / count;
+        b[c] = 2.f * dvar / count;
+    } else { a[c] = 0.f; b[c] = 0.f; }
+}
+
+template <typename T>
+__global__ void affine_fix_kernel(T* __restrict__ dH, const T* __restrict__ H, const float* __restrict__ a, const float* __restrict__ b,
+                                  int64_t n4, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * 4) % C);
+        float d[4], h[4];
+        ld4<T>(dH + i * 4, d); ld4<T>(H + i * 4, h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] += a[c0 + k] + b[c0 + k] * h[k];
+        st4<T>(dH + i * 4, d);
+    }
+}
+
+// pair grid backward: rows (b,i,j), channel = thread.  Block = (b, chunk of IC rows i): dU rows complete, dV via atomics.
+template <typename T, int IC>
+__global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA, const T* __restrict__ U, const T* __restrict__ V,
+                                                       const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
+                                                       float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C) {
+    const int b = blockIdx.y, i0 = blockIdx.x * IC;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float s = sc[c], h = sh[c], mu = mean[c];
+        float u[IC], au[IC];
+#pragma unroll
+        for (int k = 0; k < IC; ++k) { u[k] = (i0 + k < N) ? Cvt<T>::to_f(U[((int64_t)b * N + i0 + k) * C + c]) : 0.f; au[k] = 0.f; }
+        float a_sc = 0.f, a_sh = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float v = Cvt<T>::to_f(V[((int64_t)b * N + j) * C + c]);
+            float av = 0.f;
+#pragma unroll
+            for (int k = 0; k < IC; ++k) {
+                if (i0 + k < N) {
+                    const float g = Cvt<T>::to_f(dA[(((int64_t)b * N + i0 + k) * N + j) * C + c]);
+                    const float p = u[k] + v;
+                    const float dz = (p * s + h > 0.f) ? g : 0.f;
+                    a_sc += dz * (p - mu); a_sh += dz;
+                    au[k] += dz * s; av += dz * s;
+                }
+            }
+            atomicAdd(dV + ((int64_t)b * N + j) * C + c, av);
+        }
+#pragma unroll
+        for (int k = 0; k < IC; ++k) if (i0 + k < N) dU[((int64_t)b * N + i0 + k) * C + c] = au[k];
+        atomicAdd(acc + c, a_sc); atomicAdd(acc + C + c, a_sh);
+    }
+}
+
+// BN1 statistics were closed-form in U, V: dU[b,i] += N*a + b1*(N*U[b,i] + sum_j V[b,j]), dV symmetric
+template <typename T>
+__global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restrict__ V, const float* __restrict__ a, const float* __restrict__ bco,
+                                      float* __restrict__ dU, float* __restrict__ dV, int N, int C) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float su = 0.f, sv = 0.f;
+        for (int i = 0; i < N; ++i) { su += Cvt<T>::to_f(U[((int64_t)b * N + i) * C + c]); sv += Cvt<T>::to_f(V[((int64_t)b * N + i) * C + c]); }
+        const float ac = (float)N * a[c], bc = bco[c];
+        for (int i = 0; i < N; ++i) {
+            const int64_t o = ((int64_t)b * N + i) * C + c;
+            dU[o] += ac + bc * ((float)N * Cvt<T>::to_f(U[o]) + sv);
+            dV[o] += ac + bc * ((float)N * Cvt<T>::to_f(V[o]) + su);
+        }
+    }
+}
+
+inline int grid_rows(int64_t rows, int rows_per_block) {
+    int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean, const float* w4,
+                                 void* dHd, float* acc, int64_t R, int C, int N, int transpose, int dtype, void* stream) {
+    P3_CHECK(H && scale && shift && mean && dHd && acc && R > 0, P3_EINVAL, "p3_row_affine_bwd: bad arguments");
+    P3_CHECK((dS != nullptr) != (dA != nullptr), P3_EINVAL, "p3_row_affine_bwd: exactly one of dS (tail) / dA (matrix)");
+    P3_CHECK(dS ? (C == 64 && w4) : (C == 128), P3_EUNSUP, "p3_row_affine_bwd: tail needs C = 64, matrix mode C = 128");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_rows(R, 64)), b(256);
+    if (dS) {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 64, true>), g, b, 0, s, nullptr, dS, (const bf16_t*)H, scale, shift, mean, w4, (bf16_t*)dHd, acc, R, N, transpose);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 64, true>), g, b, 0, s, nullptr, dS, (const float*)H, scale, shift, mean, w4, (float*)dHd, acc, R, N, transpose);
+    } else {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 128, false>), g, b, 0, s, (const bf16_t*)dA, nullptr, (const bf16_t*)H, scale, shift, mean, nullptr, (bf16_t*)dHd, acc, R, N, 0);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 128, false>), g, b, 0, s, (const float*)dA, nullptr, (const float*)H, scale, shift, mean, nullptr, (float*)dHd, acc, R, N, 0);
+    }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd, float count,
+                                int training, int C, float* dgamma, float* dbeta, float* a, float* b, void* stream) {
+    P3_CHECK(dscale && dshift && gamma && mean && rstd && dgamma && dbeta && a && b && C > 0, P3_EINVAL, "p3_bn_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, dscale, dshift, gamma, mean, rstd, count, training, C,
+                       dgamma, dbeta, a, b);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_affine_fix(void* dH, const void* H, const float* a, const float* b, int64_t R, int C, int dtype, void* stream) {
+    P3_CHECK(dH && H && a && b && R > 0 && C % 4 == 0, P3_EINVAL, "p3_affine_fix: bad arguments");
+    const int64_t n4 = R * C / 4;
+    int64_t g = (n4 + 255) / 256; if (g > 8192) g = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((affine_fix_kernel<bf16_t>), dim3((int)g), dim3(256), 0, s, (bf16_t*)dH, (const bf16_t*)H, a, b, n4, C);
+    else hipLaunchKernelGGL((affine_fix_kernel<float>), dim3((int)g), dim3(256), 0, s, (float*)dH, (const float*)H, a, b, n4, C);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
+                           int B, int N, int C, int dtype, void* stream) {
+    P3_CHECK(dA && U && V && scale && shift && mean && dU && dV && acc && B > 0, P3_EINVAL, "p3_pair_bwd: bad arguments");
+    constexpr int IC = 16;
+    dim3 g((N + IC - 1) / IC, B), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_bwd_kernel<bf16_t, IC>), g, b, 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift, mean, dU, dV, acc, N, C);
+    else hipLaunchKernelGGL((pair_bwd_kernel<float, IC>), g, b, 0, s, (const float*)dA, (const float*)U, (const float*)V, scale, shift, mean, dU, dV, acc, N, C);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
+                                 void* stream) {
+    P3_CHECK(U && V && a && b && dU && dV && B > 0, P3_EINVAL, "p3_pair_stats_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_stats_bwd_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, a, b, dU, dV, N, C);
+    else hipLaunchKernelGGL((pair_stats_bwd_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)U, (const float*)V, a, b, dU, dV, N, C);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}

@@ -13,9 +13,9 @@ __device__ __forceinline__ float lse_wave(float mx_local, float (&vals)[8], int 
     const float mx = wave_max(mx_local);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (k < cnt) s += expf(vals[k] - mx);
+    for (int k = 0; k < 8; ++k) if (k < cnt) s += __expf(vals[k] - mx);   // arguments <= 0: v_exp_f32 path, rel. error ~1e-7
     s = wave_sum(s);
-    return mx + logf(s);
+    return mx + __logf(s);
 }
 
 __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
                 for (int c = 0; c < SK_MAXC; ++c) {
                     const int j = lane + 64 * c;
                     if (j < N1) {
-                        const float q = expf(Z[i * N1 + j] + ui + vt[j] - (j < n ? norm : b_last)) * dv[j];
+                        const float q = __expf(Z[i * N1 + j] + ui + vt[j] - (j < n ? norm : b_last)) * dv[j];
                         dZ[k][c] -= q; acc += q;
                     }
                 }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
                 for (int k = 0; k < SK_MAXK; ++k) {
                     const int i = w + 16 * k;
                     if (i < M1) {
-                        const float r = expf(Z[i * N1 + j] + vj + ut[i] - (i < m ? norm : a_last)) * du[i];
+                        const float r = __expf(Z[i * N1 + j] + vj + ut[i] - (i < m ? norm : a_last)) * du[i];
                         dZ[k][c] -= r; acc += r;
                     }
                 }

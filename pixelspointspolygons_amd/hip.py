@@ -482,3 +482,49 @@ def bce_loss_bwd(p, y, gscale):
 def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, shadow=None):
     check(lib().p3_adamw(ptr(params), ptr(grads), ptr(m), ptr(v), c_int64(params.numel()), ptr(hyper), c_float(beta1), c_float(beta2),
                          c_float(eps), c_float(wd), c_float(grad_scale), ptr(shadow), stream()), "p3_adamw")
+
+
+# ------------------------------------------------------------------------------------------ ScoreNet backward
+def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=None):
+    M_ = a.shape[0] if M is None else M
+    N, K = a.shape[1], b.shape[1]
+    check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
+                              c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
+                              stream()), "p3_gemm_tn_ex")
+    return out
+
+
+def row_affine_bwd(H, scale, shift, mean, acc, *, dA=None, dS=None, w4=None, N=0, transpose=False, out=None):
+    R, C = H.shape
+    out = out if out is not None else torch.empty_like(H)
+    check(lib().p3_row_affine_bwd(ptr(dA), ptr(dS), ptr(H), ptr(scale), ptr(shift), ptr(mean), ptr(w4), ptr(out), ptr(acc), c_int64(R), c_int(C), c_int(N),
+                                  c_int(int(transpose)), c_int(dt(H)), stream()), "p3_row_affine_bwd")
+    return out
+
+
+def bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
+    C = gamma.shape[0]
+    o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    check(lib().p3_bn_bwd_coeffs(ptr(dscale), ptr(dshift), ptr(gamma), ptr(mean), ptr(rstd), c_float(count), c_int(int(training)), c_int(C),
+                                 ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), stream()), "p3_bn_bwd_coeffs")
+    return o[0], o[1], o[2], o[3]
+
+
+def affine_fix(dH, H, a, b):
+    R, C = H.shape
+    check(lib().p3_affine_fix(ptr(dH), ptr(H), ptr(a), ptr(b), c_int64(R), c_int(C), c_int(dt(H)), stream()), "p3_affine_fix")
+    return dH
+
+
+def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
+    C = U.shape[1]
+    dU = torch.empty((B * N, C), dtype=torch.float32, device=U.device)
+    dV = torch.zeros((B * N, C), dtype=torch.float32, device=U.device)
+    check(lib().p3_pair_bwd(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),
+                            c_int(dt(U)), stream()), "p3_pair_bwd")
+    return dU, dV
+
+
+def pair_stats_bwd(U, V, a, b, dU, dV, B, N):
+    check(lib().p3_pair_stats_bwd(ptr(U), ptr(V), ptr(a), ptr(b), ptr(dU), ptr(dV), c_int(B), c_int(N), c_int(U.shape[1]), c_int(dt(U)),
+                                  stream()), "p3_pair_stats_bwd")
