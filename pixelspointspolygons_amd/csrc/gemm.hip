@@ -15,6 +15,7 @@ struct GemmArgs {
     const void* A; const void* W; void* C;
     p3_gemm_desc d;
     int tiles_m, tiles_n;
+    int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
 };
 
 constexpr int BM = 128, BN = 128;
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // rows handled per thread per operand per stage
     constexpr int ROWS_PER_PASS = 256 / (BK / VEC);  // bf16: 32, f32: 64
     constexpr int NPASS = BM / ROWS_PER_PASS;        // bf16: 4,  f32: 2
-    __shared__ __attribute__((aligned(16))) T lds[4 * LDSE];
+    constexpr int LDS_BYTES = (4 * LDSE * (int)sizeof(T) > 128 * 132 * 4) ? 4 * LDSE * (int)sizeof(T) : 128 * 132 * 4;
+    __shared__ __attribute__((aligned(16))) T lds[LDS_BYTES / sizeof(T)];
 
     const p3_gemm_desc& d = g.d;
     const T* A = reinterpret_cast<const T*>(g.A);
@@ -220,14 +222,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    TO* C = reinterpret_cast<TO*>(g.C);
-    TO* aux = reinterpret_cast<TO*>(d.aux);
-    const bool has_res = d.residual != nullptr;
-    const bool res_bf = d.dtype_res == P3_BF16;
+    // ---- epilogue: accumulators (+bias) -> LDS as fp32 [128][132] -> whole 8-element row chunks per thread ----------
+    // A row-per-lane epilogue would issue 64 two-byte stores and 64 dependent residual loads per thread (measured: the
+    // epilogue, not the MFMA loop, bounded the K <= 1536 GEMMs of this path); staging through the now idle operand LDS
+    // makes every residual load / aux store / output store a 16-byte access (guide T21 idea, done through LDS).
+    constexpr int EP = 132;
+    float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = tn * BN + wn * 64 + j * 32 + l31;
+        const int cl = wn * 64 + j * 32 + l31;
+        const int col = tn * BN + cl;
         const bool cok = col < d.N;
         const float bias = (d.bias && cok) ? d.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
@@ -235,24 +239,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = tm * BM + wm * 64 + i * 32 + crow32(r, hi);
-                if (row < d.M && cok) {
-                    float v = acc[i][j][r] + bias;
-                    s1 += v; s2 += v * v;
-                    if (aux) aux[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
-                    if (d.act == P3_ACT_GELU) v = gelu_erf(v);
-                    else if (d.act == P3_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (has_res) {
-                        const int64_t ri = (int64_t)row * d.ldr + col;
-                        v += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
-                    }
-                    C[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
-                }
+                const int rl = wm * 64 + i * 32 + crow32(r, hi);
+                const float v = acc[i][j][r] + bias;
+                stage[rl * EP + cl] = v;
+                if (tm * BM + rl < d.M && cok) { s1 += v; s2 += v * v; }
             }
         }
         if (d.colsum) {
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
             if (hi == 0 && cok) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+        }
+    }
+    __syncthreads();
+    TO* C = reinterpret_cast<TO*>(g.C);
+    TO* aux = reinterpret_cast<TO*>(d.aux);
+    const bool has_res = d.residual != nullptr;
+    const bool res_bf = d.dtype_res == P3_BF16;
+    const int act = d.act;
+#pragma unroll 2
+    for (int c = 0; c < 8; ++c) {
+        const int id = tid + 256 * c;
+        const int rl = id >> 4, cl = (id & 15) * 8;
+        const int row = tm * BM + rl, col = tn * BN + cl;
+        if (row >= d.M || col >= d.N) continue;
+        float v[8];
+        {
+            const float4 v0 = *reinterpret_cast<const float4*>(stage + rl * EP + cl);
+            const float4 v1 = *reinterpret_cast<const float4*>(stage + rl * EP + cl + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
+        const int64_t co = (int64_t)row * d.ldc + col;
+        if (g.vec_epi && col + 8 <= d.N) {
+            if (aux) {
+                if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+            }
+            if (act == P3_ACT_GELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+            } else if (act == P3_ACT_RELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (has_res) {
+                const int64_t ro = (int64_t)row * d.ldr + col;
+                if (res_bf) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.residual) + ro);
+                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+                } else {
+                    const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro);
+                    const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro + 4);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+            }
+            if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(C + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+        } else {
+            for (int k = 0; k < 8 && col + k < d.N; ++k) {
+                float x = v[k];
+                if (aux) aux[co + k] = Cvt<TO>::from_f(x);
+                if (act == P3_ACT_GELU) x = gelu_erf(x);
+                else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
+                if (has_res) {
+                    const int64_t ri = (int64_t)row * d.ldr + col + k;
+                    x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
+                }
+                C[co + k] = Cvt<TO>::from_f(x);
+            }
         }
     }
 }
@@ -296,6 +351,12 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     g.A = A; g.W = W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
+    {
+        const int vo = d->dtype_out == P3_BF16 ? 8 : 4;     // elements per 16 bytes
+        bool ok = (d->ldc % vo == 0) && ((uintptr_t)C % 16 == 0) && (!d->aux || (uintptr_t)d->aux % 16 == 0);
+        if (d->residual) { const int vr = d->dtype_res == P3_BF16 ? 8 : 4; ok = ok && (d->ldr % vr == 0) && ((uintptr_t)d->residual % 16 == 0); }
+        g.vec_epi = ok ? 1 : 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype_in == P3_BF16) return d->dtype_out == P3_BF16 ? launch_mode<bf16_t, bf16_t>(g, s) : launch_mode<bf16_t, float>(g, s);
     return d->dtype_out == P3_BF16 ? launch_mode<float, bf16_t>(g, s) : launch_mode<float, float>(g, s);

@@ -193,9 +193,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     }
 }
 
-// column sums of a [M, N] matrix (bias gradients, positional-embedding gradients): out[c] += sum_m x[m, c]
+// column sums of a [M, N] matrix (bias / positional-embedding gradients): out[c] += sum_m x[m, c]
+// block = 64 column-quads x 4 row lanes: 8/16-byte coalesced loads, register accumulation, LDS fold, one atomic per column per block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c0 = (blockIdx.y * 64 + lane) * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < N) {
+        for (int64_t r = r0 + ry; r < r1; r += 4) {
+            const T* p = x + r * ld + c0;
+            if constexpr (sizeof(T) == 2) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(p);
+                a[0] += __uint_as_float(raw.x << 16); a[1] += __uint_as_float(raw.x & 0xffff0000u);
+                a[2] += __uint_as_float(raw.y << 16); a[3] += __uint_as_float(raw.y & 0xffff0000u);
+            } else {
+                const float4 raw = *reinterpret_cast<const float4*>(p);
+                a[0] += raw.x; a[1] += raw.y; a[2] += raw.z; a[3] += raw.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[ry][lane * 4 + k] = a[k];
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// scalar fallback for N / ld not a multiple of 4
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     for (int c = threadIdx.x + blockIdx.y * 256; c < N; c += 256 * gridDim.y) {
@@ -243,13 +273,20 @@ extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, 
 
 extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream) {
     P3_CHECK(x && out && M >= 0 && N > 0, P3_EINVAL, "p3_colsum: bad arguments");
+    P3_CHECK(dtype == P3_BF16 || dtype == P3_F32, P3_EUNSUP, "p3_colsum: dtype");
     if (M == 0) return P3_OK;
-    const int rpb = M > 65536 ? 256 : (M > 4096 ? 64 : 16);
-    dim3 grid(p3_ceil_div(M, rpb), N > 1024 ? 4 : 1), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
-    else if (dtype == P3_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
-    else { p3_set_error("p3_colsum: dtype"); return P3_EUNSUP; }
+    const int es = dtype == P3_BF16 ? 2 : 4;
+    const bool vec = (N % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)x % (4 * es) == 0);
+    const int rpb = M > 16384 ? 128 : (M > 2048 ? 32 : 8);
+    dim3 grid(p3_ceil_div(M, rpb), p3_ceil_div(N, 256)), block(256);
+    if (vec) {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
+        else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
+    } else {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
+        else hipLaunchKernelGGL((colsum_scalar_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
+    }
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
