@@ -80,7 +80,12 @@ class FlatAdamW:
         self.lr_lambda = lambda step: 1.0
         # gradient buckets for the data-parallel all-reduce (in arena order)
         nb = max(1, int(bucket_mb * (1 << 20) // 4))
-        self.buckets = [(s, min(total, s + nb)) for s in range(0, total, nb)]
+        self.buckets, start = [], 0          # whole parameters per bucket: a bucket is complete when its parameters are
+        for i, o in enumerate(offs):
+            end = offs[i + 1] if i + 1 < len(offs) else total
+            if end - start >= nb or i + 1 == len(offs):
+                self.buckets.append((start, end))
+                start = end
 
     def set_linear_schedule(self, num_training_steps, warmup_frac=0.05):
         """transformers.get_linear_schedule_with_warmup as used at trainer_pix2poly.py:62-77."""
