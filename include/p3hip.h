@@ -203,7 +203,8 @@ int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, vo
 /* dpre = dy * act'(.)  (GELU: saved = pre-activation; ReLU: saved = output) */
 int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act, void* stream);
 int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream);
-int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift,
+/* dscale is the centred sum  sum dz*(src - mean)  when mean != NULL (feeds p3_bn_bwd_coeffs) */
+int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* mean,
                            void* dsrc, float* dscale, float* dshift, int B, int np, int D, void* stream);
 int p3_pool_pos_bwd(const void* dout, int dtype_dout, void* dy, int dtype_dy, int B, int np, int Din, int Dout, void* stream);
 int p3_pair_mean_bwd(const float* dF, void* dfeats, int dtype, int B, int L, int N, int D, int accumulate, void* stream);

@@ -200,38 +200,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
         }
-        // ---- scale, bias, masks, online softmax ----
+        // ---- online softmax in the log2 domain: p = exp2(s*c - m), c = scale*log2(e); m_run, lse bookkeeping in log2 units ----
+        // A tile that needs no masking (entirely inside [0, Lk), entirely at or below the causal diagonal of this wave's
+        // first query) and has no key bias takes the short VALU path: max, one fma + one v_exp_f32 per score.
+        const float c = d.scale * 1.4426950408889634f;
+        const bool full = (kv0 + KT <= d.Lk) && (!d.causal || kv0 + KT - 1 <= qblk + wave * 32) && !kbias;
         float mx = -INFINITY;
+        if (full) {
 #pragma unroll
-        for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + h2 * 32 + crow32(r, hi);
-                float s = sacc[h2][r] * d.scale;
-                if (kbias) s += kbias[kv < d.Lk ? kv : d.Lk - 1];
-                if (kv >= d.Lk || (d.causal && kv > q)) s = -INFINITY;
-                sacc[h2][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[h2][r]);
+            mx *= c;                                      // c > 0: max commutes with the scaling
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + h2 * 32 + crow32(r, hi);
+                    float s2 = sacc[h2][r] * c;
+                    if (kbias) s2 += kbias[kv < d.Lk ? kv : d.Lk - 1] * 1.4426950408889634f;
+                    if (kv >= d.Lk || (d.causal && kv > q)) s2 = -INFINITY;
+                    sacc[h2][r] = s2;
+                    mx = fmaxf(mx, s2);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);
         float psum = 0.f;
+        if (full) {
 #pragma unroll
-        for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(sacc[h2][r] - m_use);
-                sacc[h2][r] = p;
-                psum += p;
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[h2][r], c, -m_use));
+                    sacc[h2][r] = p;
+                    psum += p;
+                }
+        } else {
 #pragma unroll
-        for (int j = 0; j < NDJ; ++j)
+            for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[h2][r] - m_use);
+                    sacc[h2][r] = p;
+                    psum += p;
+                }
+        }
+        // rescale the running state only when some row's maximum moved (wave-uniform test; alpha == 1 exactly otherwise)
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            l_run *= alpha;
+#pragma unroll
+            for (int j = 0; j < NDJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
 
         // ---- O^T += V^T . P^T ----
         if constexpr (BF) {
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
-        if (d.lse && hi == 0) d.lse[((int64_t)b * d.H + h) * d.Lq + q] = m_run + __logf(l_tot);
+        if (d.lse && hi == 0) d.lse[((int64_t)b * d.H + h) * d.Lq + q] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
     }
 }
 

@@ -43,14 +43,14 @@ __global__ void embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __rest
 // backward of tokens_assemble: dsrc = dz * scale (or dx), dscale += sum dz*src, dshift += sum dz, with dz = dx * (src*scale+shift > 0)
 template <typename TS>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const TS* __restrict__ src, int src_ld,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                                                            TS* __restrict__ dsrc, float* __restrict__ dscale, float* __restrict__ dshift,
                                                            int B, int np, int D, int rows_per_block) {
     const int64_t rows = (int64_t)B * np;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (int c = threadIdx.x; c < D; c += 256) {
-        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f, mu = mean ? mean[c] : 0.f;   // centred sum if mean given
         float a1 = 0.f, a2 = 0.f;
         for (int64_t r = r0; r < r1; ++r) {
             const int64_t b = r / np, p = r - b * np;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
             if (scale) {
                 const float s = Cvt<TS>::to_f(src[r * src_ld + c]);
                 if (s * sc + sh <= 0.f) g = 0.f;
-                a1 += g * s; a2 += g;
+                a1 += g * (s - mu); a2 += g;
                 g *= sc;
             }
             dsrc[r * D + c] = Cvt<TS>::from_f(g);
@@ -138,15 +138,15 @@ extern "C" int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tok
     return P3_OK;
 }
 
-extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift,
+extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* mean,
                                       void* dsrc, float* dscale, float* dshift, int B, int np, int D, void* stream) {
     P3_CHECK(dx && src && dsrc && B > 0, P3_EINVAL, "p3_tokens_assemble_bwd: bad arguments");
     P3_CHECK(!scale || (shift && dscale && dshift), P3_EINVAL, "p3_tokens_assemble_bwd: scale needs shift/dscale/dshift");
     hipStream_t s = (hipStream_t)stream;
     const int rpb = 64;
     dim3 g(p3_ceil_div((int64_t)B * np, rpb)), b(256);
-    if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb);
-    else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, (float*)dsrc, dscale, dshift, B, np, D, rpb);
+    if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, mean, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb);
+    else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, mean, (float*)dsrc, dscale, dshift, B, np, D, rpb);
     else { p3_set_error("p3_tokens_assemble_bwd: dtype"); return P3_EUNSUP; }
     P3_LAUNCH_CHECK();
     return P3_OK;

@@ -48,8 +48,8 @@ class EarlyFusionViT(nn.Module):
             if torch.rand(1).item() <= p:
                 canvas = _zero_lidar(canvas, D)
         conv, bn = self.fusion_layer[0], self.fusion_layer[1]
-        pre, scale, shift = _FusionConvBN.apply(canvas, conv.weight, conv.bias, bn.weight, bn.bias, self, B)
-        return self.vit.forward_tokens(pre, B, scale=scale, shift=shift)
+        pre, scale, shift, mean = _FusionConvBN.apply(canvas, conv.weight, conv.bias, bn.weight, bn.bias, self, B)
+        return self.vit.forward_tokens(pre, B, scale=scale, shift=shift, mean=mean)
 
     def forward(self, x_image, x_lidar):
         y = self.fused_tokens(x_image, x_lidar)
@@ -79,13 +79,39 @@ class _FusionConvBN(torch.autograd.Function):
                                                    bn.eps, bn.momentum, training, save=True)
         if training:
             bn.num_batches_tracked += 1
-        ctx.save_for_backward(canvas, w, b, gamma, beta)
+        ctx.save_for_backward(canvas, pre, w, gamma, mean, rstd)
         ctx.mod, ctx.B = mod, B
-        return pre, scale, shift
+        ctx.mark_non_differentiable(mean)
+        return pre, scale, shift, mean
 
     @staticmethod
-    def backward(ctx, dpre, dscale, dshift):
-        from .backward import fusion_conv_bn_backward
-        canvas, w, b, gamma, beta = ctx.saved_tensors
-        dc, dw, db, dg, dbt = fusion_conv_bn_backward(ctx.mod, canvas, w, b, gamma, beta, ctx.B, dpre, dscale, dshift)
-        return dc, dw, db, dg, dbt, None, None
+    def backward(ctx, dpre, dscC, dshift, _dmean):
+        """Hand-written backward: BN through scale/shift/statistics (centred sums), conv weight gradient = 9 shifted TN GEMMs over
+        zero-bordered copies, conv input gradient = implicit-GEMM conv with the flipped / transposed kernel."""
+        canvas, pre, w, gamma, mean, rstd = ctx.saved_tensors
+        mod, B = ctx.mod, ctx.B
+        cd, g, D = mod.cd, mod.g, mod.D
+        M = B * g * g
+        dpre = dpre.contiguous()
+        dg, dbt, a, b = hip.bn_bwd_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training)
+        if mod.training:
+            hip.affine_fix(dpre, pre, a, b)
+        db = hip.colsum(dpre)
+        # weight gradient: dW[co, tap, ci] = sum_rows dpre[r, co] * canvas[r + shift(tap), ci] in the zero-bordered row space
+        P = g + 2
+        dp = torch.zeros((B, P, P, D), dtype=cd, device=dpre.device)
+        dp[:, 1:g + 1, 1:g + 1] = dpre.view(B, g, g, D)
+        cp = torch.zeros((B, P, P, 2 * D), dtype=cd, device=dpre.device)
+        cp[:, 1:g + 1, 1:g + 1] = canvas.view(B, g, g, 2 * D)
+        dp2, cp2 = dp.view(B * P * P, D), cp.view(B * P * P, 2 * D)
+        R = B * P * P
+        dW2 = torch.zeros((D, 9 * 2 * D), dtype=torch.float32, device=dpre.device)
+        for t in range(9):
+            s = (t // 3 - 1) * P + (t % 3 - 1)
+            r0, r1 = max(0, -s), R - max(0, s)
+            hip.gemm_tn(dp2[r0:r1], cp2[r0 + s:r1 + s], out=dW2[:, t * 2 * D:(t + 1) * 2 * D])
+        dw = dW2.view(D, 3, 3, 2 * D).permute(0, 3, 1, 2).contiguous()
+        # input gradient: correlation with the flipped kernel, [Ci, (ky', kx', co)]
+        wf = ops.shadow(w, cd, key="flipT", fn=lambda t_: t_.flip(2, 3).permute(1, 2, 3, 0).reshape(t_.shape[1], -1))
+        dcanvas = hip.gemm(dpre, wf, a_mode=hip.A_CONV3X3, conv=(B, g, g, D), lda=D, out_dtype=cd).view(B, g * g, 2 * D)
+        return dcanvas, dw, db, dg, dbt, None, None

@@ -415,12 +415,12 @@ def embed_tokens_bwd(dx, tokens, emb_shape, pos_shape):
     return demb, dpos
 
 
-def tokens_assemble_bwd(dx, tok, scale, shift, B, np_, D, src_ld):
+def tokens_assemble_bwd(dx, tok, scale, shift, B, np_, D, src_ld, mean=None):
     dsrc = torch.empty((B * np_, D), dtype=tok.dtype, device=dx.device)
     dscale = torch.zeros(D, dtype=torch.float32, device=dx.device) if scale is not None else None
     dshift = torch.zeros(D, dtype=torch.float32, device=dx.device) if scale is not None else None
     check(lib().p3_tokens_assemble_bwd(ptr(dx.contiguous()), ptr(tok), c_int(tok.stride(-2) if src_ld is None else src_ld), c_int(dt(tok)),
-                                       ptr(scale), ptr(shift), ptr(dsrc), ptr(dscale), ptr(dshift), c_int(B), c_int(np_), c_int(D), stream()),
+                                       ptr(scale), ptr(shift), ptr(mean), ptr(dsrc), ptr(dscale), ptr(dshift), c_int(B), c_int(np_), c_int(D), stream()),
           "p3_tokens_assemble_bwd")
     return dsrc, dscale, dshift
 

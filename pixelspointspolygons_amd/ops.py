@@ -14,6 +14,8 @@ from . import hip
 _shadow_cache = {}
 _registered = {}     # id(param) -> (param, bf16 view of the optimizer's shadow arena; refreshed by the AdamW kernel itself)
 _epoch = [0]         # bumped by the optimizer: parameters changed behind autograd's back (flat arena update)
+DIRECT_GRAD = [False]   # set by FlatAdamW: weight / bias / LayerNorm gradients are accumulated straight into the flat gradient
+                        # arena by the split-M atomics of the TN GEMM / colsum kernels (no zero-fill, no AccumulateGrad add pass)
 
 
 def register_shadow(p, view):
@@ -72,6 +74,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows):
         w = shadow(weight, cd)
+        ctx.bias_param = bias
         if rows is not None:
             w = w[rows[0]:rows[1]]
             bias = bias[rows[0]:rows[1]] if bias is not None else None
@@ -114,6 +117,17 @@ class _Linear(torch.autograd.Function):
             wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
             wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
             dx = hip.gemm(dpre, wt, out_dtype=cd).view(ctx.xshape)
+        direct = DIRECT_GRAD[0] and weight.grad is not None and dpre.shape[1] == n_true
+        bias_p = ctx.bias_param
+        if direct:
+            r0, r1 = rows if rows is not None else (0, weight.shape[0])
+            if ctx.needs_input_grad[1]:
+                hip.gemm_tn(dpre, x2, out=weight.grad[r0:r1])
+            if ctx.has_bias and ctx.needs_input_grad[2] and bias_p.grad is not None:
+                hip.colsum(dpre, out=bias_p.grad[r0:r1])
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dpre)
+            return dx, None, db, dres, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
             if rows is not None:
@@ -139,6 +153,7 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, out_dtype):
         need = any(ctx.needs_input_grad)
+        ctx.beta_param = beta
         if need:
             y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
             ctx.save_for_backward(x, gamma, mean, rstd)
@@ -149,6 +164,10 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
+        beta = ctx.beta_param
+        if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad)
+            return dx, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
         dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db)

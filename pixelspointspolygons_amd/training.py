@@ -51,7 +51,7 @@ def pix2poly_loss(logits, perm, y_expected, y_perm, w_vertex=1.0, w_perm=10.0, p
 class FlatAdamW:
     """torch.optim.AdamW semantics over one flat arena; `model.parameters()` become views (state_dict unchanged)."""
 
-    def __init__(self, model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), eps=1e-8, compute_dtype=torch.bfloat16, bucket_mb=32):
+    def __init__(self, model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), eps=1e-8, compute_dtype=torch.bfloat16, bucket_mb=32, direct_grad=True):
         params = [p for p in model.parameters() if p.requires_grad]
         dev = params[0].device
         offs, total = [], 0
@@ -74,6 +74,7 @@ class FlatAdamW:
         if self.shadow is not None:
             self.shadow.copy_(self.flat)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        ops.DIRECT_GRAD[0] = bool(direct_grad)   # kernels accumulate parameter gradients in place in the arena
         self.step_count = 0
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(3)
@@ -129,7 +130,8 @@ class GradBucketReducer:
     asynchronously (RCCL runs it on its own stream) while backward continues.
     """
 
-    def __init__(self, opt: FlatAdamW, process_group=None):
+    def __init__(self, opt: FlatAdamW, process_group=None, overlap=True):
+        """overlap=False: no hooks; `finish()` reduces all buckets after backward (used when backward runs inside a hipGraph)."""
         self.opt, self.pg = opt, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.handles = []
@@ -139,7 +141,8 @@ class GradBucketReducer:
             self.bucket_of.append(b)
             self.expect[b] += 1
         self.count = [0] * len(opt.buckets)
-        if self.world > 1:
+        self.overlap = overlap
+        if self.world > 1 and overlap:
             for i, p in enumerate(opt.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -159,7 +162,7 @@ class GradBucketReducer:
         """call after backward: flush buckets whose parameters got no gradient, wait, return the 1/world scale for AdamW."""
         if self.world > 1:
             for b in range(len(self.count)):
-                if self.count[b] != self.expect[b]:
+                if not self.overlap or self.count[b] != self.expect[b]:
                     self._launch(b)
             for h in self.handles:
                 h.wait()

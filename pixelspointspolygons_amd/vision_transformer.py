@@ -140,12 +140,12 @@ class VisionTransformer(nn.Module):
             if m.bias is not None:
                 nn.init.zeros_(m.bias)
 
-    def forward_tokens(self, tok, B, scale=None, shift=None, src_ld=None):
+    def forward_tokens(self, tok, B, scale=None, shift=None, src_ld=None, mean=None):
         """tok: [B*np, D] patch/pillar/fused tokens (any dtype) -> LN'd tokens [B, np+1, D] in compute dtype.
 
         timm `_pos_embed` (cat CLS, + pos_embed) is fused with the optional BN+ReLU affine of the fusion layer."""
         np_ = self.pos_embed.shape[1] - 1
-        x = _Assemble.apply(tok, self.cls_token, self.pos_embed, scale, shift, B, np_, self.embed_dim, src_ld)
+        x = _Assemble.apply(tok, self.cls_token, self.pos_embed, scale, shift, B, np_, self.embed_dim, src_ld, mean)
         for blk in self.blocks:
             x = blk.run(x, self.cd)
         return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=self.cd)
@@ -166,7 +166,8 @@ class VisionTransformer(nn.Module):
 
 class _Assemble(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tok, cls, pos, scale, shift, B, np_, D, src_ld):
+    def forward(ctx, tok, cls, pos, scale, shift, B, np_, D, src_ld, mean):
+        ctx.mean = mean
         x = hip.tokens_assemble(tok, cls.reshape(-1), pos.reshape(-1), B, np_, D, scale=scale, shift=shift, src_ld=src_ld)
         ctx.save_for_backward(tok, scale, shift)
         ctx.meta = (B, np_, D, src_ld, tok.dtype)
@@ -176,10 +177,12 @@ class _Assemble(torch.autograd.Function):
     def backward(ctx, dx):
         tok, scale, shift = ctx.saved_tensors
         B, np_, D, src_ld, tdt = ctx.meta
-        dcls = dx[:, 0, :].sum(0).view(1, 1, D)
-        dpos = dx.sum(0, keepdim=True)
-        dtok, dscale, dshift = hip.tokens_assemble_bwd(dx, tok, scale, shift, B, np_, D, src_ld)
-        return dtok, dcls, dpos, dscale, dshift, None, None, None, None
+        dxc = dx.contiguous()
+        dpos = hip.batch_sum(dxc).view(1, np_ + 1, D)
+        dcls = hip.colsum(dxc.view(B, (np_ + 1) * D)[:, :D]).view(1, 1, D)
+        # dscale comes back CENTRED (sum dz*(pre - mean)) when the BatchNorm mean is known: see p3_bn_bwd_coeffs
+        dtok, dscale, dshift = hip.tokens_assemble_bwd(dxc, tok, scale, shift, B, np_, D, src_ld, mean=ctx.mean)
+        return dtok, dcls, dpos, dscale, dshift, None, None, None, None, None
 
 
 class ViT(nn.Module):
