@@ -18,6 +18,7 @@ struct TnArgs {
     // optional generated B operand (ScoreNet backward): B'[m,k] = relu((B[m',k] (+ V[m'',k])) * b_scale[k] + b_shift[k])
     int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j)
     const float* b_scale; const float* b_shift; const void* pair_V; int pair_n;
+    float* colsum;              // optional [N]: += column sums of A (bias gradient), accumulated by the tk == 0 tiles from the staged registers
 };
 
 template <typename T> struct TTr;
@@ -109,7 +110,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
             }
         }
     };
+    float csum[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) csum[q] = 0.f;
+    const bool do_cs = g.colsum != nullptr && tk == 0;
     auto store_step = [&](int buf) __attribute__((always_inline)) {
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                if constexpr (BF) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { csum[2 * q] += __uint_as_float(ra[i][q] << 16); csum[2 * q + 1] += __uint_as_float(ra[i][q] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) csum[q] += __uint_as_float(ra[i][q]);
+                }
+            }
+        }
         T* as = lds + buf * ELEMS;
         T* bs = lds + (2 + buf) * ELEMS;
         if constexpr (BF) {
@@ -179,6 +196,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
         if (t + 1 < nsteps) store_step(cur ^ 1);
         __syncthreads();
     }
+    if (do_cs) {   // fold the per-thread column partials (threads with equal cv) through the idle LDS, one atomic per column
+        float* red = reinterpret_cast<float*>(lds);
+        constexpr int NRT = 256 / TPR;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) red[rt * TN + cv + q] = csum[q];
+        __syncthreads();
+        if (tid < TN && tn * TN + tid < g.N) {
+            float a = 0.f;
+            for (int r = 0; r < NRT; ++r) a += red[r * TN + tid];
+            atomicAdd(g.colsum + tn * TN + tid, a);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = tk * TK + wn * 64 + j * 32 + l31;
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict_
 }  // namespace
 
 extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
-                             const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, void* stream) {
+                             const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, void* stream) {
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
     P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU, P3_EINVAL, "p3_gemm_tn: b_mode");
     P3_CHECK(b_mode == 0 || (b_scale && b_shift), P3_EINVAL, "p3_gemm_tn: generated B operand needs b_scale / b_shift");
@@ -248,7 +277,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     P3_CHECK(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0, P3_EALIGN, "p3_gemm_tn: N, K, lda, ldb must be multiples of 8 (bf16) / 4 (f32)");
     P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, P3_EALIGN, "p3_gemm_tn: 16-byte base alignment");
     TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.b_mode = b_mode; g.b_scale = b_scale; g.b_shift = b_shift; g.pair_V = pair_V; g.pair_n = pair_n;
+    g.b_mode = b_mode; g.b_scale = b_scale; g.b_shift = b_shift; g.pair_V = pair_V; g.pair_n = pair_n; g.colsum = colsum;
     const int tiles_n = p3_ceil_div(N, TN);
     g.tiles_k = p3_ceil_div(K, TK);
     const int tiles = tiles_n * g.tiles_k;
@@ -268,7 +297,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
 }
 
 extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
-    return p3_gemm_tn_ex(A, B, C, M, N, K, lda, ldb, ldc, dtype, 0, nullptr, nullptr, nullptr, 0, stream);
+    return p3_gemm_tn_ex(A, B, C, M, N, K, lda, ldb, ldc, dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream) {

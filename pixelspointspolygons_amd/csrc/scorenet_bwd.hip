@@ -126,37 +126,59 @@ __global__ void affine_fix_kernel(T* __restrict__ dH, const T* __restrict__ H, c
     }
 }
 
-// pair grid backward: rows (b,i,j), channel = thread.  Block = (b, chunk of IC rows i): dU rows complete, dV via atomics.
+// pair grid backward: rows (b,i,j).  Block = (b, chunk of IC rows i), 4 wave-groups split the j range, a lane owns 4 channels
+// (8-byte loads): dU rows are completed inside the block (LDS fold over the groups), dV[b,j] gets one atomic per block.
 template <typename T, int IC>
 __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA, const T* __restrict__ U, const T* __restrict__ V,
                                                        const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
                                                        float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C) {
+    __shared__ float red[4][IC + 2][256];     // C == 256
     const int b = blockIdx.y, i0 = blockIdx.x * IC;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float s = sc[c], h = sh[c], mu = mean[c];
-        float u[IC], au[IC];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c0 = lane * 4;
+    float s[4], h[4], mu[4];
 #pragma unroll
-        for (int k = 0; k < IC; ++k) { u[k] = (i0 + k < N) ? Cvt<T>::to_f(U[((int64_t)b * N + i0 + k) * C + c]) : 0.f; au[k] = 0.f; }
-        float a_sc = 0.f, a_sh = 0.f;
-        for (int j = 0; j < N; ++j) {
-            const float v = Cvt<T>::to_f(V[((int64_t)b * N + j) * C + c]);
-            float av = 0.f;
+    for (int k = 0; k < 4; ++k) { s[k] = sc[c0 + k]; h[k] = sh[c0 + k]; mu[k] = mean[c0 + k]; }
+    float u[IC][4], au[IC][4];
 #pragma unroll
-            for (int k = 0; k < IC; ++k) {
-                if (i0 + k < N) {
-                    const float g = Cvt<T>::to_f(dA[(((int64_t)b * N + i0 + k) * N + j) * C + c]);
-                    const float p = u[k] + v;
-                    const float dz = (p * s + h > 0.f) ? g : 0.f;
-                    a_sc += dz * (p - mu); a_sh += dz;
-                    au[k] += dz * s; av += dz * s;
+    for (int i = 0; i < IC; ++i) {
+        if (i0 + i < N) ld4<T>(U + ((int64_t)b * N + i0 + i) * C + c0, u[i]);
+        else { u[i][0] = u[i][1] = u[i][2] = u[i][3] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) au[i][k] = 0.f;
+    }
+    float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0};
+    for (int j = grp; j < N; j += 4) {
+        float v[4], av[4] = {0, 0, 0, 0};
+        ld4<T>(V + ((int64_t)b * N + j) * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < IC; ++i) {
+            if (i0 + i < N) {
+                float g[4];
+                ld4<T>(dA + (((int64_t)b * N + i0 + i) * N + j) * C + c0, g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float p = u[i][k] + v[k];
+                    const float dz = (p * s[k] + h[k] > 0.f) ? g[k] : 0.f;
+                    a_sc[k] += dz * (p - mu[k]); a_sh[k] += dz;
+                    au[i][k] += dz * s[k]; av[k] += dz * s[k];
                 }
             }
-            atomicAdd(dV + ((int64_t)b * N + j) * C + c, av);
         }
 #pragma unroll
-        for (int k = 0; k < IC; ++k) if (i0 + k < N) dU[((int64_t)b * N + i0 + k) * C + c] = au[k];
-        atomicAdd(acc + c, a_sc); atomicAdd(acc + C + c, a_sh);
+        for (int k = 0; k < 4; ++k) atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k, av[k]);
     }
+#pragma unroll
+    for (int i = 0; i < IC; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[grp][i][c0 + k] = au[i][k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[grp][IC][c0 + k] = a_sc[k]; red[grp][IC + 1][c0 + k] = a_sh[k]; }
+    __syncthreads();
+    const int c = threadIdx.x;
+    for (int i = 0; i < IC; ++i)
+        if (i0 + i < N) dU[((int64_t)b * N + i0 + i) * C + c] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
+    atomicAdd(acc + c, (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]));
+    atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
 }
 
 // BN1 statistics were closed-form in U, V: dU[b,i] += N*a + b1*(N*U[b,i] + sum_j V[b,j]), dV symmetric
@@ -224,7 +246,8 @@ extern "C" int p3_affine_fix(void* dH, const void* H, const float* a, const floa
 extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
                            int B, int N, int C, int dtype, void* stream) {
     P3_CHECK(dA && U && V && scale && shift && mean && dU && dV && acc && B > 0, P3_EINVAL, "p3_pair_bwd: bad arguments");
-    constexpr int IC = 16;
+    P3_CHECK(C == 256, P3_EUNSUP, "p3_pair_bwd: ScoreNet conv1 width must be 256 (model_pix2poly.py:74)");
+    constexpr int IC = 8;
     dim3 g((N + IC - 1) / IC, B), b(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P3_BF16) hipLaunchKernelGGL((pair_bwd_kernel<bf16_t, IC>), g, b, 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift, mean, dU, dV, acc, N, C);

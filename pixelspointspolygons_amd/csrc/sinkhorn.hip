@@ -37,28 +37,53 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
     const float norm = -logf((float)(m + n));
     const float lmu_last = logf((float)n) + norm, lnu_last = logf((float)m) + norm;
     __syncthreads();
-    const int ncj = (N1 + 63) / 64, nci = (M1 + 63) / 64;   // <= 8 supported (dims <= 511)
+    // Each LSE is split over 4 thread groups (thread = (row | column, quarter)): sequential online max/sum over a quarter of
+    // the line (one exp per element, no cross-lane shuffles), partials folded through LDS.  Row walk: lanes = consecutive rows,
+    // stride N1 words (odd -> conflict free); column walk: lanes = consecutive columns.
+    float* pm = v + N1;            // [4][256] partial maxima
+    float* ps = pm + 1024;         // [4][256] partial sums
+    const int idx = tid & 255, part = tid >> 8;
+    const int chj = (N1 + 3) / 4, chi = (M1 + 3) / 4;
     for (int it = 0; it < iters; ++it) {
-        for (int r = w; r < M1; r += 16) {
-            float vals[8]; float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int c = lane + 64 * k;
-                if (k < ncj) { vals[k] = c < N1 ? Z[r * N1 + c] + v[c] : -INFINITY; mx = fmaxf(mx, vals[k]); }
+        {   // u = log_mu - LSE_j(Z + v)
+            float m = -INFINITY, sacc = 0.f;
+            if (idx < M1) {
+                const int c0 = part * chj, c1 = min(N1, c0 + chj);
+                const float* zr = Z + idx * N1;
+                for (int c = c0; c < c1; ++c) {
+                    const float x = zr[c] + v[c];
+                    const float e = __expf(-fabsf(x - m));
+                    if (x > m) { sacc = sacc * e + 1.f; m = x; } else { sacc += e; }
+                }
             }
-            const float l = lse_wave(mx, vals, ncj);
-            if (lane == 0) u[r] = (r < m ? norm : lmu_last) - l;
+            pm[part * 256 + idx] = m; ps[part * 256 + idx] = sacc;
         }
         __syncthreads();
-        for (int c = w; c < N1; c += 16) {
-            float vals[8]; float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = lane + 64 * k;
-                if (k < nci) { vals[k] = r < M1 ? Z[r * N1 + c] + u[r] : -INFINITY; mx = fmaxf(mx, vals[k]); }
+        if (tid < M1) {
+            const float m0 = pm[tid], m1 = pm[256 + tid], m2 = pm[512 + tid], m3 = pm[768 + tid];
+            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float ss = ps[tid] * __expf(m0 - mm) + ps[256 + tid] * __expf(m1 - mm) + ps[512 + tid] * __expf(m2 - mm) + ps[768 + tid] * __expf(m3 - mm);
+            u[tid] = (tid < m ? norm : lmu_last) - (mm + __logf(ss));
+        }
+        __syncthreads();
+        {   // v = log_nu - LSE_i(Z + u)
+            float m = -INFINITY, sacc = 0.f;
+            if (idx < N1) {
+                const int r0 = part * chi, r1 = min(M1, r0 + chi);
+                for (int r = r0; r < r1; ++r) {
+                    const float x = Z[r * N1 + idx] + u[r];
+                    const float e = __expf(-fabsf(x - m));
+                    if (x > m) { sacc = sacc * e + 1.f; m = x; } else { sacc += e; }
+                }
             }
-            const float l = lse_wave(mx, vals, nci);
-            if (lane == 0) v[c] = (c < n ? norm : lnu_last) - l;
+            pm[part * 256 + idx] = m; ps[part * 256 + idx] = sacc;
+        }
+        __syncthreads();
+        if (tid < N1) {
+            const float m0 = pm[tid], m1 = pm[256 + tid], m2 = pm[512 + tid], m3 = pm[768 + tid];
+            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float ss = ps[tid] * __expf(m0 - mm) + ps[256 + tid] * __expf(m1 - mm) + ps[512 + tid] * __expf(m2 - mm) + ps[768 + tid] * __expf(m3 - mm);
+            v[tid] = (tid < n ? norm : lnu_last) - (mm + __logf(ss));
         }
         __syncthreads();
         if (uv_hist) {
@@ -101,8 +126,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
 extern "C" int p3_sinkhorn(const float* scores, const float* alpha, int B, int m, int n, int iters, float* perm, float* z_full,
                            float* uv_hist, void* stream) {
     P3_CHECK(scores && alpha && B > 0 && m > 0 && n > 0 && iters >= 0, P3_EINVAL, "p3_sinkhorn: bad arguments");
-    P3_CHECK(m < 511 && n < 511, P3_EUNSUP, "p3_sinkhorn: m, n must be < 511");
-    const size_t lds = ((size_t)(m + 1) * (n + 1) + (m + 1) + (n + 1)) * sizeof(float);
+    P3_CHECK(m < 255 && n < 255, P3_EUNSUP, "p3_sinkhorn: m, n must be < 255");
+    const size_t lds = ((size_t)(m + 1) * (n + 1) + (m + 1) + (n + 1) + 2048) * sizeof(float);
     P3_CHECK(lds <= 160 * 1024, P3_EUNSUP, "p3_sinkhorn: coupling matrix does not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {

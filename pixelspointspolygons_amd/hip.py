@@ -373,14 +373,15 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
     return dq, dk, dv
 
 
-def gemm_tn(a, b, out=None):
-    """out[N,K] (+)= a[M,N]^T @ b[M,K]  (fp32 out; zero-filled when not given)."""
+def gemm_tn(a, b, out=None, colsum_out=None):
+    """out[N,K] (+)= a[M,N]^T @ b[M,K]  (fp32 out; zero-filled when not given); colsum_out[N] += column sums of a (bias gradient)."""
     M, N = a.shape
     K = b.shape[1]
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
-    check(lib().p3_gemm_tn(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
-                           c_int(out.stride(0)), c_int(dt(a)), stream()), "p3_gemm_tn")
+    check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
+                              c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
+                              stream()), "p3_gemm_tn")
     return out
 
 
@@ -490,7 +491,7 @@ def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=Non
     N, K = a.shape[1], b.shape[1]
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
-                              stream()), "p3_gemm_tn_ex")
+                              ptr(None), stream()), "p3_gemm_tn_ex")
     return out
 
 

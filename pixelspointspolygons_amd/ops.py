@@ -121,12 +121,14 @@ class _Linear(torch.autograd.Function):
         bias_p = ctx.bias_param
         if direct:
             r0, r1 = rows if rows is not None else (0, weight.shape[0])
-            if ctx.needs_input_grad[1]:
-                hip.gemm_tn(dpre, x2, out=weight.grad[r0:r1])
-            if ctx.has_bias and ctx.needs_input_grad[2] and bias_p.grad is not None:
-                hip.colsum(dpre, out=bias_p.grad[r0:r1])
-            elif ctx.has_bias and ctx.needs_input_grad[2]:
-                db = hip.colsum(dpre)
+            fuse_b = ctx.has_bias and ctx.needs_input_grad[2] and bias_p.grad is not None and ctx.needs_input_grad[1]
+            if ctx.needs_input_grad[1]:     # bias gradient = column sums of dpre, folded into the same TN GEMM launch
+                hip.gemm_tn(dpre, x2, out=weight.grad[r0:r1], colsum_out=bias_p.grad[r0:r1] if fuse_b else None)
+            if ctx.has_bias and ctx.needs_input_grad[2] and not fuse_b:
+                if bias_p.grad is not None:
+                    hip.colsum(dpre, out=bias_p.grad[r0:r1])
+                else:
+                    db = hip.colsum(dpre)
             return dx, None, db, dres, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32

@@ -33,9 +33,11 @@ def test_gemm_tn_and_colsum(dtype, tol, M, N, K):
     h = _h()
     a, b = _rand(M, N, seed=1).to(dtype), _rand(M, K, seed=2).to(dtype)
     ref = a.float().t() @ b.float()
-    out = h.gemm_tn(a.to(DEV), b.to(DEV)).cpu()
+    cs = torch.zeros(N, device=DEV)
+    out = h.gemm_tn(a.to(DEV), b.to(DEV), colsum_out=cs).cpu()
     assert rel_err(out, ref) < tol * 10
     assert rel_err(h.colsum(a.to(DEV)).cpu(), a.float().sum(0)) < 1e-4
+    assert rel_err(cs.cpu(), a.float().sum(0)) < 1e-4          # bias gradient folded into the TN GEMM
 
 
 def test_gemm_tn_strided_operand_and_accumulate():
