@@ -226,7 +226,8 @@ int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_s
  * p3_gemm_tn_ex: weight gradient with a generated B operand  B' = relu((B (+V)) * b_scale + b_shift)  (b_mode = P3_A_*). */
 int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
                   const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum /* optional [N]: += column sums of A */,
-                  void* stream);
+                  float* slabs /* optional scratch [max_slabs][N][K] fp32: split-M partials stored + reduced instead of fp32 atomics */,
+                  int max_slabs, void* stream);
 /* tail (dS != NULL, C = 64): dS [B,N,N] (read transposed if transpose) -> dHd = dz*scale, acc = [dscale(C) | dshift(C) | dw4(C) | db4]
  * matrix (dA != NULL, C = 128): dA [R,C] -> dHd = dA*(z>0)*scale (may alias dA), acc = [dscale(C) | dshift(C)] */
 int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean, const float* w4,

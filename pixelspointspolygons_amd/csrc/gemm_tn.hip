@@ -18,11 +18,17 @@ struct TnArgs {
     // optional generated B operand (ScoreNet backward): B'[m,k] = relu((B[m',k] (+ V[m'',k])) * b_scale[k] + b_shift[k])
     int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j)
     const float* b_scale; const float* b_shift; const void* pair_V; int pair_n;
+    float* slabs;               // optional [splits][N][K] fp32: partial tiles are STORED here (coalesced) and summed by tn_reduce_kernel
+                                // instead of splits x N x K fp32 atomics on C (measured: the atomics, not the MFMAs, bounded this kernel)
     float* colsum;              // optional [N]: += column sums of A (bias gradient), accumulated by the tk == 0 tiles from the staged registers
 };
 
 template <typename T> struct TTr;
-template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 72, ELEMS = TN * 72; };   // [col][m]  (transposed)
+// bf16: [col][m] transposed image, 128-byte rows, 16-byte chunks XOR-swizzled by key(col) = (col ^ col>>3) & 7.  The writer lanes of a
+// wave own columns 8 apart (one 16-byte global load = 8 columns), which with any 16-byte-aligned padded pitch land on ONE bank
+// (16-way conflict on every transposing ds_write_b32 - measured 2x on the whole kernel); the swizzle spreads both the writes
+// (columns 8 apart) and the ds_read_b128 fragment reads (consecutive columns) to <= 2-way.
+template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 64, ELEMS = TN * 64; };
 template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS = 16 * 132; };  // [m][col]
 
 template <typename T>
@@ -138,10 +144,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t a0 = ra[2 * pp][j], a1 = ra[2 * pp + 1][j], b0 = rb[2 * pp][j], b1 = rb[2 * pp + 1][j];
-                    pa[((cv + 2 * j) * PITCH + mloc) / 2] = (a0 & 0xffffu) | (a1 << 16);
-                    pa[((cv + 2 * j + 1) * PITCH + mloc) / 2] = (a0 >> 16) | (a1 & 0xffff0000u);
-                    pb[((cv + 2 * j) * PITCH + mloc) / 2] = (b0 & 0xffffu) | (b1 << 16);
-                    pb[((cv + 2 * j + 1) * PITCH + mloc) / 2] = (b0 >> 16) | (b1 & 0xffff0000u);
+                    const int c0 = cv + 2 * j, c1 = c0 + 1;
+                    const int o0 = (c0 * PITCH + ((((mloc >> 3) ^ ((c0 ^ (c0 >> 3)) & 7)) << 3) | (mloc & 7))) >> 1;
+                    const int o1 = (c1 * PITCH + ((((mloc >> 3) ^ ((c1 ^ (c1 >> 3)) & 7)) << 3) | (mloc & 7))) >> 1;
+                    pa[o0] = (a0 & 0xffffu) | (a1 << 16);
+                    pa[o1] = (a0 >> 16) | (a1 & 0xffff0000u);
+                    pb[o0] = (b0 & 0xffffu) | (b1 << 16);
+                    pb[o1] = (b0 >> 16) | (b1 & 0xffff0000u);
                 }
             }
         } else {
@@ -167,8 +176,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
                 s16x8 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const s16x8*>(as + (wm * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
-                    bf[i] = *reinterpret_cast<const s16x8*>(bs + (wn * 64 + i * 32 + l31) * PITCH + kk * 16 + 8 * hi);
+                    const int ca = wm * 64 + i * 32 + l31, cb = wn * 64 + i * 32 + l31;
+                    af[i] = *reinterpret_cast<const s16x8*>(as + ca * PITCH + (((kk * 2 + hi) ^ ((ca ^ (ca >> 3)) & 7)) << 3));
+                    bf[i] = *reinterpret_cast<const s16x8*>(bs + cb * PITCH + (((kk * 2 + hi) ^ ((cb ^ (cb >> 3)) & 7)) << 3));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -217,8 +227,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tn * TN + wm * 64 + i * 32 + crow32(r, hi);
-                if (row < g.N) atomicAdd(g.C + (int64_t)row * g.ldc + col, acc[i][j][r]);
+                if (row < g.N) {
+                    if (g.slabs) g.slabs[((int64_t)split * g.N + row) * g.K + col] = acc[i][j][r];
+                    else atomicAdd(g.C + (int64_t)row * g.ldc + col, acc[i][j][r]);
+                }
             }
+    }
+}
+
+// C[n,k] += sum_s slabs[s][n][k]
+__global__ void tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int N, int K, int ldc, int splits) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += slabs[(int64_t)s * total + i];
+        const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+        C[(int64_t)n * ldc + k] += a;
     }
 }
 
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict_
 }  // namespace
 
 extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
-                             const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, void* stream) {
+                             const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, float* slabs, int max_slabs, void* stream) {
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
     P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU, P3_EINVAL, "p3_gemm_tn: b_mode");
     P3_CHECK(b_mode == 0 || (b_scale && b_shift), P3_EINVAL, "p3_gemm_tn: generated B operand needs b_scale / b_shift");
@@ -282,22 +306,28 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.tiles_k = p3_ceil_div(K, TK);
     const int tiles = tiles_n * g.tiles_k;
     const int bm = dtype == P3_BF16 ? 64 : 16;
-    int splits = p3_ceil_div(1024, tiles);
+    int splits = p3_ceil_div(slabs ? 768 : 1024, tiles);
+    if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     g.rows_per_split = p3_ceil_div(p3_ceil_div(M, splits), bm) * bm;
     splits = p3_ceil_div(M, g.rows_per_split);
+    g.slabs = (slabs && splits > 1) ? slabs : nullptr;
     dim3 grid(tiles, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 0, s, g);
+    if (g.slabs) {
+        int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
+    }
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
 
 extern "C" int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream) {
-    return p3_gemm_tn_ex(A, B, C, M, N, K, lda, ldb, ldc, dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, stream);
+    return p3_gemm_tn_ex(A, B, C, M, N, K, lda, ldb, ldc, dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream) {

@@ -373,6 +373,16 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
     return dq, dk, dv
 
 
+TN_MAX_SLABS = 0     # > 0: store split-M partials in scratch slabs + reduce (measured slower than the fp32 atomics on MI355X; kept for A/B)
+
+
+def _tn_slabs(N, K, device):
+    """scratch for the split-M partial tiles of the weight-gradient GEMM (stored + reduced instead of fp32 atomics)."""
+    if TN_MAX_SLABS <= 0:
+        return None
+    return workspace(TN_MAX_SLABS * N * K * 4 + 16, device, "tn_slabs")
+
+
 def gemm_tn(a, b, out=None, colsum_out=None):
     """out[N,K] (+)= a[M,N]^T @ b[M,K]  (fp32 out; zero-filled when not given); colsum_out[N] += column sums of a (bias gradient)."""
     M, N = a.shape
@@ -381,7 +391,7 @@ def gemm_tn(a, b, out=None, colsum_out=None):
         out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
-                              stream()), "p3_gemm_tn")
+                              ptr(_tn_slabs(N, K, a.device)), c_int(TN_MAX_SLABS), stream()), "p3_gemm_tn")
     return out
 
 
@@ -491,7 +501,7 @@ def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=Non
     N, K = a.shape[1], b.shape[1]
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
-                              ptr(None), stream()), "p3_gemm_tn_ex")
+                              ptr(None), ptr(_tn_slabs(N, K, a.device)), c_int(TN_MAX_SLABS), stream()), "p3_gemm_tn_ex")
     return out
 
 
