@@ -42,6 +42,7 @@ extern "C" {
 #define P3_A_CONV3X3 1 /* A is an NHWC map [B,H,W,lda]; K = 9*C, zero padding 1 (implicit GEMM) */
 #define P3_A_AFFINE_RELU 2 /* A'[m,k] = relu(A[m,k]*a_scale[k] + a_shift[k])  (BN+ReLU folded into the load) */
 #define P3_A_PAIR_AFFINE_RELU 3 /* A'[(b,i,j),k] = relu((U[b,i,k]+V[b,j,k])*a_scale[k]+a_shift[k]) ScoreNet conv1 */
+#define P3_A_CONV3X3_AFFINE_RELU 4 /* CONV3X3 over relu(A*a_scale[c]+a_shift[c]) (a_scale/a_shift indexed by input channel): FFL heads */
 
 int p3_version(void);
 const char* p3_last_error_string(void);
@@ -242,6 +243,20 @@ int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale
                 int B, int N, int C, int dtype, void* stream);
 int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FFL / *CNN encoder tails (models/fusion_layers/early_fusion_vit_cnn.py:87-104, models/vision_transformer/vit_cnn.py:45-57,
+ * models/ffl/model_ffl.py:53-96).  The 3x3 convolutions are p3_gemm with P3_A_CONV3X3 / P3_A_CONV3X3_AFFINE_RELU.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.Upsample(size=(H,W), mode='bilinear', align_corners=False) of the token map: src tokens [B, src_tok_per_img, C] starting at token
+ * src_tok_off (1 = CLS dropped) viewed as [h, w] -> NHWC dst [B, H, W, ld] */
+int p3_upsample_bilinear(const void* src, int dtype_src, void* dst, int dtype_dst, int B, int h, int w, int C, int H, int W, int ld,
+                         int src_tok_off, int src_tok_per_img, void* stream);
+/* Conv1x1(256 -> n_out) on relu(x*scale+shift) + Sigmoid (act 0) | post_mul*Tanh (act 1); out NCHW fp32 [B, n_out, H*W]; optionally the
+ * first output is also written to copy_dst[r*copy_ld] (the seg channel concatenated to the features, model_ffl.py:87-89) */
+int p3_head1x1(const void* X, int ld, int dtype, const float* scale, const float* shift, const float* W, const float* bias, int n_out,
+               int act, float post_mul, float* out_nchw, void* copy_dst, int copy_ld, int64_t R, int64_t HW, void* stream);
+int p3_nhwc_to_nchw(const void* X, int ld, int dtype, const float* scale, const float* shift, float* out, int B, int C, int64_t HW, void* stream);
 
 #ifdef __cplusplus
 }

@@ -504,3 +504,46 @@ def make_inputs(batch, seed=1234, n_points=3000, jitter=300, n_vertices=MAX_VERT
         for k in range(n, n_vertices):
             perm[b, k, k] = 1.0
     return dict(image=img, lidar_values=vals, lidar_offsets=offsets, y=y, y_perm=perm)
+
+
+def make_ffl_state_dict(kind="fusion", cfg=VIT_S8, seed=42, feat=256):
+    """FFL model weights with the reference's key names (model_ffl.py:28-68; early_fusion_vit_cnn.py:76-81)."""
+    base = make_state_dict(kind, cfg, seed=seed)
+    sd = {k: v for k, v in base.items() if k.startswith("encoder.")}
+    g = torch.Generator().manual_seed(seed + 1)
+    rn = lambda *s, std=0.02: torch.randn(*s, generator=g) * std
+
+    def bn(pre, c):
+        sd[pre + ".weight"] = 1 + rn(c, std=0.1)
+        sd[pre + ".bias"] = rn(c, std=0.1)
+        sd[pre + ".running_mean"] = rn(c, std=0.1)
+        sd[pre + ".running_var"] = 1 + rn(c, std=0.1).abs()
+        sd[pre + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    D = cfg["dim"]
+    sd["encoder.proj.1.weight"] = rn(feat, D, 3, 3, std=0.03)
+    sd["encoder.proj.1.bias"] = rn(feat)
+    bn("encoder.proj.2", feat)
+    sd["seg_module.0.weight"] = rn(feat, feat, 3, 3, std=0.03)
+    sd["seg_module.0.bias"] = rn(feat)
+    bn("seg_module.1", feat)
+    sd["seg_module.3.weight"] = rn(1, feat, 1, 1, std=0.1)
+    sd["seg_module.3.bias"] = rn(1)
+    sd["crossfield_module.0.weight"] = rn(feat, feat + 1, 3, 3, std=0.03)
+    sd["crossfield_module.0.bias"] = rn(feat)
+    bn("crossfield_module.1", feat)
+    sd["crossfield_module.3.weight"] = rn(4, feat, 1, 1, std=0.1)
+    sd["crossfield_module.3.bias"] = rn(4)
+    return sd
+
+
+def ffl_forward(sd, img=None, lidar=None, cfg=VIT_S8, size=224, training=False):
+    """ffl EncoderDecoder.inference (model_ffl.py:71-96) over the ViT-CNN encoders."""
+    if img is not None and lidar is not None:
+        x = fusion_stem(img, lidar[0], lidar[1], sd, cfg, "encoder.", training).flatten(2).transpose(1, 2)
+    elif img is not None:
+        x = patch_embed(img, sd, "encoder.vit.patch_embed.", cfg["patch"]).flatten(2).transpose(1, 2)
+    else:
+        x = pillar_stem(lidar[0], lidar[1], sd, "encoder.vit.patch_embed.", training=training).flatten(2).transpose(1, 2)
+    tok = vit_blocks(x, sd, "encoder.vit.", cfg["depth"], cfg["heads"], cfg["eps"])
+    feats = vitcnn_tail(tok, sd, "encoder.", size, training)
+    return ffl_heads(feats, sd, training), feats

@@ -62,7 +62,7 @@ def make_config(encoder="early_fusion_vit", model="pix2poly", *, in_size=224, pa
                        pad_idx=None, generation_steps=None),
         sinkhorn_iterations=sinkhorn_iterations, vertex_loss_weight=1.0, perm_loss_weight=10.0,
         batch_size=batch_size, learning_rate=3e-4, weight_decay=1e-4, num_epochs=200,
-        compute_seg=True, compute_crossfield=True,
+        compute_seg=True, compute_crossfield=True, seg=dict(compute_interior=True, compute_edge=False, compute_vertex=False),
     )
     return AttrDict.wrap(dict(
         experiment=dict(encoder=enc, model=mdl, lidar_dropout=lidar_dropout),

@@ -36,7 +36,7 @@ template <int AMODE>
 __device__ __forceinline__ RowSrc make_row(const p3_gemm_desc& d, int gm) {
     RowSrc r; r.off = 0; r.off2 = 0; r.y = 0; r.x = 0; r.img = 0;
     if (gm >= d.M) gm = d.M - 1;
-    if (AMODE == P3_A_CONV3X3) {
+    if (AMODE == P3_A_CONV3X3 || AMODE == P3_A_CONV3X3_AFFINE_RELU) {
         int hw = d.conv_H * d.conv_W;
         int b = gm / hw, p = gm - b * hw;
         r.y = p / d.conv_W; r.x = p - r.y * d.conv_W;
@@ -80,11 +80,19 @@ template <typename T, int AMODE>
 __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const RowSrc& r, int k) {
     constexpr int VEC = Tr<T>::VEC;
     uint4 raw = make_uint4(0, 0, 0, 0);
-    if (AMODE == P3_A_CONV3X3) {
+    if (AMODE == P3_A_CONV3X3 || AMODE == P3_A_CONV3X3_AFFINE_RELU) {
         int tap = k / d.conv_C, c = k - tap * d.conv_C;
         int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
-        if ((yy >= 0) && (yy < d.conv_H) && (xx >= 0) && (xx < d.conv_W))
+        if ((yy >= 0) && (yy < d.conv_H) && (xx >= 0) && (xx < d.conv_W)) {
             raw = *reinterpret_cast<const uint4*>(A + r.img + (int64_t)(yy * d.conv_W + xx) * d.lda + c);
+            if (AMODE == P3_A_CONV3X3_AFFINE_RELU) {   // BN + ReLU of the producer folded into the gather; zero padding stays zero
+                float v[VEC];
+                unpack<T>(raw, v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i] * d.a_scale[c + i] + d.a_shift[c + i], 0.f);
+                raw = repack<T>(v);
+            }
+        }
         return raw;
     }
     raw = *reinterpret_cast<const uint4*>(A + r.off + k);
@@ -320,6 +328,7 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
         case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3>), grid, block, 0, s, g); break;
         case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU>), grid, block, 0, s, g); break;
         case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU>), grid, block, 0, s, g); break;
         default: p3_set_error("p3_gemm: bad a_mode"); return P3_EINVAL;
     }
     P3_LAUNCH_CHECK();
@@ -338,11 +347,11 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK(d->K % bk == 0, P3_ESHAPE, "p3_gemm: K must be a multiple of 64 (bf16) / 16 (f32)");
     P3_CHECK(d->lda % vec == 0 && d->ldb % vec == 0, P3_EALIGN, "p3_gemm: lda/ldb must keep 16-byte row alignment");
     P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, P3_EALIGN, "p3_gemm: A/W must be 16-byte aligned");
-    if (d->a_mode == P3_A_CONV3X3) {
+    if (d->a_mode == P3_A_CONV3X3 || d->a_mode == P3_A_CONV3X3_AFFINE_RELU) {
         P3_CHECK(d->conv_C > 0 && d->conv_C % bk == 0 && d->K == 9 * d->conv_C, P3_ESHAPE, "p3_gemm: conv3x3 needs K == 9*C, C % BK == 0");
         P3_CHECK(d->M % (d->conv_H * d->conv_W) == 0, P3_ESHAPE, "p3_gemm: conv3x3 needs M == B*H*W");
     }
-    if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU)
+    if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU || d->a_mode == P3_A_CONV3X3_AFFINE_RELU)
         P3_CHECK(d->a_scale && d->a_shift, P3_EINVAL, "p3_gemm: affine mode needs a_scale/a_shift");
     if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
         P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");

@@ -50,7 +50,7 @@ class _KernelTimer:
 
 
 KTIMER = _KernelTimer()
-_AMODE_NAMES = {0: "plain", 1: "conv3x3", 2: "affine_relu", 3: "pair_affine_relu"}
+_AMODE_NAMES = {0: "plain", 1: "conv3x3", 2: "affine_relu", 3: "pair_affine_relu", 4: "conv3x3_affine_relu"}
 
 
 def dt(t):
@@ -93,7 +93,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     """C[M,N] = act(A'[M,K] @ W[N,K]^T + bias) + residual.  a: [..., K] (2-D view), w: [N, K]."""
     _dev(a)
     N, K = w.shape
-    if a_mode == A_CONV3X3:
+    if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
         B, H, W_, C = conv
         M_ = B * H * W_
         lda_ = lda if lda is not None else a.stride(-2)
@@ -539,3 +539,30 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
 def pair_stats_bwd(U, V, a, b, dU, dV, B, N):
     check(lib().p3_pair_stats_bwd(ptr(U), ptr(V), ptr(a), ptr(b), ptr(dU), ptr(dV), c_int(B), c_int(N), c_int(U.shape[1]), c_int(dt(U)),
                                   stream()), "p3_pair_stats_bwd")
+
+
+# ------------------------------------------------------------------------------------------ FFL / *CNN tails
+A_CONV3X3_AFFINE_RELU = 4
+
+
+def upsample_bilinear(tokens, B, h, w, H, W, out, tok_off=1):
+    """tokens [B, tok_off + h*w, C] -> out [B, H, W, ld] (writes channels 0..C-1)."""
+    C = tokens.shape[-1]
+    check(lib().p3_upsample_bilinear(ptr(tokens), c_int(dt(tokens)), ptr(out), c_int(dt(out)), c_int(B), c_int(h), c_int(w), c_int(C), c_int(H),
+                                     c_int(W), c_int(out.stride(-2)), c_int(tok_off), c_int(tokens.shape[1]), stream()), "p3_upsample_bilinear")
+    return out
+
+
+def head1x1(X, ld, scale, shift, W, bias, act, post_mul, B, HW, copy_dst=None, copy_ld=0):
+    n_out = W.shape[0]
+    out = torch.empty((B, n_out, HW), dtype=torch.float32, device=X.device)
+    check(lib().p3_head1x1(ptr(X), c_int(ld), c_int(dt(X)), ptr(scale), ptr(shift), ptr(W), ptr(bias), c_int(n_out), c_int(act), c_float(post_mul),
+                           ptr(out), ptr(copy_dst), c_int(copy_ld), c_int64(B * HW), c_int64(HW), stream()), "p3_head1x1")
+    return out
+
+
+def nhwc_to_nchw(X, ld, scale, shift, B, C, HW):
+    out = torch.empty((B, C, HW), dtype=torch.float32, device=X.device)
+    check(lib().p3_nhwc_to_nchw(ptr(X), c_int(ld), c_int(dt(X)), ptr(scale), ptr(shift), ptr(out), c_int(B), c_int(C), c_int64(HW), stream()),
+          "p3_nhwc_to_nchw")
+    return out

@@ -1,0 +1,77 @@
+"""FFL (frame-field) model on the HIP path vs the oracle: ViT-CNN encoders + seg / crossfield heads."""
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(encoder, precision, kind, cfg_o, **kw):
+    from oracle import p3_oracle as O
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.ffl import FFLModel
+    cfg = make_config(encoder, model="ffl", precision=precision, **kw)
+    m = FFLModel(cfg, 0)
+    sd = O.make_ffl_state_dict(kind, cfg_o, seed=11)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m, sd, cfg
+
+
+SMALL = dict(dim=384, depth=2, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("training", [False, True])
+def test_ffl_early_fusion_forward(precision, tol, training):
+    from oracle import p3_oracle as O
+    m, sd, cfg = _model("early_fusion_vit_cnn", precision, "fusion", SMALL, vit_depth=2)
+    B = 2 if training else 1
+    d = O.make_inputs(B, seed=5)
+    img, lidar_vals, lidar_offs = d["image"], d["lidar_values"], d["lidar_offsets"]
+    m.train(training)
+    nt = torch.nested.nested_tensor_from_jagged(lidar_vals.cuda(), lidar_offs.cuda())
+    with torch.no_grad():
+        out = m({"image": img.cuda(), "lidar": nt})
+        ref, feats = O.ffl_forward({k: v.clone() for k, v in sd.items()}, img, (lidar_vals, lidar_offs), SMALL, 224, training)
+    assert out["seg"].shape == (B, 1, 224, 224) and out["crossfield"].shape == (B, 4, 224, 224)
+    if precision == "bf16":
+        # bf16 storage through three batch-normalised 3x3 convs: single pixels near a ReLU / tanh knee move by ~0.1; the bound that
+        # means something is the L2-relative error of the whole map (max-abs checked loosely)
+        l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        assert l2(out["seg"].cpu(), ref["seg"]) < tol / 2 and l2(out["crossfield"].cpu(), ref["crossfield"]) < tol / 2
+        assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < 0.2
+    else:
+        assert rel_err(out["seg"].cpu(), ref["seg"]) < tol
+        assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < tol
+    # the encoder's own forward (NCHW features) — the reference's EarlyFusionViTCNN.forward contract
+    if not training:
+        with torch.no_grad():
+            f = m.encoder(img.cuda(), nt)
+        assert f.shape == (B, 256, 224, 224)
+        assert rel_err(f.cpu(), feats) < tol
+
+
+@pytest.mark.parametrize("encoder,kind", [("vit_cnn", "image"), ("pointpillars_vit_cnn", "lidar")])
+def test_ffl_single_modality(encoder, kind):
+    from oracle import p3_oracle as O
+    m, sd, cfg = _model(encoder, "fp32", kind, SMALL, vit_depth=2)
+    d = O.make_inputs(1, seed=6)
+    img, lidar_vals, lidar_offs = d["image"], d["lidar_values"], d["lidar_offsets"]
+    nt = torch.nested.nested_tensor_from_jagged(lidar_vals.cuda(), lidar_offs.cuda())
+    m.eval()
+    with torch.no_grad():
+        if kind == "image":
+            out = m({"image": img.cuda()})
+            ref, _ = O.ffl_forward(sd, img=img, cfg=SMALL)
+        else:
+            out = m({"lidar": nt})
+            ref, _ = O.ffl_forward(sd, lidar=(lidar_vals, lidar_offs), cfg=SMALL)
+    assert rel_err(out["seg"].cpu(), ref["seg"]) < 1e-3
+    assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < 1e-3
+
+
+def test_ffl_refuses_grad():
+    m, sd, cfg = _model("vit_cnn", "bf16", "image", SMALL, vit_depth=2)
+    with pytest.raises(NotImplementedError):
+        m({"image": torch.rand(1, 3, 224, 224, device="cuda")})
