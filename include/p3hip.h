@@ -149,6 +149,15 @@ int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1,
 /* byte offsets (13 int64) of the workspace sections the training path re-reads in backward: sorted, vox_xy, vox_start, vox_cnt,
  * vox_row, nvox, X2, H2, hmax, hmin, F8 (decorated point features per X2 row), row_vox (pillar slot per row, -1 unused), row_w */
 int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* offsets);
+/* Backward of p3_pillar_stem w.r.t. the PillarFeatureNet parameters (what autograd produces for
+ * PointPillarsEncoder.forward, pointpillars_o3d.py:85-107: voxel_encoder.pfn_layers.{0,1}.{linear.weight, norm.weight, norm.bias};
+ * the point coordinates carry no gradient).  dcanvas: gradient of the token-major canvas the forward wrote (same dtype, row stride
+ * dcanvas_ld; columns d->out_col_off .. +C are read).  w2t = pfn_layers.1.linear.weight transposed, [64, C] in the compute dtype.
+ * `workspace` must be the buffer the matching forward call filled (pillar tables, layer inputs / outputs, BatchNorm statistics) and
+ * is consumed.  Outputs (fp32, overwritten): dw1 [32,8], dg1/db1 [32], dw2 [C,64], dg2/db2 [C]. */
+int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
+                       const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
+                       float* dw2, float* dg2, float* db2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HBM-bound glue of the encoders / decoder (each replaces a chain of ATen elementwise kernels)

@@ -20,7 +20,9 @@ namespace {
 constexpr int C1 = 32;      // PFN layer-0 units (feat_channels[0] / 2)
 constexpr int K2 = 64;      // layer-1 input = [x | xmax]
 constexpr int SORT_THREADS = 1024, SORT_WAVES = 16;
-constexpr int MAX_CELLS = 1900;   // (16 + 5) * nc * 4 B of LDS must stay below 160 KB
+constexpr int MAX_CELLS = 1900;
+// layer-0 backward accumulators: S_dyf[32][8] | S_xf[32][8] | S_f[8] | dbeta[32] | dgamma[32]
+constexpr int ACC_DYF = 0, ACC_XF = 256, ACC_F = 512, ACC_DB = 520, ACC_DG = 552, ACC1_FLOATS = 584;   // (16 + 5) * nc * 4 B of LDS must stay below 160 KB
 
 struct PillarGeom {
     int nx, ny, ncx, ncy, nc;  // ncx = nx+1 (cell nx holds x == xmax), nc = ncx*ncy*2
@@ -328,11 +330,180 @@ __global__ __launch_bounds__(256) void pfn_scatter_kernel(VoxTab t, int max_voxe
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward through the PFN parameters.  The dense [V, max_points] slot tensor of the reference never exists here either: the
+// "real rows + one representative padded row (multiplicity P - cnt)" layout of the forward carries through, a padded row's
+// gradient being the SUM over the identical slots it stands for.
+// ------------------------------------------------------------------------------------------------
+// step 1: per pillar / channel  g = dout * [relu'(y2 at the arg-max row)], BatchNorm-2 dbeta / dgamma.  hmax <- g, hmin <- selected h
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max_voxels, int nslots, int C, int ncell,
+                                                               const T* __restrict__ dcanvas, int dld, const float* __restrict__ sc2,
+                                                               const float* __restrict__ sh2, const float* __restrict__ mean2,
+                                                               const float* __restrict__ rstd2, float* __restrict__ hmax,
+                                                               float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int lane = threadIdx.x & 63;
+    constexpr int MAXJ = 12;
+    float s1[MAXJ], s2[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int nj = C / 64;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        const int b = v / max_voxels;
+        if ((v % max_voxels) >= t.nvox[b]) continue;
+        const int xyf = t.xy[v];
+        const bool live = (xyf & (1 << 30)) == 0;
+        const T* src = dcanvas + ((int64_t)b * ncell + (xyf & 0xffffff)) * dld;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (j < nj) {
+                const int c = lane + 64 * j;
+                const float sc = sc2[c];
+                const int64_t i = (int64_t)v * C + c;
+                const float hs = sc > 0.f ? hmax[i] : hmin[i];
+                const float y = sc * hs + sh2[c];
+                const float gv = (live && y > 0.f) ? Cvt<T>::to_f(src[c]) : 0.f;
+                hmax[i] = gv; hmin[i] = hs;
+                s1[j] += gv; s2[j] += gv * (hs - mean2[c]) * rstd2[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+        if (j < nj) { atomicAdd(dbeta + lane + 64 * j, s1[j]); atomicAdd(dgamma + lane + 64 * j, s2[j]); }
+}
+
+// step 2: H2 rows -> dH2 rows in place:  gamma*rstd * (g [first arg-max row] - w_row * (dbeta + xhat * dgamma) / n)
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_bwd_l2_rows_kernel(VoxTab t, int max_voxels, int max_points, int nslots, int C, T* __restrict__ H2,
+                                                              const float* __restrict__ g, const float* __restrict__ hsel,
+                                                              const float* __restrict__ gamma2, const float* __restrict__ mean2,
+                                                              const float* __restrict__ rstd2, const float* __restrict__ dbeta,
+                                                              const float* __restrict__ dgamma, const int* __restrict__ totals, int training) {
+    const int lane = threadIdx.x & 63;
+    const int nj = C / 64;
+    const float inv_n = training ? 1.f / fmaxf((float)totals[0] * (float)max_points, 1.f) : 0.f;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        const int cnt = t.cnt[v];
+        const int nrow = cnt + (cnt < max_points ? 1 : 0);
+        T* base = H2 + (int64_t)t.row[v] * C;
+        for (int j = 0; j < nj; ++j) {
+            const int c = lane + 64 * j;
+            const float mean = mean2[c], rstd = rstd2[c], gm = gamma2[c] * rstd;
+            const float a = dbeta[c] * inv_n, bb = dgamma[c] * inv_n;
+            const float gv = g[(int64_t)v * C + c], hs = hsel[(int64_t)v * C + c];
+            bool found = false;
+            for (int r = 0; r < nrow; ++r) {
+                const float val = Cvt<T>::to_f(base[(int64_t)r * C + c]);
+                const float wgt = r < cnt ? 1.f : (float)(max_points - cnt);
+                float dv = -wgt * (a + (val - mean) * rstd * bb);
+                if (!found && val == hs) { dv += gv; found = true; }
+                base[(int64_t)r * C + c] = Cvt<T>::from_f(gm * dv);
+            }
+        }
+    }
+}
+
+// step 3: layer 0.  lane = (channel c = lane & 31, row parity = lane >> 5); per-lane sequential walk over the pillar's rows.
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxels, int max_points, int nslots, const float* __restrict__ F8,
+                                                         const T* __restrict__ dX2, const float* __restrict__ w1, const float* __restrict__ sc1,
+                                                         const float* __restrict__ sh1, const float* __restrict__ mean1,
+                                                         const float* __restrict__ rstd1, float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    float wr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[k] = w1[c * 8 + k];
+    const float s = sc1[c], sh = sh1[c], m1 = mean1[c], r1 = rstd1[c];
+    float a_dyf[8], a_xf[8], a_f[8], db = 0.f, dg = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a_dyf[k] = 0.f; a_xf[k] = 0.f; a_f[k] = 0.f; }
+    for (int v = blockIdx.x * 4 + wave; v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        const int cnt = t.cnt[v];
+        const bool has_pad = cnt < max_points;
+        const int nrow = cnt + (has_pad ? 1 : 0);
+        const int64_t row0 = t.row[v];
+        float best = -INFINITY; int bi = 0x7fffffff;
+        float dxm = 0.f;
+        for (int r = half; r < nrow; r += 2) {
+            dxm += Cvt<T>::to_f(dX2[(row0 + r) * K2 + C1 + c]);
+            if (r < cnt) {
+                const float4 f0 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8), f1 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4);
+                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                float h = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
+                const float x = fmaxf(h * s + sh, 0.f);
+                if (x > best) { best = x; bi = r; }
+            }
+        }
+        {
+            const float ob = __shfl_xor(best, 32, 64); const int oi = __shfl_xor(bi, 32, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            dxm += __shfl_xor(dxm, 32, 64);
+        }
+        const bool pad_arg = has_pad && fmaxf(sh, 0.f) > best;
+        for (int r = half; r < cnt; r += 2) {
+            const float4 f0 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8), f1 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4);
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            float h = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
+            const float y = h * s + sh;
+            float dy = Cvt<T>::to_f(dX2[(row0 + r) * K2 + c]) + ((r == bi && !pad_arg) ? dxm : 0.f);
+            dy = y > 0.f ? dy : 0.f;
+            const float xh = (h - m1) * r1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a_dyf[k] += dy * f[k]; a_xf[k] += xh * f[k]; a_f[k] += f[k]; }
+            db += dy; dg += dy * xh;
+        }
+        if (has_pad && half == 0) {   // the padded slots: h = 0, y = shift; their summed gradient sits in the representative row
+            float dp = Cvt<T>::to_f(dX2[(row0 + cnt) * K2 + c]) + (pad_arg ? dxm : 0.f);
+            dp = sh > 0.f ? dp : 0.f;
+            db += dp; dg += dp * (0.f - m1) * r1;
+        }
+    }
+    // fold the two row parities, then the block's 4 waves, then one atomic per value per block
+    __shared__ float red[4][ACC1_FLOATS];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a_dyf[k] += __shfl_xor(a_dyf[k], 32, 64); a_xf[k] += __shfl_xor(a_xf[k], 32, 64); a_f[k] += __shfl_xor(a_f[k], 32, 64);
+    }
+    db += __shfl_xor(db, 32, 64); dg += __shfl_xor(dg, 32, 64);
+    if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[wave][ACC_DYF + c * 8 + k] = a_dyf[k]; red[wave][ACC_XF + c * 8 + k] = a_xf[k]; }
+        red[wave][ACC_DB + c] = db; red[wave][ACC_DG + c] = dg;
+        if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[wave][ACC_F + k] = a_f[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ACC1_FLOATS; i += 256) atomicAdd(acc + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+}
+
+// step 4: dW1 = gamma*rstd * (S_dyf - dbeta/n * S_f - dgamma/n * S_xf), dgamma1, dbeta1
+__global__ void pfn_bwd_l1_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ gamma1, const float* __restrict__ rstd1,
+                                           const int* __restrict__ totals, int max_points, int training, float* __restrict__ dw1,
+                                           float* __restrict__ dg1, float* __restrict__ db1) {
+    const int i = threadIdx.x, c = i >> 3, k = i & 7;
+    const float inv_n = training ? 1.f / fmaxf((float)totals[0] * (float)max_points, 1.f) : 0.f;
+    const float dbv = acc[ACC_DB + c], dgv = acc[ACC_DG + c];
+    dw1[i] = gamma1[c] * rstd1[c] * (acc[ACC_DYF + i] - dbv * inv_n * acc[ACC_F + k] - dgv * inv_n * acc[ACC_XF + i]);
+    if (k == 0) { dg1[c] = dgv; db1[c] = dbv; }
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Ws {
     int* sorted; int* vox_xy; int* vox_start; int* vox_cnt; int* vox_row; int* nvox; int* totals;
     float* sums1; float* sums2; float* sc1; float* sh1; float* sc2; float* sh2; float* hmax; float* hmin;
+    float* m1; float* r1; float* m2; float* r2;   // saved BatchNorm mean / rstd (backward)
+    float* acc1;                                  // backward accumulators of PFN layer 0 (ACC1_FLOATS)
     void* X2; void* H2; float* F8; int* row_vox; float* row_w;
     size_t bytes;
 };
@@ -349,6 +520,9 @@ Ws carve(void* base, const p3_pillar_desc* d) {
     const size_t zero_end = off;   // [0, zero_end) is cleared every call
     w.sc1 = (float*)take(C1 * 4); w.sh1 = (float*)take(C1 * 4);
     w.sc2 = (float*)take((size_t)d->C * 4); w.sh2 = (float*)take((size_t)d->C * 4);
+    w.m1 = (float*)take(C1 * 4); w.r1 = (float*)take(C1 * 4);
+    w.m2 = (float*)take((size_t)d->C * 4); w.r2 = (float*)take((size_t)d->C * 4);
+    w.acc1 = (float*)take(ACC1_FLOATS * 4);
     w.sorted = (int*)take((size_t)(d->total_points > 0 ? d->total_points : 1) * 4);
     w.vox_xy = (int*)take(nv * 4); w.vox_start = (int*)take(nv * 4); w.vox_cnt = (int*)take(nv * 4); w.vox_row = (int*)take(nv * 4);
     w.nvox = (int*)take((size_t)d->B * 4);
@@ -415,7 +589,7 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
         P3_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, w.sums1, C1, w.totals, (float)d->max_points, 0.f, bn1_gamma, bn1_beta,
-                       bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, (float*)nullptr, (float*)nullptr);
+                       bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, w.m1, w.r1);
     P3_LAUNCH_CHECK();
     if (d->dtype == P3_BF16)
         hipLaunchKernelGGL((pfn_l1_apply_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (bf16_t*)w.X2, w.F8, w.row_vox, w.row_w);
@@ -435,12 +609,66 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
         hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     P3_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, s, w.sums2, d->C, w.totals, (float)d->max_points, 0.f, bn2_gamma,
-                       bn2_beta, bn2_rmean, bn2_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc2, w.sh2, (float*)nullptr, (float*)nullptr);
+                       bn2_beta, bn2_rmean, bn2_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc2, w.sh2, w.m2, w.r2);
     P3_LAUNCH_CHECK();
     if (d->dtype == P3_BF16)
         hipLaunchKernelGGL((pfn_scatter_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, nslots, d->C, d->nx * d->ny, w.hmax, w.hmin, w.sc2, w.sh2, (bf16_t*)out + d->out_col_off, d->out_ld);
     else
         hipLaunchKernelGGL((pfn_scatter_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, nslots, d->C, d->nx * d->ny, w.hmax, w.hmin, w.sc2, w.sh2, (float*)out + d->out_col_off, d->out_ld);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+
+
+// Backward of p3_pillar_stem w.r.t. the PFN parameters.  `workspace` is the buffer the matching forward call filled; it is consumed.
+extern "C" int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
+                                  const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
+                                  float* dw2, float* dg2, float* db2, void* stream) {
+    P3_CHECK(dcanvas && w1 && bn1_gamma && w2t && bn2_gamma && workspace && d && dw1 && dg1 && db1 && dw2 && dg2 && db2, P3_EINVAL,
+             "p3_pillar_stem_bwd: null pointer");
+    P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
+    hipStream_t s = (hipStream_t)stream;
+    Ws w = carve(workspace, d);
+    const int nslots = d->B * d->max_voxels;
+    const size_t rows = (size_t)d->total_points + (size_t)nslots;
+    const int C = d->C;
+    hipError_t e = hipMemsetAsync(w.acc1, 0, ACC1_FLOATS * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dg2, 0, (size_t)C * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(db2, 0, (size_t)C * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dw2, 0, (size_t)C * K2 * 4, s);
+    if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+    VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
+    const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
+    const int sgrid = vgrid < 512 ? vgrid : 512;
+    const int ncell = d->nx * d->ny;
+    const bool bf = d->dtype == P3_BF16;
+    if (bf)
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+    else
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+    P3_LAUNCH_CHECK();
+    if (bf)
+        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, db2, dg2, w.totals, d->training);
+    else
+        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, db2, dg2, w.totals, d->training);
+    P3_LAUNCH_CHECK();
+    // dW2[C, 64] = dH2^T . X2
+    int rc = p3_gemm_tn_ex(w.H2, w.X2, dw2, (int)rows, C, K2, C, K2, K2, d->dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+    if (rc != P3_OK) return rc;
+    // dX2[rows, 64] = dH2 . W2  (written over X2, which the weight-gradient GEMM above has finished with)
+    p3_gemm_desc gd;
+    memset(&gd, 0, sizeof(gd));
+    gd.M = (int)rows; gd.N = K2; gd.K = C; gd.lda = C; gd.ldb = C; gd.ldc = K2;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    rc = p3_gemm(w.H2, w2t, w.X2, &gd, stream);
+    if (rc != P3_OK) return rc;
+    if (bf)
+        hipLaunchKernelGGL((pfn_bwd_l1_kernel<bf16_t>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const bf16_t*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1);
+    else
+        hipLaunchKernelGGL((pfn_bwd_l1_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const float*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1);
+    P3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pfn_bwd_l1_finalize_kernel, dim3(1), dim3(256), 0, s, w.acc1, bn1_gamma, w.r1, w.totals, d->max_points, d->training, dw1, dg1, db1);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

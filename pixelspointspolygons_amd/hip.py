@@ -219,8 +219,9 @@ def workspace(nbytes, device, tag="default"):
 
 
 def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax, max_points, max_voxels, training,
-                col_off=0, total_points=None, want_tables=False):
-    """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas."""
+                col_off=0, total_points=None, keep_workspace=False):
+    """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas.
+    keep_workspace: run in a workspace of its own and return (out, workspace, desc) for p3_pillar_stem_bwd."""
     _dev(values)
     d = PillarDesc()
     d.B = B
@@ -236,24 +237,23 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     L = lib()
     L.p3_pillar_stem_workspace_bytes.restype = c_int64
     nbytes = L.p3_pillar_stem_workspace_bytes(byref(d))
-    ws = workspace(nbytes, values.device, "pillar")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=values.device) if keep_workspace else workspace(nbytes, values.device, "pillar")
     check(L.p3_pillar_stem(ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
                            ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d), stream()),
           "p3_pillar_stem")
-    if not want_tables:
-        return out
-    off = (c_int64 * 13)()
-    check(L.p3_pillar_stem_layout(byref(d), off), "p3_pillar_stem_layout")
-    nv, npts = B * max_voxels, int(d.total_points)
-    rows = npts + nv
+    return (out, ws, d) if keep_workspace else out
 
-    def sect(o, n, dtype):
-        return ws[o:o + 4 * n].view(dtype).clone()
 
-    # static-shape views of the forward's tables (fixed capacity: graph-capturable, no host sync)
-    tables = dict(xy=sect(off[1], nv, torch.int32), nvox=sect(off[5], B, torch.int32), F8=sect(off[10], rows * 8, torch.float32).view(rows, 8),
-                  row_vox=sect(off[11], rows, torch.int32), row_w=sect(off[12], rows, torch.float32), MV=max_voxels)
-    return out, tables
+def pillar_stem_bwd(dcanvas, w1, g1, w2t, g2, ws, d):
+    """-> (dw1 [32,8], dg1, db1, dw2 [C,64], dg2, db2) fp32; consumes the forward's workspace."""
+    dev, C = dcanvas.device, d.C
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    dw1, dg1, db1, dw2, dg2, db2 = f(32, 8), f(32), f(32), f(C, 64), f(C), f(C)
+    if dt(dcanvas) != d.dtype:
+        raise P3Error("pillar_stem_bwd: canvas gradient dtype differs from the forward's")
+    check(lib().p3_pillar_stem_bwd(ptr(dcanvas), c_int(dcanvas.stride(-2)), ptr(w1), ptr(g1), ptr(w2t), ptr(g2), ptr(ws), byref(d), ptr(dw1),
+                                   ptr(dg1), ptr(db1), ptr(dw2), ptr(dg2), ptr(db2), stream()), "p3_pillar_stem_bwd")
+    return dw1, dg1, db1, dw2, dg2, db2
 
 
 # ------------------------------------------------------------------------------------------ glue ops

@@ -90,23 +90,27 @@ class _PillarStem(torch.autograd.Function):
                             (g2.detach(), b2.detach(), l1.norm.running_mean, l1.norm.running_var), canvas, B=B, grid=(mod.nx, mod.ny),
                             voxel=mod.voxel, zmax=mod.zmax, max_points=mod.max_points,
                             max_voxels=mod.max_voxels[0] if training else mod.max_voxels[1], training=training, col_off=col_off,
-                            want_tables=need)
+                            keep_workspace=need)
         if training:
             l0.norm.num_batches_tracked += 1
             l1.norm.num_batches_tracked += 1
         ctx.mark_dirty(canvas)
         if need:
-            ctx.tables = r[1]
-            ctx.save_for_backward(values)
-        ctx.mod, ctx.B, ctx.col_off = mod, B, col_off
+            _, ctx.ws, ctx.desc = r
+            ctx.save_for_backward(w1, g1, w2, g2)
+        ctx.mod = mod
         return canvas
 
     @staticmethod
     def backward(ctx, dcanvas):
-        from .backward import pillar_stem_backward
-        (values,) = ctx.saved_tensors
-        g = pillar_stem_backward(ctx.mod, values, ctx.tables, ctx.B, dcanvas, ctx.col_off)
-        return None, None, g[0], g[1], g[2], g[3], g[4], g[5], dcanvas, None, None, None
+        """Hand-written HIP backward (csrc/pillars.hip: p3_pillar_stem_bwd) over the forward's own workspace."""
+        w1, g1, w2, g2 = ctx.saved_tensors
+        cd = ctx.mod.cd
+        w2t = ops.shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())
+        dc = dcanvas if dcanvas.dtype == cd else dcanvas.to(cd)
+        dw1, dg1, db1, dw2, dg2, db2 = hip.pillar_stem_bwd(dc, w1.detach(), g1.detach(), w2t, g2.detach(), ctx.ws, ctx.desc)
+        ctx.ws = None
+        return None, None, dw1, dg1, db1, dw2, dg2, db2, dcanvas, None, None, None
 
 
 class PointPillarsViT(nn.Module):

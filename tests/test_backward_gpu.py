@@ -241,3 +241,31 @@ def test_scorenet_backward_native_vs_oracle_autograd(transpose, train, N, B):
         err = l2_err(prm.grad.cpu(), p["scorenet1." + k].grad, floor=1e-3 * gnorm)
         assert err < 1e-3, (k, err)
     assert l2_err(fd.grad.cpu(), f.grad) < 1e-3
+
+
+@pytest.mark.parametrize("train,max_points,n_points", [(True, 64, 3000), (False, 64, 3000), (True, 8, 6000), (True, 64, 400)])
+def test_pillar_stem_backward_native_vs_oracle_autograd(train, max_points, n_points):
+    """p3_pillar_stem_bwd (PFN parameter gradients) vs float64 autograd of the oracle's dense [V, max_points] formulation:
+    truncated pillars (max_points 8), mostly-padded pillars (400 points), train- and eval-mode BatchNorm."""
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pointpillars import PointPillarsEncoder
+    B = 3
+    sd = O.make_state_dict("lidar", seed=13)
+    pre = "encoder.vit.patch_embed."
+    inp = O.make_inputs(B, seed=77, n_points=n_points, jitter=n_points // 10)
+    p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+         for k, v in sd.items() if k.startswith(pre)}
+    ref = O.pillar_stem(inp["lidar_values"], inp["lidar_offsets"], p, pre, max_points=max_points, training=train)   # [B, C, ny, nx]
+    g = _rand(B, 784, 384, seed=8)
+    ref.flatten(2).transpose(1, 2).backward(g.double())
+    cfg = make_config("pointpillars_vit", precision="fp32", device=DEV, max_num_points_per_voxel=max_points)
+    enc = PointPillarsEncoder(cfg).to(DEV)
+    enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    enc.train(train)
+    out = enc((inp["lidar_values"].to(DEV), inp["lidar_offsets"].to(DEV)))
+    assert rel_err(out.detach().cpu(), ref.detach().flatten(2).transpose(1, 2)) < 1e-4
+    out.backward(g.to(DEV))
+    gnorm = max(float(v.grad.norm()) for v in p.values() if v.is_floating_point() and v.requires_grad)
+    for k, prm in enc.named_parameters():
+        err = l2_err(prm.grad.cpu(), p[pre + k].grad, floor=1e-3 * gnorm)
+        assert err < 2e-3, (k, err)
