@@ -69,7 +69,9 @@ class Stepper:
     """Static input buffers + (optionally) one captured hipGraph of forward + loss + backward + AdamW."""
 
     def __init__(self, model, opt, reducer, pool, kind, use_graph):
+        from pixelspointspolygons_amd import ops
         from pixelspointspolygons_amd.training import pix2poly_loss
+        self.ops = ops
         self.model, self.opt, self.reducer, self.kind = model, opt, reducer, kind
         self.loss_fn = pix2poly_loss
         cap = max(int(b["lidar_values"].shape[0]) for b in pool) if kind != "image" else 0
@@ -91,6 +93,7 @@ class Stepper:
     def _fwd_bwd(self):
         s = self.static
         y = s["y"]
+        self.ops.advance_rng(y.device)           # new decoder dropout masks every step (device counter: replays with the graph)
         lidar = (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
         logits, perm = self.model(s.get("image"), lidar, y[:, :-1])
         loss, ce, bce = self.loss_fn(logits, perm, y[:, 1:], s["y_perm"], 1.0, 10.0, 226)
@@ -194,7 +197,8 @@ def main():
     tk = Tokenizer(cfg)
     model = Pix2PolyModel(cfg, tk.vocab_size, local)
     model.train()
-    model.decoder.set_dropout(0.0)           # HIP decoder is dropout-free (known gap)
+    # decoder dropout stays at the reference's training defaults (0.1 in nn.TransformerDecoderLayer incl. the attention
+    # probabilities, 0.05 on both positional sums, model_pix2poly.py:136-143): fused into the GEMM epilogues / attention kernels
     opt = FlatAdamW(model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=compute_dtype(cfg),
                     direct_grad=bool(args.graph) or world == 1)   # hook-driven overlap (eager N > 1) needs autograd's AccumulateGrad
     opt.set_linear_schedule(200 * 1000)

@@ -57,6 +57,19 @@ const char* p3_last_error_string(void);
  *   ScoreNet conv1..3               models/pix2poly/model_pix2poly.py:74-80            (P3_A_PAIR_AFFINE_RELU / P3_A_AFFINE_RELU)
  * K must be a multiple of 64 (bf16) / 16 (f32); M, N arbitrary.
  * ------------------------------------------------------------------------------------------ */
+/* Counter-based dropout (nn.Dropout / the attention-probability dropout of nn.MultiheadAttention in training mode, reference
+ * Decoder: model_pix2poly.py:136,139,143): element (row, col) of site `site` is kept iff 16 bits of hash(seed, site, row, col) are
+ * >= round(p * 65536), and scaled by 1/(1-p); the mask is never stored, backward kernels regenerate it.  `seed` points to a DEVICE counter (advance it once per
+ * training step with p3_rng_advance, inside the captured graph).  seed == NULL disables dropout. */
+typedef struct {
+    const unsigned long long* seed;
+    unsigned int site;
+    float p;
+} p3_dropout;
+int p3_rng_advance(unsigned long long* seed, void* stream);
+/* out[i] = keep(i / ncols, i % ncols) ? in[i] / (1-p) : 0   (elementwise dropout forward, and its backward applied to the gradient) */
+int p3_dropout_apply(const void* in, int dtype_in, void* out, int dtype_out, int64_t n, int64_t ncols, const p3_dropout* drop, void* stream);
+
 typedef struct {
     int M, N, K;
     int lda, ldb, ldc;
@@ -76,6 +89,7 @@ typedef struct {
     int pair_n;
     float* colsum;        /* optional [N]: += sum over rows of (A'W^T + bias)   (train-mode BatchNorm statistics) */
     float* colsumsq;      /* optional [N]: += sum of squares */
+    p3_dropout drop;      /* dropout of act(A'W^T + bias) before the residual add; element = (row, col) */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 
@@ -111,6 +125,7 @@ typedef struct {
     const float* key_bias; /* [B, Lk] or NULL */
     int dtype;             /* Q,K,V,O dtype */
     float* lse;            /* [B,H,Lq] or NULL */
+    p3_dropout drop;       /* dropout of the attention probabilities; element = (row (b*H + h)*Lq + q, col k) */
 } p3_attn_desc;
 int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream);
 
@@ -211,7 +226,9 @@ int p3_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
 int p3_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, void* stream);
 int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, void* stream);
 /* dpre = dy * act'(.)  (GELU: saved = pre-activation; ReLU: saved = output) */
-int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act, void* stream);
+/* scale: extra factor on dy (1/(1-p) when a dropout followed the activation: the saved ReLU output is already masked) */
+int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act, float scale,
+               void* stream);
 int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream);
 /* dscale is the centred sum  sum dz*(src - mean)  when mean != NULL (feeds p3_bn_bwd_coeffs) */
 int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* mean,

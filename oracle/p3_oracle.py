@@ -244,8 +244,9 @@ def create_mask(tgt, pad_idx=PAD):
     return causal, (tgt == pad_idx).to(torch.float32)
 
 
-def _mha(xq, xkv, sd, pre, heads, bias=None):
-    """nn.MultiheadAttention (packed in_proj), batch-first here.  bias: additive [B,1|H,Lq,Lk] or None."""
+def _mha(xq, xkv, sd, pre, heads, bias=None, pmask=None):
+    """nn.MultiheadAttention (packed in_proj), batch-first here.  bias: additive [B,1|H,Lq,Lk] or None.
+    pmask: optional [B,H,Lq,Lk] dropout mask (already scaled by 1/(1-p)) applied to the softmax output (training mode)."""
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
     W, b = sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"]
@@ -257,28 +258,40 @@ def _mha(xq, xkv, sd, pre, heads, bias=None):
     s = (sp(q, Lq) @ sp(k, Lk).transpose(-2, -1)) / math.sqrt(hd)
     if bias is not None:
         s = s + bias
-    a = torch.softmax(s, -1) @ sp(v, Lk)
+    pr = torch.softmax(s, -1)
+    if pmask is not None:
+        pr = pr * pmask
+    a = pr @ sp(v, Lk)
     a = a.transpose(1, 2).reshape(B, Lq, D)
     return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
 
-def decoder_forward(enc, tgt, sd, prefix="decoder.", heads=8, layers=6, pad_idx=PAD, eps=1e-5):
-    """Decoder.forward (model_pix2poly.py:158-185), eval / dropout-free.  Returns (logits, feats)."""
+def decoder_forward(enc, tgt, sd, prefix="decoder.", heads=8, layers=6, pad_idx=PAD, eps=1e-5, masks=None):
+    """Decoder.forward (model_pix2poly.py:158-185).  Returns (logits, feats).
+
+    masks=None: eval / dropout-free.  Training mode: `masks(site, shape)` returns the dropout mask (0 or 1/(1-p)) of one of the
+    reference's dropout sites — decoder_pos_drop (site 250, :136), encoder_pos_drop (251, :143) and, per nn.TransformerDecoderLayer i
+    (default dropout 0.1, :139), 8*i + {0: self-attn probabilities, 1: dropout1, 2: cross-attn probabilities, 3: dropout2,
+    4: FFN activation dropout, 5: dropout3} — so that a run with the product's own masks is comparable element by element."""
+    mk = (lambda site, t: t) if masks is None else (lambda site, t: t * masks(site, tuple(t.shape)).to(t.dtype))
+    pm = (lambda site, shape: None) if masks is None else (lambda site, shape: masks(site, shape))
     causal, kpm = create_mask(tgt, pad_idx)
-    L = tgt.shape[1]
-    x = sd[prefix + "embedding.weight"][tgt] + sd[prefix + "decoder_pos_embed"][:, :L]
-    mem = enc + sd[prefix + "encoder_pos_embed"]
+    B, L = tgt.shape
+    x = mk(250, sd[prefix + "embedding.weight"][tgt] + sd[prefix + "decoder_pos_embed"][:, :L])
+    mem = mk(251, enc + sd[prefix + "encoder_pos_embed"])
+    Lm = mem.shape[1]
     bias = causal.view(1, 1, L, L) + kpm.view(-1, 1, 1, L)           # float kpm => additive (+1.0)
     D = x.shape[-1]
     for i in range(layers):
         p = f"{prefix}decoder.layers.{i}."
-        x = F.layer_norm(x + _mha(x, x, sd, p + "self_attn.", heads, bias), (D,),
+        s0 = 8 * i
+        x = F.layer_norm(x + mk(s0 + 1, _mha(x, x, sd, p + "self_attn.", heads, bias, pm(s0, (B, heads, L, L)))), (D,),
                          sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
-        x = F.layer_norm(x + _mha(x, mem, sd, p + "multihead_attn.", heads), (D,),
+        x = F.layer_norm(x + mk(s0 + 3, _mha(x, mem, sd, p + "multihead_attn.", heads, None, pm(s0 + 2, (B, heads, L, Lm)))), (D,),
                          sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
-        h = F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
+        h = F.linear(mk(s0 + 4, F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"]))),
                      sd[p + "linear2.weight"], sd[p + "linear2.bias"])
-        x = F.layer_norm(x + h, (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], eps)
+        x = F.layer_norm(x + mk(s0 + 5, h), (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], eps)
     return F.linear(x, sd[prefix + "output.weight"], sd[prefix + "output.bias"]), x
 
 
@@ -330,7 +343,7 @@ def perm_head(feats, sd, iters=100, training=False):
     return torch.softmax(z, -1), s
 
 
-def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, training=False):
+def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, training=False, dec_masks=None):
     """EncoderDecoder.forward (model_pix2poly.py:245-266).  lidar = (values, offsets)."""
     if img is not None and lidar is not None:
         enc = encoder_fusion(img, lidar[0], lidar[1], sd, cfg, training=training)
@@ -338,7 +351,7 @@ def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, trainin
         enc = encoder_vit(img, sd, cfg)
     else:
         enc = encoder_lidar(lidar[0], lidar[1], sd, cfg, training=training)
-    logits, feats = decoder_forward(enc, y, sd)
+    logits, feats = decoder_forward(enc, y, sd, masks=dec_masks)
     perm, _ = perm_head(feats, sd, iters, training)
     return logits, perm
 

@@ -119,7 +119,7 @@ __device__ __forceinline__ void attn_store_tile(int tid, T* Ks, T* Vs, const u32
         }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     using TR = ATr<T, D>;
     constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV, NH2 = KT / 32, NDJ = D / 32;
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (d.causal) { int lim = qblk + 128; if (lim < kv_end) kv_end = lim; }  // keys beyond the block's last query are masked
     const int ntiles = (kv_end + KT - 1) / KT;
     const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
+    DropKey dk; uint32_t drop_rk = 0;
+    if constexpr (DROP) { dk = drop_key(d.drop); drop_rk = drop_rowkey(dk, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
 
     // staging registers
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
@@ -259,6 +261,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             m_run = m_new;
         }
         l_run += psum;
+        if constexpr (DROP) {   // attention-probability dropout: the row sum above stays undropped (softmax first, then dropout)
+#pragma unroll
+            for (int h2 = 0; h2 < NH2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {   // registers r, r+1 hold keys 2j, 2j+1: one hash per pair
+                    const uint32_t bits = drop_bits(drop_rk, drop_colkey(dk, (uint32_t)(kv0 + h2 * 32 + crow32(r, hi))));
+                    sacc[h2][r] = drop_keep_lo(dk, bits) ? sacc[h2][r] * dk.inv_keep : 0.f;
+                    sacc[h2][r + 1] = drop_keep_hi(dk, bits) ? sacc[h2][r + 1] * dk.inv_keep : 0.f;
+                }
+        }
 
         // ---- O^T += V^T . P^T ----
         if constexpr (BF) {
@@ -336,13 +348,19 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d;
     dim3 grid(p3_ceil_div(d->Lq, 128), d->H, d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const bool drop = d->drop.seed != nullptr && d->drop.p > 0.f;
+    P3_CHECK(!drop || d->drop.p < 1.f, P3_EINVAL, "p3_attention: dropout p must be < 1");
+#define P3_ATTN_FWD(T, D)                                                                                   \
+    do {                                                                                                    \
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<T, D, true>), grid, block, 0, s, a);                  \
+        else hipLaunchKernelGGL((attn_fwd_kernel<T, D, false>), grid, block, 0, s, a);                      \
+    } while (0)
     if (d->dtype == P3_BF16) {
-        if (d->head_dim == 64) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 64>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 32>), grid, block, 0, s, a);
+        if (d->head_dim == 64) P3_ATTN_FWD(bf16_t, 64); else P3_ATTN_FWD(bf16_t, 32);
     } else {
-        if (d->head_dim == 64) hipLaunchKernelGGL((attn_fwd_kernel<float, 64>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<float, 32>), grid, block, 0, s, a);
+        if (d->head_dim == 64) P3_ATTN_FWD(float, 64); else P3_ATTN_FWD(float, 32);
     }
+#undef P3_ATTN_FWD
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -181,7 +181,7 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int KT = BF ? 64 : 32;
@@ -214,6 +214,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     if (d.causal) { const int lim = qblk + 128; if (lim < kv_end) kv_end = lim; }
     const int ntiles = (kv_end + KT - 1) / KT;
     const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
+    DropKey dkey; uint32_t drop_rk = 0;
+    if constexpr (DROP) { dkey = drop_key(d.drop); drop_rk = drop_rowkey(dkey, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();
@@ -231,7 +233,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
                 if (kbias) sv += kbias[kv < d.Lk ? kv : d.Lk - 1];
                 const bool masked = kv >= d.Lk || (d.causal && kv > q);
                 const float p = masked ? 0.f : __expf(sv - lse);
-                s[r] = p * (dp[r] - dlt);                                     // dS^T
+                float dpv = dp[r];
+                if constexpr (DROP) {
+                    const uint32_t bits = drop_bits(drop_rk, drop_colkey(dkey, (uint32_t)kv));   // pairs (r, r+1) share it: CSE'd
+                    dpv = ((r & 1) ? drop_keep_hi(dkey, bits) : drop_keep_lo(dkey, bits)) ? dpv * dkey.inv_keep : 0.f;
+                }
+                s[r] = p * (dpv - dlt);                                       // dS^T
             }
             accum_mma<T, D, KT>(Krow, Ktr, sub, s, dq, l31, hi);              // dQ^T[d, q] += K^T . dS^T
         }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, int D>
+template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int QT = BF ? 64 : 32;
@@ -272,6 +279,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
     const int q_begin = d.causal ? (kblk / QT) * QT : 0;   // queries before the block's first key never see it
+    DropKey dkey; uint32_t drop_ck = 0; uint64_t drop_bh = 0;
+    if constexpr (DROP) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
     for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
         __syncthreads();
@@ -292,8 +301,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
                 const int ql = sub * 32 + crow32(r, hi), qq = q0 + ql;
                 const bool masked = qq >= d.Lq || kv >= d.Lk || (d.causal && kv > qq);
                 const float p = masked ? 0.f : __expf(s[r] * d.scale + bias - Ls[ql]);
-                s[r] = p;
-                ds[r] = p * (dp[r] - Ds[ql]);
+                float pd = p, dpv = dp[r];
+                if constexpr (DROP) {
+                    const uint32_t bits = drop_bits(drop_rowkey(dkey, drop_bh + (uint64_t)(qq < d.Lq ? qq : d.Lq - 1)), drop_ck);
+                    const bool keep = (kvc & 1) ? drop_keep_hi(dkey, bits) : drop_keep_lo(dkey, bits);
+                    pd = keep ? p * dkey.inv_keep : 0.f;
+                    dpv = keep ? dpv * dkey.inv_keep : 0.f;
+                }
+                s[r] = pd;
+                ds[r] = p * (dpv - Ds[ql]);
             }
             accum_mma<T, D, QT>(Grow, Gtr, sub, s, dv, l31, hi);              // dV^T[d, kv] += dO^T . P
             accum_mma<T, D, QT>(Qrow, Qtr, sub, ds, dk, l31, hi);             // dK^T[d, kv] += Q^T . dS
@@ -311,8 +327,13 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
     const int64_t rows = (int64_t)d.B * d.H * d.Lq;
     int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
     hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(g), dim3(256), 0, s, a, D);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+    if (d.drop.seed != nullptr && d.drop.p > 0.f) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+    }
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

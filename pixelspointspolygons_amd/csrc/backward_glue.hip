@@ -10,9 +10,9 @@ inline int grid_for(int64_t work) {
 
 // dpre = dy * act'(.) ; GELU: saved = pre-activation ; ReLU: saved = output
 template <typename TDY, typename TS, typename TO>
-__global__ void act_bwd_kernel(const TDY* __restrict__ dy, const TS* __restrict__ saved, TO* __restrict__ out, int64_t n, int act) {
+__global__ void act_bwd_kernel(const TDY* __restrict__ dy, const TS* __restrict__ saved, TO* __restrict__ out, int64_t n, int act, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float g = Cvt<TDY>::to_f(dy[i]), x = Cvt<TS>::to_f(saved[i]);
+        const float g = Cvt<TDY>::to_f(dy[i]) * scale, x = Cvt<TS>::to_f(saved[i]);
         float d;
         if (act == P3_ACT_GELU) {
             const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
@@ -104,12 +104,12 @@ __global__ void pair_mean_bwd_kernel(const float* __restrict__ dF, T* __restrict
 }  // namespace
 
 extern "C" int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act,
-                          void* stream) {
+                          float scale, void* stream) {
     P3_CHECK(dy && saved && out && (act == P3_ACT_GELU || act == P3_ACT_RELU), P3_EINVAL, "p3_act_bwd: bad arguments");
     if (n <= 0) return P3_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_for(n)), b(256);
-#define AB(TDY, TS, TO) hipLaunchKernelGGL((act_bwd_kernel<TDY, TS, TO>), g, b, 0, s, (const TDY*)dy, (const TS*)saved, (TO*)out, n, act)
+#define AB(TDY, TS, TO) hipLaunchKernelGGL((act_bwd_kernel<TDY, TS, TO>), g, b, 0, s, (const TDY*)dy, (const TS*)saved, (TO*)out, n, act, scale)
     const int key = dtype_dy * 4 + dtype_saved * 2 + dtype_out;
     switch (key) {
         case 0: AB(float, float, float); break;

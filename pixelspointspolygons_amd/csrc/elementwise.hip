@@ -201,6 +201,19 @@ __global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ b, int64_
         b[i] = Cvt<TO>::from_f(Cvt<TI>::to_f(a[i]));
 }
 
+template <typename TI, typename TO>
+__global__ void dropout_apply_kernel(const TI* __restrict__ a, TO* __restrict__ b, int64_t n, int64_t ncols, p3_dropout dr) {
+    const DropKey k = drop_key(dr);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ncols;
+        b[i] = Cvt<TO>::from_f((!k.on || drop_keep(k, (uint64_t)row, (uint32_t)(i - row * ncols))) ? Cvt<TI>::to_f(a[i]) * k.inv_keep : 0.f);
+    }
+}
+
+__global__ void rng_advance_kernel(unsigned long long* seed) {
+    seed[0] = seed[0] * 6364136223846793005ull + 1442695040888963407ull;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF, CALL_F32, name)                 \
@@ -324,6 +337,30 @@ extern "C" int p3_add_pos(const void* x, const float* pos, void* out, int B, int
     const int64_t total = (int64_t)B * L * D, LD = (int64_t)L * D;
     DISPATCH_T(dtype, hipLaunchKernelGGL((add_pos_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, pos, (bf16_t*)out, total, LD),
                hipLaunchKernelGGL((add_pos_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, pos, (float*)out, total, LD), "p3_add_pos");
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_rng_advance(unsigned long long* seed, void* stream) {
+    P3_CHECK(seed, P3_EINVAL, "p3_rng_advance: null pointer");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_dropout_apply(const void* in, int dtype_in, void* out, int dtype_out, int64_t n, int64_t ncols, const p3_dropout* drop,
+                                void* stream) {
+    P3_CHECK(in && out && drop && n >= 0 && ncols > 0, P3_EINVAL, "p3_dropout_apply: bad arguments");
+    P3_CHECK(drop->p >= 0.f && drop->p < 1.f, P3_EINVAL, "p3_dropout_apply: p must be in [0, 1)");
+    if (n == 0) return P3_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for(n)), blk(256);
+    const p3_dropout dr = *drop;
+    if (dtype_in == P3_F32 && dtype_out == P3_BF16) hipLaunchKernelGGL((dropout_apply_kernel<float, bf16_t>), g, blk, 0, s, (const float*)in, (bf16_t*)out, n, ncols, dr);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_F32) hipLaunchKernelGGL((dropout_apply_kernel<bf16_t, float>), g, blk, 0, s, (const bf16_t*)in, (float*)out, n, ncols, dr);
+    else if (dtype_in == P3_F32 && dtype_out == P3_F32) hipLaunchKernelGGL((dropout_apply_kernel<float, float>), g, blk, 0, s, (const float*)in, (float*)out, n, ncols, dr);
+    else if (dtype_in == P3_BF16 && dtype_out == P3_BF16) hipLaunchKernelGGL((dropout_apply_kernel<bf16_t, bf16_t>), g, blk, 0, s, (const bf16_t*)in, (bf16_t*)out, n, ncols, dr);
+    else { p3_set_error("p3_dropout_apply: dtype"); return P3_EUNSUP; }
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const bool has_res = d.residual != nullptr;
     const bool res_bf = d.dtype_res == P3_BF16;
     const int act = d.act;
+    const DropKey dk = drop_key(d.drop);
 #pragma unroll 2
     for (int c = 0; c < 8; ++c) {
         const int id = tid + 256 * c;
@@ -289,6 +290,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             }
+            if (dk.on) {
+                const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const uint32_t bits = drop_bits(rk, drop_colkey(dk, (uint32_t)(col + k)));
+                    v[k] = drop_keep_lo(dk, bits) ? v[k] * dk.inv_keep : 0.f;
+                    v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
+                }
+            }
             if (has_res) {
                 const int64_t ro = (int64_t)row * d.ldr + col;
                 if (res_bf) {
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (aux) aux[co + k] = Cvt<TO>::from_f(x);
                 if (act == P3_ACT_GELU) x = gelu_erf(x);
                 else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
+                if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
                 if (has_res) {
                     const int64_t ri = (int64_t)row * d.ldr + col + k;
                     x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];

@@ -44,6 +44,39 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- counter-based dropout (p3_dropout) ---------------------------------------------------------------------------------
+// Element (row, col) of a site: bits = hash32(rowkey(row) ^ colkey(col >> 1)), 16 bits per element (low half: even col, high half:
+// odd col); kept iff bits16 >= p * 65536.  A lane that owns one row (attention fwd / dQ, GEMM epilogue) pays one 2-multiply hash
+// per TWO elements; v_mul_lo_u32 is quarter rate on CDNA, so the multiply count is what matters.
+__device__ __forceinline__ uint32_t p3_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropKey { uint32_t k0, k1, thresh; float inv_keep; bool on; };
+__device__ __forceinline__ DropKey drop_key(const p3_dropout& dr) {
+    DropKey k; k.on = dr.seed != nullptr && dr.p > 0.f; k.k0 = 0; k.k1 = 0; k.thresh = 0; k.inv_keep = 1.f;
+    if (k.on) {
+        const unsigned long long s = *dr.seed;
+        k.k0 = p3_hash32((uint32_t)s ^ (dr.site * 0x9E3779B9u));
+        k.k1 = p3_hash32((uint32_t)(s >> 32) + dr.site * 0x85EBCA6Bu + 0x1234567u);
+        k.thresh = (uint32_t)(dr.p * 65536.f + 0.5f);
+        if (k.thresh > 65535u) k.thresh = 65535u;
+        k.inv_keep = 65536.f / (float)(65536u - k.thresh);
+    }
+    return k;
+}
+__device__ __forceinline__ uint32_t drop_rowkey(const DropKey& k, uint64_t row) {
+    return (uint32_t)row * 0x9E3779B1u + (uint32_t)(row >> 32) * 0x7FEB352Du + k.k0;
+}
+__device__ __forceinline__ uint32_t drop_colkey(const DropKey& k, uint32_t col) { return (col >> 1) * 0x85EBCA77u + k.k1; }
+__device__ __forceinline__ uint32_t drop_bits(uint32_t rowkey, uint32_t colkey) { return p3_hash32(rowkey ^ colkey); }
+__device__ __forceinline__ bool drop_keep_lo(const DropKey& k, uint32_t bits) { return (bits & 0xffffu) >= k.thresh; }
+__device__ __forceinline__ bool drop_keep_hi(const DropKey& k, uint32_t bits) { return (bits >> 16) >= k.thresh; }
+__device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t row, uint32_t col) {
+    const uint32_t bits = drop_bits(drop_rowkey(k, row), drop_colkey(k, col));
+    return (col & 1u) ? drop_keep_hi(k, bits) : drop_keep_lo(k, bits);
+}
+
 // row index of accumulator register r of a 32x32 MFMA C/D fragment (col = lane & 31)
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -78,19 +78,31 @@ def _dev(t):
         raise P3Error("p3hip ops need device tensors (there is no CPU path)")
 
 
+class Dropout(Structure):
+    """p3_dropout: (device seed pointer, site id, p).  Built from a python triple (seed_tensor int64[1], site, p) by _drop()."""
+    _fields_ = [("seed", c_void_p), ("site", ctypes.c_uint), ("p", c_float)]
+
+
+def _drop(spec):
+    d = Dropout()
+    if spec is not None and spec[2] > 0.0:
+        d.seed, d.site, d.p = spec[0].data_ptr(), int(spec[1]), float(spec[2])
+    return d
+
+
 class GemmDesc(Structure):
     _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype_in", c_int), ("dtype_out", c_int), ("act", c_int), ("a_mode", c_int),
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("dtype_res", c_int), ("aux", c_void_p),
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
-                ("colsum", c_void_p), ("colsumsq", c_void_p)]
+                ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None):
-    """C[M,N] = act(A'[M,K] @ W[N,K]^T + bias) + residual.  a: [..., K] (2-D view), w: [N, K]."""
+         lda=None, ldc=None, drop=None):
+    """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p)."""
     _dev(a)
     N, K = w.shape
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
@@ -126,6 +138,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         d.pair_V, d.pair_n = pair_v.data_ptr(), pair_n
     if colsum is not None:
         d.colsum, d.colsumsq = colsum.data_ptr(), colsumsq.data_ptr()
+    d.drop = _drop(drop)
     ev = KTIMER.begin()
     check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
     KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K)
@@ -165,10 +178,11 @@ class AttnDesc(Structure):
     _fields_ = [("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("head_dim", c_int),
                 ("q_bs", c_int64), ("k_bs", c_int64), ("v_bs", c_int64), ("o_bs", c_int64),
                 ("q_rs", c_int), ("k_rs", c_int), ("v_rs", c_int), ("o_rs", c_int),
-                ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p)]
+                ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p),
+                ("drop", Dropout)]
 
 
-def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse):
+def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None):
     B, Lq, Dm = q.shape
     Lk = k.shape[1]
     d = AttnDesc()
@@ -178,10 +192,11 @@ def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse):
     d.scale, d.causal, d.dtype = scale, int(causal), dt(q)
     d.key_bias = key_bias.data_ptr() if key_bias is not None else None
     d.lse = lse.data_ptr() if lse is not None else None
+    d.drop = _drop(drop)
     return d
 
 
-def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False):
+def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False, drop=None):
     """q [B,Lq,H*D], k/v [B,Lk,H*D] (arbitrary batch/row strides, unit inner stride) -> o [B,Lq,H*D]."""
     _dev(q)
     for t in (q, k, v):
@@ -189,7 +204,7 @@ def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False
             raise P3Error("attention: inner stride must be 1")
     o = torch.empty((q.shape[0], q.shape[1], q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if need_lse else None
-    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse)
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop)
     ev = KTIMER.begin()
     check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
     KTIMER.end(ev, f"attn_fwd_kernel<{'bf16' if d.dtype == BF16 else 'f32'},{d.head_dim}>",
@@ -356,7 +371,7 @@ def add_pos(x, pos):
 
 
 # ------------------------------------------------------------------------------------------ backward / training ops
-def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None):
+def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None, drop=None):
     """dq/dk/dv get the same batch/row strides as q/k/v (pass views of a packed buffer to get a packed gradient)."""
     dq = torch.empty_like(q) if dq is None else dq
     dk = torch.empty_like(k) if dk is None else dk
@@ -366,7 +381,7 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
             raise P3Error("attention_bwd: gradient strides must equal input strides")
     if do.stride() != o.stride():
         raise P3Error("attention_bwd: dO strides must equal O strides")
-    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None)
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None, drop)
     delta = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
     check(lib().p3_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta), byref(d),
                                  stream()), "p3_attention_bwd")
@@ -409,11 +424,11 @@ def batch_sum(x):
     return colsum(x.reshape(B, -1)).view(x.shape[1:])
 
 
-def act_bwd(dy, saved, act, out_dtype):
+def act_bwd(dy, saved, act, out_dtype, scale=1.0):
     out = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
     dyc, sc = dy.contiguous(), saved.contiguous()
     check(lib().p3_act_bwd(ptr(dyc), c_int(dt(dyc)), ptr(sc), c_int(dt(sc)), ptr(out), c_int(dt(out)), c_int64(dy.numel()), c_int(act),
-                           stream()), "p3_act_bwd")
+                           c_float(scale), stream()), "p3_act_bwd")
     return out
 
 
@@ -565,4 +580,19 @@ def nhwc_to_nchw(X, ld, scale, shift, B, C, HW):
     out = torch.empty((B, C, HW), dtype=torch.float32, device=X.device)
     check(lib().p3_nhwc_to_nchw(ptr(X), c_int(ld), c_int(dt(X)), ptr(scale), ptr(shift), ptr(out), c_int(B), c_int(C), c_int64(HW), stream()),
           "p3_nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ dropout
+def rng_advance(seed):
+    check(lib().p3_rng_advance(ptr(seed), stream()), "p3_rng_advance")
+
+
+def dropout_apply(x, out_dtype, drop, out=None):
+    """out = keep ? x / (1 - p) : 0 with the counter-based mask of (seed, site); element = (flat row, last-dim column) of x."""
+    xc = x.contiguous()
+    out = torch.empty(xc.shape, dtype=out_dtype, device=x.device) if out is None else out
+    d = _drop(drop)
+    check(lib().p3_dropout_apply(ptr(xc), c_int(dt(xc)), ptr(out), c_int(dt(out)), c_int64(xc.numel()), c_int64(xc.shape[-1]), byref(d), stream()),
+          "p3_dropout_apply")
     return out

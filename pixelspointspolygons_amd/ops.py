@@ -18,6 +18,29 @@ DIRECT_GRAD = [False]   # set by FlatAdamW: weight / bias / LayerNorm gradients 
                         # arena by the split-M atomics of the TN GEMM / colsum kernels (no zero-fill, no AccumulateGrad add pass)
 
 
+_rng = {}
+
+
+def rng_seed(device):
+    """Device-resident dropout counter (int64[1]); every dropout site hashes (this value, its site id, the element index)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = str(device)
+    if key not in _rng:
+        _rng[key] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+    return _rng[key]
+
+
+def manual_seed(seed, device):
+    rng_seed(device).fill_(int(seed))
+
+
+def advance_rng(device):
+    """Once per training step (captured into the step graph): new masks for every site."""
+    hip.rng_advance(rng_seed(device))
+
+
 def register_shadow(p, view):
     _registered[id(p)] = (p, view)
 
@@ -72,7 +95,7 @@ class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x [.., K] compute dtype; W [N, K] fp32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows):
+    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows, drop):
         w = shadow(weight, cd)
         ctx.bias_param = bias
         if rows is not None:
@@ -85,7 +108,10 @@ class _Linear(torch.autograd.Function):
         if need and act == hip.ACT_GELU:
             aux = torch.empty((x2.shape[0], w.shape[0]), dtype=out_dtype, device=x.device)
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
-        y = hip.gemm(x2, w, bias=bias, act=act, residual=res2, out_dtype=out_dtype, aux=aux)
+        y = hip.gemm(x2, w, bias=bias, act=act, residual=res2, out_dtype=out_dtype, aux=aux, drop=drop)
+        ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
+        if ctx.drop is not None and act == hip.ACT_GELU:
+            raise NotImplementedError("dropout after GELU is not on the reference path")
         ctx.act, ctx.cd, ctx.has_res, ctx.has_bias = act, cd, residual is not None, bias is not None
         ctx.xshape = x.shape
         if need:
@@ -99,10 +125,14 @@ class _Linear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dres = dy if ctx.has_res else None
         # dpre = dy * act'(pre), in compute dtype
+        drop = ctx.drop
         if ctx.act == hip.ACT_NONE:
-            dpre = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
-        else:
-            dpre = hip.act_bwd(dy2, saved, ctx.act, cd)
+            if drop is not None:        # same (seed, site, row*N + col) mask as the forward epilogue, regenerated while casting
+                dpre = hip.dropout_apply(dy2, cd, drop)
+            else:
+                dpre = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
+        else:                           # ReLU then dropout: the saved output is already masked, only the 1/(1-p) factor remains
+            dpre = hip.act_bwd(dy2, saved, ctx.act, cd, scale=1.0 / (1.0 - drop[2]) if drop is not None else 1.0)
         dx = dw = db = None
         rows = ctx.rows
         n_true = dpre.shape[1]
@@ -129,7 +159,7 @@ class _Linear(torch.autograd.Function):
                     hip.colsum(dpre, out=bias_p.grad[r0:r1])
                 else:
                     db = hip.colsum(dpre)
-            return dx, None, db, dres, None, None, None, None
+            return dx, None, db, dres, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
             if rows is not None:
@@ -142,12 +172,13 @@ class _Linear(torch.autograd.Function):
                 full = torch.zeros(weight.shape[0], dtype=torch.float32, device=db.device)
                 full[rows[0]:rows[1]] = db
                 db = full
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=None, cd=torch.float32, rows=None):
-    """rows=(a, b): use only weight[a:b] / bias[a:b] (packed in_proj of nn.MultiheadAttention)."""
-    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows)
+def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=None, cd=torch.float32, rows=None, drop=None):
+    """rows=(a, b): use only weight[a:b] / bias[a:b] (packed in_proj of nn.MultiheadAttention).
+    drop=(seed, site, p): dropout of the activated output before the residual add (fused into the GEMM epilogue)."""
+    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop)
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
@@ -185,58 +216,75 @@ class _SelfAttention(torch.autograd.Function):
     """qkv [B, L, 3D] packed (output of the qkv / in_proj GEMM) -> o [B, L, D]; the gradient comes back packed."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale, causal, key_bias):
+    def forward(ctx, qkv, heads, scale, causal, key_bias, drop):
         D = qkv.shape[-1] // 3
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         if any(ctx.needs_input_grad):
-            o, lse = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, need_lse=True)
+            o, lse = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, need_lse=True, drop=drop)
             ctx.save_for_backward(qkv, o, lse, key_bias)
-            ctx.cfg = (heads, scale, causal, D)
+            ctx.cfg = (heads, scale, causal, D, drop)
         else:
-            o = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias)
+            o = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, drop=drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o, lse, key_bias = ctx.saved_tensors
-        heads, scale, causal, D = ctx.cfg
+        heads, scale, causal, D, drop = ctx.cfg
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), heads, scale, causal=causal,
-                          key_bias=key_bias, dq=dqkv[..., :D], dk=dqkv[..., D:2 * D], dv=dqkv[..., 2 * D:])
-        return dqkv, None, None, None, None
+                          key_bias=key_bias, dq=dqkv[..., :D], dk=dqkv[..., D:2 * D], dv=dqkv[..., 2 * D:], drop=drop)
+        return dqkv, None, None, None, None, None
 
 
 class _CrossAttention(torch.autograd.Function):
     """q [B, Lq, D], kv [B, Lk, 2D] packed -> o [B, Lq, D]."""
 
     @staticmethod
-    def forward(ctx, q, kv, heads, scale):
+    def forward(ctx, q, kv, heads, scale, drop):
         D = q.shape[-1]
         k, v = kv[..., :D], kv[..., D:]
         if any(ctx.needs_input_grad):
-            o, lse = hip.attention(q, k, v, heads, scale, need_lse=True)
+            o, lse = hip.attention(q, k, v, heads, scale, need_lse=True, drop=drop)
             ctx.save_for_backward(q, kv, o, lse)
-            ctx.cfg = (heads, scale, D)
+            ctx.cfg = (heads, scale, D, drop)
         else:
-            o = hip.attention(q, k, v, heads, scale)
+            o = hip.attention(q, k, v, heads, scale, drop=drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, kv, o, lse = ctx.saved_tensors
-        heads, scale, D = ctx.cfg
+        heads, scale, D, drop = ctx.cfg
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        hip.attention_bwd(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), heads, scale, dq=dq, dk=dkv[..., :D], dv=dkv[..., D:])
-        return dq, dkv, None, None
+        hip.attention_bwd(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), heads, scale, dq=dq, dk=dkv[..., :D], dv=dkv[..., D:], drop=drop)
+        return dq, dkv, None, None, None
 
 
-def self_attention(qkv, heads, causal=False, key_bias=None):
+def self_attention(qkv, heads, causal=False, key_bias=None, drop=None):
     hd = qkv.shape[-1] // 3 // heads
-    return _SelfAttention.apply(qkv, heads, 1.0 / math.sqrt(hd), causal, key_bias)
+    return _SelfAttention.apply(qkv, heads, 1.0 / math.sqrt(hd), causal, key_bias, drop)
 
 
-def cross_attention(q, kv, heads):
-    return _CrossAttention.apply(q, kv, heads, 1.0 / math.sqrt(q.shape[-1] // heads))
+def cross_attention(q, kv, heads, drop=None):
+    return _CrossAttention.apply(q, kv, heads, 1.0 / math.sqrt(q.shape[-1] // heads), drop)
+
+
+class _Dropout(torch.autograd.Function):
+    """Standalone elementwise dropout (decoder_pos_drop / encoder_pos_drop): same counter-based mask forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return hip.dropout_apply(x, x.dtype, drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.dropout_apply(dy, dy.dtype, ctx.drop), None
+
+
+def dropout(x, drop):
+    return x if drop is None or drop[2] <= 0.0 else _Dropout.apply(x, drop)
 
 
 # ---------------------------------------------------------------------------------------------- glue with autograd

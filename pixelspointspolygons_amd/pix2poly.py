@@ -203,41 +203,48 @@ class Decoder(nn.Module):
         nn.init.trunc_normal_(self.encoder_pos_embed, std=0.02)
         nn.init.trunc_normal_(self.decoder_pos_embed, std=0.02)
 
-    def _check_dropout(self):
-        if self.training and (self.decoder_pos_drop.p > 0 or self.decoder.layers[0].dropout.p > 0):
-            raise NotImplementedError(
-                "HIP decoder runs dropout-free; call set_dropout(0.0) (parity is asserted in eval() or with p = 0, SURVEY §8b)")
-
     def set_dropout(self, p):
         for m in self.modules():
             if isinstance(m, nn.Dropout):
                 m.p = p
+            elif isinstance(m, nn.MultiheadAttention):
+                m.dropout = p
+
+    # dropout site ids (p3_dropout.site): 8 per decoder layer + the two positional dropouts
+    SITE_SA_ATTN, SITE_SA_OUT, SITE_CA_ATTN, SITE_CA_OUT, SITE_FFN_ACT, SITE_FFN_OUT = range(6)
+    SITE_DEC_POS, SITE_ENC_POS = 250, 251
 
     def _run(self, encoder_out, tgt):
         cd, D, H = self.cd, self.dim, self.num_heads
         B, L = tgt.shape
+        seed = ops.rng_seed(tgt.device) if self.training else None
+        dr = (lambda site, p: (seed, site, float(p)) if p > 0.0 else None) if self.training else (lambda site, p: None)
         x, kb = ops.embed_tokens(tgt, self.embedding.weight, self.decoder_pos_embed, self.pad_idx, cd)
+        x = ops.dropout(x, dr(self.SITE_DEC_POS, self.decoder_pos_drop.p))
         enc = encoder_out if encoder_out.dtype == cd else ops.cast(encoder_out, cd)
-        mem = ops.add_pos(enc, self.encoder_pos_embed)
-        for lyr in self.decoder.layers:
+        mem = ops.dropout(ops.add_pos(enc, self.encoder_pos_embed), dr(self.SITE_ENC_POS, self.encoder_pos_drop.p))
+        for li, lyr in enumerate(self.decoder.layers):
             sa, ca = lyr.self_attn, lyr.multihead_attn
+            s0 = 8 * li
             qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)
-            a = ops.self_attention(qkv, H, causal=True, key_bias=kb)
-            y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            a = ops.self_attention(qkv, H, causal=True, key_bias=kb, drop=dr(s0 + self.SITE_SA_ATTN, sa.dropout))
+            y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
+                           drop=dr(s0 + self.SITE_SA_OUT, lyr.dropout1.p))
             x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
             q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
             kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D))
-            a = ops.cross_attention(q, kv, H)
-            y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            a = ops.cross_attention(q, kv, H, drop=dr(s0 + self.SITE_CA_ATTN, ca.dropout))
+            y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
+                           drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p))
             x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
-            h = ops.linear(x, lyr.linear1.weight, lyr.linear1.bias, act=hip.ACT_RELU, cd=cd)
-            y = ops.linear(h, lyr.linear2.weight, lyr.linear2.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            h = ops.linear(x, lyr.linear1.weight, lyr.linear1.bias, act=hip.ACT_RELU, cd=cd, drop=dr(s0 + self.SITE_FFN_ACT, lyr.dropout.p))
+            y = ops.linear(h, lyr.linear2.weight, lyr.linear2.bias, residual=x, out_dtype=torch.float32, cd=cd,
+                           drop=dr(s0 + self.SITE_FFN_OUT, lyr.dropout3.p))
             x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
         return x
 
     def forward(self, encoder_out, tgt):
         """encoder_out (N, L_enc, D), tgt (N, L) -> (logits fp32 (N, L, vocab), pre-logit features (N, L, D))."""
-        self._check_dropout()
         x = self._run(encoder_out, tgt)
         logits = ops.linear(x, self.output.weight, self.output.bias, out_dtype=torch.float32, cd=self.cd)
         return logits, x

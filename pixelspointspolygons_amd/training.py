@@ -183,6 +183,7 @@ def train_step(model, opt: FlatAdamW, batch, reducer: GradBucketReducer = None, 
     """One reference train step (trainer_pix2poly.py:305-329) -> (loss, ce, bce) device scalars (no host sync)."""
     y = batch["y"]
     pad = model.cfg.experiment.model.tokenizer.pad_idx if hasattr(model, "cfg") else 226
+    ops.advance_rng(y.device)        # fresh dropout masks (decoder) for this step
     logits, perm = model(batch.get("image"), batch.get("lidar"), y[:, :-1])
     loss, ce, bce = pix2poly_loss(logits, perm, y[:, 1:], batch["y_perm"], w_vertex, w_perm, pad)
     opt.zero_grad()

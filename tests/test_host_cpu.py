@@ -72,14 +72,16 @@ def test_factory_errors_like_the_reference():
         Pix2PolyModel(cfg, 227, 0)
 
 
-def test_decoder_refuses_silent_dropout_mismatch():
+def test_decoder_dropout_sites_match_the_reference_defaults():
+    """nn.TransformerDecoderLayer default p = 0.1 (attention probabilities, dropout/1/2/3), pos dropouts 0.05 (model_pix2poly.py:136-143)."""
     from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
     cfg = _cfg("vit")
-    m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0).train()
-    with pytest.raises(NotImplementedError):
-        m.decoder._check_dropout()
-    m.decoder.set_dropout(0.0)
-    m.decoder._check_dropout()
+    dec = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0).decoder
+    lyr = dec.decoder.layers[0]
+    assert dec.decoder_pos_drop.p == 0.05 and dec.encoder_pos_drop.p == 0.05
+    assert [lyr.dropout.p, lyr.dropout1.p, lyr.dropout2.p, lyr.dropout3.p, lyr.self_attn.dropout, lyr.multihead_attn.dropout] == [0.1] * 6
+    dec.set_dropout(0.0)
+    assert dec.decoder_pos_drop.p == 0.0 and lyr.dropout3.p == 0.0
 
 
 def test_linear_warmup_decay_schedule_matches_transformers():
