@@ -161,9 +161,18 @@ int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1,
                    const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
                    const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
                    const p3_pillar_desc* d, void* stream);
-/* byte offsets (13 int64) of the workspace sections the training path re-reads in backward: sorted, vox_xy, vox_start, vox_cnt,
- * vox_row, nvox, X2, H2, hmax, hmin, F8 (decorated point features per X2 row), row_vox (pillar slot per row, -1 unused), row_w */
+/* byte offsets (17 int64) of the workspace sections: sorted, vox_xy, vox_start, vox_cnt, vox_row, nvox, X2, H2, hmax, hmin, F8 (decorated
+ * point features per X2 row), row_vox (pillar slot per row, -1 unused), row_w, then the statistics SyncBatchNorm all-reduces between the
+ * phases: totals (int32: kept pillars of the batch), sums1 (fp32 [2*32]), sums2 (fp32 [2*C]), acc1 (fp32 [584]: layer-0 backward sums,
+ * dbeta1 at [520:552], dgamma1 at [552:584]) */
 int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* offsets);
+/* p3_pillar_stem split at its two BatchNorm statistics (nn.SyncBatchNorm.convert_sync_batchnorm, model_pix2poly.py:326): phases is a
+ * bit mask, 1 = pillarize + layer-0 sums, 2 = layer-0 apply + layer-1 GEMM + sums, 4 = finalize + scatter; all-reduce totals / sums1
+ * after phase 1 and sums2 after phase 2.  p3_pillar_stem == phases 7. */
+int p3_pillar_stem_phased(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
+                          const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
+                          const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
+                          const p3_pillar_desc* d, int phases, void* stream);
 /* Backward of p3_pillar_stem w.r.t. the PillarFeatureNet parameters (what autograd produces for
  * PointPillarsEncoder.forward, pointpillars_o3d.py:85-107: voxel_encoder.pfn_layers.{0,1}.{linear.weight, norm.weight, norm.bias};
  * the point coordinates carry no gradient).  dcanvas: gradient of the token-major canvas the forward wrote (same dtype, row stride
@@ -173,6 +182,12 @@ int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* offsets);
 int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
                        const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
                        float* dw2, float* dg2, float* db2, void* stream);
+/* The same in phases (1 = layer-1 arg-max gradients + local dg2/db2, 2 = dH2 rows + GEMMs + layer-0 sums, 4 = layer-0 finalize) for
+ * SyncBatchNorm: stat2 = all-reduced [db2 (C) | dg2 (C)], stat1 = all-reduced [dbeta1 (32) | dgamma1 (32)] (acc1[520:584]) feed the
+ * input-gradient terms; NULL = this rank's own sums.  The parameter gradients written to dg*, db* stay per-rank, as in torch. */
+int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
+                              const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
+                              float* dw2, float* dg2, float* db2, const float* stat2, const float* stat1, int phases, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HBM-bound glue of the encoders / decoder (each replaces a chain of ATen elementwise kernels)

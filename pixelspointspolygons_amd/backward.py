@@ -21,7 +21,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     acc3 = torch.zeros(3 * 64 + 1, **f32)
     dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dout.contiguous(), w4=net.conv4.weight.detach().reshape(-1), N=N, transpose=transpose_acc)
     dw4, db4 = acc3[128:192].view(1, 64, 1, 1), acc3[192:193]
-    dg3, dbt3, a3, b3 = hip.bn_bwd_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training)
+    dg3, dbt3, a3, b3 = ops.bn_backward_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training)
     if training:
         hip.affine_fix(dH3, H3, a3, b3)
     # ---- conv3 (+ BN2/ReLU in front of it)
@@ -31,7 +31,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
     dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3)
-    dg2, dbt2, a2, b2 = hip.bn_bwd_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training)
+    dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training)
     if training:
         hip.affine_fix(dH2, H2, a2, b2)
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
@@ -41,7 +41,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
     acc1 = torch.zeros(2 * 256, **f32)
     dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
-    dg1, dbt1, a1, b1 = hip.bn_bwd_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training)
+    dg1, dbt1, a1, b1 = ops.bn_backward_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training)
     if training:
         hip.pair_stats_bwd(U, V, a1, b1, dU, dV, B, N)
     # ---- conv1 (separable): U = F W1a^T + b1, V = F W1b^T

@@ -487,14 +487,15 @@ __global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxel
 }
 
 // step 4: dW1 = gamma*rstd * (S_dyf - dbeta/n * S_f - dgamma/n * S_xf), dgamma1, dbeta1
-__global__ void pfn_bwd_l1_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ gamma1, const float* __restrict__ rstd1,
+__global__ void pfn_bwd_l1_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ stat /*[dbeta(32) | dgamma(32)]*/,
+                                           const float* __restrict__ gamma1, const float* __restrict__ rstd1,
                                            const int* __restrict__ totals, int max_points, int training, float* __restrict__ dw1,
                                            float* __restrict__ dg1, float* __restrict__ db1) {
     const int i = threadIdx.x, c = i >> 3, k = i & 7;
     const float inv_n = training ? 1.f / fmaxf((float)totals[0] * (float)max_points, 1.f) : 0.f;
-    const float dbv = acc[ACC_DB + c], dgv = acc[ACC_DG + c];
+    const float dbv = stat[c], dgv = stat[C1 + c];
     dw1[i] = gamma1[c] * rstd1[c] * (acc[ACC_DYF + i] - dbv * inv_n * acc[ACC_F + k] - dgv * inv_n * acc[ACC_XF + i]);
-    if (k == 0) { dg1[c] = dgv; db1[c] = dbv; }
+    if (k == 0) { dg1[c] = acc[ACC_DG + c]; db1[c] = acc[ACC_DB + c]; }
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -542,10 +543,12 @@ extern "C" int64_t p3_pillar_stem_workspace_bytes(const p3_pillar_desc* d) {
     return (int64_t)carve(nullptr, d).bytes;
 }
 
-extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
-                              const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
-                              const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
-                              const p3_pillar_desc* d, void* stream) {
+// phases (bit mask): 1 = pillarize + layer-0 BatchNorm sums | 2 = layer 0 apply, layer-1 GEMM, reduce + BatchNorm sums |
+// 4 = finalize + scatter.  SyncBatchNorm all-reduces the workspace's `totals`/`sums1` after phase 1 and `sums2` after phase 2.
+extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
+                                     const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
+                                     const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
+                                     const p3_pillar_desc* d, int phases, void* stream) {
     P3_CHECK(values && offsets && w1 && w2 && out && workspace && d, P3_EINVAL, "p3_pillar_stem: null pointer");
     P3_CHECK(d->B > 0 && d->nx > 0 && d->ny > 0 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem: max_points must be 1..64");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768, P3_ESHAPE, "p3_pillar_stem: C must be a multiple of 64, <= 768");
@@ -562,6 +565,9 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     const size_t es = d->dtype == P3_BF16 ? 2 : 4;
     const size_t rows = (size_t)d->total_points + (size_t)nslots;
     hipError_t e;
+    VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
+    const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
+    if (phases & 1) {
     e = hipMemsetAsync(w.totals, 0, (char*)w.sc1 - (char*)w.totals, s);
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
@@ -582,12 +588,12 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     }
     hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
     P3_LAUNCH_CHECK();
-    VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
-    const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
     if (d->training) {
         hipLaunchKernelGGL(pfn_l1_stats_kernel, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
         P3_LAUNCH_CHECK();
     }
+    }
+    if (phases & 2) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, w.sums1, C1, w.totals, (float)d->max_points, 0.f, bn1_gamma, bn1_beta,
                        bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, w.m1, w.r1);
     P3_LAUNCH_CHECK();
@@ -608,6 +614,8 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     else
         hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     P3_LAUNCH_CHECK();
+    }
+    if (phases & 4) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, s, w.sums2, d->C, w.totals, (float)d->max_points, 0.f, bn2_gamma,
                        bn2_beta, bn2_rmean, bn2_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc2, w.sh2, w.m2, w.r2);
     P3_LAUNCH_CHECK();
@@ -616,15 +624,28 @@ extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const
     else
         hipLaunchKernelGGL((pfn_scatter_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, nslots, d->C, d->nx * d->ny, w.hmax, w.hmin, w.sc2, w.sh2, (float*)out + d->out_col_off, d->out_ld);
     P3_LAUNCH_CHECK();
+    }
     return P3_OK;
+}
+
+extern "C" int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,
+                              const float* bn1_beta, float* bn1_rmean, float* bn1_rvar, const void* w2, const float* bn2_gamma,
+                              const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
+                              const p3_pillar_desc* d, void* stream) {
+    return p3_pillar_stem_phased(values, offsets, w1, bn1_gamma, bn1_beta, bn1_rmean, bn1_rvar, w2, bn2_gamma, bn2_beta, bn2_rmean, bn2_rvar,
+                                 out, workspace, d, 7, stream);
 }
 
 
 
 // Backward of p3_pillar_stem w.r.t. the PFN parameters.  `workspace` is the buffer the matching forward call filled; it is consumed.
-extern "C" int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
-                                  const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
-                                  float* dw2, float* dg2, float* db2, void* stream) {
+// phases: 1 = layer-1 arg-max gradients + local dgamma2 / dbeta2 | 2 = dH2 rows, both GEMMs, layer-0 accumulation | 4 = layer-0 finalize.
+// stat2 = [dbeta2 (C) | dgamma2 (C)] and stat1 = [dbeta1 (32) | dgamma1 (32)] are the sums the BatchNorm input gradients use: NULL =
+// this rank's own (plain BatchNorm); SyncBatchNorm passes their all-reduced copies (the parameter gradients stay local, like torch).
+extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
+                                         const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1,
+                                         float* db1, float* dw2, float* dg2, float* db2, const float* stat2, const float* stat1, int phases,
+                                         void* stream) {
     P3_CHECK(dcanvas && w1 && bn1_gamma && w2t && bn2_gamma && workspace && d && dw1 && dg1 && db1 && dw2 && dg2 && db2, P3_EINVAL,
              "p3_pillar_stem_bwd: null pointer");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
@@ -633,25 +654,32 @@ extern "C" int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const flo
     const int nslots = d->B * d->max_voxels;
     const size_t rows = (size_t)d->total_points + (size_t)nslots;
     const int C = d->C;
-    hipError_t e = hipMemsetAsync(w.acc1, 0, ACC1_FLOATS * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(dg2, 0, (size_t)C * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(db2, 0, (size_t)C * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(dw2, 0, (size_t)C * K2 * 4, s);
-    if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+    if (phases & 1) {
+        hipError_t e = hipMemsetAsync(w.acc1, 0, ACC1_FLOATS * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(dg2, 0, (size_t)C * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(db2, 0, (size_t)C * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(dw2, 0, (size_t)C * K2 * 4, s);
+        if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
+    }
+    const float* s2_db = stat2 ? stat2 : db2;
+    const float* s2_dg = stat2 ? stat2 + C : dg2;
     VoxTab t{w.sorted, w.vox_xy, w.vox_start, w.vox_cnt, w.vox_row, w.nvox};
     const int vgrid = (nslots + 3) / 4 < 2048 ? (nslots + 3) / 4 : 2048;
     const int sgrid = vgrid < 512 ? vgrid : 512;
     const int ncell = d->nx * d->ny;
     const bool bf = d->dtype == P3_BF16;
+    if (phases & 1) {
     if (bf)
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     P3_LAUNCH_CHECK();
+    }
+    if (phases & 2) {
     if (bf)
-        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, db2, dg2, w.totals, d->training);
+        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
     else
-        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, db2, dg2, w.totals, d->training);
+        hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
     P3_LAUNCH_CHECK();
     // dW2[C, 64] = dH2^T . X2
     int rc = p3_gemm_tn_ex(w.H2, w.X2, dw2, (int)rows, C, K2, C, K2, K2, d->dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
@@ -668,13 +696,24 @@ extern "C" int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const flo
     else
         hipLaunchKernelGGL((pfn_bwd_l1_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const float*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1);
     P3_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pfn_bwd_l1_finalize_kernel, dim3(1), dim3(256), 0, s, w.acc1, bn1_gamma, w.r1, w.totals, d->max_points, d->training, dw1, dg1, db1);
+    }
+    if (phases & 4) {
+    hipLaunchKernelGGL(pfn_bwd_l1_finalize_kernel, dim3(1), dim3(256), 0, s, w.acc1, stat1 ? stat1 : w.acc1 + ACC_DB, bn1_gamma, w.r1, w.totals,
+                       d->max_points, d->training, dw1, dg1, db1);
     P3_LAUNCH_CHECK();
+    }
     return P3_OK;
 }
 
+extern "C" int p3_pillar_stem_bwd(const void* dcanvas, int dcanvas_ld, const float* w1, const float* bn1_gamma, const void* w2t,
+                                  const float* bn2_gamma, void* workspace, const p3_pillar_desc* d, float* dw1, float* dg1, float* db1,
+                                  float* dw2, float* dg2, float* db2, void* stream) {
+    return p3_pillar_stem_bwd_phased(dcanvas, dcanvas_ld, w1, bn1_gamma, w2t, bn2_gamma, workspace, d, dw1, dg1, db1, dw2, dg2, db2, nullptr,
+                                     nullptr, 7, stream);
+}
+
 // byte offsets of the workspace sections (for the training path, which re-reads the pillar tables in backward)
-extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[13]*/) {
+extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[17]*/) {
     P3_CHECK(d && off, P3_EINVAL, "p3_pillar_stem_layout: null pointer");
     char* base = (char*)256;   // any non-null base: only differences are used
     Ws w = carve(base, d);
@@ -682,5 +721,6 @@ extern "C" int p3_pillar_stem_layout(const p3_pillar_desc* d, int64_t* off /*[13
     off[3] = (char*)w.vox_cnt - base; off[4] = (char*)w.vox_row - base; off[5] = (char*)w.nvox - base;
     off[6] = (char*)w.X2 - base; off[7] = (char*)w.H2 - base; off[8] = (char*)w.hmax - base; off[9] = (char*)w.hmin - base;
     off[10] = (char*)w.F8 - base; off[11] = (char*)w.row_vox - base; off[12] = (char*)w.row_w - base;
+    off[13] = (char*)w.totals - base; off[14] = (char*)w.sums1 - base; off[15] = (char*)w.sums2 - base; off[16] = (char*)w.acc1 - base;
     return P3_OK;
 }

@@ -28,6 +28,8 @@ def _khwc(w, cpad=None):
 
 
 def _bn_affine(sums, count, bn, training):
+    if training:
+        count = count * ops.sync_stats(sums)        # SyncBatchNorm: global sums / global count
     sc, sh = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum, training)
     if training:
         bn.num_batches_tracked += 1
@@ -207,6 +209,7 @@ class FFLModel(torch.nn.Module):
         model = EncoderDecoder(encoder=encoder, cfg=cfg)
         model.to(cfg.host.device)
         if cfg.host.multi_gpu:
+            ops.SYNC_BN[0] = True
             model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
             model = DDP(model, device_ids=[local_rank], find_unused_parameters=cfg.run_type.name == "debug")
         return model

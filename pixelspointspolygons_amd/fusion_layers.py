@@ -75,7 +75,8 @@ class _FusionConvBN(torch.autograd.Function):
         sums = torch.zeros(2 * D, dtype=torch.float32, device=canvas.device) if training else None
         pre = hip.gemm(canvas.view(B * g * g, 2 * D), w2, bias=b.detach(), a_mode=hip.A_CONV3X3, conv=(B, g, g, 2 * D), lda=2 * D,
                        out_dtype=cd, colsum=sums[:D] if training else None, colsumsq=sums[D:] if training else None)
-        scale, shift, mean, rstd = hip.bn_finalize(sums, float(B * g * g), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
+        world = ops.sync_stats(sums) if training else 1
+        scale, shift, mean, rstd = hip.bn_finalize(sums, float(B * g * g * world), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum, training, save=True)
         if training:
             bn.num_batches_tracked += 1
@@ -93,7 +94,7 @@ class _FusionConvBN(torch.autograd.Function):
         cd, g, D = mod.cd, mod.g, mod.D
         M = B * g * g
         dpre = dpre.contiguous()
-        dg, dbt, a, b = hip.bn_bwd_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training)
+        dg, dbt, a, b = ops.bn_backward_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training)
         if mod.training:
             hip.affine_fix(dpre, pre, a, b)
         db = hip.colsum(dpre)

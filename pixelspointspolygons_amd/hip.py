@@ -234,9 +234,10 @@ def workspace(nbytes, device, tag="default"):
 
 
 def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax, max_points, max_voxels, training,
-                col_off=0, total_points=None, keep_workspace=False):
+                col_off=0, total_points=None, keep_workspace=False, sync=None):
     """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas.
-    keep_workspace: run in a workspace of its own and return (out, workspace, desc) for p3_pillar_stem_bwd."""
+    keep_workspace: run in a workspace of its own and return (out, workspace, desc) for p3_pillar_stem_bwd.
+    sync: callable(*tensors) all-reducing statistic buffers in place (SyncBatchNorm) or None."""
     _dev(values)
     d = PillarDesc()
     d.B = B
@@ -253,21 +254,49 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     L.p3_pillar_stem_workspace_bytes.restype = c_int64
     nbytes = L.p3_pillar_stem_workspace_bytes(byref(d))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=values.device) if keep_workspace else workspace(nbytes, values.device, "pillar")
-    check(L.p3_pillar_stem(ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
-                           ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d), stream()),
-          "p3_pillar_stem")
+    args = (ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
+            ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d))
+    if sync is None or not training:
+        check(L.p3_pillar_stem(*args, stream()), "p3_pillar_stem")
+    else:   # SyncBatchNorm: all-reduce the pillar count / BatchNorm sums between the phases
+        sec = _pillar_sections(ws, d)
+        check(L.p3_pillar_stem_phased(*args, c_int(1), stream()), "p3_pillar_stem")
+        sync(sec["totals"], sec["sums1"])
+        check(L.p3_pillar_stem_phased(*args, c_int(2), stream()), "p3_pillar_stem")
+        sync(sec["sums2"])
+        check(L.p3_pillar_stem_phased(*args, c_int(4), stream()), "p3_pillar_stem")
     return (out, ws, d) if keep_workspace else out
 
 
-def pillar_stem_bwd(dcanvas, w1, g1, w2t, g2, ws, d):
-    """-> (dw1 [32,8], dg1, db1, dw2 [C,64], dg2, db2) fp32; consumes the forward's workspace."""
+def _pillar_sections(ws, d):
+    off = (c_int64 * 17)()
+    check(lib().p3_pillar_stem_layout(byref(d), off), "p3_pillar_stem_layout")
+    sect = lambda o, n, dtype: ws[o:o + 4 * n].view(dtype)
+    return dict(totals=sect(off[13], 1, torch.int32), sums1=sect(off[14], 64, torch.float32), sums2=sect(off[15], 2 * d.C, torch.float32),
+                acc1_stat=sect(off[16] + 4 * 520, 64, torch.float32))
+
+
+def pillar_stem_bwd(dcanvas, w1, g1, w2t, g2, ws, d, sync=None):
+    """-> (dw1 [32,8], dg1, db1, dw2 [C,64], dg2, db2) fp32; consumes the forward's workspace.  sync: SyncBatchNorm all-reduce."""
     dev, C = dcanvas.device, d.C
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    dw1, dg1, db1, dw2, dg2, db2 = f(32, 8), f(32), f(32), f(C, 64), f(C), f(C)
+    dw1, dg1, db1, dw2, dgb2 = f(32, 8), f(32), f(32), f(C, 64), f(2 * C)
+    db2, dg2 = dgb2[:C], dgb2[C:]
     if dt(dcanvas) != d.dtype:
         raise P3Error("pillar_stem_bwd: canvas gradient dtype differs from the forward's")
-    check(lib().p3_pillar_stem_bwd(ptr(dcanvas), c_int(dcanvas.stride(-2)), ptr(w1), ptr(g1), ptr(w2t), ptr(g2), ptr(ws), byref(d), ptr(dw1),
-                                   ptr(dg1), ptr(db1), ptr(dw2), ptr(dg2), ptr(db2), stream()), "p3_pillar_stem_bwd")
+    args = (ptr(dcanvas), c_int(dcanvas.stride(-2)), ptr(w1), ptr(g1), ptr(w2t), ptr(g2), ptr(ws), byref(d), ptr(dw1),
+            ptr(dg1), ptr(db1), ptr(dw2), ptr(dg2), ptr(db2))
+    L = lib()
+    if sync is None or not d.training:
+        check(L.p3_pillar_stem_bwd(*args, stream()), "p3_pillar_stem_bwd")
+    else:
+        check(L.p3_pillar_stem_bwd_phased(*args, ptr(None), ptr(None), c_int(1), stream()), "p3_pillar_stem_bwd")
+        stat2 = dgb2.clone()
+        sync(stat2)
+        check(L.p3_pillar_stem_bwd_phased(*args, ptr(stat2), ptr(None), c_int(2), stream()), "p3_pillar_stem_bwd")
+        stat1 = _pillar_sections(ws, d)["acc1_stat"].clone()
+        sync(stat1)
+        check(L.p3_pillar_stem_bwd_phased(*args, ptr(stat2), ptr(stat1), c_int(4), stream()), "p3_pillar_stem_bwd")
     return dw1, dg1, db1, dw2, dg2, db2
 
 

@@ -18,6 +18,43 @@ DIRECT_GRAD = [False]   # set by FlatAdamW: weight / bias / LayerNorm gradients 
                         # arena by the split-M atomics of the TN GEMM / colsum kernels (no zero-fill, no AccumulateGrad add pass)
 
 
+SYNC_BN = [False]       # set by the model factories when cfg.host.multi_gpu (nn.SyncBatchNorm.convert_sync_batchnorm, model_pix2poly.py:326)
+
+
+def sync_stats(*tensors):
+    """SyncBatchNorm: SUM the per-rank statistic buffers (BatchNorm sums, counts, backward sums) across ranks, in place.
+    Returns the world size the batch count must be multiplied by (1 when SyncBatchNorm is off / single process)."""
+    if not SYNC_BN[0]:
+        return 1
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1
+    for t in tensors:
+        if dist.get_backend() == "gloo" and t.is_cuda:     # test rigs (world-2 on one GPU): gloo reduces through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return dist.get_world_size()
+
+
+def sync_active():
+    import torch.distributed as dist
+    return SYNC_BN[0] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def bn_backward_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
+    """(dgamma, dbeta, a, b) of a BatchNorm backward: parameter gradients from THIS rank's sums (DDP averages them), input-gradient
+    coefficients from the all-reduced sums and the global count when SyncBatchNorm is on (torch's SyncBatchNorm backward)."""
+    dg, dbt, a, b = hip.bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training)
+    if training and sync_active():
+        gs, gh = dscale.clone(), dshift.clone()
+        w = sync_stats(gs, gh)
+        _, _, a, b = hip.bn_bwd_coeffs(gs, gh, gamma, mean, rstd, count * w, training)
+    return dg, dbt, a, b
+
+
 _rng = {}
 
 
@@ -307,6 +344,8 @@ class _EmbedTokens(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, emb, pos, pad_idx, cd):
         L = tokens.shape[1]
+        if L > pos.shape[-2]:
+            raise hip.P3Error(f"embed_tokens: sequence length {L} exceeds decoder_pos_embed length {pos.shape[-2]}")
         tokens = tokens.contiguous()          # y[:, :-1] is a strided view: the kernels index [B, L] densely
         x, kb = hip.embed_tokens(tokens, emb.detach(), pos.detach().reshape(-1, pos.shape[-1])[:L].contiguous(), pad_idx, cd)
         ctx.save_for_backward(tokens)

@@ -121,6 +121,8 @@ class ScoreNet(nn.Module):
 
 
 def _bn_scale_shift(sums, count, bn, training, save=False):
+    if training:
+        count = count * ops.sync_stats(sums)        # SyncBatchNorm: global sums / global count
     r = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                         training, save=save)
     if training:
@@ -347,6 +349,7 @@ class Pix2PolyModel(torch.nn.Module):
         model = EncoderDecoder(encoder=encoder, decoder=decoder, cfg=cfg)
         model.to(cfg.host.device)
         if cfg.host.multi_gpu:
+            ops.SYNC_BN[0] = True      # the HIP BatchNorm sites all-reduce their statistics (ops.sync_stats)
             model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
             model = DDP(model, device_ids=[local_rank], find_unused_parameters=cfg.run_type.name == "debug")
         return model

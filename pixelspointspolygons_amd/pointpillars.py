@@ -90,7 +90,7 @@ class _PillarStem(torch.autograd.Function):
                             (g2.detach(), b2.detach(), l1.norm.running_mean, l1.norm.running_var), canvas, B=B, grid=(mod.nx, mod.ny),
                             voxel=mod.voxel, zmax=mod.zmax, max_points=mod.max_points,
                             max_voxels=mod.max_voxels[0] if training else mod.max_voxels[1], training=training, col_off=col_off,
-                            keep_workspace=need)
+                            keep_workspace=need, sync=ops.sync_stats if ops.sync_active() else None)
         if training:
             l0.norm.num_batches_tracked += 1
             l1.norm.num_batches_tracked += 1
@@ -108,7 +108,8 @@ class _PillarStem(torch.autograd.Function):
         cd = ctx.mod.cd
         w2t = ops.shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())
         dc = dcanvas if dcanvas.dtype == cd else dcanvas.to(cd)
-        dw1, dg1, db1, dw2, dg2, db2 = hip.pillar_stem_bwd(dc, w1.detach(), g1.detach(), w2t, g2.detach(), ctx.ws, ctx.desc)
+        dw1, dg1, db1, dw2, dg2, db2 = hip.pillar_stem_bwd(dc, w1.detach(), g1.detach(), w2t, g2.detach(), ctx.ws, ctx.desc,
+                                                           sync=ops.sync_stats if ops.sync_active() else None)
         ctx.ws = None
         return None, None, dw1, dg1, db1, dw2, dg2, db2, dcanvas, None, None, None
 

@@ -23,3 +23,9 @@ def rel_err(a, b):
     """max |a-b| / max|b|  (the 'within 1e-3 rel' metric of BASELINE.json north_star)."""
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def l2_err(a, b, floor=0.0):
+    """||a-b|| / max(||b||, floor): robust to the isolated ReLU-mask flips that dominate max-abs metrics of gradients."""
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / max(float(b.norm()), floor, 1e-30))

@@ -186,3 +186,28 @@ def test_state_dict_contract_matches_reference_key_list():
     mine = m.state_dict()
     assert set(mine) == set(sd)
     assert all(tuple(mine[k].shape) == tuple(sd[k].shape) for k in sd)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL32), ("bf16", TOL16)])
+def test_pix2poly_vit_b16_forward_vs_oracle(precision, tol):
+    """BASELINE.json configs[1]: image-only ViT-B/16 (dim 768, 12 heads, 196 patches -> cross-attention over 196 keys)."""
+    sd = O.make_state_dict("image", O.VIT_B16, seed=17)
+    m, cfg = _model("image", precision, sd, patch_size=16, patch_feature_dim=768, vit_heads=12)
+    inp = O.make_inputs(2, seed=31)
+    with torch.no_grad():
+        ref_logits, ref_perm = O.pix2poly_forward({k: v.clone() for k, v in sd.items()}, inp["y"][:, :-1], inp["image"], None, cfg=O.VIT_B16)
+        d = _to_dev(inp)
+        logits, perm = m(d["image"], None, d["y"][:, :-1])
+    assert rel_err(logits.float().cpu(), ref_logits) < tol
+    assert rel_err(perm.float().cpu(), ref_perm) < tol * 5
+    if precision == "fp32":
+        assert torch.equal(logits.float().cpu().argmax(-1), ref_logits.argmax(-1))
+
+
+def test_embed_tokens_rejects_sequences_longer_than_the_positional_table():
+    from pixelspointspolygons_amd.hip import P3Error
+    m, cfg = _model("image", "fp32", None, max_num_vertices=16)
+    y = torch.zeros(1, 385, dtype=torch.long, device=DEV)
+    with pytest.raises(P3Error):
+        with torch.no_grad():
+            m(torch.rand(1, 3, 224, 224, device=DEV), None, y)
