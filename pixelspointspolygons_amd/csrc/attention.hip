@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) T Vs[TR::V_ELEMS];
 
     const p3_attn_desc& d = a.d;
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128;
+    // 1-D grid, XCD-aware: the q-blocks of one (batch, head) run back to back on ONE XCD, so K/V are fetched into one L2 once
+    // (PMC r01: 579 MB fetched per ViT launch with the (q-block, head, batch) grid = 7x the 77 MB of K/V, one copy per XCD)
+    const int nqb = (d.Lq + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = (lid % nqb) * 128, h = (lid / nqb) % d.H, b = lid / (nqb * d.H);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -346,7 +350,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % 4 == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
     P3_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, P3_EALIGN, "p3_attention: 16-byte base alignment");
     AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d;
-    dim3 grid(p3_ceil_div(d->Lq, 128), d->H, d->B), block(256);
+    dim3 grid(p3_ceil_div(d->Lq, 128) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool drop = d->drop.seed != nullptr && d->drop.p > 0.f;
     P3_CHECK(!drop || d->drop.p < 1.f, P3_EINVAL, "p3_attention: dropout p must be < 1");

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) T Vrow[TK::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Ktr[BF ? TK::TR_ELEMS : 8];
     const p3_attn_desc& d = a.d;
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128;
+    const int nqb = (d.Lq + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);      // blocks of one (batch, head) share an XCD's L2 (see attention.hip)
+    const int qblk = (lid % nqb) * 128, h = (lid / nqb) % d.H, b = lid / (nqb * d.H);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -258,7 +260,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) T Gtr[BF ? TQ::TR_ELEMS : 8];
     __shared__ float Ls[QT], Ds[QT];
     const p3_attn_desc& d = a.d;
-    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x * 128;
+    const int nkb = (d.Lk + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = (lid % nkb) * 128, h = (lid / nkb) % d.H, b = lid / (nkb * d.H);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -328,11 +332,11 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
     int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
     hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(g), dim3(256), 0, s, a, D);
     if (d.drop.seed != nullptr && d.drop.p > 0.f) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3(p3_ceil_div(d.Lq, 128) * d.H * d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3(p3_ceil_div(d.Lk, 128) * d.H * d.B), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3(p3_ceil_div(d.Lq, 128), d.H, d.B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3(p3_ceil_div(d.Lk, 128), d.H, d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3(p3_ceil_div(d.Lq, 128) * d.H * d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3(p3_ceil_div(d.Lk, 128) * d.H * d.B), dim3(256), 0, s, a);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

@@ -14,7 +14,7 @@ constexpr int TN = 128, TK = 128;
 
 struct TnArgs {
     const void* A; const void* B; float* C;
-    int M, N, K, lda, ldb, ldc, rows_per_split, tiles_k;
+    int M, N, K, lda, ldb, ldc, rows_per_split, tiles_k, splits;
     // optional generated B operand (ScoreNet backward): B'[m,k] = relu((B[m',k] (+ V[m'',k])) * b_scale[k] + b_shift[k])
     int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j)
     const float* b_scale; const float* b_shift; const void* pair_V; int pair_n;
@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // 1-D grid, XCD-aware: all (n, k) tiles of one M-split (they read the same rows of A and B) run on ONE XCD, so those rows
+    // come from HBM once instead of once per XCD (PMC r01: 395 MB fetched per launch on average, ~3x the operand bytes)
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_all = gridDim.x / g.splits;
+    const int tile = lid % tiles_all, split = lid / tiles_all;
     const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
     const int m_beg = split * g.rows_per_split;
     const int m_end = min(g.M, m_beg + g.rows_per_split);
@@ -314,7 +318,8 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.rows_per_split = p3_ceil_div(p3_ceil_div(M, splits), bm) * bm;
     splits = p3_ceil_div(M, g.rows_per_split);
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
-    dim3 grid(tiles, splits), block(256);
+    g.splits = splits;
+    dim3 grid(tiles * splits), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 0, s, g);

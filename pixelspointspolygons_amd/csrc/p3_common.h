@@ -77,6 +77,14 @@ __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t row, uint32
     return (col & 1u) ? drop_keep_hi(k, bits) : drop_keep_lo(k, bits);
 }
 
+// XCD-aware bijective block remap: hardware hands consecutive workgroup ids round-robin to the 8 XCDs (each with its own 4 MiB L2);
+// this gives XCD x the CONSECUTIVE logical ids [x*n/8, (x+1)*n/8), so blocks that share operands (same attention head, same
+// M-split of a weight gradient, same A row panel) run on one XCD and hit its L2 instead of fetching the operand 8 times.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // row index of accumulator register r of a 32x32 MFMA C/D fragment (col = lane & 31)
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
