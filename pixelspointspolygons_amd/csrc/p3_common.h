@@ -14,14 +14,15 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even like torch .to(bfloat16); native casts so that hipcc emits gfx950's v_cvt_pk_bf16_f32 (one VALU op per PAIR;
+// the integer RNE sequence this replaces cost ~5 ops per element and sat in every epilogue and in the attention P / dS packing)
+typedef float p3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const p3_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, p3_bf16x2));
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
