@@ -43,23 +43,51 @@ template <typename T, int D, int R> struct Tile {
     static constexpr int TR_ELEMS = BF ? D * PT : 0;
 };
 
-// stage R rows (row0.., clamped to nvalid-1) of a [*, row_stride] tensor into LDS; WANT_ROW / WANT_TR select the images
-template <typename T, int D, int R, bool WANT_ROW, bool WANT_TR>
-__device__ __forceinline__ void stage(const T* __restrict__ src, int row0, int nvalid, int row_stride, T* rowimg, T* trimg, int tid) {
-    using TL = Tile<T, D, R>;
-    if constexpr (TL::BF) {
-        // items: (row pair, 4 dims)
-        constexpr int ITEMS = (R / 2) * (D / 4);
+// Staging of R rows (row0.., clamped to nvalid-1) of a [*, row_stride] tensor is split in two (guide T14): stage_load issues the
+// global loads of tile t+1 into registers BEFORE the MFMAs of tile t, stage_store writes them to LDS after the barrier that retires
+// tile t's readers.  (PMC r01, synchronous staging: waves parked 47-58 % of their cycles in the dQ / dKV kernels.)
+template <typename T, int D, int R> struct StageRegs {
+    static constexpr bool BF = sizeof(T) == 2;
+    static constexpr int ITEMS = BF ? (R / 2) * (D / 4) : R * (D / 4);
+    static constexpr int N = (ITEMS + 255) / 256;
+    u32x4 v[N];   // bf16: {row 2rp: 8 B, row 2rp+1: 8 B}; f32: one float4
+};
+
+template <typename T, int D, int R>
+__device__ __forceinline__ void stage_load(const T* __restrict__ src, int row0, int nvalid, int row_stride, StageRegs<T, D, R>& rg, int tid) {
+    using SR = StageRegs<T, D, R>;
 #pragma unroll
-        for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
-            const int item = tid + 256 * it;
-            if (ITEMS % 256 == 0 || item < ITEMS) {
+    for (int it = 0; it < SR::N; ++it) {
+        const int item = tid + 256 * it;
+        if (SR::ITEMS % 256 == 0 || item < SR::ITEMS) {
+            if constexpr (SR::BF) {
                 const int dg = item % (D / 4), rp = item / (D / 4);
                 int ra = row0 + 2 * rp, rb = ra + 1;
                 if (ra >= nvalid) ra = nvalid - 1;
                 if (rb >= nvalid) rb = nvalid - 1;
                 const uint2 va = *reinterpret_cast<const uint2*>(src + (int64_t)ra * row_stride + dg * 4);
                 const uint2 vb = *reinterpret_cast<const uint2*>(src + (int64_t)rb * row_stride + dg * 4);
+                rg.v[it] = u32x4{va.x, va.y, vb.x, vb.y};
+            } else {
+                const int cv = item % (D / 4), r = item / (D / 4);
+                int rr = row0 + r; if (rr >= nvalid) rr = nvalid - 1;
+                rg.v[it] = *reinterpret_cast<const u32x4*>(src + (int64_t)rr * row_stride + cv * 4);
+            }
+        }
+    }
+}
+
+template <typename T, int D, int R, bool WANT_ROW, bool WANT_TR>
+__device__ __forceinline__ void stage_store(const StageRegs<T, D, R>& rg, T* rowimg, T* trimg, int tid) {
+    using TL = Tile<T, D, R>;
+    using SR = StageRegs<T, D, R>;
+#pragma unroll
+    for (int it = 0; it < SR::N; ++it) {
+        const int item = tid + 256 * it;
+        if (SR::ITEMS % 256 == 0 || item < SR::ITEMS) {
+            if constexpr (SR::BF) {
+                const int dg = item % (D / 4), rp = item / (D / 4);
+                const uint2 va = make_uint2(rg.v[it].x, rg.v[it].y), vb = make_uint2(rg.v[it].z, rg.v[it].w);
                 if constexpr (WANT_ROW) {
                     *reinterpret_cast<uint2*>(rowimg + (2 * rp) * TL::PR + dg * 4) = va;
                     *reinterpret_cast<uint2*>(rowimg + (2 * rp + 1) * TL::PR + dg * 4) = vb;
@@ -71,19 +99,11 @@ __device__ __forceinline__ void stage(const T* __restrict__ src, int row0, int n
                     p[((dg * 4 + 2) * TL::PT) / 2 + rp] = (va.y & 0xffffu) | (vb.y << 16);
                     p[((dg * 4 + 3) * TL::PT) / 2 + rp] = (va.y >> 16) | (vb.y & 0xffff0000u);
                 }
-            }
-        }
-    } else {
-        constexpr int ITEMS = R * (D / 4);
-#pragma unroll
-        for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
-            const int item = tid + 256 * it;
-            if (ITEMS % 256 == 0 || item < ITEMS) {
+            } else {
                 const int cv = item % (D / 4), r = item / (D / 4);
-                int rr = row0 + r; if (rr >= nvalid) rr = nvalid - 1;
-                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)rr * row_stride + cv * 4);
                 float* p = reinterpret_cast<float*>(rowimg) + r * TL::PR + cv * 4;
-                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+                p[0] = __uint_as_float(rg.v[it].x); p[1] = __uint_as_float(rg.v[it].y);
+                p[2] = __uint_as_float(rg.v[it].z); p[3] = __uint_as_float(rg.v[it].w);
             }
         }
     }
@@ -218,12 +238,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
     DropKey dkey; uint32_t drop_rk = 0;
     if constexpr (DROP) { dkey = drop_key(d.drop); drop_rk = drop_rowkey(dkey, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
+    StageRegs<T, D, KT> kreg, vreg;
+    if (ntiles > 0) { stage_load<T, D, KT>(Kp, 0, d.Lk, d.k_rs, kreg, tid); stage_load<T, D, KT>(Vp, 0, d.Lk, d.v_rs, vreg, tid); }
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();
-        stage<T, D, KT, true, true>(Kp, kv0, d.Lk, d.k_rs, Krow, Ktr, tid);
-        stage<T, D, KT, true, false>(Vp, kv0, d.Lk, d.v_rs, Vrow, nullptr, tid);
+        stage_store<T, D, KT, true, true>(kreg, Krow, Ktr, tid);
+        stage_store<T, D, KT, true, false>(vreg, Vrow, nullptr, tid);
         __syncthreads();
+        if (t + 1 < ntiles) { stage_load<T, D, KT>(Kp, kv0 + KT, d.Lk, d.k_rs, kreg, tid); stage_load<T, D, KT>(Vp, kv0 + KT, d.Lk, d.v_rs, vreg, tid); }
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, l31, hi);       // S^T[kv, q]
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int QT = BF ? 64 : 32;
     using TQ = Tile<T, D, QT>;
@@ -286,15 +309,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     DropKey dkey; uint32_t drop_ck = 0; uint64_t drop_bh = 0;
     if constexpr (DROP) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
+    StageRegs<T, D, QT> qreg, greg;
+    if (q_begin < d.Lq) { stage_load<T, D, QT>(Qp, q_begin, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q_begin, d.Lq, d.o_rs, greg, tid); }
     for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
         __syncthreads();
-        stage<T, D, QT, true, true>(Qp, q0, d.Lq, d.q_rs, Qrow, Qtr, tid);
-        stage<T, D, QT, true, true>(dOp, q0, d.Lq, d.o_rs, Grow, Gtr, tid);
+        stage_store<T, D, QT, true, true>(qreg, Qrow, Qtr, tid);
+        stage_store<T, D, QT, true, true>(greg, Grow, Gtr, tid);
         if (tid < QT) {
             const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
             Ls[tid] = a.lse[stat_base + qq]; Ds[tid] = a.delta[stat_base + qq];
         }
         __syncthreads();
+        if (q0 + QT < d.Lq) { stage_load<T, D, QT>(Qp, q0 + QT, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q0 + QT, d.Lq, d.o_rs, greg, tid); }
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
             f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, l31, hi);       // S[q, kv]
