@@ -251,33 +251,46 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, float* __restr
 }
 
 // column sums of a [M, N] matrix (bias / positional-embedding gradients): out[c] += sum_m x[m, c]
-// block = 64 column-quads x 4 row lanes: 8/16-byte coalesced loads, register accumulation, LDS fold, one atomic per column per block
+// block = ncq column-quads x (256 / ncq) row lanes (ncq = 64 for N >= 256, else N/4 rounded up to a power of two, so narrow
+// matrices such as the ScoreNet's [B*N*N, 64] still use every lane); 8/16-byte coalesced loads, 4 rows in flight per thread,
+// register accumulation, LDS fold, one atomic per column per block with ~2048 blocks (r01: one atomic per 128 rows = 2.4 M
+// atomics on 128 addresses made this kernel run at 1.5 TB/s).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block) {
-    __shared__ float red[4][256];
-    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c0 = (blockIdx.y * 64 + lane) * 4;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block,
+                                                     int ncq) {
+    __shared__ float red[1024];
+    const int q = threadIdx.x % ncq, ry = threadIdx.x / ncq, nrl = 256 / ncq;
+    const int c0 = (blockIdx.y * 64 + q) * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c0 < N) {
-        for (int64_t r = r0 + ry; r < r1; r += 4) {
-            const T* p = x + r * ld + c0;
-            if constexpr (sizeof(T) == 2) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(p);
-                a[0] += __uint_as_float(raw.x << 16); a[1] += __uint_as_float(raw.x & 0xffff0000u);
-                a[2] += __uint_as_float(raw.y << 16); a[3] += __uint_as_float(raw.y & 0xffff0000u);
-            } else {
-                const float4 raw = *reinterpret_cast<const float4*>(p);
-                a[0] += raw.x; a[1] += raw.y; a[2] += raw.z; a[3] += raw.w;
-            }
+    auto add = [&](const T* p) {
+        if constexpr (sizeof(T) == 2) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(p);
+            a[0] += __uint_as_float(raw.x << 16); a[1] += __uint_as_float(raw.x & 0xffff0000u);
+            a[2] += __uint_as_float(raw.y << 16); a[3] += __uint_as_float(raw.y & 0xffff0000u);
+        } else {
+            const float4 raw = *reinterpret_cast<const float4*>(p);
+            a[0] += raw.x; a[1] += raw.y; a[2] += raw.z; a[3] += raw.w;
         }
+    };
+    if (c0 < N) {
+        int64_t r = r0 + ry;
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            const T* p = x + r * ld + c0;
+            add(p); add(p + (int64_t)nrl * ld); add(p + (int64_t)2 * nrl * ld); add(p + (int64_t)3 * nrl * ld);
+        }
+        for (; r < r1; r += nrl) add(x + r * ld + c0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) red[ry][lane * 4 + k] = a[k];
+    for (int k = 0; k < 4; ++k) red[ry * (ncq * 4) + q * 4 + k] = a[k];
     __syncthreads();
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c < N) atomicAdd(out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if ((int)threadIdx.x < ncq * 4) {
+        float s = 0.f;
+        for (int y = 0; y < nrl; ++y) s += red[y * (ncq * 4) + threadIdx.x];
+        const int c = blockIdx.y * 256 + threadIdx.x;
+        if (c < N) atomicAdd(out + c, s);
+    }
 }
 
 // scalar fallback for N / ld not a multiple of 4
@@ -342,12 +355,22 @@ extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, in
     hipStream_t s = (hipStream_t)stream;
     const int es = dtype == P3_BF16 ? 2 : 4;
     const bool vec = (N % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)x % (4 * es) == 0);
-    const int rpb = M > 16384 ? 128 : (M > 2048 ? 32 : 8);
-    dim3 grid(p3_ceil_div(M, rpb), p3_ceil_div(N, 256)), block(256);
+    int rpb = M > 16384 ? 128 : (M > 2048 ? 32 : 8);
     if (vec) {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
-        else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
-    } else {
+        int ncq = 64;
+        if (N < 256) { const int nq = (N + 3) / 4; ncq = 1; while (ncq < nq) ncq <<= 1; }
+        const int cols_blocks = p3_ceil_div(N, 256);
+        const int64_t want = 2048 / cols_blocks > 0 ? 2048 / cols_blocks : 1;        // ~2048 blocks in total
+        const int64_t r = (M + want - 1) / want;
+        if (r > rpb) rpb = (int)r;
+        dim3 grid(p3_ceil_div(M, rpb), cols_blocks), block(256);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb, ncq);
+        else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb, ncq);
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
+    dim3 grid(p3_ceil_div(M, rpb), p3_ceil_div(N, 256)), block(256);
+    {
         if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
         else hipLaunchKernelGGL((colsum_scalar_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
     }
