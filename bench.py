@@ -176,6 +176,23 @@ def cpu_baseline(O, args, kind):
             "sample": f"oracle train step (fwd+CE+10*BCE+bwd+AdamW, fp32), batch {B}, {n} timed steps after 1 warm-up, host CPU"}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
+    runs of `bench.py --graph 0`; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE as reported; tools/pmc_traffic.py).
+    bench.py cannot collect counters on itself, so this is the number of the same kernel on the same workload from profiles/."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or not kernel_label.startswith("gemm_kernel<bf16,plain"):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    tot = n = 0.0
+    for k, v in t.items():
+        if k.startswith("gemm_kernel<unsigned short,") and k.endswith(", 0>"):     # bf16 in, bf16 / f32 out, plain A operand
+            tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
+            n += v["launches"]
+    return (round(tot / n) if n else None), "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, mean per launch over the train step)"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -271,8 +288,9 @@ def main():
             name, rec = max(kt.items(), key=lambda kv: kv[1]["ms"])
             peak = 2500.0 if args.precision == "bf16" else 157.3
             ach = rec["flop"] / (rec["ms"] * 1e-3) / 1e12
+            traffic, tsrc = pmc_traffic(name)
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": None, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+                        "traffic": traffic, "traffic_source": tsrc, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
                         "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3)}
 
     if rank == 0:
