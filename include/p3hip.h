@@ -90,6 +90,11 @@ typedef struct {
     float* colsum;        /* optional [N]: += sum over rows of (A'W^T + bias)   (train-mode BatchNorm statistics) */
     float* colsumsq;      /* optional [N]: += sum of squares */
     p3_dropout drop;      /* dropout of act(A'W^T + bias) before the residual add; element = (row, col) */
+    /* backward of an upstream activation fused into this (dX) GEMM's epilogue: C = (A'W^T) * act'(bwd_saved) * bwd_scale, with
+     * bwd_saved [M,N] (ldc, dtype_out) = the pre-activation (P3_ACT_GELU) or the activation output (P3_ACT_RELU) saved by forward */
+    const void* bwd_saved;
+    int bwd_act;
+    float bwd_scale;
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 
@@ -101,6 +106,10 @@ int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* 
  * ------------------------------------------------------------------------------------------ */
 int p3_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int cols, int ldx, int ldy,
                  float eps, int dtype_in, int dtype_out, float* save_mean, float* save_rstd, void* stream);
+/* dres (optional, dtype_dx, [rows, cols]): gradient arriving at x through a residual connection; added to dx in the same pass */
+int p3_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                         void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
+                         void* stream);
 int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                      void* stream);

@@ -112,6 +112,16 @@ __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const
     return raw;
 }
 
+// act'(.) for the fused activation backward: GELU' of the saved pre-activation, ReLU' from the saved output
+__device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == P3_ACT_GELU) {
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+        return cdf + x * pdf;
+    }
+    return x > 0.f ? 1.f : 0.f;
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 load_w(const T* W, int64_t rowoff, int k) {
     return *reinterpret_cast<const uint4*>(W + rowoff + k);
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     TO* aux = reinterpret_cast<TO*>(d.aux);
     const bool has_res = d.residual != nullptr;
     const bool res_bf = d.dtype_res == P3_BF16;
+    const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
     const int act = d.act;
     const DropKey dk = drop_key(d.drop);
 #pragma unroll 2
@@ -299,6 +310,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
                 }
             }
+            if (bwd_saved) {
+                float sv[8];
+                if constexpr (sizeof(TO) == 2) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(bwd_saved + co);
+                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sv[2 * k] = __uint_as_float(w[k] << 16); sv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+                } else {
+                    const float4 r0 = *reinterpret_cast<const float4*>(bwd_saved + co);
+                    const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
+                    sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= act_grad(sv[k], d.bwd_act) * d.bwd_scale;
+            }
             if (has_res) {
                 const int64_t ro = (int64_t)row * d.ldr + col;
                 if (res_bf) {
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (act == P3_ACT_GELU) x = gelu_erf(x);
                 else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
                 if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
+                if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
                 if (has_res) {
                     const int64_t ri = (int64_t)row * d.ldr + col + k;
                     x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
@@ -367,6 +394,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
         P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
+    P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU or RELU");
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, BM);
@@ -375,6 +403,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         const int vo = d->dtype_out == P3_BF16 ? 8 : 4;     // elements per 16 bytes
         bool ok = (d->ldc % vo == 0) && ((uintptr_t)C % 16 == 0) && (!d->aux || (uintptr_t)d->aux % 16 == 0);
         if (d->residual) { const int vr = d->dtype_res == P3_BF16 ? 8 : 4; ok = ok && (d->ldr % vr == 0) && ((uintptr_t)d->residual % 16 == 0); }
+        if (d->bwd_saved) ok = ok && ((uintptr_t)d->bwd_saved % 16 == 0);
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;

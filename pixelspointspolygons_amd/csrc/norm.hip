@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, c
 template <typename TDY, typename TX, typename TDX>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, TDX* __restrict__ dx,
+                                                     const float* __restrict__ rstd, const TDX* __restrict__ dres, TDX* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
                                                      int cols, int rows_per_block) {
     __shared__ float sg[4][1024], sb[4][1024];
@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                 float o[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = rs * (g[c][i] * d[c][i] - s1 - xh[c][i] * s2);
+                if (dres) {   // gradient of the residual branch that forked off x: summed here instead of by a separate add pass
+                    float rr[4];
+                    load4<TDX>(dres + row * cols + ci * 4, rr);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] += rr[i];
+                }
                 store4<TDX>(dx + row * cols + ci * 4, o);
             }
         }
@@ -165,15 +171,21 @@ extern "C" int p3_layernorm(const void* x, const float* gamma, const float* beta
 extern "C" int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
                                 int dtype_dx, void* stream) {
+    return p3_layernorm_bwd_res(dy, x, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, cols, dtype_dy, dtype_x, dtype_dx, stream);
+}
+
+extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                    void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
+                                    int dtype_dx, void* stream) {
     P3_CHECK(dy && x && gamma && mean && rstd && dx, P3_EINVAL, "p3_layernorm_bwd: null pointer");
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
     if (rows <= 0) return P3_OK;
-    const int rpb = 64;
+    const int rpb = rows > 32768 ? 128 : 64;      // fewer blocks = fewer dgamma / dbeta atomics per address
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LNB(TDY, TX, TDX) \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
     if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(float, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(bf16_t, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNB(bf16_t, bf16_t, bf16_t);

@@ -96,12 +96,13 @@ class GemmDesc(Structure):
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("dtype_res", c_int), ("aux", c_void_p),
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
-                ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout)]
+                ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout),
+                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None):
+         lda=None, ldc=None, drop=None, bwd=None):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p)."""
     _dev(a)
     N, K = w.shape
@@ -139,6 +140,11 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     if colsum is not None:
         d.colsum, d.colsumsq = colsum.data_ptr(), colsumsq.data_ptr()
     d.drop = _drop(drop)
+    if bwd is not None:            # (saved tensor [M,N] in the output dtype, act, scale): out *= act'(saved) * scale
+        sv, bact, bscale = bwd
+        if sv.dtype != out.dtype or sv.stride(-2) != out.stride(-2):
+            raise P3Error("gemm: bwd_saved must match the output's dtype and row stride")
+        d.bwd_saved, d.bwd_act, d.bwd_scale = sv.data_ptr(), bact, bscale
     ev = KTIMER.begin()
     check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
     KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K)
@@ -163,13 +169,18 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
     return (out, mean, rstd) if save_stats else out
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None):
+    """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass."""
     cols = x.shape[-1]
     dy2, x2 = dy.reshape(-1, cols).contiguous(), x.reshape(-1, cols).contiguous()
     rows = x2.shape[0]
     dx = torch.empty(x.shape, dtype=dx_dtype or x.dtype, device=x.device)
-    check(lib().p3_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                 c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
+    if dres is not None:
+        dres = dres.contiguous()
+        if dres.dtype != dx.dtype:
+            raise P3Error("layernorm_bwd: dres dtype must equal the dx dtype")
+    check(lib().p3_layernorm_bwd_res(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                     c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
           "p3_layernorm_bwd")
     return dx
 

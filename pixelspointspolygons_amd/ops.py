@@ -218,6 +218,79 @@ def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=N
     return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop)
 
 
+def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
+    """(dW, db) of y = x W^T + b from dpre = dL/dy; in DIRECT_GRAD mode both are accumulated into the flat arena (returns None)."""
+    dw = db = None
+    if DIRECT_GRAD[0] and weight.grad is not None:
+        fuse_b = bias is not None and need_b and bias.grad is not None and need_w
+        if need_w:
+            hip.gemm_tn(dpre, x2, out=weight.grad, colsum_out=bias.grad if fuse_b else None)
+        if bias is not None and need_b and not fuse_b:
+            if bias.grad is not None:
+                hip.colsum(dpre, out=bias.grad)
+            else:
+                db = hip.colsum(dpre)
+        return dw, db
+    if need_w:
+        dw = hip.gemm_tn(dpre, x2)
+    if bias is not None and need_b:
+        db = hip.colsum(dpre)
+    return dw, db
+
+
+class _Mlp(torch.autograd.Function):
+    """y = drop2(W2 drop1(act(W1 x + b1)) + b2) (+ residual): timm Mlp (GELU) and the FFN of nn.TransformerDecoderLayer (ReLU).
+    Backward fuses act' (and the 1/(1-p) of drop1) into the epilogue of the dH = dY W2 GEMM: no separate act_bwd pass, dH never
+    hits HBM un-multiplied."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, out_dtype, cd, drop1, drop2):
+        if w1.shape[0] % 64 or w2.shape[0] % 64:
+            raise hip.P3Error("mlp: hidden / output widths must be multiples of 64")
+        w1c, w2c = shadow(w1, cd), shadow(w2, cd)
+        x2 = x.reshape(-1, x.shape[-1])
+        need = any(ctx.needs_input_grad)
+        drop1 = drop1 if (drop1 is not None and drop1[2] > 0.0) else None
+        drop2 = drop2 if (drop2 is not None and drop2[2] > 0.0) else None
+        if drop1 is not None and act != hip.ACT_RELU:
+            raise NotImplementedError("dropout after GELU is not on the reference path")
+        aux = torch.empty((x2.shape[0], w1.shape[0]), dtype=cd, device=x.device) if (need and act == hip.ACT_GELU) else None
+        h = hip.gemm(x2, w1c, bias=b1, act=act, out_dtype=cd, aux=aux, drop=drop1)
+        res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+        y = hip.gemm(h, w2c, bias=b2, residual=res2, out_dtype=out_dtype, drop=drop2)
+        ctx.cfg = (act, cd, residual is not None, drop1, drop2, x.shape)
+        ctx.b1, ctx.b2 = b1, b2
+        if need:
+            ctx.save_for_backward(x2, h, aux, w1, w2)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, aux, w1, w2 = ctx.saved_tensors
+        act, cd, has_res, drop1, drop2, xshape = ctx.cfg
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dres = dy if has_res else None
+        if drop2 is not None:
+            dpre2 = hip.dropout_apply(dy2, cd, drop2)
+        else:
+            dpre2 = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
+        dw2, db2 = _weight_grads(dpre2, h, w2, ctx.b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                       # [hidden, out]
+        saved = aux if act == hip.ACT_GELU else h
+        scale = 1.0 / (1.0 - drop1[2]) if drop1 is not None else 1.0
+        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=(saved, act, scale))                  # dH * act'(.) in the epilogue
+        dw1, db1 = _weight_grads(dpre1, x2, w1, ctx.b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())                   # [in, hidden]
+            dx = hip.gemm(dpre1, w1t, out_dtype=cd).view(xshape)
+        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
+
+
+def mlp(x, w1, b1, w2, b2, *, act, residual=None, out_dtype=None, cd=torch.float32, drop_act=None, drop_out=None):
+    return _Mlp.apply(x, w1, b1, w2, b2, residual, act, out_dtype or cd, cd, drop_act, drop_out)
+
+
 # ---------------------------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
@@ -246,6 +319,40 @@ class _LayerNorm(torch.autograd.Function):
 
 def layernorm(x, gamma, beta, eps, out_dtype=None):
     return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype)
+
+
+class _LayerNormFork(torch.autograd.Function):
+    """(x, LN(x)) for a pre-norm residual block  x + f(LN(x)):  the gradient of the residual path comes back as the gradient of
+    the first output and is added to the LayerNorm input gradient inside the ln_bwd kernel (no separate accumulate pass)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        ctx.beta_param = beta
+        if any(ctx.needs_input_grad):
+            y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
+            ctx.save_for_backward(x, gamma, mean, rstd)
+        else:
+            y = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        beta = ctx.beta_param
+        if dres is not None and dres.dtype != x.dtype:
+            dres = dres.to(x.dtype)
+        if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres)
+            return dx, None, None, None, None
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, dres=dres)
+        return dx, dg, db, None, None
+
+
+def layernorm_fork(x, gamma, beta, eps, out_dtype=None):
+    """-> (x, LN(x)); use the returned x for the residual connection of the block."""
+    return _LayerNormFork.apply(x, gamma, beta, eps, out_dtype or x.dtype)
 
 
 # ---------------------------------------------------------------------------------------------- attention

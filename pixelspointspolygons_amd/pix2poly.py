@@ -239,9 +239,9 @@ class Decoder(nn.Module):
             y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
                            drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p))
             x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
-            h = ops.linear(x, lyr.linear1.weight, lyr.linear1.bias, act=hip.ACT_RELU, cd=cd, drop=dr(s0 + self.SITE_FFN_ACT, lyr.dropout.p))
-            y = ops.linear(h, lyr.linear2.weight, lyr.linear2.bias, residual=x, out_dtype=torch.float32, cd=cd,
-                           drop=dr(s0 + self.SITE_FFN_OUT, lyr.dropout3.p))
+            y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
+                        out_dtype=torch.float32, cd=cd, drop_act=dr(s0 + self.SITE_FFN_ACT, lyr.dropout.p),
+                        drop_out=dr(s0 + self.SITE_FFN_OUT, lyr.dropout3.p))
             x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
         return x
 

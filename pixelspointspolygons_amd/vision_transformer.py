@@ -95,14 +95,13 @@ class Block(nn.Module):
 
     def run(self, x, cd):
         """x: fp32 residual stream [B, L, D]."""
-        D = x.shape[-1]
-        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
+        x, h = ops.layernorm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
         qkv = ops.linear(h, self.attn.qkv.weight, self.attn.qkv.bias, cd=cd)
         a = ops.self_attention(qkv, self.attn.num_heads)
         x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
-        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
-        h = ops.linear(h, self.mlp.fc1.weight, self.mlp.fc1.bias, act=hip.ACT_GELU, cd=cd)
-        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, out_dtype=torch.float32, cd=cd)
+        x, h = ops.layernorm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
+        return ops.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, act=hip.ACT_GELU, residual=x,
+                       out_dtype=torch.float32, cd=cd)
 
 
 _TIMM_SHAPES = {  # model_name prefix -> (dim, depth, heads)
