@@ -5,6 +5,8 @@ Pix2PolyModel, Tokenizer); every forward runs on the HIP library.  torch.nn modu
 only (nn.TransformerDecoder, nn.Conv2d, nn.BatchNorm2d: identical key names and initialisation), never called.
 """
 import numpy as np
+import math
+
 import torch
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
@@ -261,6 +263,54 @@ class Decoder(nn.Module):
         return logits, x
 
 
+    @torch.no_grad()
+    def generate_cached(self, encoder_out, steps, bos):
+        """Greedy decode with per-layer key/value caches: step t runs the decoder on ONE new position.
+
+        Same arithmetic per (position, channel) as `predict`'s full re-run — the decoder is causal, GEMM / LayerNorm rows are
+        independent and the attention kernels are lane-local per query — so the token sequence and the returned features are
+        bit-identical to `steps` calls of `predict` (tests/test_model_gpu.py), at 1/385 of the decoder FLOPs.
+        Returns (tokens [B, steps + 1] incl. BOS, features [B, steps, D])."""
+        cd, D, H = self.cd, self.dim, self.num_heads
+        B, dev = encoder_out.shape[0], encoder_out.device
+        if steps > self.max_len - 1:
+            raise hip.P3Error(f"generate: {steps} steps exceed the positional table ({self.max_len - 1})")
+        scale = 1.0 / math.sqrt(D // H)
+        layers = self.decoder.layers
+        enc = encoder_out if encoder_out.dtype == cd else hip.cast(encoder_out.contiguous(), cd)
+        mem = hip.add_pos(enc.contiguous(), self.encoder_pos_embed.detach().reshape(-1, D))
+        kv_mem = [ops.linear(mem, l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias, cd=cd, rows=(D, 3 * D)) for l in layers]
+        kv_self = [torch.empty((B, steps, 2 * D), dtype=cd, device=dev) for _ in layers]
+        kb = torch.zeros((B, steps), dtype=torch.float32, device=dev)
+        feats = torch.empty((B, steps, D), dtype=cd, device=dev)
+        preds = torch.full((B, steps + 1), self.pad_idx, dtype=torch.long, device=dev)
+        preds[:, 0] = bos
+        emb = self.embedding.weight.detach()
+        pos = self.decoder_pos_embed.detach().reshape(-1, D)
+        for t in range(steps):
+            x, kbt = hip.embed_tokens(preds[:, t:t + 1].contiguous(), emb, pos[t:t + 1], self.pad_idx, cd)      # [B,1,D], [B,1]
+            kb[:, t:t + 1] = kbt
+            kbc = kb[:, :t + 1].contiguous()
+            for li, lyr in enumerate(layers):
+                sa, ca = lyr.self_attn, lyr.multihead_attn
+                qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)                                  # [B,1,3D]
+                kv_self[li][:, t] = qkv[:, 0, D:]
+                a = hip.attention(qkv[..., :D], kv_self[li][:, :t + 1, :D], kv_self[li][:, :t + 1, D:], H, scale, key_bias=kbc)
+                y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+                x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
+                q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
+                a = hip.attention(q, kv_mem[li][..., :D], kv_mem[li][..., D:], H, scale)
+                y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+                x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
+                y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
+                            out_dtype=torch.float32, cd=cd)
+                x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
+            feats[:, t] = x[:, 0]
+            logits = ops.linear(x[:, 0, :], self.output.weight, self.output.bias, out_dtype=torch.float32, cd=cd)
+            preds[:, t + 1] = hip.argmax(logits)
+        return preds, feats
+
+
 # ------------------------------------------------------------------------------------------------ EncoderDecoder
 class EncoderDecoder(nn.Module):
     def __init__(self, encoder, decoder, cfg):
@@ -305,12 +355,20 @@ class EncoderDecoder(nn.Module):
         return self.decoder.predict(encoded_image, tgt)
 
     @torch.no_grad()
-    def generate(self, encoded, steps=None, bos=None):
-        """Greedy decode (predictor_pix2poly.py:188-207 contract: softmax -> argmax, full pass per step)."""
+    def generate(self, encoded, steps=None, bos=None, use_cache=True):
+        """Greedy decode (predictor_pix2poly.py:188-207 contract: softmax -> argmax).  use_cache=False reproduces the reference's
+        loop literally (full `predict` pass per step); the default runs the same arithmetic incrementally over KV caches."""
         tk = self.cfg.experiment.model.tokenizer
         steps = steps if steps is not None else (tk.generation_steps or 2 * tk.max_num_vertices + 1)
         bos = bos if bos is not None else tk.num_bins
         B = encoded.shape[0]
+        if use_cache:
+            was_training = self.decoder.training
+            self.decoder.eval()
+            try:
+                return self.decoder.generate_cached(encoded, steps, bos)
+            finally:
+                self.decoder.train(was_training)
         preds = torch.full((B, 1), bos, dtype=torch.long, device=encoded.device)
         feats = None
         for _ in range(steps):

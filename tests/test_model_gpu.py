@@ -211,3 +211,48 @@ def test_embed_tokens_rejects_sequences_longer_than_the_positional_table():
     with pytest.raises(P3Error):
         with torch.no_grad():
             m(torch.rand(1, 3, 224, 224, device=DEV), None, y)
+
+
+def test_kv_cached_decode_is_bit_identical_to_the_full_rerun_and_to_the_reference_golden():
+    """incremental greedy decode over KV caches == the reference's loop of full `predict` passes (golden tokens)."""
+    d, _ = load_golden("greedy_d256.npz")
+    sd = O.make_state_dict("image", dict(dim=64, depth=2, heads=2, mlp=128, patch=8, img=32, eps=1e-6), seed=77, n_vertices=10,
+                           dec_dim=256, dec_layers=2)
+    dec = _decoder_from(sd, 2, 10, 16).eval()
+    from pixelspointspolygons_amd import hip
+    enc = d["enc"].to(DEV)
+    preds = torch.full((3, 1), O.BOS, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        for _ in range(21):
+            lg, feats = dec.predict(enc, preds)
+            preds = torch.cat([preds, hip.argmax(lg).view(-1, 1)], 1)
+        toks, cfeats = dec.generate_cached(enc, 21, O.BOS)
+    assert torch.equal(toks.cpu(), d["tokens"])                      # the reference's own greedy sequence
+    assert torch.equal(toks, preds)
+    assert torch.equal(cfeats, feats[:, :21])                        # bit-identical features (fp32 mode)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_kv_cached_generate_full_model(precision):
+    """Whole early-fusion model, full 385-step decode: cached == literal loop on a prefix; timing of both printed."""
+    import time
+    sd = O.make_state_dict("fusion", seed=42)
+    m, cfg = _model("fusion", precision, sd)
+    inp = O.make_inputs(2, seed=3)
+    d = _to_dev(inp)
+    with torch.no_grad():
+        lj = torch.nested.nested_tensor_from_jagged(d["lidar_values"], d["lidar_offsets"])
+        enc = m.encoder(d["image"], lj)
+        torch.cuda.synchronize(); t0 = time.time()
+        toks, feats = m.generate(enc)
+        torch.cuda.synchronize(); t_cached = time.time() - t0
+        assert toks.shape == (2, 386) and feats.shape == (2, 385, 256)
+        torch.cuda.synchronize(); t0 = time.time()
+        ref_toks, ref_feats = m.generate(enc, steps=24, use_cache=False)
+        torch.cuda.synchronize(); t_full24 = time.time() - t0
+    print(f"\\n[{precision}] cached 385 steps: {t_cached:.2f} s; literal loop 24 steps: {t_full24:.2f} s (x{385 / 24:.0f} for 385)")
+    assert torch.equal(toks[:, :25], ref_toks)
+    if precision == "fp32":
+        assert torch.equal(feats[:, :24], ref_feats[:, :24])
+        ref = O.greedy_generate(O.encoder_fusion(inp["image"], inp["lidar_values"], inp["lidar_offsets"], sd), sd, steps=12)[0]
+        assert torch.equal(toks[:, :13].cpu(), ref)
