@@ -157,7 +157,7 @@ typedef struct {
     int nx, ny;           /* pillar grid (patch_feature_width/height) */
     float vx, vy, vz;     /* in_voxel_size */
     float zmax;           /* point_cloud_range z max (range min is 0) */
-    int max_points;       /* max_num_points_per_voxel (<= 64) */
+    int max_points;       /* max_num_points_per_voxel (1..4096; > 64 = the lidar_density_ablation{128,256,512} configs) */
     int max_voxels;       /* max_num_voxels.{train,test} */
     int C;                /* patch_feature_dim */
     int training;

@@ -154,16 +154,27 @@ __global__ __launch_bounds__(SORT_THREADS) void pillar_sort_kernel(const float* 
 struct VoxTab { const int* sorted; const int* xy; const int* start; const int* cnt; const int* row; const int* nvox; };
 
 // decorated features of slot `lane` of a pillar (valid iff lane < cnt); h = W1 . f
-__device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxTab& t, int v, int lane, const PillarGeom& g,
-                                       const float* __restrict__ w1s, float (&h)[C1], int& cnt_out, bool& valid_out, float (&fo)[8]) {
+// pillar mean over ALL its slots (max_points > 64: several 64-slot chunks per wave)
+__device__ __forceinline__ void pfn_mean(const float* __restrict__ pts, const VoxTab& t, int v, int lane, float& mx, float& my, float& mz) {
     const int cnt = t.cnt[v];
-    const bool valid = lane < cnt;
     float x = 0.f, y = 0.f, z = 0.f;
-    if (valid) { const float* p = pts + 3 * (int64_t)t.sorted[t.start[v] + lane]; x = p[0]; y = p[1]; z = p[2]; }
-    const float inv = 1.f / (float)cnt;
+    for (int s = lane; s < cnt; s += 64) { const float* p = pts + 3 * (int64_t)t.sorted[t.start[v] + s]; x += p[0]; y += p[1]; z += p[2]; }
+    mx = wave_sum(x) / (float)cnt; my = wave_sum(y) / (float)cnt; mz = wave_sum(z) / (float)cnt;
+}
+
+// MULTI = false: slot == lane (max_points <= 64), the mean is taken here.  MULTI = true: slot = s0 + lane, mean passed in (pfn_mean).
+template <bool MULTI = false>
+__device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxTab& t, int v, int lane, const PillarGeom& g,
+                                       const float* __restrict__ w1s, float (&h)[C1], int& cnt_out, bool& valid_out, float (&fo)[8],
+                                       int s0 = 0, float gmx = 0.f, float gmy = 0.f, float gmz = 0.f) {
+    const int cnt = t.cnt[v];
+    const bool valid = s0 + lane < cnt;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) { const float* p = pts + 3 * (int64_t)t.sorted[t.start[v] + s0 + lane]; x = p[0]; y = p[1]; z = p[2]; }
     // same operation order as the reference: sum over slots, then divide
-    const float mx = wave_sum(x) / (float)cnt, my = wave_sum(y) / (float)cnt, mz = wave_sum(z) / (float)cnt;
-    (void)inv;
+    float mx, my, mz;
+    if constexpr (MULTI) { mx = gmx; my = gmy; mz = gmz; }
+    else { mx = wave_sum(x) / (float)cnt; my = wave_sum(y) / (float)cnt; mz = wave_sum(z) / (float)cnt; }
     const int xy = t.xy[v] & 0xffffff;
     const int cx = xy % g.nx, cy = xy / g.nx;
     float f[8] = {x, y, z, x - mx, y - my, z - mz, x - ((float)cx * g.vx + 0.5f * g.vx), y - ((float)cy * g.vy + 0.5f * g.vy)};
@@ -179,6 +190,7 @@ __device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxT
     cnt_out = cnt; valid_out = valid;
 }
 
+template <bool MULTI>
 __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
                                                            int nslots, const float* __restrict__ w1, float* __restrict__ sums /*[2*C1]*/) {
     __shared__ float w1s[C1 * 8];
@@ -191,9 +203,20 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         float h[C1]; int cnt; bool valid; float f8[8];
-        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
+        if constexpr (MULTI) {
+            float mx, my, mz;
+            pfn_mean(pts, t, v, lane, mx, my, mz);
+            const int cn = t.cnt[v];
+            for (int s0 = 0; s0 < cn; s0 += 64) {
+                pfn_l0<true>(pts, t, v, lane, g, w1s, h, cnt, valid, f8, s0, mx, my, mz);
 #pragma unroll
-        for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
+                for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
+            }
+        } else {
+            pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
+#pragma unroll
+            for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
+        }
     }
     // block-level reduction first: one atomic per channel per block (8k waves hammering 64 addresses cost 3 ms)
     __shared__ float red[4][2 * C1];
@@ -232,7 +255,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, const 
     if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
 }
 
-template <typename T>
+template <typename T, bool MULTI>
 __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
                                                            int max_points, int nslots, const float* __restrict__ w1,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -247,6 +270,35 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         float h[C1]; int cnt; bool valid; float f8[8];
+        if constexpr (MULTI) {
+            // max_points > 64: pass 1 = per-channel max over all 64-slot chunks, pass 2 = recompute and write the rows
+            float mx, my, mz;
+            pfn_mean(pts, t, v, lane, mx, my, mz);
+            const int cn = t.cnt[v];
+            const bool pad = cn < max_points;
+            float xm[C1];
+#pragma unroll
+            for (int c = 0; c < C1; ++c) xm[c] = pad ? fmaxf(ss[C1 + c], 0.f) : -INFINITY;
+            for (int s0 = 0; s0 < cn; s0 += 64) {
+                pfn_l0<true>(pts, t, v, lane, g, w1s, h, cnt, valid, f8, s0, mx, my, mz);
+#pragma unroll
+                for (int c = 0; c < C1; ++c) xm[c] = fmaxf(xm[c], wave_max(valid ? fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f) : -INFINITY));
+            }
+            for (int s0 = 0; s0 <= cn; s0 += 64) {     // <= : the chunk that holds the representative padded slot (index cn)
+                pfn_l0<true>(pts, t, v, lane, g, w1s, h, cnt, valid, f8, s0, mx, my, mz);
+                const int slot = s0 + lane;
+                if (valid || (pad && slot == cn)) {
+                    const int64_t row = (int64_t)t.row[v] + slot;
+                    row_vox[row] = v; row_w[row] = valid ? 1.f : (float)(max_points - cn);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) F8[row * 8 + k] = f8[k];
+                    T* dst = X2 + row * K2;
+#pragma unroll
+                    for (int c = 0; c < C1; ++c) { dst[c] = Cvt<T>::from_f(fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f)); dst[C1 + c] = Cvt<T>::from_f(xm[c]); }
+                }
+            }
+            continue;
+        }
         pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
         const bool has_pad = cnt < max_points;
         float xm[C1];
@@ -550,7 +602,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
                                      const float* bn2_beta, float* bn2_rmean, float* bn2_rvar, void* out, void* workspace,
                                      const p3_pillar_desc* d, int phases, void* stream) {
     P3_CHECK(values && offsets && w1 && w2 && out && workspace && d, P3_EINVAL, "p3_pillar_stem: null pointer");
-    P3_CHECK(d->B > 0 && d->nx > 0 && d->ny > 0 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem: max_points must be 1..64");
+    P3_CHECK(d->B > 0 && d->nx > 0 && d->ny > 0 && d->max_points > 0 && d->max_points <= 4096, P3_ESHAPE, "p3_pillar_stem: max_points must be 1..4096");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768, P3_ESHAPE, "p3_pillar_stem: C must be a multiple of 64, <= 768");
     P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_pillar_stem: dtype");
     P3_CHECK(d->vz >= d->zmax, P3_EUNSUP, "p3_pillar_stem: only one z cell (voxel z size == z range) is supported");
@@ -589,7 +641,8 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
     P3_LAUNCH_CHECK();
     if (d->training) {
-        hipLaunchKernelGGL(pfn_l1_stats_kernel, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
+        if (d->max_points > 64) hipLaunchKernelGGL(pfn_l1_stats_kernel<true>, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
+        else hipLaunchKernelGGL(pfn_l1_stats_kernel<false>, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
         P3_LAUNCH_CHECK();
     }
     }
@@ -597,10 +650,10 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, w.sums1, C1, w.totals, (float)d->max_points, 0.f, bn1_gamma, bn1_beta,
                        bn1_rmean, bn1_rvar, d->bn_eps, d->bn_momentum, d->training, w.sc1, w.sh1, w.m1, w.r1);
     P3_LAUNCH_CHECK();
-    if (d->dtype == P3_BF16)
-        hipLaunchKernelGGL((pfn_l1_apply_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (bf16_t*)w.X2, w.F8, w.row_vox, w.row_w);
-    else
-        hipLaunchKernelGGL((pfn_l1_apply_kernel<float>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (float*)w.X2, w.F8, w.row_vox, w.row_w);
+#define P3_L1_APPLY(T, MULTI) hipLaunchKernelGGL((pfn_l1_apply_kernel<T, MULTI>), dim3(vgrid), dim3(256), 0, s, values, t, g, d->max_voxels, d->max_points, nslots, w1, w.sc1, w.sh1, (T*)w.X2, w.F8, w.row_vox, w.row_w)
+    if (d->dtype == P3_BF16) { if (d->max_points > 64) P3_L1_APPLY(bf16_t, true); else P3_L1_APPLY(bf16_t, false); }
+    else { if (d->max_points > 64) P3_L1_APPLY(float, true); else P3_L1_APPLY(float, false); }
+#undef P3_L1_APPLY
     P3_LAUNCH_CHECK();
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
@@ -648,7 +701,7 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
                                          void* stream) {
     P3_CHECK(dcanvas && w1 && bn1_gamma && w2t && bn2_gamma && workspace && d && dw1 && dg1 && db1 && dw2 && dg2 && db2, P3_EINVAL,
              "p3_pillar_stem_bwd: null pointer");
-    P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 64, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
+    P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 4096, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
     hipStream_t s = (hipStream_t)stream;
     Ws w = carve(workspace, d);
     const int nslots = d->B * d->max_voxels;

@@ -243,13 +243,14 @@ def test_scorenet_backward_native_vs_oracle_autograd(transpose, train, N, B):
     assert l2_err(fd.grad.cpu(), f.grad) < 1e-3
 
 
-@pytest.mark.parametrize("train,max_points,n_points", [(True, 64, 3000), (False, 64, 3000), (True, 8, 6000), (True, 64, 400)])
+@pytest.mark.parametrize("train,max_points,n_points", [(True, 64, 3000), (False, 64, 3000), (True, 8, 6000), (True, 64, 400),
+                                                       (True, 128, 90000), (True, 256, 120000)])   # density-ablation configs: > 64 slots
 def test_pillar_stem_backward_native_vs_oracle_autograd(train, max_points, n_points):
     """p3_pillar_stem_bwd (PFN parameter gradients) vs float64 autograd of the oracle's dense [V, max_points] formulation:
     truncated pillars (max_points 8), mostly-padded pillars (400 points), train- and eval-mode BatchNorm."""
     from pixelspointspolygons_amd.config import make_config
     from pixelspointspolygons_amd.pointpillars import PointPillarsEncoder
-    B = 3
+    B = 3 if n_points < 50000 else 2
     sd = O.make_state_dict("lidar", seed=13)
     pre = "encoder.vit.patch_embed."
     inp = O.make_inputs(B, seed=77, n_points=n_points, jitter=n_points // 10)
