@@ -6,6 +6,8 @@
 // the NT kernel.  f32 (v_mfma_f32_32x32x2_f32 takes one element per lane) needs no transpose.
 // Grid = tiles_n x tiles_k x splits; every split adds its partial tile with fp32 atomics (C must be zero-filled or hold
 // the gradient being accumulated).  Rows >= M contribute zeros.
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -323,7 +325,12 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.tiles_k = p3_ceil_div(K, TK);
     const int tiles = tiles_n * g.tiles_k;
     const int bm = dtype == P3_BF16 ? 64 : 16;
-    int splits = p3_ceil_div(slabs ? 768 : 1024, tiles);
+    // M-split count (measured r01, tools/mb_tn.py sweep 512..2048): ~768 workgroups (1.5 x the 512 that fit the chip at 2 per CU)
+    // balances per-block prologue / atomic-epilogue overhead against tail imbalance: +8..13 % over 1024; exactly one full wave of
+    // 512 blocks is better still when the tile count divides it (decoder linear1: 64 vs 82 us).  P3_TN_BLOCKS overrides for sweeps.
+    static int target_blocks = 0;
+    if (target_blocks == 0) { const char* e = getenv("P3_TN_BLOCKS"); target_blocks = e ? atoi(e) : -1; if (target_blocks == 0) target_blocks = -1; }
+    int splits = target_blocks > 0 ? p3_ceil_div(target_blocks, tiles) : ((512 % tiles == 0) ? 512 / tiles : p3_ceil_div(768, tiles));
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
     if (splits > max_splits) splits = max_splits;

@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 import pixelspointspolygons_amd.hip as h
 from tools.microbench import timeit
 B = 64
-for slabs in (0, 24):
+for slabs in (0,):
     h.TN_MAX_SLABS = slabs
     for (M, N, K, tag) in ((B * 785, 1536, 384, "fc1.dW"), (B * 785, 384, 1536, "fc2.dW"), (B * 785, 1152, 384, "qkv.dW"), (B * 785, 384, 384, "proj.dW"),
                            (B * 385, 2048, 256, "lin1.dW"), (B * 385, 768, 256, "inproj.dW"), (B * 900, 384, 768, "conv tap")):
