@@ -7,6 +7,8 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, BK = 64, LDS rows padded to 72 elements (ds_read_b128, conflict free)
 //   f32 : v_mfma_f32_32x32x2_f32 (exact fp32, = fmaf chain), BK = 16, LDS k-major [16][132]
 // The A operand can be generated on the fly (implicit 3x3 conv gather, BN+ReLU fold, ScoreNet pair sum).
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -20,9 +22,14 @@ struct GemmArgs {
 
 constexpr int BM = 128, BN = 128;
 
-template <typename T> struct Tr;
-template <> struct Tr<bf16_t> { static constexpr int BK = 64, PITCH = 72, VEC = 8, LDS_ELEMS = BM * 72; };
-template <> struct Tr<float> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
+// Two bf16 K-slice depths.  BK = 64 (74 KB of LDS, 2 workgroups / CU, one-pass epilogue) is the default.  BK = 32 (rows padded to
+// 40 elements = 80 B, conflict free for ds_read_b128; 40 KB operands + two-pass 34 KB epilogue staging -> 3 workgroups / CU) serves
+// K % 64 != 0 and is kept for A/B runs (P3_GEMM_BK=32): in isolation it is +5..20 % on the K <= 512 shapes and -8..13 % from
+// K = 1536 up (tools/microbench.py), inside the train step the two are within 1 % (r01: 62.8 vs 62.1 ms), so one variant runs.
+template <typename T, int BKSEL> struct Tr;
+template <int BKSEL> struct Tr<bf16_t, BKSEL> { static constexpr int BK = BKSEL, PITCH = BKSEL + 8, VEC = 8, LDS_ELEMS = BM * (BKSEL + 8); };
+template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
+template <typename T> struct VecOf { static constexpr int VEC = 16 / (int)sizeof(T); };
 
 // ---- per-thread A-row descriptor (fixed over the K loop) -------------------------------------
 struct RowSrc {
@@ -55,7 +62,7 @@ __device__ __forceinline__ RowSrc make_row(const p3_gemm_desc& d, int gm) {
 
 // ---- 16-byte staged vectors: 8 bf16 or 4 f32 -------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void unpack(const uint4& raw, float (&v)[Tr<T>::VEC]) {
+__device__ __forceinline__ void unpack(const uint4& raw, float (&v)[VecOf<T>::VEC]) {
     if constexpr (sizeof(T) == 2) {
         const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
@@ -65,7 +72,7 @@ __device__ __forceinline__ void unpack(const uint4& raw, float (&v)[Tr<T>::VEC])
     }
 }
 template <typename T>
-__device__ __forceinline__ uint4 repack(const float (&v)[Tr<T>::VEC]) {
+__device__ __forceinline__ uint4 repack(const float (&v)[VecOf<T>::VEC]) {
     uint4 p;
     if constexpr (sizeof(T) == 2) {
         p.x = pack_bf2(v[0], v[1]); p.y = pack_bf2(v[2], v[3]); p.z = pack_bf2(v[4], v[5]); p.w = pack_bf2(v[6], v[7]);
@@ -78,7 +85,7 @@ __device__ __forceinline__ uint4 repack(const float (&v)[Tr<T>::VEC]) {
 // load VEC consecutive k-elements of one A row starting at global k index `k`
 template <typename T, int AMODE>
 __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const RowSrc& r, int k) {
-    constexpr int VEC = Tr<T>::VEC;
+    constexpr int VEC = VecOf<T>::VEC;
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (AMODE == P3_A_CONV3X3 || AMODE == P3_A_CONV3X3_AFFINE_RELU) {
         int tap = k / d.conv_C, c = k - tap * d.conv_C;
@@ -128,25 +135,28 @@ __device__ __forceinline__ uint4 load_w(const T* W, int64_t rowoff, int k) {
 }
 
 // store one thread's staged vector into LDS.  bf16: row-major [row][PITCH]; f32: k-major [k][PITCH]
-template <typename T>
+template <typename T, int PITCH>
 __device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v) {
     if constexpr (sizeof(T) == 2) {
-        *reinterpret_cast<uint4*>(buf + row * Tr<T>::PITCH + kq) = v;
+        *reinterpret_cast<uint4*>(buf + row * PITCH + kq) = v;
     } else {
-        buf[(kq + 0) * Tr<T>::PITCH + row] = __uint_as_float(v.x);
-        buf[(kq + 1) * Tr<T>::PITCH + row] = __uint_as_float(v.y);
-        buf[(kq + 2) * Tr<T>::PITCH + row] = __uint_as_float(v.z);
-        buf[(kq + 3) * Tr<T>::PITCH + row] = __uint_as_float(v.w);
+        buf[(kq + 0) * PITCH + row] = __uint_as_float(v.x);
+        buf[(kq + 1) * PITCH + row] = __uint_as_float(v.y);
+        buf[(kq + 2) * PITCH + row] = __uint_as_float(v.z);
+        buf[(kq + 3) * PITCH + row] = __uint_as_float(v.w);
     }
 }
 
-template <typename T, typename TO, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    constexpr int BK = Tr<T>::BK, PITCH = Tr<T>::PITCH, VEC = Tr<T>::VEC, LDSE = Tr<T>::LDS_ELEMS;
+template <typename T, typename TO, int AMODE, int BKSEL>
+__global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmArgs g) {
+    using TR = Tr<T, BKSEL>;
+    constexpr int BK = TR::BK, PITCH = TR::PITCH, VEC = TR::VEC, LDSE = TR::LDS_ELEMS;
+    constexpr int EPI_PASSES = BKSEL == 32 ? 2 : 1;  // epilogue staged through LDS in 1 pass of 128 rows or 2 passes of 64
+    constexpr int EPI_ROWS = BM / EPI_PASSES;
     // rows handled per thread per operand per stage
     constexpr int ROWS_PER_PASS = 256 / (BK / VEC);  // bf16: 32, f32: 64
     constexpr int NPASS = BM / ROWS_PER_PASS;        // bf16: 4,  f32: 2
-    constexpr int LDS_BYTES = (4 * LDSE * (int)sizeof(T) > 128 * 132 * 4) ? 4 * LDSE * (int)sizeof(T) : 128 * 132 * 4;
+    constexpr int LDS_BYTES = (4 * LDSE * (int)sizeof(T) > EPI_ROWS * 132 * 4) ? 4 * LDSE * (int)sizeof(T) : EPI_ROWS * 132 * 4;
     __shared__ __attribute__((aligned(16))) T lds[LDS_BYTES / sizeof(T)];
 
     const p3_gemm_desc& d = g.d;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) { ra[p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[p] = load_w<T>(W, wrow[p], kq); }
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { lds_put<T>(lds, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+    for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(lds, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { lds_put<T>(an, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T>(bn, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+            for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(an, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
         }
         __syncthreads();
     }
@@ -246,29 +256,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // makes every residual load / aux store / output store a 16-byte access (guide T21 idea, done through LDS).
     constexpr int EP = 132;
     float* stage = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cl = wn * 64 + j * 32 + l31;
-        const int col = tn * BN + cl;
-        const bool cok = col < d.N;
-        const float bias = (d.bias && cok) ? d.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + i * 32 + crow32(r, hi);
-                const float v = acc[i][j][r] + bias;
-                stage[rl * EP + cl] = v;
-                if (tm * BM + rl < d.M && cok) { s1 += v; s2 += v * v; }
-            }
-        }
-        if (d.colsum) {
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (hi == 0 && cok) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
-        }
-    }
-    __syncthreads();
     TO* C = reinterpret_cast<TO*>(g.C);
     TO* aux = reinterpret_cast<TO*>(d.aux);
     const bool has_res = d.residual != nullptr;
@@ -276,101 +263,144 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
     const int act = d.act;
     const DropKey dk = drop_key(d.drop);
-#pragma unroll 2
-    for (int c = 0; c < 8; ++c) {
-        const int id = tid + 256 * c;
-        const int rl = id >> 4, cl = (id & 15) * 8;
-        const int row = tm * BM + rl, col = tn * BN + cl;
-        if (row >= d.M || col >= d.N) continue;
-        float v[8];
-        {
-            const float4 v0 = *reinterpret_cast<const float4*>(stage + rl * EP + cl);
-            const float4 v1 = *reinterpret_cast<const float4*>(stage + rl * EP + cl + 4);
-            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+#pragma unroll
+    for (int pass = 0; pass < EPI_PASSES; ++pass) {
+        if (pass > 0) __syncthreads();               // the previous pass's readers are done with the staging buffer
+        if (EPI_PASSES == 1 || wm == pass) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + l31;
+                const int col = tn * BN + cl;
+                const bool cok = col < d.N;
+                const float bias = (d.bias && cok) ? d.bias[col] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rw = wm * 64 + i * 32 + crow32(r, hi);     // row inside the 128-row tile
+                        const float v = acc[i][j][r] + bias;
+                        stage[(rw - pass * EPI_ROWS) * EP + cl] = v;
+                        if (tm * BM + rw < d.M && cok) { s1 += v; s2 += v * v; }
+                    }
+                }
+                if (d.colsum) {
+                    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                    if (hi == 0 && cok) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+                }
+            }
         }
-        const int64_t co = (int64_t)row * d.ldc + col;
-        if (g.vec_epi && col + 8 <= d.N) {
-            if (aux) {
-                if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+        __syncthreads();
+    #pragma unroll 2
+        for (int c = 0; c < 8 / EPI_PASSES; ++c) {
+            const int id = tid + 256 * c;
+            const int rl = id >> 4, cl = (id & 15) * 8;
+            const int row = tm * BM + pass * EPI_ROWS + rl, col = tn * BN + cl;
+            if (row >= d.M || col >= d.N) continue;
+            float v[8];
+            {
+                const float4 v0 = *reinterpret_cast<const float4*>(stage + rl * EP + cl);
+                const float4 v1 = *reinterpret_cast<const float4*>(stage + rl * EP + cl + 4);
+                v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
             }
-            if (act == P3_ACT_GELU) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
-            } else if (act == P3_ACT_RELU) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-            }
-            if (dk.on) {
-                const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    const uint32_t bits = drop_bits(rk, drop_colkey(dk, (uint32_t)(col + k)));
-                    v[k] = drop_keep_lo(dk, bits) ? v[k] * dk.inv_keep : 0.f;
-                    v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
+            const int64_t co = (int64_t)row * d.ldc + col;
+            if (g.vec_epi && col + 8 <= d.N) {
+                if (aux) {
+                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
                 }
-            }
-            if (bwd_saved) {
-                float sv[8];
-                if constexpr (sizeof(TO) == 2) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(bwd_saved + co);
-                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { sv[2 * k] = __uint_as_float(w[k] << 16); sv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
-                } else {
-                    const float4 r0 = *reinterpret_cast<const float4*>(bwd_saved + co);
-                    const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
-                    sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
+                if (act == P3_ACT_GELU) {
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+                } else if (act == P3_ACT_RELU) {
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= act_grad(sv[k], d.bwd_act) * d.bwd_scale;
-            }
-            if (has_res) {
-                const int64_t ro = (int64_t)row * d.ldr + col;
-                if (res_bf) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.residual) + ro);
-                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
-                } else {
-                    const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro);
-                    const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro + 4);
-                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                if (dk.on) {
+                    const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
+    #pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const uint32_t bits = drop_bits(rk, drop_colkey(dk, (uint32_t)(col + k)));
+                        v[k] = drop_keep_lo(dk, bits) ? v[k] * dk.inv_keep : 0.f;
+                        v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
+                    }
                 }
-            }
-            if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(C + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-            else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
-        } else {
-            for (int k = 0; k < 8 && col + k < d.N; ++k) {
-                float x = v[k];
-                if (aux) aux[co + k] = Cvt<TO>::from_f(x);
-                if (act == P3_ACT_GELU) x = gelu_erf(x);
-                else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
-                if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
-                if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
+                if (bwd_saved) {
+                    float sv[8];
+                    if constexpr (sizeof(TO) == 2) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(bwd_saved + co);
+                        const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) { sv[2 * k] = __uint_as_float(w[k] << 16); sv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+                    } else {
+                        const float4 r0 = *reinterpret_cast<const float4*>(bwd_saved + co);
+                        const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
+                        sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
+                    }
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= act_grad(sv[k], d.bwd_act) * d.bwd_scale;
+                }
                 if (has_res) {
-                    const int64_t ri = (int64_t)row * d.ldr + col + k;
-                    x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
+                    const int64_t ro = (int64_t)row * d.ldr + col;
+                    if (res_bf) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.residual) + ro);
+                        const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+                    } else {
+                        const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro);
+                        const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    }
                 }
-                C[co + k] = Cvt<TO>::from_f(x);
+                if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(C + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+            } else {
+                for (int k = 0; k < 8 && col + k < d.N; ++k) {
+                    float x = v[k];
+                    if (aux) aux[co + k] = Cvt<TO>::from_f(x);
+                    if (act == P3_ACT_GELU) x = gelu_erf(x);
+                    else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
+                    if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
+                    if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
+                    if (has_res) {
+                        const int64_t ri = (int64_t)row * d.ldr + col + k;
+                        x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
+                    }
+                    C[co + k] = Cvt<TO>::from_f(x);
+                }
             }
         }
     }
 }
 
-template <typename T, typename TO>
-int launch_mode(const GemmArgs& g, hipStream_t s) {
+template <typename T, typename TO, int BKSEL>
+int launch_bk(const GemmArgs& g, hipStream_t s) {
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
     switch (g.d.a_mode) {
-        case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN>), grid, block, 0, s, g); break;
-        case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3>), grid, block, 0, s, g); break;
-        case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU>), grid, block, 0, s, g); break;
-        case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU>), grid, block, 0, s, g); break;
-        case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU>), grid, block, 0, s, g); break;
+        case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN, BKSEL>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3, BKSEL>), grid, block, 0, s, g); break;
+        case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
+        case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
         default: p3_set_error("p3_gemm: bad a_mode"); return P3_EINVAL;
     }
     P3_LAUNCH_CHECK();
     return P3_OK;
+}
+
+template <typename T, typename TO>
+int launch_mode(const GemmArgs& g, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static int force = -1;                        // P3_GEMM_BK=32|64 forces one variant (A/B sweeps)
+        if (force < 0) { const char* e = getenv("P3_GEMM_BK"); force = e ? atoi(e) : 0; }
+        const bool conv = g.d.a_mode == P3_A_CONV3X3 || g.d.a_mode == P3_A_CONV3X3_AFFINE_RELU;
+        const bool can64 = g.d.K % 64 == 0 && (!conv || g.d.conv_C % 64 == 0);
+        const bool deep = force == 32 ? false : can64;
+        return deep ? launch_bk<T, TO, 64>(g, s) : launch_bk<T, TO, 32>(g, s);
+    } else {
+        return launch_bk<T, TO, 16>(g, s);
+    }
 }
 
 }  // namespace
@@ -378,11 +408,11 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm: empty problem");
-    const int bk = d->dtype_in == P3_BF16 ? 64 : 16;
+    const int bk = d->dtype_in == P3_BF16 ? 32 : 16;
     const int vec = d->dtype_in == P3_BF16 ? 8 : 4;
     P3_CHECK(d->dtype_in == P3_BF16 || d->dtype_in == P3_F32, P3_EUNSUP, "p3_gemm: dtype_in");
     P3_CHECK(d->dtype_out == P3_BF16 || d->dtype_out == P3_F32, P3_EUNSUP, "p3_gemm: dtype_out");
-    P3_CHECK(d->K % bk == 0, P3_ESHAPE, "p3_gemm: K must be a multiple of 64 (bf16) / 16 (f32)");
+    P3_CHECK(d->K % bk == 0, P3_ESHAPE, "p3_gemm: K must be a multiple of 32 (bf16) / 16 (f32)");
     P3_CHECK(d->lda % vec == 0 && d->ldb % vec == 0, P3_EALIGN, "p3_gemm: lda/ldb must keep 16-byte row alignment");
     P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, P3_EALIGN, "p3_gemm: A/W must be 16-byte aligned");
     if (d->a_mode == P3_A_CONV3X3 || d->a_mode == P3_A_CONV3X3_AFFINE_RELU) {
