@@ -202,7 +202,7 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int KT = BF ? 64 : 32;
     using TK = Tile<T, D, KT>;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int QT = BF ? 64 : 32;
     using TQ = Tile<T, D, QT>;

@@ -34,7 +34,7 @@ template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 64, ELEMS
 template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS = 16 * 132; };  // [m][col]
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
