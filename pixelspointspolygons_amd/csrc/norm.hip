@@ -73,18 +73,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, c
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma/dbeta accumulated with one atomic per block-column
-template <typename TDY, typename TX, typename TDX>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+// NV = float4-chunks per lane (1: cols <= 256, 2: <= 512, 4: <= 1024): the per-row register arrays scale with it
+template <typename TDY, typename TX, typename TDX, int NV>
+__global__ __launch_bounds__(256, (NV == 4 ? 2 : 4)) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const TDX* __restrict__ dres, TDX* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
                                                      int cols, int rows_per_block) {
-    __shared__ float sg[4][1024], sb[4][1024];
+    __shared__ float sg[4][NV * 256], sb[4][NV * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = cols >> 2;
-    float ag[MAXV][4], ab[MAXV][4];
+    float ag[NV][4], ab[NV][4];
 #pragma unroll
-    for (int c = 0; c < MAXV; ++c)
+    for (int c = 0; c < NV; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
     const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     if (rend > rows) rend = rows;
     for (int64_t row = rbeg + w; row < rend; row += 4) {
         const float mu = mean[row], rs = rstd[row];
-        float g[MAXV][4], xh[MAXV][4], d[MAXV][4];
+        float g[NV][4], xh[NV][4], d[NV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXV; ++c) {
+        for (int c = 0; c < NV; ++c) {
             const int ci = lane + 64 * c;
             if (ci < nchunk) {
                 float xv[4];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         s1 = wave_sum(s1) / (float)cols;
         s2 = wave_sum(s2) / (float)cols;
 #pragma unroll
-        for (int c = 0; c < MAXV; ++c) {
+        for (int c = 0; c < NV; ++c) {
             const int ci = lane + 64 * c;
             if (ci < nchunk) {
                 float o[4];
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     }
     if (dgamma) {
 #pragma unroll
-        for (int c = 0; c < MAXV; ++c) {
+        for (int c = 0; c < NV; ++c) {
             const int ci = lane + 64 * c;
             if (ci < nchunk)
 #pragma unroll
@@ -184,14 +185,17 @@ extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* 
     const int rpb = rows > 32768 ? 128 : 64;      // fewer blocks = fewer dgamma / dbeta atomics per address
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
+#define LNB_NV(TDY, TX, TDX, NV) \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NV>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
 #define LNB(TDY, TX, TDX) \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
+    do { if (cols <= 256) LNB_NV(TDY, TX, TDX, 1); else if (cols <= 512) LNB_NV(TDY, TX, TDX, 2); else LNB_NV(TDY, TX, TDX, 4); } while (0)
     if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(float, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(bf16_t, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNB(bf16_t, bf16_t, bf16_t);
     else if (dtype_dy == P3_F32 && dtype_x == P3_BF16 && dtype_dx == P3_F32) LNB(float, bf16_t, float);
     else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
 #undef LNB
+#undef LNB_NV
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
