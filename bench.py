@@ -286,12 +286,27 @@ def main():
         _ops.SYNC_BN[0] = was_sync
         if kt:
             name, rec = max(kt.items(), key=lambda kv: kv[1]["ms"])
-            peak = 2500.0 if args.precision == "bf16" else 157.3
-            ach = rec["flop"] / (rec["ms"] * 1e-3) / 1e12
+            peak_tf = 2500.0 if args.precision == "bf16" else 157.3
+            peak_gb = 8000.0
+            sec = rec["ms"] * 1e-3
+            ach_tf = rec["flop"] / sec / 1e12
+            ach_gb = rec["bytes"] / sec / 1e9 if rec["bytes"] else 0.0
+            ai = rec["flop"] / rec["bytes"] if rec["bytes"] else float("inf")
+            ridge = peak_tf * 1e12 / (peak_gb * 1e9)
             traffic, tsrc = pmc_traffic(name)
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_source": tsrc, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
-                        "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3)}
+            common = {"kernel": name, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+                      "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3),
+                      "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                      "traffic": traffic, "traffic_source": tsrc,
+                      "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]), "algorithmic_flop_per_launch": round(rec["flop"] / rec["n"])}
+            # the bound is the one the launch mix sits under: K = 384 GEMMs with fp32 residual / bf16 outputs move 77-290 FLOP per
+            # byte, below the 312 FLOP/B ridge of MI355X (2.5 PF / 8 TB/s) -> HBM bound; both fractions are reported
+            if ai < ridge:
+                roofline = {"bound": "hbm", "achieved": round(ach_gb, 1), "peak": peak_gb, "unit": "GB/s", "frac": round(ach_gb / peak_gb, 4),
+                            "mfma_achieved_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak_tf, 4), **common}
+            else:
+                roofline = {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
+                            "hbm_achieved_gbs": round(ach_gb, 1), "hbm_frac": round(ach_gb / peak_gb, 4), **common}
 
     if rank == 0:
         tiles = args.batch * world * args.steps

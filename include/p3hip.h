@@ -37,6 +37,7 @@ extern "C" {
 #define P3_ACT_NONE 0
 #define P3_ACT_GELU 1 /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
 #define P3_ACT_RELU 2
+#define P3_ACT_MUL 3  /* p3_gemm_desc.bwd_act only: the saved tensor already holds act'(pre) (aux_mode = 1): plain multiply */
 
 #define P3_A_PLAIN 0
 #define P3_A_CONV3X3 1 /* A is an NHWC map [B,H,W,lda]; K = 9*C, zero padding 1 (implicit GEMM) */
@@ -95,6 +96,8 @@ typedef struct {
     const void* bwd_saved;
     int bwd_act;
     float bwd_scale;
+    int aux_mode;         /* what `aux` receives: 0 = the pre-activation, 1 = act'(pre) (GELU: cdf + x*pdf, computed with the
+                           * activation from the same erf / exp), so that backward is a multiply with no transcendental */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 

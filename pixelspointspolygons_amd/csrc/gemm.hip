@@ -121,11 +121,8 @@ __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const
 
 // act'(.) for the fused activation backward: GELU' of the saved pre-activation, ReLU' from the saved output
 __device__ __forceinline__ float act_grad(float x, int act) {
-    if (act == P3_ACT_GELU) {
-        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-        return cdf + x * pdf;
-    }
+    if (act == P3_ACT_MUL) return x;                 // the forward already stored act'(pre)
+    if (act == P3_ACT_GELU) { float h, g; gelu_and_grad(x, h, g); return g; }
     return x > 0.f ? 1.f : 0.f;
 }
 
@@ -261,6 +258,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
     const bool has_res = d.residual != nullptr;
     const bool res_bf = d.dtype_res == P3_BF16;
     const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
+    const bool aux_grad = d.aux_mode == 1;
     const int act = d.act;
     const DropKey dk = drop_key(d.drop);
 #pragma unroll
@@ -305,16 +303,23 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
             }
             const int64_t co = (int64_t)row * d.ldc + col;
             if (g.vec_epi && col + 8 <= d.N) {
-                if (aux) {
-                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                    else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
-                }
                 if (act == P3_ACT_GELU) {
-    #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
-                } else if (act == P3_ACT_RELU) {
-    #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    float gd[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float x = v[k]; gelu_and_grad(x, v[k], gd[k]); if (!aux_grad) gd[k] = x; }
+                    if (aux) {   // pre-activation (aux_mode 0) or GELU'(pre) (aux_mode 1)
+                        if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(gd[0], gd[1]), pack_bf2(gd[2], gd[3]), pack_bf2(gd[4], gd[5]), pack_bf2(gd[6], gd[7]));
+                        else { *reinterpret_cast<float4*>(aux + co) = make_float4(gd[0], gd[1], gd[2], gd[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(gd[4], gd[5], gd[6], gd[7]); }
+                    }
+                } else {
+                    if (aux) {
+                        if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                        else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+                    }
+                    if (act == P3_ACT_RELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
                 }
                 if (dk.on) {
                     const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
@@ -358,9 +363,14 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
             } else {
                 for (int k = 0; k < 8 && col + k < d.N; ++k) {
                     float x = v[k];
-                    if (aux) aux[co + k] = Cvt<TO>::from_f(x);
-                    if (act == P3_ACT_GELU) x = gelu_erf(x);
-                    else if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
+                    if (act == P3_ACT_GELU) {
+                        const float pre = x; float gd;
+                        gelu_and_grad(pre, x, gd);
+                        if (aux) aux[co + k] = Cvt<TO>::from_f(aux_grad ? gd : pre);
+                    } else {
+                        if (aux) aux[co + k] = Cvt<TO>::from_f(x);
+                        if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
+                    }
                     if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
                     if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
                     if (has_res) {
@@ -424,7 +434,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
         P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
-    P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU or RELU");
+    P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, BM);

@@ -89,7 +89,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // row index of accumulator register r of a 32x32 MFMA C/D fragment (col = lane & 31)
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact (erf) GELU and its derivative from ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 parity
+// tolerances by four orders), exp(-z^2) with z = x/sqrt(2) is also the Gaussian pdf of GELU'.  ~20 VALU ops for both values; the
+// libm erff + expf pair this replaces made the fc1 epilogue cost as much as its whole K = 384 main loop (r01: 146 vs 97 us).
+__device__ __forceinline__ void gelu_and_grad(float x, float& h, float& g) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    const float e = __expf(-z * z);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
+    h = x * cdf;
+    g = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+__device__ __forceinline__ float gelu_erf(float x) { float h, g; gelu_and_grad(x, h, g); return h; }
 
 static inline int p3_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -7,7 +7,7 @@ import torch
 from ._lib import P3Error, check, lib
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL = 0, 1, 2, 3
 A_PLAIN, A_CONV3X3, A_AFFINE_RELU, A_PAIR_AFFINE_RELU = 0, 1, 2, 3
 
 
@@ -97,12 +97,12 @@ class GemmDesc(Structure):
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
                 ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout),
-                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float)]
+                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None, bwd=None):
+         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p)."""
     _dev(a)
     N, K = w.shape
@@ -131,6 +131,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         d.residual, d.ldr, d.dtype_res = residual.data_ptr(), residual.stride(-2), dt(residual)
     if aux is not None:
         d.aux = aux.data_ptr()
+        d.aux_mode = 1 if aux_grad else 0          # aux receives act'(pre) instead of the pre-activation
     if conv is not None:
         d.conv_H, d.conv_W, d.conv_C = conv[1], conv[2], conv[3]
     if a_scale is not None:
@@ -147,7 +148,24 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         d.bwd_saved, d.bwd_act, d.bwd_scale = sv.data_ptr(), bact, bscale
     ev = KTIMER.begin()
     check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
-    KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K)
+    if ev is not None:
+        # algorithmic HBM bytes of this launch: A read once (generated A: its sources), W once, C written once, residual / aux /
+        # saved-activation streams once each
+        esi, eso = a.element_size(), out.element_size()
+        if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
+            a_bytes = M_ * conv[3] * esi
+        elif a_mode == A_PAIR_AFFINE_RELU:
+            a_bytes = 2 * (M_ // pair_n) * K * esi
+        else:
+            a_bytes = M_ * K * esi
+        nbytes = a_bytes + N * K * esi + M_ * N * eso
+        if residual is not None:
+            nbytes += M_ * N * residual.element_size()
+        if aux is not None:
+            nbytes += M_ * N * eso
+        if bwd is not None:
+            nbytes += M_ * N * eso
+        KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K, float(nbytes))
     return out
 
 

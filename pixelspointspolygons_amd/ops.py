@@ -255,7 +255,7 @@ class _Mlp(torch.autograd.Function):
         if drop1 is not None and act != hip.ACT_RELU:
             raise NotImplementedError("dropout after GELU is not on the reference path")
         aux = torch.empty((x2.shape[0], w1.shape[0]), dtype=cd, device=x.device) if (need and act == hip.ACT_GELU) else None
-        h = hip.gemm(x2, w1c, bias=b1, act=act, out_dtype=cd, aux=aux, drop=drop1)
+        h = hip.gemm(x2, w1c, bias=b1, act=act, out_dtype=cd, aux=aux, aux_grad=True, drop=drop1)   # aux <- GELU'(pre), not pre
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
         y = hip.gemm(h, w2c, bias=b2, residual=res2, out_dtype=out_dtype, drop=drop2)
         ctx.cfg = (act, cd, residual is not None, drop1, drop2, x.shape)
@@ -276,9 +276,9 @@ class _Mlp(torch.autograd.Function):
             dpre2 = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
         dw2, db2 = _weight_grads(dpre2, h, w2, ctx.b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                       # [hidden, out]
-        saved = aux if act == hip.ACT_GELU else h
         scale = 1.0 / (1.0 - drop1[2]) if drop1 is not None else 1.0
-        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=(saved, act, scale))                  # dH * act'(.) in the epilogue
+        bwd = (aux, hip.ACT_MUL, 1.0) if act == hip.ACT_GELU else (h, act, scale)            # GELU' was stored by the forward epilogue
+        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=bwd)                                  # dH * act'(.) in the epilogue
         dw1, db1 = _weight_grads(dpre1, x2, w1, ctx.b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
