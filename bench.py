@@ -322,10 +322,11 @@ def main():
             "final_loss": round(loss_val, 4),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the host cores are shared by the ranks otherwise)
             line["cpu_baseline"] = cpu_baseline(O, args, kind)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                                    # rank 0 runs the instrumented leg alone: leave together
         dist.destroy_process_group()
 
 

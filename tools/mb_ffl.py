@@ -1,0 +1,22 @@
+"""FFL (early_fusion_vit_cnn) inference forward throughput on synthetic tiles (BASELINE configs[4] shape, forward only)."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from oracle import p3_oracle as O
+from pixelspointspolygons_amd.config import make_config
+from pixelspointspolygons_amd.ffl import FFLModel
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+cfg = make_config("early_fusion_vit_cnn", model="ffl", precision="bf16")
+m = FFLModel(cfg, 0).eval()
+d = O.make_inputs(B, seed=1)
+img = d["image"].cuda()
+nt = torch.nested.nested_tensor_from_jagged(d["lidar_values"].cuda(), d["lidar_offsets"].cuda())
+with torch.no_grad():
+    for _ in range(3):
+        out = m({"image": img, "lidar": nt})
+    torch.cuda.synchronize(); t0 = time.time()
+    n = 10
+    for _ in range(n):
+        out = m({"image": img, "lidar": nt})
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+gf = 2 * 129.5 * B
+print(f"FFL early-fusion forward bs={B}: {dt*1e3:.2f} ms/batch, {B/dt:.1f} tiles/s, {gf/dt/1e3:.0f} TFLOP/s of the dense count ({gf/dt/1e3/2500:.1%} of 2.5 PF); peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
