@@ -291,6 +291,8 @@ int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const floa
 int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd, float count,
                      int training, int C, float* dgamma, float* dbeta, float* a, float* b, void* stream);
 int p3_affine_fix(void* dH, const void* H, const float* a, const float* b, int64_t R, int C, int dtype, void* stream);
+/* same with a row stride on H (dH stays dense [R, C]) */
+int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a, const float* b, int64_t R, int C, int dtype, void* stream);
 /* pair grid: dA [B*N*N, C] -> dU (written), dV (+=, zero-filled by the caller) [B*N, C] fp32, acc = [dscale(C) | dshift(C)] */
 int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
                 int B, int N, int C, int dtype, void* stream);
@@ -310,6 +312,25 @@ int p3_upsample_bilinear(const void* src, int dtype_src, void* dst, int dtype_ds
 int p3_head1x1(const void* X, int ld, int dtype, const float* scale, const float* shift, const float* W, const float* bias, int n_out,
                int act, float post_mul, float* out_nchw, void* copy_dst, int copy_ld, int64_t R, int64_t HW, void* stream);
 int p3_nhwc_to_nchw(const void* X, int ld, int dtype, const float* scale, const float* shift, float* out, int B, int C, int64_t HW, void* stream);
+
+/* ---- backward of the FFL / *CNN tail (autograd of models/ffl/model_ffl.py:71-96 and of the *CNN encoders' `proj`) ----
+ * p3_head1x1_bwd: through Conv1x1 + Sigmoid | post_mul*Tanh and the BatchNorm + ReLU in front of it.  out_nchw / dout_nchw are the
+ *   forward output and its gradient [B, n_out, HW] fp32.  dHd [R,256] = dy*scale (add the batch-statistics term with p3_affine_fix).
+ *   acc (zeroed by the caller) += [dscale centred (256) | dshift (256) | dW (n_out*256) | db (n_out)].
+ * p3_affine_relu_bwd256: dA = gradient w.r.t. relu(bn(H)) -> dHd = dA*[bn(H) > 0]*scale, acc += [dscale centred | dshift].
+ * p3_pad_nhwc: [B*H*W, ld_src] -> zero-bordered [B, H+2, W+2, Cp] image (channels < c_aff through relu(x*scale+shift) when scale is
+ *   given) that the shifted-row weight-gradient GEMMs (p3_gemm_tn) read.
+ * p3_upsample_bilinear_bwd: adjoint of p3_upsample_bilinear (separable, gather form, deterministic); tmp = fp32 [B, H, w, C]. */
+int p3_head1x1_bwd(const void* H, int dtype, const float* scale, const float* shift, const float* mean, const float* W, int n_out,
+                   const float* out_nchw, const float* dout_nchw, int act, float post_mul, void* dHd, float* acc, int64_t R, int64_t HW,
+                   void* stream);
+int p3_affine_relu_bwd256(const void* dA, const void* H, int ldh, int dtype, const float* scale, const float* shift, const float* mean,
+                          void* dHd, float* acc, int64_t R, void* stream);
+int p3_pad_nhwc(const void* src, int ld_src, int dtype, const float* scale, const float* shift, int c_aff, int C, int Cp, void* dst, int B, int H,
+                int W, void* stream);
+int p3_upsample_bilinear_bwd(const void* dUp, int dtype, float* tmp, void* dtok, int B, int h, int w, int C, int H, int W, int tok_off,
+                             int tok_per_img, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -115,11 +115,12 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dscale, const flo
 
 template <typename T>
 __global__ void affine_fix_kernel(T* __restrict__ dH, const T* __restrict__ H, const float* __restrict__ a, const float* __restrict__ b,
-                                  int64_t n4, int C) {
+                                  int64_t n4, int C, int ldh) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)((i * 4) % C);
+        const int64_t r = (i * 4) / C;
         float d[4], h[4];
-        ld4<T>(dH + i * 4, d); ld4<T>(H + i * 4, h);
+        ld4<T>(dH + i * 4, d); ld4<T>(H + r * ldh + c0, h);
 #pragma unroll
         for (int k = 0; k < 4; ++k) d[k] += a[c0 + k] + b[c0 + k] * h[k];
         st4<T>(dH + i * 4, d);
@@ -233,12 +234,16 @@ extern "C" int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const 
 }
 
 extern "C" int p3_affine_fix(void* dH, const void* H, const float* a, const float* b, int64_t R, int C, int dtype, void* stream) {
-    P3_CHECK(dH && H && a && b && R > 0 && C % 4 == 0, P3_EINVAL, "p3_affine_fix: bad arguments");
+    return p3_affine_fix_ld(dH, H, C, a, b, R, C, dtype, stream);
+}
+
+extern "C" int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a, const float* b, int64_t R, int C, int dtype, void* stream) {
+    P3_CHECK(dH && H && a && b && R > 0 && C % 4 == 0 && ldh >= C && ldh % 4 == 0, P3_EINVAL, "p3_affine_fix: bad arguments");
     const int64_t n4 = R * C / 4;
     int64_t g = (n4 + 255) / 256; if (g > 8192) g = 8192;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == P3_BF16) hipLaunchKernelGGL((affine_fix_kernel<bf16_t>), dim3((int)g), dim3(256), 0, s, (bf16_t*)dH, (const bf16_t*)H, a, b, n4, C);
-    else hipLaunchKernelGGL((affine_fix_kernel<float>), dim3((int)g), dim3(256), 0, s, (float*)dH, (const float*)H, a, b, n4, C);
+    if (dtype == P3_BF16) hipLaunchKernelGGL((affine_fix_kernel<bf16_t>), dim3((int)g), dim3(256), 0, s, (bf16_t*)dH, (const bf16_t*)H, a, b, n4, C, ldh);
+    else hipLaunchKernelGGL((affine_fix_kernel<float>), dim3((int)g), dim3(256), 0, s, (float*)dH, (const float*)H, a, b, n4, C, ldh);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -5,7 +5,8 @@ Data flow on the device (never the reference's NCHW round trips): LN'd ViT token
 3x3 conv as implicit GEMM (BatchNorm statistics in the epilogue) into a [B*H*W, 320]-strided feature buffer whose channel 256 later
 receives the detached seg map (the reference's torch.cat(features, seg)); the BN+ReLU of every producer is folded into the A-tile loader
 of its consumer (P3_A_CONV3X3_AFFINE_RELU), so no post-activation map is ever materialised.
-ROUND-1 STATUS: forward (eval and train-mode BatchNorm) only; backward of these tails is not implemented yet.
+Training: `_FFLTail` (autograd.Function) covers tokens -> {seg, crossfield} with a hand-written backward (head / BatchNorm / 3x3 conv
+weight + input gradients on the MFMA GEMMs / adjoint of the bilinear upsample); the encoders' own NCHW `forward` stays forward-only.
 """
 import torch
 import torch.nn as nn
@@ -27,13 +28,14 @@ def _khwc(w, cpad=None):
     return w.reshape(w.shape[0], -1)
 
 
-def _bn_affine(sums, count, bn, training):
+def _bn_affine(sums, count, bn, training, save=False):
     if training:
         count = count * ops.sync_stats(sums)        # SyncBatchNorm: global sums / global count
-    sc, sh = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum, training)
+    r = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
+                        save=save)
     if training:
         bn.num_batches_tracked += 1
-    return sc, sh
+    return r
 
 
 def _no_grad_only(*tensors):
@@ -54,8 +56,9 @@ class _CNNTailMixin:
         if cout != 256:
             raise NotImplementedError("HIP FFL heads are specialised for in_feature_dim = 256 (config/model/ffl.yaml at 224 px)")
 
-    def features_nhwc(self, tokens):
-        """LN'd tokens [B, 1+g*g, D] -> (buf [B*H*W, LDF] with the PRE-BatchNorm conv output in channels 0..255, scale, shift)."""
+    def features_nhwc(self, tokens, keep=None):
+        """LN'd tokens [B, 1+g*g, D] -> (buf [B*H*W, LDF] with the PRE-BatchNorm conv output in channels 0..255, scale, shift).
+        keep (dict): also store what the backward needs (upsampled map, BatchNorm mean / rstd)."""
         B, _, D = tokens.shape
         H = W = self.out_size
         cd = tokens.dtype
@@ -69,7 +72,11 @@ class _CNNTailMixin:
         sums = torch.zeros(512, dtype=torch.float32, device=tokens.device) if training else None
         hip.gemm(up.view(-1, D), w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, W, D), lda=D, out=buf[:, :256],
                  colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
-        sc, sh = _bn_affine(sums, float(B * H * W), bn, training)
+        if keep is not None:
+            sc, sh, mean, rstd = _bn_affine(sums, float(B * H * W), bn, training, save=True)
+            keep.update(up=up, bnP=(sc, sh, mean, rstd))
+        else:
+            sc, sh = _bn_affine(sums, float(B * H * W), bn, training)
         return buf, sc, sh
 
     def _nchw(self, tokens):
@@ -124,6 +131,93 @@ class EarlyFusionViTCNN(EarlyFusionViT, _CNNTailMixin):
         return self._nchw(self.fused_tokens(x_image, x_lidar))
 
 
+
+def _conv3x3_bwd(dY, Xpad, ldx, cin, w, cd, B, H, ci_dx, key, residual=None):
+    """3x3 / pad 1 convolution backward on the MFMA GEMMs.
+    dY [R, Co] dense (compute dtype); Xpad = zero-bordered activated input [B, H+2, H+2, ldx] whose first `cin` channels feed the conv.
+    -> (dW2 fp32 [Co, 9, cin] in (ky, kx, ci) order, dX [R, ci_dx] = gradient w.r.t. the first ci_dx input channels (+ residual))."""
+    Co, P = dY.shape[1], H + 2
+    Rp = B * P * P
+    dYpad = hip.pad_nhwc(dY, Co, None, None, 0, Co, Co, B, H, H)
+    dp2, cp2 = dYpad.view(Rp, Co), Xpad.view(Rp, ldx)[:, :cin]
+    dW2 = torch.zeros((Co, 9 * cin), dtype=torch.float32, device=dY.device)
+    for t in range(9):      # dW[co, tap, ci] = sum_rows dY[r, co] * X[r + shift(tap), ci] in the zero-bordered row space
+        s = (t // 3 - 1) * P + (t % 3 - 1)
+        r0, r1 = max(0, -s), Rp - max(0, s)
+        hip.gemm_tn(dp2[r0:r1], cp2[r0 + s:r1 + s], out=dW2[:, t * cin:(t + 1) * cin])
+    del dYpad
+    # input gradient: correlation with the flipped kernel, weight laid out [ci, (ky', kx', co)]
+    wf = ops.shadow(w, cd, key=key, fn=lambda t_: t_[:, :ci_dx].flip(2, 3).permute(1, 2, 3, 0).reshape(ci_dx, -1))
+    dX = hip.gemm(dY, wf, a_mode=hip.A_CONV3X3, conv=(B, H, H, Co), lda=Co, out_dtype=cd, residual=residual)
+    return dW2.view(Co, 3, 3, cin), dX
+
+
+class _FFLTail(torch.autograd.Function):
+    """tokens -> (seg, crossfield) with a hand-written backward (see module docstring)."""
+
+    @staticmethod
+    def forward(ctx, tokens, model, *params):
+        keep = {}
+        out = model._tail(tokens.detach(), keep)
+        ctx.model, ctx.keep = model, keep
+        ctx.meta = (tokens.shape, tokens.dtype)
+        return out["seg"], out["crossfield"]
+
+    @staticmethod
+    def backward(ctx, dseg, dcf):
+        model, k = ctx.model, ctx.keep
+        (B, L, D), cd = ctx.meta
+        enc = model.encoder
+        H, g = enc.out_size, enc.grid
+        HW, R, dev, training = H * H, B * H * H, k["buf"].device, model.training
+        cnt = float(R)
+        buf, up, S1, C1 = k["buf"], k["up"], k["S1"], k["C1"]
+        (scP, shP, mP, rP), (scS, shS, mS, rS), (scC, shC, mC, rC) = k["bnP"], k["bnS"], k["bnC"]
+        pconv, pbn = enc.proj[1], enc.proj[2]
+        sconv, sbn, shead = model.seg_module[0], model.seg_module[1], model.seg_module[3]
+        cconv, cbn, chead = model.crossfield_module[0], model.crossfield_module[1], model.crossfield_module[3]
+        zeros = lambda t: torch.zeros_like(t)
+        dseg = zeros(k["seg_out"]) if dseg is None else dseg.contiguous().float()
+        dcf = zeros(k["cf_out"]) if dcf is None else dcf.contiguous().float()
+        # zero-bordered image of the conv inputs: channels 0..255 relu(bn(P)), channel 256 the (detached) seg map
+        Xpad = hip.pad_nhwc(buf, LDF, scP, shP, 256, 257, LDF, B, H, H)
+        # ---- crossfield branch
+        dC1, acc = hip.head1x1_bwd(C1, scC, shC, mC, chead.weight.detach().reshape(4, 256).contiguous(), k["cf_out"], dcf, 1, 2.0, B, HW)
+        g_chw, g_chb = acc[512:512 + 1024].view(4, 256, 1, 1), acc[1536:1540]
+        g_cbn_w, g_cbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], cbn.weight.detach(), mC, rC, cnt, training)
+        if training:
+            hip.affine_fix(dC1, C1, a_, b_)
+        g_cconv_b = hip.colsum(dC1)
+        dWc, dA = _conv3x3_bwd(dC1, Xpad, LDF, 264, cconv.weight, cd, B, H, 256, "flipT256")    # 257 input channels, padded to a multiple of 8
+        g_cconv_w = dWc[..., :257].permute(0, 3, 1, 2).contiguous()
+        del dC1
+        # ---- seg branch
+        dS1, acc = hip.head1x1_bwd(S1, scS, shS, mS, shead.weight.detach().reshape(1, 256).contiguous(), k["seg_out"], dseg, 0, 1.0, B, HW)
+        g_shw, g_shb = acc[512:768].view(1, 256, 1, 1), acc[768:769]
+        g_sbn_w, g_sbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], sbn.weight.detach(), mS, rS, cnt, training)
+        if training:
+            hip.affine_fix(dS1, S1, a_, b_)
+        g_sconv_b = hip.colsum(dS1)
+        dWs, dA = _conv3x3_bwd(dS1, Xpad, LDF, 256, sconv.weight, cd, B, H, 256, "flipT256", residual=dA)   # both branches summed
+        g_sconv_w = dWs.permute(0, 3, 1, 2).contiguous()
+        del dS1, Xpad
+        # ---- through BatchNorm + ReLU of proj, then the proj conv and the upsample
+        dP, acc = hip.affine_relu_bwd256(dA, buf, LDF, scP, shP, mP, R)
+        g_pbn_w, g_pbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], pbn.weight.detach(), mP, rP, cnt, training)
+        if training:
+            hip.affine_fix(dP, buf, a_, b_, ldh=LDF)
+        g_pconv_b = hip.colsum(dP)
+        Upad = hip.pad_nhwc(up, D, None, None, 0, D, D, B, H, H)
+        dWp, dUp = _conv3x3_bwd(dP, Upad, D, D, pconv.weight, cd, B, H, D, "flipT")
+        g_pconv_w = dWp.permute(0, 3, 1, 2).contiguous()
+        del Upad, dP
+        dtok = hip.upsample_bilinear_bwd(dUp.view(B, H, H, D), B, g, g, H, H)
+        ctx.keep = None
+        return (dtok, None, g_pconv_w, g_pconv_b, g_pbn_w, g_pbn_b,
+                g_sconv_w, g_sconv_b, g_sbn_w, g_sbn_b, g_shw, g_shb,
+                g_cconv_w, g_cconv_b, g_cbn_w, g_cbn_b, g_chw, g_chb)
+
+
 class EncoderDecoder(nn.Module):
     """models/ffl/model_ffl.py:28-104"""
 
@@ -144,29 +238,26 @@ class EncoderDecoder(nn.Module):
         if c != 256 or seg_channels not in (0, 1):
             raise NotImplementedError("HIP FFL heads: out_feature_dim 256 and the shipped seg config (interior only) are supported")
 
-    def inference(self, x_images, x_lidar):
-        enc = self.cfg.experiment.encoder
-        if not (enc.use_images or enc.use_lidar):
-            raise ValueError("At least one of use_images or use_lidar must be True")
-        if not hasattr(self.encoder, "features_nhwc"):
-            raise NotImplementedError("HIP FFL heads need one of the ViT-CNN encoders (vit_cnn, pointpillars_vit_cnn, early_fusion_vit_cnn)")
-        _no_grad_only(x_images, *[p for p in self.parameters()])
-        tokens = self.encoder.tokens(x_images, x_lidar)
-        buf, sc, sh = self.encoder.features_nhwc(tokens)
+    def _tail(self, tokens, keep=None):
+        """LN'd tokens -> {"seg", "crossfield"} (the part of `inference` after the ViT)."""
+        buf, sc, sh = self.encoder.features_nhwc(tokens, keep)
         B, H = tokens.shape[0], self.encoder.out_size
         HW, cd, dev, training = H * H, buf.dtype, buf.device, self.training
         outputs = {}
         cnt = float(B * HW)
+        save = keep is not None
         if self.cfg.experiment.model.compute_seg:
             conv, bn, head = self.seg_module[0], self.seg_module[1], self.seg_module[3]
             w2 = ops.shadow(conv.weight, cd, key="khwc", fn=_khwc)
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
             s1 = hip.gemm(buf, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3_AFFINE_RELU, conv=(B, H, H, 256), lda=LDF, a_scale=sc, a_shift=sh,
                           out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
-            ssc, ssh = _bn_affine(sums, cnt, bn, training)
-            seg = hip.head1x1(s1, 256, ssc, ssh, head.weight.detach().reshape(1, 256).contiguous(), head.bias.detach(), 0, 1.0, B, HW,
+            bnS = _bn_affine(sums, cnt, bn, training, save=save)
+            seg = hip.head1x1(s1, 256, bnS[0], bnS[1], head.weight.detach().reshape(1, 256).contiguous(), head.bias.detach(), 0, 1.0, B, HW,
                               copy_dst=buf[:, 256:], copy_ld=LDF)           # seg.clone().detach() -> channel 256 (torch.cat, model_ffl.py:87-89)
             outputs["seg"] = seg.view(B, 1, H, H)
+            if save:
+                keep.update(S1=s1, bnS=bnS, seg_out=seg)
         if self.cfg.experiment.model.compute_crossfield:
             conv, bn, head = self.crossfield_module[0], self.crossfield_module[1], self.crossfield_module[3]
             w2 = ops.shadow(conv.weight, cd, key="khwc320", fn=lambda t: _khwc(t, LDF))
@@ -175,10 +266,36 @@ class EncoderDecoder(nn.Module):
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
             c1 = hip.gemm(buf, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3_AFFINE_RELU, conv=(B, H, H, LDF), lda=LDF, a_scale=sc320, a_shift=sh320,
                           out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
-            csc, csh = _bn_affine(sums, cnt, bn, training)
-            cf = hip.head1x1(c1, 256, csc, csh, head.weight.detach().reshape(4, 256).contiguous(), head.bias.detach(), 1, 2.0, B, HW)
+            bnC = _bn_affine(sums, cnt, bn, training, save=save)
+            cf = hip.head1x1(c1, 256, bnC[0], bnC[1], head.weight.detach().reshape(4, 256).contiguous(), head.bias.detach(), 1, 2.0, B, HW)
             outputs["crossfield"] = cf.view(B, 4, H, H)
+            if save:
+                keep.update(C1=c1, bnC=bnC, cf_out=cf)
+        if save:
+            keep.update(buf=buf)
         return outputs
+
+    def _tail_params(self):
+        p, sm, cm = self.encoder.proj, self.seg_module, self.crossfield_module
+        return [p[1].weight, p[1].bias, p[2].weight, p[2].bias,
+                sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias,
+                cm[0].weight, cm[0].bias, cm[1].weight, cm[1].bias, cm[3].weight, cm[3].bias]
+
+    def inference(self, x_images, x_lidar):
+        enc = self.cfg.experiment.encoder
+        if not (enc.use_images or enc.use_lidar):
+            raise ValueError("At least one of use_images or use_lidar must be True")
+        if not hasattr(self.encoder, "features_nhwc"):
+            raise NotImplementedError("HIP FFL heads need one of the ViT-CNN encoders (vit_cnn, pointpillars_vit_cnn, early_fusion_vit_cnn)")
+        tokens = self.encoder.tokens(x_images, x_lidar)
+        mc = self.cfg.experiment.model
+        needs_grad = torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not needs_grad:
+            return self._tail(tokens)
+        if not (mc.compute_seg and mc.compute_crossfield):
+            raise NotImplementedError("p3hip FFL training path needs compute_seg and compute_crossfield (the shipped config/model/ffl.yaml)")
+        seg, cf = _FFLTail.apply(tokens, self, *self._tail_params())
+        return {"seg": seg, "crossfield": cf}
 
     def forward(self, x_batch):
         return self.inference(x_batch.get("image", None), x_batch.get("lidar", None))

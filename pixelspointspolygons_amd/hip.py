@@ -594,9 +594,11 @@ def bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
     return o[0], o[1], o[2], o[3]
 
 
-def affine_fix(dH, H, a, b):
-    R, C = H.shape
-    check(lib().p3_affine_fix(ptr(dH), ptr(H), ptr(a), ptr(b), c_int64(R), c_int(C), c_int(dt(H)), stream()), "p3_affine_fix")
+def affine_fix(dH, H, a, b, ldh=None):
+    """dH [R, C] (dense) += a + b * H;  H may be a strided view (row stride ldh)."""
+    R, C = dH.shape
+    check(lib().p3_affine_fix_ld(ptr(dH), ptr(H), c_int(ldh if ldh is not None else H.stride(0)), ptr(a), ptr(b), c_int64(R), c_int(C),
+                                 c_int(dt(dH)), stream()), "p3_affine_fix")
     return dH
 
 
@@ -654,3 +656,42 @@ def dropout_apply(x, out_dtype, drop, out=None):
     check(lib().p3_dropout_apply(ptr(xc), c_int(dt(xc)), ptr(out), c_int(dt(out)), c_int64(xc.numel()), c_int64(xc.shape[-1]), byref(d), stream()),
           "p3_dropout_apply")
     return out
+
+
+# ------------------------------------------------------------------------------------------ FFL / *CNN tail backward
+def head1x1_bwd(H, scale, shift, mean, W, out_nchw, dout_nchw, act, post_mul, B, HW):
+    """-> (dHd [R,256] = dy*scale in H's dtype, acc fp32 [512 + n_out*256 + n_out] = dscale(centred) | dshift | dW | db)."""
+    n_out = W.shape[0]
+    R = B * HW
+    dHd = torch.empty((R, 256), dtype=H.dtype, device=H.device)
+    acc = torch.zeros(512 + n_out * 256 + n_out, dtype=torch.float32, device=H.device)
+    check(lib().p3_head1x1_bwd(ptr(H), c_int(dt(H)), ptr(scale), ptr(shift), ptr(mean), ptr(W), c_int(n_out), ptr(out_nchw), ptr(dout_nchw),
+                               c_int(act), c_float(post_mul), ptr(dHd), ptr(acc), c_int64(R), c_int64(HW), stream()), "p3_head1x1_bwd")
+    return dHd, acc
+
+
+def affine_relu_bwd256(dA, H, ldh, scale, shift, mean, R, out=None):
+    out = dA if out is None else out
+    acc = torch.zeros(512, dtype=torch.float32, device=dA.device)
+    check(lib().p3_affine_relu_bwd256(ptr(dA), ptr(H), c_int(ldh), c_int(dt(dA)), ptr(scale), ptr(shift), ptr(mean), ptr(out), ptr(acc), c_int64(R),
+                                      stream()), "p3_affine_relu_bwd256")
+    return out, acc
+
+
+def pad_nhwc(src, ld_src, scale, shift, c_aff, C, Cp, B, H, W, out=None):
+    """-> zero-bordered [B, H+2, W+2, Cp] copy (channels < c_aff through relu(x*scale + shift) when scale is given)."""
+    if out is None:
+        out = torch.empty((B, H + 2, W + 2, Cp), dtype=src.dtype, device=src.device)
+    check(lib().p3_pad_nhwc(ptr(src), c_int(ld_src), c_int(dt(src)), ptr(scale), ptr(shift), c_int(c_aff), c_int(C), c_int(Cp), ptr(out), c_int(B),
+                            c_int(H), c_int(W), stream()), "p3_pad_nhwc")
+    return out
+
+
+def upsample_bilinear_bwd(dUp, B, h, w, H, W, tok_off=1):
+    """dUp [B, H, W, C] -> dtokens [B, tok_off + h*w, C] (rows before tok_off are zero)."""
+    C = dUp.shape[-1]
+    tmp = torch.empty((B, H, w, C), dtype=torch.float32, device=dUp.device)
+    dtok = torch.zeros((B, tok_off + h * w, C), dtype=dUp.dtype, device=dUp.device)
+    check(lib().p3_upsample_bilinear_bwd(ptr(dUp), c_int(dt(dUp)), ptr(tmp), ptr(dtok), c_int(B), c_int(h), c_int(w), c_int(C), c_int(H), c_int(W),
+                                         c_int(tok_off), c_int(tok_off + h * w), stream()), "p3_upsample_bilinear_bwd")
+    return dtok

@@ -71,7 +71,42 @@ def test_ffl_single_modality(encoder, kind):
     assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < 1e-3
 
 
-def test_ffl_refuses_grad():
+def test_cnn_encoder_nchw_forward_refuses_grad():
+    """The *CNN encoders' own NCHW forward is inference-only; training goes through FFLModel (hand-written backward)."""
     m, sd, cfg = _model("vit_cnn", "bf16", "image", SMALL, vit_depth=2)
     with pytest.raises(NotImplementedError):
-        m({"image": torch.rand(1, 3, 224, 224, device="cuda")})
+        m.encoder(torch.rand(1, 3, 224, 224, device="cuda"))
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_ffl_backward_vs_oracle_autograd(training):
+    """FFL training path (a-14): gradients of every parameter (heads, BatchNorms, 3x3 convs, proj, fusion stem, ViT) for a random
+    linear functional of (seg, crossfield) vs float64 autograd of the oracle; train- and eval-mode BatchNorm."""
+    from oracle import p3_oracle as O
+    from helpers import l2_err
+    m, sd, cfg = _model("early_fusion_vit_cnn", "fp32", "fusion", SMALL, vit_depth=2)
+    B = 1
+    d = O.make_inputs(B, seed=9)
+    img, lv, lo = d["image"], d["lidar_values"], d["lidar_offsets"]
+    gen = torch.Generator().manual_seed(4)
+    g1, g2 = torch.randn(B, 1, 224, 224, generator=gen), torch.randn(B, 4, 224, 224, generator=gen)
+    p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+         for k, v in sd.items()}
+    ref, _ = O.ffl_forward(p, img.double(), (lv, lo), SMALL, 224, training)
+    ((ref["seg"] * g1.double()).sum() + (ref["crossfield"] * g2.double()).sum()).backward()
+    m.train(training)
+    nt = torch.nested.nested_tensor_from_jagged(lv.cuda(), lo.cuda())
+    out = m({"image": img.cuda(), "lidar": nt})
+    assert rel_err(out["seg"].detach().cpu(), ref["seg"].detach()) < 1e-3
+    ((out["seg"] * g1.cuda()).sum() + (out["crossfield"] * g2.cuda()).sum()).backward()
+    gnorm = max(float(v.grad.norm()) for v in p.values() if v.is_floating_point() and v.requires_grad and v.grad is not None)
+    bad = {}
+    for k, prm in m.named_parameters():
+        r = p[k].grad
+        if r is None:
+            continue
+        assert prm.grad is not None, k
+        e = l2_err(prm.grad.float().cpu(), r, floor=1e-3 * gnorm)
+        if not e < 1.5e-2:
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
