@@ -173,3 +173,14 @@ def test_oracle_pillarize_known_answers():
     assert npts.tolist() == [2, 1, 1]
     assert pidx.tolist() == [[0, 2], [1, -1], [4, -1]]
     assert torch.equal(vox[1, 1], torch.zeros(3))
+
+
+def test_smoke_configuration_loads_the_oracle_weights():
+    """__graft_entry__.smoke() builds this model / state_dict pair on the GPU box; keep the pair consistent (CPU-checkable part)."""
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    vc = dict(dim=384, depth=2, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
+    sd = O.make_state_dict("fusion", vc, seed=5)
+    cfg = make_config("early_fusion_vit", vit_depth=2, precision="fp32", device="cpu")
+    m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+    m.load_state_dict(sd, strict=True)
