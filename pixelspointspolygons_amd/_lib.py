@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3hip.so")
+# P3HIP_LIB selects another build of the same library (A/B runs of two kernel variants on one box: tools/ab.sh)
+LIB_PATH = os.environ.get("P3HIP_LIB") or os.path.join(_HERE, "libp3hip.so")
 _lib = None
 
 

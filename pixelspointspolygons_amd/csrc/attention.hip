@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_fwd_kernel(AttnAr
     T* Op = reinterpret_cast<T*>(a.O) + (int64_t)b * d.o_bs + h * D;
 
     const int q = qblk + wave * 32 + l31;          // this lane's query row
+    const bool wave_live = qblk + wave * 32 < d.Lq;
     const int qc = q < d.Lq ? q : d.Lq - 1;        // clamped for loads
 
     // ---- Q fragments (B operand of S^T) ----
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_fwd_kernel(AttnAr
         __syncthreads();
         if (t + 1 < ntiles) attn_load_tile<T, D, KPT, VPT>(t + 1, tid, d, Kp, Vp, kreg, vreg);
         const int kv0 = t * KT;
+        // a wave whose 32 queries all lie beyond Lq (tail q-block: L = 785 -> 17 live rows, L = 385 -> 1) only helps with the staging
+        if (!wave_live) continue;
 
         // ---- S^T = K . Q^T ----
         f32x16 sacc[NH2];

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
         stage_store<T, D, KT, true, false>(vreg, Vrow, nullptr, tid);
         __syncthreads();
         if (t + 1 < ntiles) { stage_load<T, D, KT>(Kp, kv0 + KT, d.Lk, d.k_rs, kreg, tid); stage_load<T, D, KT>(Vp, kv0 + KT, d.Lk, d.v_rs, vreg, tid); }
+        if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, l31, hi);       // S^T[kv, q]
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
         }
         __syncthreads();
         if (q0 + QT < d.Lq) { stage_load<T, D, QT>(Qp, q0 + QT, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q0 + QT, d.Lq, d.o_rs, greg, tid); }
+        if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
             f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, l31, hi);       // S[q, kv]
