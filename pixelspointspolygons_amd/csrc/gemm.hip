@@ -22,10 +22,11 @@ struct GemmArgs {
 
 constexpr int BM = 128, BN = 128;
 
-// Two bf16 K-slice depths.  BK = 64 (74 KB of LDS, 2 workgroups / CU, one-pass epilogue) is the default.  BK = 32 (rows padded to
-// 40 elements = 80 B, conflict free for ds_read_b128; 40 KB operands + two-pass 34 KB epilogue staging -> 3 workgroups / CU) serves
-// K % 64 != 0 and is kept for A/B runs (P3_GEMM_BK=32): in isolation it is +5..20 % on the K <= 512 shapes and -8..13 % from
-// K = 1536 up (tools/microbench.py), inside the train step the two are within 1 % (r01: 62.8 vs 62.1 ms), so one variant runs.
+// Two bf16 K-slice depths.  BK = 32 (rows padded to 40 elements = 80 B, conflict free for ds_read_b128; 40 KB operand buffers +
+// two-pass 34 KB epilogue staging -> more workgroups per CU) is the default: the GEMMs of this path are short-K and HBM / latency
+// bound.  BK = 64 (74 KB, 2 workgroups / CU, half the barriers per FLOP, one-pass epilogue) takes over from K = 2048 (decoder linear2,
+// the 3x3 convolutions).  Same-box A/B of the whole train step (tools/ab.sh, r01): all-64 61.4 ms, all-32 60.1, 64 above K = 512
+// 61.1, 64 from K = 2048 60.0.  P3_GEMM_BK=32 | 64 | <K threshold> overrides for such sweeps.
 template <typename T, int BKSEL> struct Tr;
 template <int BKSEL> struct Tr<bf16_t, BKSEL> { static constexpr int BK = BKSEL, PITCH = BKSEL + 8, VEC = 8, LDS_ELEMS = BM * (BKSEL + 8); };
 template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
@@ -406,7 +407,8 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
         if (force < 0) { const char* e = getenv("P3_GEMM_BK"); force = e ? atoi(e) : 0; }
         const bool conv = g.d.a_mode == P3_A_CONV3X3 || g.d.a_mode == P3_A_CONV3X3_AFFINE_RELU;
         const bool can64 = g.d.K % 64 == 0 && (!conv || g.d.conv_C % 64 == 0);
-        const bool deep = force == 32 ? false : can64;
+        const int thr = force > 64 ? force : (force == 64 ? 0 : 2047);   // P3_GEMM_BK=<threshold>: BK = 64 only for K above it
+        const bool deep = force == 32 ? false : (can64 && g.d.K > thr);
         return deep ? launch_bk<T, TO, 64>(g, s) : launch_bk<T, TO, 32>(g, s);
     } else {
         return launch_bk<T, TO, 16>(g, s);
