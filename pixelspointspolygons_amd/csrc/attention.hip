@@ -120,7 +120,7 @@ __device__ __forceinline__ void attn_store_tile(int tid, T* Ks, T* Vs, const u32
 }
 
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     using TR = ATr<T, D>;
     constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV, NH2 = KT / 32, NDJ = D / 32;
     constexpr bool BF = sizeof(T) == 2;
