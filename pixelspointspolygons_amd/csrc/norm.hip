@@ -1,5 +1,7 @@
 // p3hip LayerNorm forward / backward (HBM-bound; one wave per row, 4 rows per 256-thread block).
 // cols <= 1024 and cols % 4 == 0 (the path uses 384, 768 and 256).
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -182,7 +184,11 @@ extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* 
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
     if (rows <= 0) return P3_OK;
-    const int rpb = rows > 32768 ? 128 : 64;      // fewer blocks = fewer dgamma / dbeta atomics per address
+    static int rpb_env = -1;
+    if (rpb_env < 0) { const char* e = getenv("P3_LN_RPB"); rpb_env = e ? atoi(e) : 0; }
+    // rows per block trades resident waves (one row in flight per wave) against dgamma / dbeta atomics per address; same-box sweep of
+    // the train step (r01, P3_LN_RPB): 16 -> 60.9 ms, 32 -> 60.2, 48 -> 59.8, 96 -> 60.3, 128 -> 60.5, 256 -> 62.7
+    const int rpb = rpb_env > 0 ? rpb_env : 48;
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LNB_NV(TDY, TX, TDX, NV) \
