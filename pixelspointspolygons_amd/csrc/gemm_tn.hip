@@ -330,7 +330,8 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // 512 blocks is better still when the tile count divides it (decoder linear1: 64 vs 82 us).  P3_TN_BLOCKS overrides for sweeps.
     static int target_blocks = 0;
     if (target_blocks == 0) { const char* e = getenv("P3_TN_BLOCKS"); target_blocks = e ? atoi(e) : -1; if (target_blocks == 0) target_blocks = -1; }
-    int splits = target_blocks > 0 ? p3_ceil_div(target_blocks, tiles) : ((512 % tiles == 0) ? 512 / tiles : p3_ceil_div(768, tiles));
+    const int tgt = target_blocks > 0 ? target_blocks : 896;   // same-box sweep r01: 600 -> 60.1 ms, 700 -> 59.6, 768 -> 59.6, 850 -> 59.3, 950 -> 59.3
+    int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
     if (splits > max_splits) splits = max_splits;
