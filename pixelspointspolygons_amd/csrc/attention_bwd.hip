@@ -226,7 +226,27 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     load_rowfrags<T, D>(Qp, qc, d.q_rs, qb, qf, hi);
     load_rowfrags<T, D>(dOp, qc, d.o_rs, gb, gf, hi);
     const float lse = a.lse[((int64_t)b * d.H + h) * d.Lq + qc];
-    const float dlt = a.delta[((int64_t)b * d.H + h) * d.Lq + qc];
+    // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the same row fragments the lane already holds for dO (each half-wave
+    // lane has 32 of the 64 / 16 of the 32 elements) and published for the dK/dV kernel, which runs after this one on the stream:
+    // no separate delta kernel (r01: 24 launches, 1.1 ms per step).
+    float dlt;
+    {
+        const T* Op = reinterpret_cast<const T*>(a.O) + (int64_t)b * d.o_bs + h * D;
+        float part = 0.f;
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                const s16x8 ob = *reinterpret_cast<const s16x8*>(Op + (int64_t)qc * d.o_rs + ks * 16 + 8 * hi);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += bf2f((bf16_t)ob[e]) * bf2f((bf16_t)gb[ks][e]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < D / 2; ++ks) part += Op[(int64_t)qc * d.o_rs + 2 * ks + hi] * gf[ks];
+        }
+        dlt = part + __shfl_xor(part, 32, 64);
+        if (hi == 0 && q < d.Lq) a.delta[((int64_t)b * d.H + h) * d.Lq + q] = dlt;
+    }
     f32x16 dq[D / 32];
 #pragma unroll
     for (int j = 0; j < D / 32; ++j)
@@ -358,7 +378,7 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
     const p3_attn_desc& d = a.d;
     const int64_t rows = (int64_t)d.B * d.H * d.Lq;
     int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
-    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(g), dim3(256), 0, s, a, D);
+    (void)g;   // delta is produced by the dQ kernel (attn_delta_kernel kept for reference / standalone use)
     if (d.drop.seed != nullptr && d.drop.p > 0.f) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3(p3_ceil_div(d.Lq, 128) * d.H * d.B), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3(p3_ceil_div(d.Lk, 128) * d.H * d.B), dim3(256), 0, s, a);
