@@ -9,6 +9,8 @@
 //   row_affine_bwd<MAT>    dA -> dH' = dA*(z>0)*sc, d(sc, sh)          (C = 128)
 //   pair_bwd               dA2 [R,256] -> dU, dV [B*N,256], d(sc1, sh1) (sums over j / i of the pair grid)
 //   pair_stats_bwd         closed-form BN1 statistics path into dU, dV
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -252,11 +254,14 @@ extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const f
                            int B, int N, int C, int dtype, void* stream) {
     P3_CHECK(dA && U && V && scale && shift && mean && dU && dV && acc && B > 0, P3_EINVAL, "p3_pair_bwd: bad arguments");
     P3_CHECK(C == 256, P3_EUNSUP, "p3_pair_bwd: ScoreNet conv1 width must be 256 (model_pix2poly.py:74)");
-    constexpr int IC = 8;
-    dim3 g((N + IC - 1) / IC, B), b(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_bwd_kernel<bf16_t, IC>), g, b, 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift, mean, dU, dV, acc, N, C);
-    else hipLaunchKernelGGL((pair_bwd_kernel<float, IC>), g, b, 0, s, (const float*)dA, (const float*)U, (const float*)V, scale, shift, mean, dU, dV, acc, N, C);
+    static int ic_env = -1;
+    if (ic_env < 0) { const char* e = getenv("P3_PAIR_IC"); ic_env = e ? atoi(e) : 0; }
+    const int ic = ic_env > 0 ? ic_env : 16;     // rows i per block: dV gets N/IC atomic adds per element (same-box sweep r01: 4 -> 60.2 ms, 8 -> 58.0, 12 -> 57.7, 16 -> 57.6)
+#define PB(T, IC) hipLaunchKernelGGL((pair_bwd_kernel<T, IC>), dim3((N + IC - 1) / IC, B), dim3(256), 0, s, (const T*)dA, (const T*)U, (const T*)V, scale, shift, mean, dU, dV, acc, N, C)
+    if (dtype == P3_BF16) { if (ic == 16) PB(bf16_t, 16); else if (ic == 12) PB(bf16_t, 12); else if (ic == 4) PB(bf16_t, 4); else PB(bf16_t, 8); }
+    else PB(float, 8);
+#undef PB
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
