@@ -26,7 +26,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
         hip.affine_fix(dH3, H3, a3, b3)
     # ---- conv3 (+ BN2/ReLU in front of it)
     dW3 = hip.gemm_tn_ex(dH3, H2, torch.zeros(64, 128, **f32), hip.A_AFFINE_RELU, sc2, sh2)
-    db3 = hip.colsum(dH3)
+    db3 = ops.bias_grad_before_bn(dH3, training)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
@@ -36,7 +36,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
         hip.affine_fix(dH2, H2, a2, b2)
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
     dW2 = hip.gemm_tn_ex(dH2, U, torch.zeros(128, 256, **f32), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
-    db2 = hip.colsum(dH2)
+    db2 = ops.bias_grad_before_bn(dH2, training)
     w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
     dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
     acc1 = torch.zeros(2 * 256, **f32)
@@ -50,7 +50,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dW1 = torch.zeros(256, 2 * D, **f32)
     hip.gemm_tn(dUc, F2, out=dW1[:, :D])
     hip.gemm_tn(dVc, F2, out=dW1[:, D:])
-    db1 = hip.colsum(dU)
+    db1 = ops.bias_grad_before_bn(dU, training)
     w1t = ops.shadow(net.conv1.weight, cd, key="2dT2", fn=lambda t: torch.cat([t.reshape(256, -1)[:, :D].t(), t.reshape(256, -1)[:, D:].t()], 0))  # [2D, 256]
     dF = hip.gemm(dUc, w1t[:D], out_dtype=torch.float32)
     dF = hip.gemm(dVc, w1t[D:], out_dtype=torch.float32, residual=dF)

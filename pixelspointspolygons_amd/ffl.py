@@ -187,7 +187,7 @@ class _FFLTail(torch.autograd.Function):
         g_cbn_w, g_cbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], cbn.weight.detach(), mC, rC, cnt, training)
         if training:
             hip.affine_fix(dC1, C1, a_, b_)
-        g_cconv_b = hip.colsum(dC1)
+        g_cconv_b = ops.bias_grad_before_bn(dC1, training)
         dWc, dA = _conv3x3_bwd(dC1, Xpad, LDF, 264, cconv.weight, cd, B, H, 256, "flipT256")    # 257 input channels, padded to a multiple of 8
         g_cconv_w = dWc[..., :257].permute(0, 3, 1, 2).contiguous()
         del dC1
@@ -197,7 +197,7 @@ class _FFLTail(torch.autograd.Function):
         g_sbn_w, g_sbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], sbn.weight.detach(), mS, rS, cnt, training)
         if training:
             hip.affine_fix(dS1, S1, a_, b_)
-        g_sconv_b = hip.colsum(dS1)
+        g_sconv_b = ops.bias_grad_before_bn(dS1, training)
         dWs, dA = _conv3x3_bwd(dS1, Xpad, LDF, 256, sconv.weight, cd, B, H, 256, "flipT256", residual=dA)   # both branches summed
         g_sconv_w = dWs.permute(0, 3, 1, 2).contiguous()
         del dS1, Xpad
@@ -206,7 +206,7 @@ class _FFLTail(torch.autograd.Function):
         g_pbn_w, g_pbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], pbn.weight.detach(), mP, rP, cnt, training)
         if training:
             hip.affine_fix(dP, buf, a_, b_, ldh=LDF)
-        g_pconv_b = hip.colsum(dP)
+        g_pconv_b = ops.bias_grad_before_bn(dP, training)
         Upad = hip.pad_nhwc(up, D, None, None, 0, D, D, B, H, H)
         dWp, dUp = _conv3x3_bwd(dP, Upad, D, D, pconv.weight, cd, B, H, D, "flipT")
         g_pconv_w = dWp.permute(0, 3, 1, 2).contiguous()

@@ -97,7 +97,7 @@ class _FusionConvBN(torch.autograd.Function):
         dg, dbt, a, b = ops.bn_backward_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training)
         if mod.training:
             hip.affine_fix(dpre, pre, a, b)
-        db = hip.colsum(dpre)
+        db = ops.bias_grad_before_bn(dpre, mod.training)
         # weight gradient: dW[co, tap, ci] = sum_rows dpre[r, co] * canvas[r + shift(tap), ci] in the zero-bordered row space
         P = g + 2
         dp = torch.zeros((B, P, P, D), dtype=cd, device=dpre.device)

@@ -44,6 +44,16 @@ def sync_active():
     return SYNC_BN[0] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def bias_grad_before_bn(dH, training):
+    """Gradient of a conv / linear bias that feeds a BatchNorm directly.  In training mode it is identically zero (the batch mean
+    absorbs any constant: sum over rows of the BatchNorm input gradient vanishes), so the column sum over the [rows, C] gradient
+    (0.3-0.6 GB per ScoreNet layer) is not computed; the reference's autograd produces rounding noise (~1e-9) there.  Eval mode
+    (running statistics) has a real gradient."""
+    if training:
+        return torch.zeros(dH.shape[1], dtype=torch.float32, device=dH.device)
+    return hip.colsum(dH)
+
+
 def bn_backward_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
     """(dgamma, dbeta, a, b) of a BatchNorm backward: parameter gradients from THIS rank's sums (DDP averages them), input-gradient
     coefficients from the all-reduced sums and the global count when SyncBatchNorm is on (torch's SyncBatchNorm backward)."""
