@@ -256,6 +256,7 @@ int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, int dtype, vo
 /* scale: extra factor on dy (1/(1-p) when a dropout followed the activation: the saved ReLU output is already masked) */
 int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved, void* out, int dtype_out, int64_t n, int act, float scale,
                void* stream);
+/* dpos may be NULL (then take it as the column sums of dx viewed as [B, L*D]: no atomics) */
 int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream);
 /* dscale is the centred sum  sum dz*(src - mean)  when mean != NULL (feeds p3_bn_bwd_coeffs) */
 int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* mean,

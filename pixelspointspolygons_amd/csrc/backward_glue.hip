@@ -36,7 +36,7 @@ __global__ void embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __rest
         const int t = (int)(bt % L);
         const float g = Cvt<T>::to_f(dx[i]);
         atomicAdd(demb + tok[bt] * D + c, g);
-        atomicAdd(dpos + (int64_t)t * D + c, g);
+        if (dpos) atomicAdd(dpos + (int64_t)t * D + c, g);   // NULL: the caller takes dpos = sum over the batch with p3_colsum (no atomics)
     }
 }
 
@@ -128,7 +128,7 @@ extern "C" int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int d
 }
 
 extern "C" int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream) {
-    P3_CHECK(dx && tokens && demb && dpos && B > 0, P3_EINVAL, "p3_embed_tokens_bwd: bad arguments");
+    P3_CHECK(dx && tokens && demb && B > 0, P3_EINVAL, "p3_embed_tokens_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * L * D;
     if (dtype == P3_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dx, tokens, demb, dpos, B, L, D);
