@@ -187,7 +187,8 @@ def pmc_traffic(kernel_label):
         t = json.load(fh)
     tot = n = 0.0
     for k, v in t.items():
-        if k.startswith("gemm_kernel<unsigned short,") and k.endswith(", 0>"):     # bf16 in, bf16 / f32 out, plain A operand
+        parts = [x.strip() for x in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
+        if k.startswith("gemm_kernel<unsigned short,") and len(parts) >= 3 and parts[2] == "0":   # bf16 in, bf16 / f32 out, plain A
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
     return (round(tot / n) if n else None), "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, mean per launch over the train step)"
