@@ -68,6 +68,10 @@ typedef struct {
     float p;
 } p3_dropout;
 int p3_rng_advance(unsigned long long* seed, void* stream);
+/* Batched 2-D bf16 transposes inside one arena (the W^T copies the dX GEMMs read, refreshed after the optimizer step in one launch).
+ * table: device array of n_entries records {int64 src_off, int64 dst_off, int32 rows, int32 cols, int32 first_tile, int32 tiles_c}
+ * (element offsets; 32x32 tiles, tiles_c = ceil(cols / 32), first_tile = running sum of tile counts); grid = total_tiles blocks. */
+int p3_transpose_many(const void* src, void* dst, const void* table, int n_entries, int total_tiles, void* stream);
 /* out[i] = keep(i / ncols, i % ncols) ? in[i] / (1-p) : 0   (elementwise dropout forward, and its backward applied to the gradient) */
 int p3_dropout_apply(const void* in, int dtype_in, void* out, int dtype_out, int64_t n, int64_t ncols, const p3_dropout* drop, void* stream);
 

@@ -210,6 +210,30 @@ __global__ void dropout_apply_kernel(const TI* __restrict__ a, TO* __restrict__ 
     }
 }
 
+// Batched 2-D transposes inside one bf16 arena: entry e = {src offset, dst offset, rows, cols, first tile}; one 32x32 tile per block
+// through LDS.  Refreshes the W^T copies every dX GEMM reads after the optimizer step with ONE launch (r01: 96 strided-copy launches).
+struct TransEntry { long long src, dst; int rows, cols; int tile0, tiles_c; };
+__global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const TransEntry* __restrict__ tab, int n) {
+    __shared__ bf16_t tile[32][33];
+    int lo = 0, hi = n - 1;                       // last entry whose tile0 <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const TransEntry e = tab[lo];
+    const int t = blockIdx.x - e.tile0, tr = t / e.tiles_c, tc = t - tr * e.tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = tr * 32 + ty + 8 * k, c = tc * 32 + tx;
+        if (r < e.rows && c < e.cols) tile[ty + 8 * k][tx] = src[e.src + (long long)r * e.cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tc * 32 + ty + 8 * k, r = tr * 32 + tx;      // dst is [cols, rows]
+        if (r < e.rows && c < e.cols) dst[e.dst + (long long)c * e.rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 __global__ void rng_advance_kernel(unsigned long long* seed) {
     seed[0] = seed[0] * 6364136223846793005ull + 1442695040888963407ull;
 }
@@ -361,6 +385,14 @@ extern "C" int p3_dropout_apply(const void* in, int dtype_in, void* out, int dty
     else if (dtype_in == P3_F32 && dtype_out == P3_F32) hipLaunchKernelGGL((dropout_apply_kernel<float, float>), g, blk, 0, s, (const float*)in, (float*)out, n, ncols, dr);
     else if (dtype_in == P3_BF16 && dtype_out == P3_BF16) hipLaunchKernelGGL((dropout_apply_kernel<bf16_t, bf16_t>), g, blk, 0, s, (const bf16_t*)in, (bf16_t*)out, n, ncols, dr);
     else { p3_set_error("p3_dropout_apply: dtype"); return P3_EUNSUP; }
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_transpose_many(const void* src, void* dst, const void* table, int n_entries, int total_tiles, void* stream) {
+    P3_CHECK(src && dst && table && n_entries > 0 && total_tiles > 0, P3_EINVAL, "p3_transpose_many: bad arguments");
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst,
+                       (const TransEntry*)table, n_entries);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

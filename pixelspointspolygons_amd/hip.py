@@ -696,3 +696,7 @@ def upsample_bilinear_bwd(dUp, B, h, w, H, W, tok_off=1):
     check(lib().p3_upsample_bilinear_bwd(ptr(dUp), c_int(dt(dUp)), ptr(tmp), ptr(dtok), c_int(B), c_int(h), c_int(w), c_int(C), c_int(H), c_int(W),
                                          c_int(tok_off), c_int(tok_off + h * w), stream()), "p3_upsample_bilinear_bwd")
     return dtok
+
+
+def transpose_many(src, dst, table, n_entries, total_tiles):
+    check(lib().p3_transpose_many(ptr(src), ptr(dst), ptr(table), c_int(n_entries), c_int(total_tiles), stream()), "p3_transpose_many")

@@ -88,8 +88,15 @@ def advance_rng(device):
     hip.rng_advance(rng_seed(device))
 
 
+_registered_T = {}   # id(param) -> (param, bf16 [in, out] transposed copy kept fresh by the optimizer (hip.transpose_many))
+
+
 def register_shadow(p, view):
     _registered[id(p)] = (p, view)
+
+
+def register_shadow_T(p, view_t):
+    _registered_T[id(p)] = (p, view_t)
 
 
 def invalidate_derived():
@@ -100,6 +107,10 @@ def shadow(p, dtype, key=None, fn=None):
     """compute-dtype (and optionally re-laid-out) copy of parameter `p`, cached until the parameter changes."""
     if dtype == torch.float32 and fn is None:
         return p.detach()
+    if key == "T" and dtype == torch.bfloat16:
+        rt = _registered_T.get(id(p))
+        if rt is not None and rt[0] is p:
+            return rt[1]
     reg = _registered.get(id(p))
     if reg is not None and reg[0] is p and dtype == torch.bfloat16:
         if fn is None:

@@ -9,6 +9,7 @@
               messages), BatchNorm statistics are summed across ranks (SyncBatchNorm semantics).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -73,6 +74,7 @@ class FlatAdamW:
                 ops.register_shadow(p, self.shadow[o:o + n].view(p.shape))
         if self.shadow is not None:
             self.shadow.copy_(self.flat)
+        self._build_transposes(params, offs, dev)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         ops.DIRECT_GRAD[0] = bool(direct_grad)   # kernels accumulate parameter gradients in place in the arena
         self.step_count = 0
@@ -87,6 +89,33 @@ class FlatAdamW:
             if end - start >= nb or i + 1 == len(offs):
                 self.buckets.append((start, end))
                 start = end
+
+    def _build_transposes(self, params, offs, dev):
+        """bf16 W^T copies ([in, out]) of every 2-D weight whose dX GEMM reads the plain transpose (out % 64 == 0): one arena, one
+        table, refreshed by ONE kernel after each AdamW step instead of one strided copy per weight per step."""
+        self.shadow_T, self.t_table, self.t_entries, self.t_tiles = None, None, 0, 0
+        if self.shadow is None or os.environ.get("P3_NO_WT") == "1":     # P3_NO_WT=1: A/B switch (per-weight strided copies instead)
+            return
+        import struct
+        recs, total, tiles = [], 0, 0
+        views = []
+        for p, o in zip(params, offs):
+            if p.dim() != 2 or p.shape[0] % 64 != 0 or p.shape[1] % 8 != 0:
+                continue
+            rows, cols = p.shape
+            tc, tr = (cols + 31) // 32, (rows + 31) // 32
+            recs.append(struct.pack("<qqiiii", o, total, rows, cols, tiles, tc))
+            views.append((p, total, rows, cols))
+            tiles += tc * tr
+            total += (rows * cols + 63) // 64 * 64
+        if not recs:
+            return
+        self.shadow_T = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        self.t_table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        self.t_entries, self.t_tiles = len(recs), tiles
+        for p, t0, rows, cols in views:
+            ops.register_shadow_T(p, self.shadow_T[t0:t0 + rows * cols].view(cols, rows))
+        hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
 
     def set_linear_schedule(self, num_training_steps, warmup_frac=0.05):
         """transformers.get_linear_schedule_with_warmup as used at trainer_pix2poly.py:62-77."""
@@ -114,6 +143,8 @@ class FlatAdamW:
         """device side (capturable): one fused kernel over the arena, also refreshes the bf16 shadow."""
         hip.adamw(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
                   grad_scale=grad_scale, shadow=self.shadow)
+        if self.shadow_T is not None:
+            hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
         ops.invalidate_derived()
 
     def step(self, grad_scale=1.0):
