@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     float qf[D / 2], gf[D / 2];
     load_rowfrags<T, D>(Qp, qc, d.q_rs, qb, qf, hi);
     load_rowfrags<T, D>(dOp, qc, d.o_rs, gb, gf, hi);
-    const float lse = a.lse[((int64_t)b * d.H + h) * d.Lq + qc];
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float lse2 = a.lse[((int64_t)b * d.H + h) * d.Lq + qc] * LOG2E;    // log2 domain: p = exp2(s*scale*log2e + bias*log2e - lse2)
+    const float c2 = d.scale * LOG2E;
     // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the same row fragments the lane already holds for dO (each half-wave
     // lane has 32 of the 64 / 16 of the 32 elements) and published for the dK/dV kernel, which runs after this one on the stream:
     // no separate delta kernel (r01: 24 launches, 1.1 ms per step).
@@ -272,13 +274,20 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
         for (int sub = 0; sub < KT / 32; ++sub) {
             f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, l31, hi);       // S^T[kv, q]
             f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, l31, hi);      // dP^T[kv, q]
+            // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
+            const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + sub * 32 + crow32(r, hi);
-                float sv = s[r] * d.scale;
-                if (kbias) sv += kbias[kv < d.Lk ? kv : d.Lk - 1];
-                const bool masked = kv >= d.Lk || (d.causal && kv > q);
-                const float p = masked ? 0.f : __expf(sv - lse);
+                float p;
+                if (full) {
+                    p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse2));
+                } else {
+                    float t2 = -lse2;
+                    if (kbias) t2 += kbias[kv < d.Lk ? kv : d.Lk - 1] * LOG2E;
+                    const bool masked = kv >= d.Lk || (d.causal && kv > q);
+                    p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, t2));
+                }
                 float dpv = dp[r];
                 if constexpr (DROP) {
                     const uint32_t bits = drop_bits(drop_rk, drop_colkey(dkey, (uint32_t)kv));   // pairs (r, r+1) share it: CSE'd
@@ -320,7 +329,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
     float kf[D / 2], vf[D / 2];
     load_rowfrags<T, D>(Kp, kvc, d.k_rs, kb, kf, hi);
     load_rowfrags<T, D>(Vp, kvc, d.v_rs, vb, vf, hi);
-    const float bias = d.key_bias ? d.key_bias[(int64_t)b * d.Lk + kvc] : 0.f;
+    const float bias2 = (d.key_bias ? d.key_bias[(int64_t)b * d.Lk + kvc] : 0.f) * 1.4426950408889634f;
+    const float c2 = d.scale * 1.4426950408889634f;
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int j = 0; j < D / 32; ++j)
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
         stage_store<T, D, QT, true, true>(greg, Grow, Gtr, tid);
         if (tid < QT) {
             const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
-            Ls[tid] = a.lse[stat_base + qq]; Ds[tid] = a.delta[stat_base + qq];
+            Ls[tid] = a.lse[stat_base + qq] * 1.4426950408889634f; Ds[tid] = a.delta[stat_base + qq];   // lse in log2 units
         }
         __syncthreads();
         if (q0 + QT < d.Lq) { stage_load<T, D, QT>(Qp, q0 + QT, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q0 + QT, d.Lq, d.o_rs, greg, tid); }
@@ -348,11 +358,13 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
             f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, l31, hi);       // S[q, kv]
             f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, l31, hi);      // dP[q, kv]
             f32x16 ds;
+            // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
+            const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = sub * 32 + crow32(r, hi), qq = q0 + ql;
-                const bool masked = qq >= d.Lq || kv >= d.Lk || (d.causal && kv > qq);
-                const float p = masked ? 0.f : __expf(s[r] * d.scale + bias - Ls[ql]);
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, bias2 - Ls[ql]));
+                if (!full) { const bool masked = qq >= d.Lq || kv >= d.Lk || (d.causal && kv > qq); p = masked ? 0.f : p; }
                 float pd = p, dpv = dp[r];
                 if constexpr (DROP) {
                     const uint32_t bits = drop_bits(drop_rowkey(dkey, drop_bh + (uint64_t)(qq < d.Lq ? qq : d.Lq - 1)), drop_ck);
