@@ -291,6 +291,11 @@ int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, i
  * matrix (dA != NULL, C = 128): dA [R,C] -> dHd = dA*(z>0)*scale (may alias dA), acc = [dscale(C) | dshift(C)] */
 int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean, const float* w4,
                       void* dHd, float* acc, int64_t R, int C, int N, int transpose, int dtype, void* stream);
+/* Two-pass form for train-mode BatchNorm: call once with dHd = NULL (sums only, nothing stored), derive (a, b) with
+ * p3_bn_bwd_coeffs, call again with acc = NULL and fix_a / fix_b to write the final gradient dz*scale + a + b*H directly. */
+int p3_row_affine_bwd2(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean,
+                       const float* w4, void* dHd, float* acc, const float* fix_a, const float* fix_b, int64_t R, int C, int N,
+                       int transpose, int dtype, void* stream);
 /* BatchNorm backward through scale/shift and (train mode) the batch statistics: d(pre) = direct + a[c] + b[c]*pre.
  * `dscale` is the CENTRED sum  sum dz*(pre - mean)  as accumulated by p3_row_affine_bwd / p3_pair_bwd (acc[0:C]) */
 int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd, float count,

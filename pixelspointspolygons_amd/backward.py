@@ -18,22 +18,25 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     w2d = lambda conv: conv.weight.reshape(conv.weight.shape[0], -1)
     f32 = dict(dtype=torch.float32, device=dev)
     # ---- tail: conv4 + BN3/ReLU
+    # train-mode BatchNorm: pass 1 = sums only (nothing stored), pass 2 writes the final gradient dz*scale + a + b*H directly
+    # (one pass over [R, C] less than "store, then affine_fix").  Eval mode: a = b = 0, single pass.
     acc3 = torch.zeros(3 * 64 + 1, **f32)
-    dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dout.contiguous(), w4=net.conv4.weight.detach().reshape(-1), N=N, transpose=transpose_acc)
+    dS, w4 = dout.contiguous(), net.conv4.weight.detach().reshape(-1)
+    dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dS, w4=w4, N=N, transpose=transpose_acc, store=not training)
     dw4, db4 = acc3[128:192].view(1, 64, 1, 1), acc3[192:193]
     dg3, dbt3, a3, b3 = ops.bn_backward_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training)
     if training:
-        hip.affine_fix(dH3, H3, a3, b3)
+        dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, None, dS=dS, w4=w4, N=N, transpose=transpose_acc, fix=(a3, b3))
     # ---- conv3 (+ BN2/ReLU in front of it)
     dW3 = hip.gemm_tn_ex(dH3, H2, torch.zeros(64, 128, **f32), hip.A_AFFINE_RELU, sc2, sh2)
     db3 = ops.bias_grad_before_bn(dH3, training)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
-    dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3)
+    dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
     dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training)
     if training:
-        hip.affine_fix(dH2, H2, a2, b2)
+        dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
     dW2 = hip.gemm_tn_ex(dH2, U, torch.zeros(128, 256, **f32), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
     db2 = ops.bias_grad_before_bn(dH2, training)

@@ -43,7 +43,10 @@ template <typename T, int C, bool TAIL>
 __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict__ dA, const float* __restrict__ dS, const T* __restrict__ H,
                                                              const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
                                                              const float* __restrict__ w4, T* __restrict__ dHd, float* __restrict__ acc,
-                                                             int64_t R, int N, int transpose) {
+                                                             int64_t R, int N, int transpose, const float* __restrict__ fix_a,
+                                                             const float* __restrict__ fix_b) {
+    // Two-pass use (train-mode BatchNorm): pass 1 with dHd == NULL only accumulates the sums (no store), pass 2 with fix_a / fix_b
+    // writes the FINAL gradient dz*sc + a + b*H in one go (acc == NULL: no sums) - one read of H less and no separate affine_fix pass.
     constexpr int LPR = C / 4, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, w = threadIdx.x >> 6;
     const int c0 = sub * 4;
@@ -51,6 +54,11 @@ __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s[k] = sc[c0 + k]; h[k] = sh[c0 + k]; mu[k] = mean[c0 + k]; wv[k] = TAIL ? w4[c0 + k] : 0.f; }
     float a_sc[4] = {0, 0, 0, 0}, a_sh[4] = {0, 0, 0, 0}, a_w[4] = {0, 0, 0, 0}, a_b = 0.f;
+    float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
+    if (fix_a) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fa[k] = fix_a[c0 + k]; fb[k] = fix_b[c0 + k]; }
+    }
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t r0 = wave_id * RPW; r0 < R; r0 += nwaves * RPW) {
         const int64_t r = r0 + rsel;
@@ -72,11 +80,12 @@ __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict
             for (int k = 0; k < 4; ++k) {
                 const float dz = (hv[k] * s[k] + h[k] > 0.f) ? g[k] : 0.f;
                 a_sc[k] += dz * (hv[k] - mu[k]); a_sh[k] += dz;   // centred: sum dz*(H - mean) is what BN backward needs (no cancellation)
-                o[k] = dz * s[k];
+                o[k] = dz * s[k] + fa[k] + fb[k] * hv[k];
             }
-            st4<T>(dHd + r * C + c0, o);
+            if (dHd) st4<T>(dHd + r * C + c0, o);
         }
     }
+    if (!acc) return;
     // combine the row groups of the wave, then the 4 waves, then one atomic per value per block
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) {
@@ -210,17 +219,24 @@ inline int grid_rows(int64_t rows, int rows_per_block) {
 
 extern "C" int p3_row_affine_bwd(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean, const float* w4,
                                  void* dHd, float* acc, int64_t R, int C, int N, int transpose, int dtype, void* stream) {
-    P3_CHECK(H && scale && shift && mean && dHd && acc && R > 0, P3_EINVAL, "p3_row_affine_bwd: bad arguments");
+    return p3_row_affine_bwd2(dA, dS, H, scale, shift, mean, w4, dHd, acc, nullptr, nullptr, R, C, N, transpose, dtype, stream);
+}
+
+extern "C" int p3_row_affine_bwd2(const void* dA, const float* dS, const void* H, const float* scale, const float* shift, const float* mean,
+                                  const float* w4, void* dHd, float* acc, const float* fix_a, const float* fix_b, int64_t R, int C, int N,
+                                  int transpose, int dtype, void* stream) {
+    P3_CHECK(H && scale && shift && mean && (dHd || acc) && R > 0, P3_EINVAL, "p3_row_affine_bwd: bad arguments");
+    P3_CHECK((fix_a == nullptr) == (fix_b == nullptr), P3_EINVAL, "p3_row_affine_bwd: fix_a and fix_b go together");
     P3_CHECK((dS != nullptr) != (dA != nullptr), P3_EINVAL, "p3_row_affine_bwd: exactly one of dS (tail) / dA (matrix)");
     P3_CHECK(dS ? (C == 64 && w4) : (C == 128), P3_EUNSUP, "p3_row_affine_bwd: tail needs C = 64, matrix mode C = 128");
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_rows(R, 64)), b(256);
     if (dS) {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 64, true>), g, b, 0, s, nullptr, dS, (const bf16_t*)H, scale, shift, mean, w4, (bf16_t*)dHd, acc, R, N, transpose);
-        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 64, true>), g, b, 0, s, nullptr, dS, (const float*)H, scale, shift, mean, w4, (float*)dHd, acc, R, N, transpose);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 64, true>), g, b, 0, s, nullptr, dS, (const bf16_t*)H, scale, shift, mean, w4, (bf16_t*)dHd, acc, R, N, transpose, fix_a, fix_b);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 64, true>), g, b, 0, s, nullptr, dS, (const float*)H, scale, shift, mean, w4, (float*)dHd, acc, R, N, transpose, fix_a, fix_b);
     } else {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 128, false>), g, b, 0, s, (const bf16_t*)dA, nullptr, (const bf16_t*)H, scale, shift, mean, nullptr, (bf16_t*)dHd, acc, R, N, 0);
-        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 128, false>), g, b, 0, s, (const float*)dA, nullptr, (const float*)H, scale, shift, mean, nullptr, (float*)dHd, acc, R, N, 0);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 128, false>), g, b, 0, s, (const bf16_t*)dA, nullptr, (const bf16_t*)H, scale, shift, mean, nullptr, (bf16_t*)dHd, acc, R, N, 0, fix_a, fix_b);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 128, false>), g, b, 0, s, (const float*)dA, nullptr, (const float*)H, scale, shift, mean, nullptr, (float*)dHd, acc, R, N, 0, fix_a, fix_b);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

@@ -579,11 +579,16 @@ def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=Non
     return out
 
 
-def row_affine_bwd(H, scale, shift, mean, acc, *, dA=None, dS=None, w4=None, N=0, transpose=False, out=None):
+def row_affine_bwd(H, scale, shift, mean, acc, *, dA=None, dS=None, w4=None, N=0, transpose=False, out=None, store=True, fix=None):
+    """store=False: sums only (pass 1 of the train-mode two-pass form); fix=(a, b): write dz*scale + a + b*H (pass 2, acc may be None)."""
     R, C = H.shape
-    out = out if out is not None else torch.empty_like(H)
-    check(lib().p3_row_affine_bwd(ptr(dA), ptr(dS), ptr(H), ptr(scale), ptr(shift), ptr(mean), ptr(w4), ptr(out), ptr(acc), c_int64(R), c_int(C), c_int(N),
-                                  c_int(int(transpose)), c_int(dt(H)), stream()), "p3_row_affine_bwd")
+    if store:
+        out = out if out is not None else torch.empty_like(H)
+    else:
+        out = None
+    fa, fb = fix if fix is not None else (None, None)
+    check(lib().p3_row_affine_bwd2(ptr(dA), ptr(dS), ptr(H), ptr(scale), ptr(shift), ptr(mean), ptr(w4), ptr(out), ptr(acc), ptr(fa), ptr(fb),
+                                   c_int64(R), c_int(C), c_int(N), c_int(int(transpose)), c_int(dt(H)), stream()), "p3_row_affine_bwd")
     return out
 
 
