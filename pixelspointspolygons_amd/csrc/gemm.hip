@@ -145,8 +145,12 @@ __device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v)
     }
 }
 
-template <typename T, typename TO, int AMODE, int BKSEL>
-__global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmArgs g) {
+// STATS = true (BatchNorm column sums requested): persistent workgroups walk the tiles vb, vb + gridDim.x, ... of ONE tile column
+// and keep the per-column sum / sum-of-squares in registers across them, so each column gets gridDim.x / tiles_n atomics instead of
+// one per 128-row tile: the tall-skinny ScoreNet / FFL GEMMs have 18 000 - 25 000 row tiles, and 37 000 same-address atomics are a
+// 0.4 ms serial chain (r01: conv3 of the ScoreNet 906 us for 39 GFLOP).
+template <typename T, typename TO, int AMODE, int BKSEL, bool STATS>
+__global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_kernel(GemmArgs g) {
     using TR = Tr<T, BKSEL>;
     constexpr int BK = TR::BK, PITCH = TR::PITCH, VEC = TR::VEC, LDSE = TR::LDS_ELEMS;
     constexpr int EPI_PASSES = BKSEL == 32 ? 2 : 1;  // epilogue staged through LDS in 1 pass of 128 rows or 2 passes of 64
@@ -161,18 +165,20 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* W = reinterpret_cast<const T*>(g.W);
 
-    // XCD-aware bijective remap: consecutive logical tiles (same A row-panel) share one XCD's L2
-    int nwg = gridDim.x, bid = blockIdx.x;
-    {
-        int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-
     const int kq = (tid % (BK / VEC)) * VEC;
     const int r0 = tid / (BK / VEC);
+    const int ntiles = g.tiles_m * g.tiles_n;
+    float cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};           // STATS: column sums of this workgroup's tiles (one tile column)
+    int tn_stats = 0;
+  int vb = blockIdx.x;
+  do {
+    // plain mode: one tile per workgroup, XCD-aware order (consecutive logical tiles = same A row-panel = one XCD's L2);
+    // STATS mode: gridDim.x is a multiple of tiles_n, so tn stays fixed along a workgroup's walk
+    const int bid = STATS ? vb : xcd_remap(vb, ntiles);
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    tn_stats = tn;
     RowSrc arow[NPASS];
     int64_t wrow[NPASS];
 #pragma unroll
@@ -283,10 +289,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
                         if (tm * BM + rw < d.M && cok) { s1 += v; s2 += v * v; }
                     }
                 }
-                if (d.colsum) {
-                    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                    if (hi == 0 && cok) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
-                }
+                if constexpr (STATS) { cs1[j] += s1; cs2[j] += s2; }
             }
         }
         __syncthreads();
@@ -383,21 +386,43 @@ __global__ __launch_bounds__(256, (BKSEL == 32 ? 3 : 2)) void gemm_kernel(GemmAr
             }
         }
     }
+    if constexpr (STATS) __syncthreads();            // the staging buffer aliases the next tile's operand buffers
+    vb += gridDim.x;
+  } while (STATS && vb < ntiles);
+    if constexpr (STATS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = tn_stats * BN + wn * 64 + j * 32 + l31;
+            const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64), s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+            if (hi == 0 && col < d.N && blockIdx.x < (unsigned)ntiles) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+        }
+    }
 }
 
-template <typename T, typename TO, int BKSEL>
-int launch_bk(const GemmArgs& g, hipStream_t s) {
-    dim3 grid(g.tiles_m * g.tiles_n), block(256);
+template <typename T, typename TO, int BKSEL, bool STATS>
+int launch_bk2(const GemmArgs& g, hipStream_t s) {
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int nwg = ntiles;
+    if (STATS) {                                      // persistent: <= ~2048 workgroups, a multiple of tiles_n
+        const int cap = (2048 / g.tiles_n) * g.tiles_n;
+        if (cap >= g.tiles_n && nwg > cap) nwg = cap;
+    }
+    dim3 grid(nwg), block(256);
     switch (g.d.a_mode) {
-        case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN, BKSEL>), grid, block, 0, s, g); break;
-        case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3, BKSEL>), grid, block, 0, s, g); break;
-        case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
-        case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
-        case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU, BKSEL>), grid, block, 0, s, g); break;
+        case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN, BKSEL, STATS>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3, BKSEL, STATS>), grid, block, 0, s, g); break;
+        case P3_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_AFFINE_RELU, BKSEL, STATS>), grid, block, 0, s, g); break;
+        case P3_A_PAIR_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PAIR_AFFINE_RELU, BKSEL, STATS>), grid, block, 0, s, g); break;
+        case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU, BKSEL, STATS>), grid, block, 0, s, g); break;
         default: p3_set_error("p3_gemm: bad a_mode"); return P3_EINVAL;
     }
     P3_LAUNCH_CHECK();
     return P3_OK;
+}
+
+template <typename T, typename TO, int BKSEL>
+int launch_bk(const GemmArgs& g, hipStream_t s) {
+    return g.d.colsum ? launch_bk2<T, TO, BKSEL, true>(g, s) : launch_bk2<T, TO, BKSEL, false>(g, s);
 }
 
 template <typename T, typename TO>
