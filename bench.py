@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--points", type=int, default=3000)
     ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph (single-GPU)")
     ap.add_argument("--sync-bn", type=int, default=1, help="N > 1: SyncBatchNorm like the reference's convert_sync_batchnorm (step runs eagerly)")
+    ap.add_argument("--no-dropout", action="store_true", help="A/B only: decoder dropout off (the headline run keeps the reference's rates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs)")
@@ -223,6 +224,8 @@ def main():
     tk = Tokenizer(cfg)
     model = Pix2PolyModel(cfg, tk.vocab_size, local)
     model.train()
+    if args.no_dropout:
+        model.decoder.set_dropout(0.0)
     # decoder dropout stays at the reference's training defaults (0.1 in nn.TransformerDecoderLayer incl. the attention
     # probabilities, 0.05 on both positional sums, model_pix2poly.py:136-143): fused into the GEMM epilogues / attention kernels
     # N > 1 with SyncBatchNorm (the reference's DDP setup, model_pix2poly.py:326-328): the 18 small statistic all-reduces sit inside
@@ -316,7 +319,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"pix2poly_{args.workload}_bs{args.batch}x{world}", "tiles_per_gpu": args.batch, "points_per_tile": args.points,
-                       "hip_graph": bool(args.graph), "sync_bn": sync_bn, "decoder_dropout": "reference defaults (0.1 / 0.05)",
+                       "hip_graph": bool(args.graph), "sync_bn": sync_bn, "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
                        "step": "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
             "fwd_ms_per_tile": round(fwd_ms / args.batch, 4), "fwd_ms_per_batch": round(fwd_ms, 3),
             "fwd_mfma_frac_of_2.5PF": round(GFLOP_FWD[args.workload] * args.batch / (fwd_ms * 1e-3) / 1e3 / 2500.0, 4) if args.precision == "bf16" else None,
