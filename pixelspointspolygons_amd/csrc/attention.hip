@@ -270,13 +270,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         l_run += psum;
         if constexpr (DROP) {   // attention-probability dropout: the row sum above stays undropped (softmax first, then dropout)
 #pragma unroll
-            for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2) {
+                uint32_t wrow = 0;                  // keep bits of this lane's 16 keys of the 32-key block (bit = key % 32)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {   // registers r, r+1 hold keys 2j, 2j+1: one hash per pair
                     const uint32_t bits = drop_bits(drop_rk, drop_colkey(dk, (uint32_t)(kv0 + h2 * 32 + crow32(r, hi))));
-                    sacc[h2][r] = drop_keep_lo(dk, bits) ? sacc[h2][r] * dk.inv_keep : 0.f;
-                    sacc[h2][r + 1] = drop_keep_hi(dk, bits) ? sacc[h2][r + 1] * dk.inv_keep : 0.f;
+                    const bool k0 = drop_keep_lo(dk, bits), k1 = drop_keep_hi(dk, bits);
+                    sacc[h2][r] = k0 ? sacc[h2][r] * dk.inv_keep : 0.f;
+                    sacc[h2][r + 1] = k1 ? sacc[h2][r + 1] * dk.inv_keep : 0.f;
+                    wrow |= ((uint32_t)k0 | ((uint32_t)k1 << 1)) << crow32(r, hi);
                 }
+                if (d.drop_rows) {                  // publish the mask for the backward kernels (they then skip the hashing)
+                    wrow |= __shfl_xor(wrow, 32, 64);
+                    if (hi == 0 && q < d.Lq)
+                        d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + q) * ((d.Lk + 31) >> 5) + (kv0 >> 5) + h2] = wrow;
+                }
+            }
         }
 
         // ---- O^T += V^T . P^T ----

@@ -201,7 +201,7 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <typename T, int D, bool DROP>
+template <typename T, int D, int DROP>
 __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int KT = BF ? 64 : 32;
@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
             f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, l31, hi);      // dP^T[kv, q]
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
+            uint32_t dword = 0;
+            if constexpr (DROP == 2) dword = d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + qc) * ((d.Lk + 31) >> 5) + (kv0 >> 5) + sub];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + sub * 32 + crow32(r, hi);
@@ -289,7 +291,9 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
                     p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, t2));
                 }
                 float dpv = dp[r];
-                if constexpr (DROP) {
+                if constexpr (DROP == 2) {
+                    dpv = ((dword >> crow32(r, hi)) & 1u) ? dpv * dkey.inv_keep : 0.f;   // mask published by the forward kernel
+                } else if constexpr (DROP == 1) {
                     const uint32_t bits = drop_bits(drop_rk, drop_colkey(dkey, (uint32_t)kv));   // pairs (r, r+1) share it: CSE'd
                     dpv = ((r & 1) ? drop_keep_hi(dkey, bits) : drop_keep_lo(dkey, bits)) ? dpv * dkey.inv_keep : 0.f;
                 }
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, int D, bool DROP>
+template <typename T, int D, int DROP>
 __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int QT = BF ? 64 : 32;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
         for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
     const int q_begin = d.causal ? (kblk / QT) * QT : 0;   // queries before the block's first key never see it
     DropKey dkey; uint32_t drop_ck = 0; uint64_t drop_bh = 0;
-    if constexpr (DROP) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
+    if constexpr (DROP != 0) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
     StageRegs<T, D, QT> qreg, greg;
     if (q_begin < d.Lq) { stage_load<T, D, QT>(Qp, q_begin, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q_begin, d.Lq, d.o_rs, greg, tid); }
@@ -360,15 +364,29 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
             f32x16 ds;
             // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
             const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
+            // DROP == 2: lane L loads the keep-bit word of query row q0 + sub*32 + (L & 31) for this wave's 32-key block; element r
+            // needs the word of row crow32(r, hi), fetched from that lane with two uniform-index readlanes + a select on hi
+            uint32_t myword = 0;
+            if constexpr (DROP == 2) {
+                const int qr = q0 + sub * 32 + l31;
+                myword = d.drop_rows[((int64_t)drop_bh + (qr < d.Lq ? qr : d.Lq - 1)) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = sub * 32 + crow32(r, hi), qq = q0 + ql;
                 float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, bias2 - Ls[ql]));
                 if (!full) { const bool masked = qq >= d.Lq || kv >= d.Lk || (d.causal && kv > qq); p = masked ? 0.f : p; }
                 float pd = p, dpv = dp[r];
-                if constexpr (DROP) {
-                    const uint32_t bits = drop_bits(drop_rowkey(dkey, drop_bh + (uint64_t)(qq < d.Lq ? qq : d.Lq - 1)), drop_ck);
-                    const bool keep = (kvc & 1) ? drop_keep_hi(dkey, bits) : drop_keep_lo(dkey, bits);
+                if constexpr (DROP != 0) {
+                    bool keep;
+                    if constexpr (DROP == 2) {
+                        const uint32_t w0 = __builtin_amdgcn_readlane(myword, crow32(r, 0)), w1 = __builtin_amdgcn_readlane(myword, crow32(r, 1));
+                        keep = ((hi ? w1 : w0) >> l31) & 1u;
+                    } else {
+                        const int64_t qrow = (int64_t)drop_bh + (qq < d.Lq ? qq : d.Lq - 1);
+                        const uint32_t bits = drop_bits(drop_rowkey(dkey, (uint64_t)qrow), drop_ck);
+                        keep = (kvc & 1) ? drop_keep_hi(dkey, bits) : drop_keep_lo(dkey, bits);
+                    }
                     pd = keep ? p * dkey.inv_keep : 0.f;
                     dpv = keep ? dpv * dkey.inv_keep : 0.f;
                 }
@@ -391,12 +409,18 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
     const int64_t rows = (int64_t)d.B * d.H * d.Lq;
     int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
     (void)g;   // delta is produced by the dQ kernel (attn_delta_kernel kept for reference / standalone use)
+    const dim3 gq(p3_ceil_div(d.Lq, 128) * d.H * d.B), gk(p3_ceil_div(d.Lk, 128) * d.H * d.B), blk(256);
     if (d.drop.seed != nullptr && d.drop.p > 0.f) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3(p3_ceil_div(d.Lq, 128) * d.H * d.B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3(p3_ceil_div(d.Lk, 128) * d.H * d.B), dim3(256), 0, s, a);
+        if (d.drop_rows) {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 2>), gq, blk, 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 2>), gk, blk, 0, s, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 1>), gq, blk, 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 1>), gk, blk, 0, s, a);
+        }
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3(p3_ceil_div(d.Lq, 128) * d.H * d.B), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3(p3_ceil_div(d.Lk, 128) * d.H * d.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 0>), gq, blk, 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 0>), gk, blk, 0, s, a);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

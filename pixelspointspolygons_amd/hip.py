@@ -208,10 +208,10 @@ class AttnDesc(Structure):
                 ("q_bs", c_int64), ("k_bs", c_int64), ("v_bs", c_int64), ("o_bs", c_int64),
                 ("q_rs", c_int), ("k_rs", c_int), ("v_rs", c_int), ("o_rs", c_int),
                 ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p),
-                ("drop", Dropout)]
+                ("drop", Dropout), ("drop_rows", c_void_p)]
 
 
-def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None):
+def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None, drop_rows=None):
     B, Lq, Dm = q.shape
     Lk = k.shape[1]
     d = AttnDesc()
@@ -222,10 +222,11 @@ def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None):
     d.key_bias = key_bias.data_ptr() if key_bias is not None else None
     d.lse = lse.data_ptr() if lse is not None else None
     d.drop = _drop(drop)
+    d.drop_rows = drop_rows.data_ptr() if drop_rows is not None else None
     return d
 
 
-def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False, drop=None):
+def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False, drop=None, drop_rows=None):
     """q [B,Lq,H*D], k/v [B,Lk,H*D] (arbitrary batch/row strides, unit inner stride) -> o [B,Lq,H*D]."""
     _dev(q)
     for t in (q, k, v):
@@ -233,7 +234,7 @@ def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False
             raise P3Error("attention: inner stride must be 1")
     o = torch.empty((q.shape[0], q.shape[1], q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if need_lse else None
-    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop)
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop, drop_rows)
     ev = KTIMER.begin()
     check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
     KTIMER.end(ev, f"attn_fwd_kernel<{'bf16' if d.dtype == BF16 else 'f32'},{d.head_dim}>",
@@ -429,7 +430,7 @@ def add_pos(x, pos):
 
 
 # ------------------------------------------------------------------------------------------ backward / training ops
-def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None, drop=None):
+def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None, drop=None, drop_rows=None):
     """dq/dk/dv get the same batch/row strides as q/k/v (pass views of a packed buffer to get a packed gradient)."""
     dq = torch.empty_like(q) if dq is None else dq
     dk = torch.empty_like(k) if dk is None else dk
@@ -439,7 +440,7 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
             raise P3Error("attention_bwd: gradient strides must equal input strides")
     if do.stride() != o.stride():
         raise P3Error("attention_bwd: dO strides must equal O strides")
-    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None, drop)
+    d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None, drop, drop_rows)
     delta = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
     check(lib().p3_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta), byref(d),
                                  stream()), "p3_attention_bwd")
@@ -705,3 +706,8 @@ def upsample_bilinear_bwd(dUp, B, h, w, H, W, tok_off=1):
 
 def transpose_many(src, dst, table, n_entries, total_tiles):
     check(lib().p3_transpose_many(ptr(src), ptr(dst), ptr(table), c_int(n_entries), c_int(total_tiles), stream()), "p3_transpose_many")
+
+
+def attention_mask_words(B, heads, Lq, Lk, device):
+    """keep-bit words the attention forward publishes for its backward (p3_attn_desc.drop_rows)."""
+    return torch.empty((B * heads * Lq, (Lk + 31) // 32), dtype=torch.int32, device=device)

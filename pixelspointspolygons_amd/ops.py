@@ -385,8 +385,11 @@ class _SelfAttention(torch.autograd.Function):
         D = qkv.shape[-1] // 3
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         if any(ctx.needs_input_grad):
-            o, lse = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, need_lse=True, drop=drop)
+            on = drop is not None and drop[2] > 0.0
+            bits = hip.attention_mask_words(qkv.shape[0], heads, qkv.shape[1], qkv.shape[1], qkv.device) if on else None
+            o, lse = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, need_lse=True, drop=drop, drop_rows=bits)
             ctx.save_for_backward(qkv, o, lse, key_bias)
+            ctx.bits = bits
             ctx.cfg = (heads, scale, causal, D, drop)
         else:
             o = hip.attention(q, k, v, heads, scale, causal=causal, key_bias=key_bias, drop=drop)
@@ -398,7 +401,7 @@ class _SelfAttention(torch.autograd.Function):
         heads, scale, causal, D, drop = ctx.cfg
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), heads, scale, causal=causal,
-                          key_bias=key_bias, dq=dqkv[..., :D], dk=dqkv[..., D:2 * D], dv=dqkv[..., 2 * D:], drop=drop)
+                          key_bias=key_bias, dq=dqkv[..., :D], dk=dqkv[..., D:2 * D], dv=dqkv[..., 2 * D:], drop=drop, drop_rows=ctx.bits)
         return dqkv, None, None, None, None, None
 
 
@@ -410,8 +413,11 @@ class _CrossAttention(torch.autograd.Function):
         D = q.shape[-1]
         k, v = kv[..., :D], kv[..., D:]
         if any(ctx.needs_input_grad):
-            o, lse = hip.attention(q, k, v, heads, scale, need_lse=True, drop=drop)
+            on = drop is not None and drop[2] > 0.0
+            bits = hip.attention_mask_words(q.shape[0], heads, q.shape[1], kv.shape[1], q.device) if on else None
+            o, lse = hip.attention(q, k, v, heads, scale, need_lse=True, drop=drop, drop_rows=bits)
             ctx.save_for_backward(q, kv, o, lse)
+            ctx.bits = bits
             ctx.cfg = (heads, scale, D, drop)
         else:
             o = hip.attention(q, k, v, heads, scale, drop=drop)
@@ -422,7 +428,8 @@ class _CrossAttention(torch.autograd.Function):
         q, kv, o, lse = ctx.saved_tensors
         heads, scale, D, drop = ctx.cfg
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        hip.attention_bwd(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), heads, scale, dq=dq, dk=dkv[..., :D], dv=dkv[..., D:], drop=drop)
+        hip.attention_bwd(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), heads, scale, dq=dq, dk=dkv[..., :D], dv=dkv[..., D:], drop=drop,
+                          drop_rows=ctx.bits)
         return dq, dkv, None, None, None
 
 
