@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             int row;
-            if constexpr (BF) row = m0 + 2 * rt + 32 * (i >> 1) + (i & 1);
+            if constexpr (BF) row = m0 + 4 * rt + i;          // 4 consecutive rows per thread -> one 8-byte transposed store per column
             else row = m0 + rt + 8 * i;
             const bool okr = row < m_end;
             ra[i] = (okr && okn) ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * g.lda + coln) : u32x4{0, 0, 0, 0};
@@ -142,22 +142,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         T* as = lds + buf * ELEMS;
         T* bs = lds + (2 + buf) * ELEMS;
         if constexpr (BF) {
+            const int mloc = 4 * rt;                 // first of this thread's 4 consecutive rows (multiple of 4: 8-byte aligned in [col][m])
+            uint2* pa = reinterpret_cast<uint2*>(as);
+            uint2* pb = reinterpret_cast<uint2*>(bs);
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int mloc = 2 * rt + 32 * pp;   // even row of the pair
-                uint32_t* pa = reinterpret_cast<uint32_t*>(as);
-                uint32_t* pb = reinterpret_cast<uint32_t*>(bs);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t a0 = ra[2 * pp][j], a1 = ra[2 * pp + 1][j], b0 = rb[2 * pp][j], b1 = rb[2 * pp + 1][j];
-                    const int c0 = cv + 2 * j, c1 = c0 + 1;
-                    const int o0 = (c0 * PITCH + ((((mloc >> 3) ^ ((c0 ^ (c0 >> 3)) & 7)) << 3) | (mloc & 7))) >> 1;
-                    const int o1 = (c1 * PITCH + ((((mloc >> 3) ^ ((c1 ^ (c1 >> 3)) & 7)) << 3) | (mloc & 7))) >> 1;
-                    pa[o0] = (a0 & 0xffffu) | (a1 << 16);
-                    pa[o1] = (a0 >> 16) | (a1 & 0xffff0000u);
-                    pb[o0] = (b0 & 0xffffu) | (b1 << 16);
-                    pb[o1] = (b0 >> 16) | (b1 & 0xffff0000u);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a0 = ra[0][j], a1 = ra[1][j], a2 = ra[2][j], a3 = ra[3][j];
+                const uint32_t b0 = rb[0][j], b1 = rb[1][j], b2 = rb[2][j], b3 = rb[3][j];
+                const int c0 = cv + 2 * j, c1 = c0 + 1;
+                const int o0 = (c0 * PITCH + ((((mloc >> 3) ^ ((c0 ^ (c0 >> 3)) & 7)) << 3) | (mloc & 7))) >> 2;   // in 8-byte units
+                const int o1 = (c1 * PITCH + ((((mloc >> 3) ^ ((c1 ^ (c1 >> 3)) & 7)) << 3) | (mloc & 7))) >> 2;
+                pa[o0] = make_uint2((a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16));
+                pa[o1] = make_uint2((a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u));
+                pb[o0] = make_uint2((b0 & 0xffffu) | (b1 << 16), (b2 & 0xffffu) | (b3 << 16));
+                pb[o1] = make_uint2((b0 >> 16) | (b1 & 0xffff0000u), (b2 >> 16) | (b3 & 0xffff0000u));
             }
         } else {
 #pragma unroll
