@@ -255,6 +255,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, const 
     if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
 }
 
+// one X2 row [x (32) | xmax (32)] + its 8 decorated features with 16-byte stores (64 two-byte stores per lane before)
+template <typename T>
+__device__ __forceinline__ void store_row(float* __restrict__ f8dst, T* __restrict__ dst, const float (&f8)[8], const float (&h)[C1], const float (&xm)[C1]) {
+    *reinterpret_cast<float4*>(f8dst) = make_float4(f8[0], f8[1], f8[2], f8[3]);
+    *reinterpret_cast<float4*>(f8dst + 4) = make_float4(f8[4], f8[5], f8[6], f8[7]);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<uint4*>(dst + 8 * q) = make_uint4(pack_bf2(h[8 * q], h[8 * q + 1]), pack_bf2(h[8 * q + 2], h[8 * q + 3]),
+                                                                pack_bf2(h[8 * q + 4], h[8 * q + 5]), pack_bf2(h[8 * q + 6], h[8 * q + 7]));
+            *reinterpret_cast<uint4*>(dst + C1 + 8 * q) = make_uint4(pack_bf2(xm[8 * q], xm[8 * q + 1]), pack_bf2(xm[8 * q + 2], xm[8 * q + 3]),
+                                                                     pack_bf2(xm[8 * q + 4], xm[8 * q + 5]), pack_bf2(xm[8 * q + 6], xm[8 * q + 7]));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+            *reinterpret_cast<float4*>(dst + C1 + 4 * q) = make_float4(xm[4 * q], xm[4 * q + 1], xm[4 * q + 2], xm[4 * q + 3]);
+        }
+    }
+}
+
 template <typename T, bool MULTI>
 __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
                                                            int max_points, int nslots, const float* __restrict__ w1,
@@ -291,10 +313,8 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
                     const int64_t row = (int64_t)t.row[v] + slot;
                     row_vox[row] = v; row_w[row] = valid ? 1.f : (float)(max_points - cn);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) F8[row * 8 + k] = f8[k];
-                    T* dst = X2 + row * K2;
-#pragma unroll
-                    for (int c = 0; c < C1; ++c) { dst[c] = Cvt<T>::from_f(fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f)); dst[C1 + c] = Cvt<T>::from_f(xm[c]); }
+                    for (int c = 0; c < C1; ++c) h[c] = fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f);
+                    store_row<T>(F8 + row * 8, X2 + row * K2, f8, h, xm);
                 }
             }
             continue;
@@ -314,11 +334,7 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
             const int64_t row = (int64_t)t.row[v] + lane;
             // training path: per-row pillar id / BN weight / decorated features (padded representative: zeros, weight P - cnt)
             row_vox[row] = v; row_w[row] = valid ? 1.f : (float)(max_points - cnt);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) F8[row * 8 + k] = f8[k];
-            T* dst = X2 + row * K2;
-#pragma unroll
-            for (int c = 0; c < C1; ++c) { dst[c] = Cvt<T>::from_f(h[c]); dst[C1 + c] = Cvt<T>::from_f(xm[c]); }
+            store_row<T>(F8 + row * 8, X2 + row * K2, f8, h, xm);
         }
     }
 }

@@ -197,12 +197,15 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
 template <typename T>
 __global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restrict__ V, const float* __restrict__ a, const float* __restrict__ bco,
                                       float* __restrict__ dU, float* __restrict__ dV, int N, int C) {
+    // grid = (B, row chunks): every block recomputes the column sums over the N rows of its sample (N*C cached loads) and then
+    // updates its own chunk of rows, so the kernel fills the chip instead of running on B = 64 workgroups
     const int b = blockIdx.x;
+    const int per = (N + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = min(N, i0 + per);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float su = 0.f, sv = 0.f;
         for (int i = 0; i < N; ++i) { su += Cvt<T>::to_f(U[((int64_t)b * N + i) * C + c]); sv += Cvt<T>::to_f(V[((int64_t)b * N + i) * C + c]); }
         const float ac = (float)N * a[c], bc = bco[c];
-        for (int i = 0; i < N; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int64_t o = ((int64_t)b * N + i) * C + c;
             dU[o] += ac + bc * ((float)N * Cvt<T>::to_f(U[o]) + sv);
             dV[o] += ac + bc * ((float)N * Cvt<T>::to_f(V[o]) + su);
@@ -286,8 +289,8 @@ extern "C" int p3_pair_stats_bwd(const void* U, const void* V, const float* a, c
                                  void* stream) {
     P3_CHECK(U && V && a && b && dU && dV && B > 0, P3_EINVAL, "p3_pair_stats_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_stats_bwd_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, a, b, dU, dV, N, C);
-    else hipLaunchKernelGGL((pair_stats_bwd_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)U, (const float*)V, a, b, dU, dV, N, C);
+    if (dtype == P3_BF16) hipLaunchKernelGGL((pair_stats_bwd_kernel<bf16_t>), dim3(B, 8), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, a, b, dU, dV, N, C);
+    else hipLaunchKernelGGL((pair_stats_bwd_kernel<float>), dim3(B, 8), dim3(256), 0, s, (const float*)U, (const float*)V, a, b, dU, dV, N, C);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
