@@ -157,9 +157,10 @@ class VisionTransformer(nn.Module):
         elif isinstance(pe, nn.Identity):
             B = x.shape[0]
             tok = x.reshape(-1, x.shape[-1])
-        else:  # PointPillarsEncoder plugged in as patch_embed (pointpillars_vit.py:64)
-            B = x.shape[0]
-            tok = pe(x, return_flattened=True).reshape(-1, self.embed_dim)
+        else:  # PointPillarsEncoder plugged in as patch_embed (pointpillars_vit.py:64); x: nested jagged tensor, (values, offsets) or dense
+            tok3 = pe(x, return_flattened=True)
+            B = tok3.shape[0]
+            tok = tok3.reshape(-1, self.embed_dim)
         return self.forward_tokens(tok, B)
 
 

@@ -256,3 +256,17 @@ def test_kv_cached_generate_full_model(precision):
         assert torch.equal(feats[:, :24], ref_feats[:, :24])
         ref = O.greedy_generate(O.encoder_fusion(inp["image"], inp["lidar_values"], inp["lidar_offsets"], sd), sd, steps=12)[0]
         assert torch.equal(toks[:, :13].cpu(), ref)
+
+
+def test_lidar_only_model_accepts_all_three_lidar_input_forms():
+    """nested jagged tensor (the reference's collate output), (values, offsets) pair (bench.py) and dense [B, N, 3]."""
+    sd = O.make_state_dict("lidar", seed=42)
+    m, cfg = _model("lidar", "fp32", sd)
+    inp = O.make_inputs(2, seed=8, n_points=500, jitter=0)
+    d = _to_dev(inp)
+    y = d["y"][:, :-1]
+    with torch.no_grad():
+        a, _ = m(None, torch.nested.nested_tensor_from_jagged(d["lidar_values"], d["lidar_offsets"]), y)
+        b, _ = m(None, (d["lidar_values"], d["lidar_offsets"]), y)
+        c, _ = m(None, d["lidar_values"].view(2, 500, 3), y)
+    assert torch.equal(a, b) and torch.equal(a, c)
