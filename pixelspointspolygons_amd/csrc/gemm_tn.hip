@@ -26,11 +26,12 @@ struct TnArgs {
 };
 
 template <typename T> struct TTr;
-// bf16: [col][m] transposed image, 128-byte rows, 16-byte chunks XOR-swizzled by key(col) = (col ^ col>>3) & 7.  The writer lanes of a
-// wave own columns 8 apart (one 16-byte global load = 8 columns), which with any 16-byte-aligned padded pitch land on ONE bank
-// (16-way conflict on every transposing ds_write_b32 - measured 2x on the whole kernel); the swizzle spreads both the writes
-// (columns 8 apart) and the ds_read_b128 fragment reads (consecutive columns) to <= 2-way.
-template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 64, ELEMS = TN * 64; };
+// bf16: the LDS image is the operand tile AS IT LIES IN MEMORY, [m][col] with 16-byte stores (no transposition, no packing VALU);
+// the k-contiguous MFMA fragments (8 consecutive m for one column) come from gfx950's transposing LDS read ds_read_b64_tr_b16:
+// per 16-lane group, lanes 4j..4j+3 point at row j's 16 elements and lane i receives column i of those 4 rows (semantics pinned by
+// tools/probe/tr_probe.hip).  Row pitch 160 elements = 80 dwords: the 4 rows of a read land 16 banks apart -> conflict free.
+// (Round-1 history: transposing ds_write_b32 stores -> XOR swizzle -> 8-byte stores; this form removes the transposing stores.)
+template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 160, ELEMS = 64 * 160; };
 template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS = 16 * 132; };  // [m][col]
 
 template <typename T>
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;          // byte offset of the tile buffers inside the LDS aperture (inline-asm reads)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     // 1-D grid, XCD-aware: all (n, k) tiles of one M-split (they read the same rows of A and B) run on ONE XCD, so those rows
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             int row;
-            if constexpr (BF) row = m0 + 4 * rt + i;          // 4 consecutive rows per thread -> one 8-byte transposed store per column
+            if constexpr (BF) row = m0 + rt + 16 * i;         // thread = (row rt + 16 i, 8 columns at cv): 16-byte row-major stores
             else row = m0 + rt + 8 * i;
             const bool okr = row < m_end;
             ra[i] = (okr && okn) ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * g.lda + coln) : u32x4{0, 0, 0, 0};
@@ -142,20 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         T* as = lds + buf * ELEMS;
         T* bs = lds + (2 + buf) * ELEMS;
         if constexpr (BF) {
-            const int mloc = 4 * rt;                 // first of this thread's 4 consecutive rows (multiple of 4: 8-byte aligned in [col][m])
-            uint2* pa = reinterpret_cast<uint2*>(as);
-            uint2* pb = reinterpret_cast<uint2*>(bs);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a0 = ra[0][j], a1 = ra[1][j], a2 = ra[2][j], a3 = ra[3][j];
-                const uint32_t b0 = rb[0][j], b1 = rb[1][j], b2 = rb[2][j], b3 = rb[3][j];
-                const int c0 = cv + 2 * j, c1 = c0 + 1;
-                const int o0 = (c0 * PITCH + ((((mloc >> 3) ^ ((c0 ^ (c0 >> 3)) & 7)) << 3) | (mloc & 7))) >> 2;   // in 8-byte units
-                const int o1 = (c1 * PITCH + ((((mloc >> 3) ^ ((c1 ^ (c1 >> 3)) & 7)) << 3) | (mloc & 7))) >> 2;
-                pa[o0] = make_uint2((a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16));
-                pa[o1] = make_uint2((a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u));
-                pb[o0] = make_uint2((b0 & 0xffffu) | (b1 << 16), (b2 & 0xffffu) | (b3 << 16));
-                pb[o1] = make_uint2((b0 >> 16) | (b1 & 0xffff0000u), (b2 >> 16) | (b3 & 0xffff0000u));
+            for (int i = 0; i < NLOAD; ++i) {
+                *reinterpret_cast<u32x4*>(as + (rt + 16 * i) * PITCH + cv) = ra[i];
+                *reinterpret_cast<u32x4*>(bs + (rt + 16 * i) * PITCH + cv) = rb[i];
             }
         } else {
 #pragma unroll
@@ -175,14 +168,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         const T* as = lds + cur * ELEMS;
         const T* bs = lds + (2 + cur) * ELEMS;
         if constexpr (BF) {
+            // lane -> (4-row block, 16-column block, row in block, 4-column chunk) of the transposing read
+            const int g4 = lane >> 4, li = lane & 15;
+            const uint32_t lane_off = (uint32_t)((((g4 >> 1) * 8 + (li >> 2)) * PITCH + (g4 & 1) * 16 + (li & 3) * 4) * 2);
+            const uint32_t abase = lds_base + (uint32_t)(cur * ELEMS * 2) + lane_off + (uint32_t)(wm * 64 * 2);
+            const uint32_t bbase = lds_base + (uint32_t)((2 + cur) * ELEMS * 2) + lane_off + (uint32_t)(wn * 64 * 2);
+            // software pipeline by hand (the compiler neither schedules nor counts inline-asm LDS reads): the reads of k-step kk+1 are
+            // in flight while the MFMAs of kk run; each wait is tied to the registers it guards
+            u32x2 fa[2][2][2], fb[2][2][2];          // [pipeline slot][32-column block][rows +0..3 | +4..7]
+            auto issue = [&](int slot, int kk) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t off = (uint32_t)(((kk * 16 + hh * 4) * PITCH + i * 32) * 2);
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fa[slot][i][hh]) : "v"(abase + off));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fb[slot][i][hh]) : "v"(bbase + off));
+                    }
+            };
+            auto wait = [&](int slot) __attribute__((always_inline)) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[slot][0][0]), "+v"(fa[slot][0][1]), "+v"(fa[slot][1][0]), "+v"(fa[slot][1][1]),
+                               "+v"(fb[slot][0][0]), "+v"(fb[slot][0][1]), "+v"(fb[slot][1][0]), "+v"(fb[slot][1][1]));
+            };
+            issue(0, 0);
+            wait(0);
 #pragma unroll
             for (int kk = 0; kk < BM / 16; ++kk) {
+                const int sl = kk & 1;
+                if (kk + 1 < BM / 16) issue(sl ^ 1, kk + 1);
                 s16x8 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int ca = wm * 64 + i * 32 + l31, cb = wn * 64 + i * 32 + l31;
-                    af[i] = *reinterpret_cast<const s16x8*>(as + ca * PITCH + (((kk * 2 + hi) ^ ((ca ^ (ca >> 3)) & 7)) << 3));
-                    bf[i] = *reinterpret_cast<const s16x8*>(bs + cb * PITCH + (((kk * 2 + hi) ^ ((cb ^ (cb >> 3)) & 7)) << 3));
+                    af[i] = __builtin_bit_cast(s16x8, u32x4{fa[sl][i][0].x, fa[sl][i][0].y, fa[sl][i][1].x, fa[sl][i][1].y});
+                    bf[i] = __builtin_bit_cast(s16x8, u32x4{fb[sl][i][0].x, fb[sl][i][0].y, fb[sl][i][1].x, fb[sl][i][1].y});
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -191,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), af[i]),
                             __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), bf[j]), acc[i][j], 0, 0, 0);
+                if (kk + 1 < BM / 16) wait(sl ^ 1);
             }
         } else {
 #pragma unroll
