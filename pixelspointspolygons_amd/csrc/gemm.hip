@@ -9,6 +9,8 @@
 // The A operand can be generated on the fly (implicit 3x3 conv gather, BN+ReLU fold, ScoreNet pair sum).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "p3_common.h"
 
 namespace {
@@ -196,20 +198,29 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[NPASS], rb[NPASS];
+    // Register-staged pipeline, PREFETCH DEPTH 2: two staging register sets.  While tile-slice t is multiplied out of LDS, slice t+1
+    // sits in one set (loaded during the previous iteration, stored to the other LDS buffer after the MFMAs) and the loads of slice
+    // t+2 are issued into the other set - two global-load latencies deep instead of one (SQ counters r01: GEMM waves parked 55 % of
+    // their cycles on vmcnt / barriers with the one-deep pipeline).
+    uint4 ra[2][NPASS], rb[2][NPASS];
     const int nk = d.K / BK;
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { ra[p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[p] = load_w<T>(W, wrow[p], kq); }
+    for (int p = 0; p < NPASS; ++p) { ra[0][p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[0][p] = load_w<T>(W, wrow[p], kq); }
+    if (nk > 1) {
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(lds, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+        for (int p = 0; p < NPASS; ++p) { ra[1][p] = load_a<T, AMODE>(d, A, arow[p], BK + kq); rb[1][p] = load_w<T>(W, wrow[p], BK + kq); }
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(lds, r0 + p * ROWS_PER_PASS, kq, ra[0][p]); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[0][p]); }
     __syncthreads();
 
-    for (int t = 0; t < nk; ++t) {
+    auto step = [&](auto SET, int t) __attribute__((always_inline)) {
+        constexpr int s0 = decltype(SET)::value;     // register set that held slice t (free now); slice t+1 is in set s0 ^ 1
         const int cur = t & 1;
-        if (t + 1 < nk) {
-            const int k = (t + 1) * BK + kq;
+        if (t + 2 < nk) {
+            const int k = (t + 2) * BK + kq;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { ra[p] = load_a<T, AMODE>(d, A, arow[p], k); rb[p] = load_w<T>(W, wrow[p], k); }
+            for (int p = 0; p < NPASS; ++p) { ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = load_w<T>(W, wrow[p], k); }
         }
         const T* as = lds + cur * LDSE;
         const T* bs = lds + (2 + cur) * LDSE;
@@ -249,9 +260,13 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(an, r0 + p * ROWS_PER_PASS, kq, ra[p]); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[p]); }
+            for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(an, r0 + p * ROWS_PER_PASS, kq, ra[s0 ^ 1][p]); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[s0 ^ 1][p]); }
         }
         __syncthreads();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) step(std::integral_constant<int, 1>{}, t + 1);
     }
 
     // ---- epilogue: accumulators (+bias) -> LDS as fp32 [128][132] -> whole 8-element row chunks per thread ----------
