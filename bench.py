@@ -275,6 +275,19 @@ def main():
             st.forward_only(pool[i % len(pool)])
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+    # inference forward: model.eval() (running BatchNorm statistics, no dropout), eager launches, same batch shape
+    fwd_eval_ms = float("nan")
+    if not args.no_fwd:
+        model.eval()
+        for i in range(3):
+            st.forward_only(pool[0], use_graph=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(5):
+            st.forward_only(pool[i % len(pool)], use_graph=False)
+        torch.cuda.synchronize()
+        fwd_eval_ms = (time.perf_counter() - t1) / 5 * 1e3
+        model.train()
 
     # dominant-kernel timing with HIP events on the launch stream (instrumented steps, after the timed region)
     roofline = None
@@ -322,6 +335,7 @@ def main():
                        "hip_graph": bool(args.graph), "sync_bn": sync_bn, "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
                        "step": "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
             "fwd_ms_per_tile": round(fwd_ms / args.batch, 4), "fwd_ms_per_batch": round(fwd_ms, 3),
+            "fwd_eval_ms_per_tile": round(fwd_eval_ms / args.batch, 4),
             "fwd_mfma_frac_of_2.5PF": round(GFLOP_FWD[args.workload] * args.batch / (fwd_ms * 1e-3) / 1e3 / 2500.0, 4) if args.precision == "bf16" else None,
             "final_loss": round(loss_val, 4),
             "roofline": roofline,
