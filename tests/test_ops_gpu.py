@@ -157,3 +157,27 @@ def test_attention_forward(dtype, B, H, Lq, Lk, hd, causal, bias):
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     assert rel_err(o.float().cpu(), ref) < tol
     assert rel_err(lse.cpu(), lse_ref) < (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("N,K,mode", [(64, 128, "affine"), (128, 256, "plain"), (256, 64, "plain")])
+def test_gemm_batchnorm_sums_persistent_path(N, K, mode):
+    """More row tiles than resident workgroups (2048): the persistent STATS path walks several tiles per workgroup and keeps the
+    column sums in registers; output and sums must equal the reference."""
+    from pixelspointspolygons_amd import hip
+    M = 128 * 2500 + 37                                   # 2501 row tiles, ragged tail
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.1).to(DEV).bfloat16()
+    bias = torch.randn(N, generator=g).to(DEV)
+    sums = torch.zeros(2 * N, device=DEV)
+    kw = {}
+    af = a.float()
+    if mode == "affine":
+        sc, sh = (torch.rand(K, generator=g) + 0.5).to(DEV), (torch.randn(K, generator=g) * 0.1).to(DEV)
+        kw = dict(a_mode=hip.A_AFFINE_RELU, a_scale=sc, a_shift=sh)
+        af = torch.relu(af * sc + sh).bfloat16().float()
+    out = hip.gemm(a, w, bias=bias, out_dtype=torch.bfloat16, colsum=sums[:N], colsumsq=sums[N:], **kw)
+    ref = af @ w.float().t() + bias
+    assert rel_err(out.float().cpu(), ref.cpu()) < 2e-2
+    assert rel_err(sums[:N].cpu(), ref.sum(0).cpu()) < 2e-3
+    assert rel_err(sums[N:].cpu(), (ref * ref).sum(0).cpu()) < 2e-3
