@@ -282,8 +282,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 }
                 if (d.drop_rows) {                  // publish the mask for the backward kernels (they then skip the hashing)
                     wrow |= __shfl_xor(wrow, 32, 64);
-                    if (hi == 0 && q < d.Lq)
-                        d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + q) * ((d.Lk + 31) >> 5) + (kv0 >> 5) + h2] = wrow;
+                    const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + h2;
+                    if (hi == 0 && q < d.Lq && kw < nkw)      // kw == nkw: the 32-key half beyond Lk of the last tile (next row's word 0!)
+                        d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + q) * nkw + kw] = wrow;
                 }
             }
         }

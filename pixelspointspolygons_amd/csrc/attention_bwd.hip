@@ -277,7 +277,10 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
             uint32_t dword = 0;
-            if constexpr (DROP == 2) dword = d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + qc) * ((d.Lk + 31) >> 5) + (kv0 >> 5) + sub];
+            if constexpr (DROP == 2) {
+                const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + sub;     // kw == nkw: the all-masked half of the last tile
+                if (kw < nkw) dword = d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + qc) * nkw + kw];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + sub * 32 + crow32(r, hi);

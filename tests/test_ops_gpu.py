@@ -181,3 +181,27 @@ def test_gemm_batchnorm_sums_persistent_path(N, K, mode):
     assert rel_err(out.float().cpu(), ref.cpu()) < 2e-2
     assert rel_err(sums[:N].cpu(), ref.sum(0).cpu()) < 2e-3
     assert rel_err(sums[N:].cpu(), (ref * ref).sum(0).cpu()) < 2e-3
+
+
+def test_attention_dropout_bits_path_equals_hash_path():
+    """Backward reading the keep-bit words the forward published == backward re-hashing (p3_attn_desc.drop_rows = NULL)."""
+    from pixelspointspolygons_amd import hip
+    B, H, Lq, Lk, hd = 2, 4, 150, 210, 32
+    g = torch.Generator().manual_seed(5)
+    q, k, v = [(torch.randn(B, L, H * hd, generator=g) * 0.5).to(DEV).bfloat16() for L in (Lq, Lk, Lk)]
+    do = (torch.randn(B, Lq, H * hd, generator=g) * 0.5).to(DEV).bfloat16()
+    seed = torch.full((1,), 777, dtype=torch.int64, device=DEV)
+    drop = (seed, 5, 0.25)
+    bits = hip.attention_mask_words(B, H, Lq, Lk, DEV)
+    o1, lse1 = hip.attention(q, k, v, H, hd ** -0.5, need_lse=True, drop=drop, drop_rows=bits)
+    o2, lse2 = hip.attention(q, k, v, H, hd ** -0.5, need_lse=True, drop=drop)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    g1 = hip.attention_bwd(q, k, v, o1, lse1, do, H, hd ** -0.5, drop=drop, drop_rows=bits)
+    g2 = hip.attention_bwd(q, k, v, o1, lse1, do, H, hd ** -0.5, drop=drop)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    # the published words are the mask itself: keep rate ~ 1 - p over the valid keys
+    w = bits.view(B * H * Lq, -1)
+    ones = sum(int(((w >> j) & 1).sum()) for j in range(32))
+    frac = ones / (B * H * Lq * ((Lk + 31) // 32) * 32)
+    assert abs(frac - 0.75) < 0.02
