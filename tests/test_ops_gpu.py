@@ -46,7 +46,9 @@ def test_gemm_f32_epilogues(act):
     assert rel_err(cs.cpu(), pre.sum(0)) < 1e-5 and rel_err(cq.cpu(), (pre * pre).sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 227, 256), (785 * 2, 1152, 384), (1000, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 227, 256), (785 * 2, 1152, 384), (1000, 384, 1536),
+                                   (700, 256, 2048), (520, 384, 6912),      # BK = 64 variant (K >= 2048)
+                                   (333, 200, 96)])                         # K % 64 != 0: BK = 32 only
 def test_gemm_bf16(M, N, K):
     h = _h()
     a = _rand(M, K, seed=1).bfloat16()
