@@ -353,3 +353,31 @@ def test_train_step_with_decoder_dropout_vs_oracle_replaying_the_masks(precision
         if not e < tol:
             bad[k] = e
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal", [(2, 4, 150, 210, 32, False), (1, 3, 97, 97, 64, True), (1, 2, 385, 784, 32, False)])
+def test_attention_dropout_forward_backward_vs_torch_with_the_same_mask(dtype, tol, B, H, Lq, Lk, hd, causal):
+    """Attention-probability dropout on ragged shapes (tails in both dimensions): output and all three gradients vs torch autograd
+    applying the mask read back from p3_dropout_apply; both backward variants (published keep-bit words, re-hash)."""
+    h = _h()
+    Dm = H * hd
+    q, k, v = [_rand(B, L, Dm, seed=s, scale=0.7).to(dtype).float().requires_grad_(True) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3))]
+    seed = torch.full((1,), 4242, dtype=torch.int64, device=DEV)
+    drop = (seed, 9, 0.2)
+    mask = h.dropout_apply(torch.ones(B * H * Lq, Lk, device=DEV), torch.float32, drop).cpu().view(B, H, Lq, Lk)
+    scale = 1 / math.sqrt(hd)
+    sp = lambda t, L: t.reshape(B, L, H, hd).transpose(1, 2)
+    s = sp(q, Lq) @ sp(k, Lk).transpose(-2, -1) * scale
+    if causal:
+        s = s + torch.full((Lq, Lk), float("-inf")).triu(1)
+    o = ((torch.softmax(s, -1) * mask) @ sp(v, Lk)).transpose(1, 2).reshape(B, Lq, Dm)
+    do = _rand(B, Lq, Dm, seed=4).to(dtype).float()
+    o.backward(do)
+    qd, kd, vd = (t.detach().to(dtype).to(DEV) for t in (q, k, v))
+    bits = h.attention_mask_words(B, H, Lq, Lk, DEV)
+    od, lse = h.attention(qd, kd, vd, H, scale, causal=causal, need_lse=True, drop=drop, drop_rows=bits)
+    assert rel_err(od.float().cpu(), o.detach()) < tol
+    for rows in (bits, None):
+        dq, dk, dv = h.attention_bwd(qd, kd, vd, od, lse, do.to(dtype).to(DEV), H, scale, causal=causal, drop=drop, drop_rows=rows)
+        assert rel_err(dq.float().cpu(), q.grad) < tol and rel_err(dk.float().cpu(), k.grad) < tol and rel_err(dv.float().cpu(), v.grad) < tol
