@@ -243,6 +243,11 @@ int p3_score_out(const void* H3, int dtype, const float* scale, const float* shi
  * uv_hist [B,iters,(m+1)+(n+1)] optional dual iterates for the backward pass. */
 int p3_sinkhorn(const float* scores, const float* alpha, int B, int m, int n, int iters, float* perm, float* z_full,
                 float* uv_hist, void* stream);
+/* scores_to_permutations (predictor_pix2poly.py:307-319): per tile scipy.optimize.linear_sum_assignment(-scores[b]) (maximize = 1),
+ * the float64 shortest-augmenting-path solver with scipy's tie rule, one wave per tile.  scores [B,N,N] fp32;
+ * col4row [B,N] (column assigned to row r; -1 if the tile failed); perm [B,N,N] 0/1 fp32 (may be NULL);
+ * status [B]: 0 ok, 1 NaN / -inf cost (scipy: ValueError "invalid numeric entries"), 2 infeasible. */
+int p3_assignment(const float* scores, int B, int N, int maximize, int32_t* col4row, float* perm, int32_t* status, void* stream);
 /* greedy decode step (predictor_pix2poly.py:165,196-197): argmax over the last dim, first maximum wins */
 int p3_argmax(const float* x, int64_t* out, int rows, int cols, int ld, void* stream);
 int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* stream);

@@ -378,6 +378,82 @@ def greedy_generate(enc, sd, steps=MAX_LEN - 1, bos=BOS):
 # ----------------------------------------------------------------------------------------------
 # FFL heads (models/ffl/model_ffl.py:28-104) + the *CNN encoder tails
 # ----------------------------------------------------------------------------------------------
+def scores_to_permutations(scores):
+    """predict/predictor_pix2poly.py:307-319, literally: scipy.optimize.linear_sum_assignment(-scores[b]) per tile (scipy is the
+    reference's own dependency; 1.15.3 in this image) -> 0/1 fp32 [B,N,N]."""
+    from scipy.optimize import linear_sum_assignment
+    sc = scores.detach().cpu().numpy()
+    perm = np.zeros_like(sc)
+    for b in range(sc.shape[0]):
+        r, c = linear_sum_assignment(-sc[b])
+        perm[b, r, c] = 1
+    return torch.tensor(perm)
+
+
+def lsap_wave_order(cost, lanes=64):
+    """Restatement of scipy's rectangular_lsap solver (shortest augmenting paths, Crouse 2016; float64) in the form the HIP kernel
+    runs it (csrc/assignment.hip): the sequential column scan is replaced by a reduction under the total order
+    (shortest path cost, key) with key = -(pos+1) for unassigned columns and pos+1 for assigned ones, pos = the column's place in
+    scipy's `remaining` list (reverse initial order, swap-with-last removal).  tests/test_oracle_cpu.py pins this against
+    scipy.optimize.linear_sum_assignment on tie-heavy integer matrices: it is the proof that the reduction keeps scipy's tie rule.
+    cost: float64 [N,N] -> col4row int array (raises ValueError like scipy on invalid / infeasible input)."""
+    cost = np.asarray(cost, dtype=np.float64)
+    n = cost.shape[0]
+    if np.isnan(cost).any() or np.isneginf(cost).any():
+        raise ValueError("matrix contains invalid numeric entries")
+    u, v = np.zeros(n), np.zeros(n)
+    path = np.full(n, -1, dtype=np.int64)
+    col4row = np.full(n, -1, dtype=np.int64)
+    row4col = np.full(n, -1, dtype=np.int64)
+    for cur in range(n):
+        pos = n - 1 - np.arange(n)
+        remaining = np.arange(n)[::-1].copy()
+        spc = np.full(n, np.inf)
+        SR = np.zeros(n, dtype=bool)
+        num_remaining, i, sink, min_val = n, cur, -1, 0.0
+        while sink == -1:
+            SR[i] = True
+            live = pos >= 0
+            r = ((min_val + cost[i]) - u[i]) - v
+            upd = live & (r < spc)
+            path[upd] = i
+            spc[upd] = r[upd]
+            key = np.where(row4col == -1, -(pos + 1), pos + 1)
+            cand = np.flatnonzero(live)
+            if cand.size == 0:
+                raise ValueError("cost matrix is infeasible")
+            order = np.lexsort((key[cand], spc[cand]))      # primary: path cost, secondary: key
+            j = int(cand[order[0]])
+            min_val = spc[j]
+            if min_val == np.inf:
+                raise ValueError("cost matrix is infeasible")
+            if row4col[j] == -1:
+                sink = j
+            else:
+                i = int(row4col[j])
+            idx = int(pos[j])
+            last = int(remaining[num_remaining - 1])
+            remaining[idx] = last
+            pos[last] = idx
+            pos[j] = -1
+            num_remaining -= 1
+        for r_ in range(n):
+            if r_ == cur:
+                u[r_] += min_val
+            elif SR[r_]:
+                u[r_] += min_val - spc[col4row[r_]]
+        sc_mask = pos < 0
+        v[sc_mask] -= min_val - spc[sc_mask]
+        j = sink
+        while True:
+            r_ = int(path[j])
+            row4col[j] = r_
+            col4row[r_], j = j, col4row[r_]
+            if r_ == cur:
+                break
+    return col4row
+
+
 def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
     x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
     return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))

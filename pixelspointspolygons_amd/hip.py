@@ -416,6 +416,20 @@ def argmax(x):
     return out
 
 
+def assignment(scores, maximize=True, want_perm=True):
+    """scipy.optimize.linear_sum_assignment per tile on the device -> (col4row int32 [B,N], perm fp32 [B,N,N] | None, status int32 [B])."""
+    B, N, N2 = scores.shape
+    if N != N2:
+        raise P3Error(f"p3_assignment: square score matrices only, got {tuple(scores.shape)}")
+    sc = scores.contiguous().float()
+    col = torch.empty((B, N), dtype=torch.int32, device=sc.device)
+    perm = torch.empty((B, N, N), dtype=torch.float32, device=sc.device) if want_perm else None
+    status = torch.empty(B, dtype=torch.int32, device=sc.device)
+    check(lib().p3_assignment(ptr(sc), c_int(B), c_int(N), c_int(1 if maximize else 0), ptr(col), ptr(perm), ptr(status), stream()),
+          "p3_assignment")
+    return col, perm, status
+
+
 def cast(a, dtype):
     out = torch.empty(a.shape, dtype=dtype, device=a.device)
     check(lib().p3_cast(ptr(a.contiguous()), c_int(dt(a)), ptr(out), c_int(dt(out)), c_int64(a.numel()), stream()), "p3_cast")

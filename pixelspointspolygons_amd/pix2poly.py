@@ -355,6 +355,11 @@ class EncoderDecoder(nn.Module):
         return self.decoder.predict(encoded_image, tgt)
 
     @torch.no_grad()
+    def permutations(self, features):
+        """inference tail of predictor_pix2poly.py:204-209: scorenet1(f) + scorenet2(f)^T -> Hungarian permutation matrices."""
+        return scores_to_permutations(self.perm_scores(features))
+
+    @torch.no_grad()
     def generate(self, encoded, steps=None, bos=None, use_cache=True):
         """Greedy decode (predictor_pix2poly.py:188-207 contract: softmax -> argmax).  use_cache=False reproduces the reference's
         loop literally (full `predict` pass per step); the default runs the same arithmetic incrementally over KV caches."""
@@ -375,6 +380,20 @@ class EncoderDecoder(nn.Module):
             logits, feats = self.decoder.predict(encoded, preds)
             preds = torch.cat([preds, hip.argmax(logits).view(B, 1)], dim=1)
         return preds, feats
+
+
+def scores_to_permutations(scores):
+    """Hungarian-optimal permutation matrices of a batch of score matrices (Predictor.scores_to_permutations,
+    predictor_pix2poly.py:307-319: scipy.optimize.linear_sum_assignment(-scores[b]) per tile on the host) solved on the device, one
+    wave per tile, bit-identical to scipy's solver incl. its tie rule.  Returns the 0/1 fp32 [B,N,N] tensor on the input's device
+    (the reference returns it on the CPU: call .cpu() where that matters); invalid scores raise like scipy does."""
+    _col, perm, status = hip.assignment(scores.detach(), maximize=True, want_perm=True)
+    st = status.cpu()
+    if bool((st == 1).any()):
+        raise ValueError("matrix contains invalid numeric entries")
+    if bool((st == 2).any()):
+        raise ValueError("cost matrix is infeasible")
+    return perm
 
 
 class Pix2PolyModel(torch.nn.Module):
