@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs)")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive leg (host uint8 tiles + point lists through the device input pipeline)")
     return ap.parse_args()
 
 
@@ -145,6 +146,38 @@ class Stepper:
                 self.fwd_out = run()
         self.fwd_graph.replay()
         return self.fwd_out
+
+
+def host_feed_leg(O, args, st, dev, kind, rank):
+    """PCIe-inclusive rate (never `value`): the same train step fed from HOST memory through pixelspointspolygons_amd.input_pipeline -
+    uint8 HWC tiles + untransformed point lists + a D4 element per tile packed into pinned staging, H2D + D4/Normalize kernels on a
+    copy stream overlapped with the previous step."""
+    import numpy as np
+    from pixelspointspolygons_amd.input_pipeline import DevicePrefetcher
+    host_pool = []
+    for s_ in range(args.pool):
+        inp = O.make_inputs(args.batch, seed=1234 + 1000 * rank + s_, n_points=args.points, jitter=args.points // 10)
+        hb = {"y": inp["y"], "y_perm": inp["y_perm"], "group": np.random.default_rng(s_).integers(0, 8, size=args.batch)}
+        if kind != "lidar":
+            hb["image"] = (inp["image"].permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8).contiguous()
+        if kind != "image":
+            off = inp["lidar_offsets"].tolist()
+            hb["lidar"] = [inp["lidar_values"][off[b]:off[b + 1]].numpy() for b in range(args.batch)]
+        host_pool.append(hb)
+    n_warm, n = 3, max(5, min(args.steps, 20))
+    pf = DevicePrefetcher((host_pool[i % len(host_pool)] for i in range(n_warm + n)), dev, max_points=int(args.batch * args.points * 1.5))
+    t0 = None
+    for i, b in enumerate(pf):
+        if i == n_warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        st.step(b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    img_mb = args.batch * 224 * 224 * 3 / 1e6 if kind != "lidar" else 0.0
+    return {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
+            "host_bytes_per_step_mb": round(img_mb + (args.batch * args.points * 12 / 1e6 if kind != "image" else 0.0) + args.batch * (386 * 8 + 192 * 192 * 4) / 1e6, 1),
+            "what": "uint8 HWC tiles + jagged points + tokens from pinned host memory, D4 + Normalize + HWC->CHW on the device, double buffered"}
 
 
 def cpu_baseline(O, args, kind):
@@ -289,6 +322,10 @@ def main():
         fwd_eval_ms = (time.perf_counter() - t1) / 5 * 1e3
         model.train()
 
+    feed = None
+    if world == 1 and not args.no_host_feed and not args.no_fwd:
+        feed = host_feed_leg(O, args, st, dev, kind, rank)
+
     # dominant-kernel timing with HIP events on the launch stream (instrumented steps, after the timed region)
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
@@ -340,6 +377,8 @@ def main():
             "final_loss": round(loss_val, 4),
             "roofline": roofline,
         }
+        if feed is not None:
+            line["pcie_inclusive"] = feed
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the host cores are shared by the ranks otherwise)
             line["cpu_baseline"] = cpu_baseline(O, args, kind)
         print(json.dumps(line), flush=True)

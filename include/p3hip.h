@@ -102,6 +102,8 @@ typedef struct {
     float bwd_scale;
     int aux_mode;         /* what `aux` receives: 0 = the pre-activation, 1 = act'(pre) (GELU: cdf + x*pdf, computed with the
                            * activation from the same erf / exp), so that backward is a multiply with no transcendental */
+    int conv_pad;         /* P3_A_CONV3X3: 1 = A is a zero-bordered image [B, conv_H+2, conv_W+2, lda] (p3_pad_nhwc): taps are read
+                           * without bounds checks; conv_H / conv_W stay the OUTPUT size */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 
@@ -348,6 +350,20 @@ int p3_pad_nhwc(const void* src, int ld_src, int dtype, const float* scale, cons
 int p3_upsample_bilinear_bwd(const void* dUp, int dtype, float* tmp, void* dtok, int B, int h, int w, int C, int H, int W, int tok_off,
                              int tok_per_img, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline on the device.  The reference augments per sample on CPU workers: albumentations
+ * D4(p=1) + Normalize + ToTensorV2 (datasets/build_datasets.py:53-75) and apply_d4_augmentations_to_lidar (datasets/p3_coco.py:115-164).
+ * group[b] in 0..7 = albumentations' D4 element of tile b: e, r90, r180, r270, v, hvt, h, t.
+ * ------------------------------------------------------------------------------------------ */
+/* src u8 [B,H,W,C] (HWC as rasterio/albumentations hold it) -> dst f32 [B,C,H,W] = ToTensorV2(Normalize(D4_g(img))):
+ * dst = ((float)px - sub[c]) * mul[c] with the HOST-side constants sub = mean*max_pixel_value, mul = 1/(std*max_pixel_value) (fp32).
+ * group may be NULL (no augmentation: validation / prediction). */
+int p3_image_prepare(const uint8_t* src, const int32_t* group, float* dst, int B, int H, int W, int C, const float* sub, const float* mul,
+                     void* stream);
+/* in-place D4 of the jagged point list values [total,3] (x, y, z) / offsets [B+1] around the centre (cx, cy) = (in_width // 2,
+ * in_height // 2): subtract centre, swap / negate as p3_coco.py:135-158, add centre - fp32, same operation order */
+int p3_points_d4(float* values, const int64_t* offsets, const int32_t* group, int B, int64_t total, float cx, float cy, void* stream);
 
 #ifdef __cplusplus
 }

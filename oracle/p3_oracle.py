@@ -454,6 +454,67 @@ def lsap_wave_order(cost, lanes=64):
     return col4row
 
 
+# ----------------------------------------------------------------------------------------------
+# Input pipeline (f-2): albumentations D4 + Normalize + ToTensorV2 (datasets/build_datasets.py:53-75), D4 of the points
+# (datasets/p3_coco.py:115-164).  albumentations itself is absent from the image ("parity unpinned vs albumentations"): its D4 is
+# restated from the published definition (geometric/functional.py `d4`: e, r90 = rot90(x,1), r180, r270 = rot90(x,3), v = vflip,
+# hvt = transpose(rot90(x,2)), h = hflip, t = transpose, on numpy arrays) and anchored on the reference's OWN point transform, which
+# must move a point with the pixel it lies on (tests/test_input_pipeline_cpu.py).
+# ----------------------------------------------------------------------------------------------
+D4_ELEMENTS = ("e", "r90", "r180", "r270", "v", "hvt", "h", "t")
+
+
+def d4_image(img_hwc, element):
+    x = np.asarray(img_hwc)
+    tr = lambda a: np.swapaxes(a, 0, 1)
+    return np.ascontiguousarray({"e": lambda a: a, "r90": lambda a: np.rot90(a, 1), "r180": lambda a: np.rot90(a, 2),
+                                 "r270": lambda a: np.rot90(a, 3), "v": lambda a: a[::-1], "hvt": lambda a: tr(np.rot90(a, 2)),
+                                 "h": lambda a: a[:, ::-1], "t": tr}[element](x))
+
+
+def normalize_to_tensor(img_hwc_u8, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0):
+    """A.Normalize + ToTensorV2: ((x - mean*max) * reciprocal(std*max)) in fp32, HWC -> CHW."""
+    C = img_hwc_u8.shape[-1]
+    m = np.array(mean[:C], dtype=np.float32) * np.float32(max_pixel_value)
+    d = np.reciprocal(np.array(std[:C], dtype=np.float32) * np.float32(max_pixel_value), dtype=np.float32)
+    x = img_hwc_u8.astype(np.float32)
+    x -= m
+    x *= d
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
+
+
+def d4_lidar(points, element, in_width=224, in_height=224):
+    """apply_d4_augmentations_to_lidar (datasets/p3_coco.py:127-164), statement for statement, on a float32 [n,3] array."""
+    lidar = np.array(points, dtype=np.float32, copy=True)
+    center = [in_width // 2, in_height // 2]
+    lidar[:, :2] -= center
+    if element == "e":
+        pass
+    elif element == "r90":
+        lidar[:, [0, 1]] = lidar[:, [1, 0]]
+        lidar[:, 1] = -lidar[:, 1]
+    elif element == "r180":
+        lidar[:, 0] = -lidar[:, 0]
+        lidar[:, 1] = -lidar[:, 1]
+    elif element == "r270":
+        lidar[:, [0, 1]] = lidar[:, [1, 0]]
+        lidar[:, 0] = -lidar[:, 0]
+    elif element == "v":
+        lidar[:, 1] = -lidar[:, 1]
+    elif element == "hvt":
+        lidar[:, [0, 1]] = lidar[:, [1, 0]]
+        lidar[:, 0] = -lidar[:, 0]
+        lidar[:, 1] = -lidar[:, 1]
+    elif element == "h":
+        lidar[:, 0] = -lidar[:, 0]
+    elif element == "t":
+        lidar[:, [0, 1]] = lidar[:, [1, 0]]
+    else:
+        raise ValueError(f"Unknown group element {element}")
+    lidar[:, :2] += center
+    return lidar
+
+
 def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
     x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
     return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))

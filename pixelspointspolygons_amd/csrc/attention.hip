@@ -353,6 +353,86 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
+// ---- decode step: ONE query per (batch, head) against a key/value cache (bf16) -------------------------------------------------
+// The tiled kernel above gives a 1-row problem a 128-query block that walks the keys 64 at a time through LDS: 13 dependent tile
+// round trips for the 784 memory tokens (r01: 17 us per call, x12 calls per decode step).  Here one 256-thread workgroup owns one
+// (b, h): every thread scores keys tid, tid + 256, ... with plain fp32 dot products (K rows are 64 / 128 contiguous bytes), the
+// softmax is one block-wide max + sum, and P V runs as 64 key slots x D/8 sixteen-byte channel chunks reduced through LDS.
+// fp32 probabilities (no bf16 rounding of P), so it differs from the tiled kernel in the last bf16 bit only.
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+    constexpr int CH = D / 8;                   // 16-byte chunks per row
+    constexpr int SLOTS = 256 / CH;             // key slots of the P V phase
+    const p3_attn_desc& d = a.d;
+    extern __shared__ float dsm[];
+    float* p = dsm;                             // [Lk] scores -> probabilities
+    float* red = dsm + ((d.Lk + 3) & ~3);       // [SLOTS][D] partial outputs, then scratch for the block reductions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / d.H, h = blockIdx.x - b * d.H;
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + (int64_t)b * d.q_bs + h * D;
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + (int64_t)b * d.k_bs + h * D;
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + (int64_t)b * d.v_bs + h * D;
+    float q[D];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(Qp + c * 8);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { q[c * 8 + 2 * i] = __uint_as_float(w[i] << 16); q[c * 8 + 2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
+    float mx = -INFINITY;
+    for (int j = tid; j < d.Lk; j += 256) {
+        const bf16_t* kr = Kp + (int64_t)j * d.k_rs;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(kr + c * 8);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s = fmaf(q[c * 8 + 2 * i], __uint_as_float(w[i] << 16), s);
+                s = fmaf(q[c * 8 + 2 * i + 1], __uint_as_float(w[i] & 0xffff0000u), s);
+            }
+        }
+        s = s * d.scale + (kbias ? kbias[j] : 0.f);
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < d.Lk; j += 256) { const float e = __expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();                            // everyone has read red[0..3]; the p[] writes are visible after the next barrier
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    __syncthreads();
+    // P V: thread = (key slot, channel chunk)
+    const int slot = tid / CH, ch = tid - slot * CH;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    for (int j = slot; j < d.Lk; j += SLOTS) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(Vp + (int64_t)j * d.v_rs + ch * 8);
+        const float pj = p[j];
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = fmaf(pj, __uint_as_float(w[i] << 16), o[2 * i]); o[2 * i + 1] = fmaf(pj, __uint_as_float(w[i] & 0xffff0000u), o[2 * i + 1]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[slot * D + ch * 8 + i] = o[i];
+    __syncthreads();
+    if (tid < D) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < SLOTS; ++sidx) acc += red[sidx * D + tid];
+        reinterpret_cast<bf16_t*>(a.O)[(int64_t)b * d.o_bs + h * D + tid] = f2bf(acc * inv);
+    }
+}
+
 extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream) {
     P3_CHECK(Q && K && V && O && d, P3_EINVAL, "p3_attention: null pointer");
     P3_CHECK(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0, P3_ESHAPE, "p3_attention: empty problem");
@@ -367,6 +447,15 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     hipStream_t s = (hipStream_t)stream;
     const bool drop = d->drop.seed != nullptr && d->drop.p > 0.f;
     P3_CHECK(!drop || d->drop.p < 1.f, P3_EINVAL, "p3_attention: dropout p must be < 1");
+    static int no_decode = -1;                        // P3_NO_SKINNY=1: A/B switch (tiled kernel for the 1-query problem too)
+    if (no_decode < 0) { const char* e = getenv("P3_NO_SKINNY"); no_decode = (e && e[0] == '1') ? 1 : 0; }
+    if (!no_decode && d->dtype == P3_BF16 && d->Lq == 1 && !d->causal && !drop && !d->lse && d->Lk <= 8192 && d->v_rs % 8 == 0 && d->v_bs % 8 == 0) {
+        const size_t lds = (size_t)(((d->Lk + 3) & ~3) + (256 / (d->head_dim / 8)) * d->head_dim) * sizeof(float);
+        if (d->head_dim == 64) hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(d->B * d->H), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<32>), dim3(d->B * d->H), dim3(256), lds, s, a);
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
 #define P3_ATTN_FWD(T, D)                                                                                   \
     do {                                                                                                    \
         if (drop) hipLaunchKernelGGL((attn_fwd_kernel<T, D, true>), grid, block, 0, s, a);                  \

@@ -50,7 +50,8 @@ __device__ __forceinline__ RowSrc make_row(const p3_gemm_desc& d, int gm) {
         int hw = d.conv_H * d.conv_W;
         int b = gm / hw, p = gm - b * hw;
         r.y = p / d.conv_W; r.x = p - r.y * d.conv_W;
-        r.img = (int64_t)b * hw * d.lda;
+        // zero-bordered source: image stride (H+2)(W+2) rows, origin moved to the first interior pixel
+        r.img = d.conv_pad ? ((int64_t)b * (d.conv_H + 2) * (d.conv_W + 2) + (d.conv_W + 2) + 1) * d.lda : (int64_t)b * hw * d.lda;
     } else if (AMODE == P3_A_PAIR_AFFINE_RELU) {
         int n = d.pair_n, nn = n * n;
         int b = gm / nn, p = gm - b * nn;
@@ -93,6 +94,7 @@ __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const
     if (AMODE == P3_A_CONV3X3 || AMODE == P3_A_CONV3X3_AFFINE_RELU) {
         int tap = k / d.conv_C, c = k - tap * d.conv_C;
         int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
+        if (d.conv_pad) return *reinterpret_cast<const uint4*>(A + r.img + (int64_t)(yy * (d.conv_W + 2) + xx) * d.lda + c);
         if ((yy >= 0) && (yy < d.conv_H) && (xx >= 0) && (xx < d.conv_W)) {
             raw = *reinterpret_cast<const uint4*>(A + r.img + (int64_t)(yy * d.conv_W + xx) * d.lda + c);
             if (AMODE == P3_A_CONV3X3_AFFINE_RELU) {   // BN + ReLU of the producer folded into the gather; zero padding stays zero
@@ -414,6 +416,89 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     }
 }
 
+// ---- skinny rows (M <= 128: the KV-cached decode step, one token per tile) -------------------------------------------------------
+// A 128x128 tile is mostly padding there and its LDS pipeline turns K = 2048 into 32 dependent global->LDS->MFMA round trips of one
+// or two workgroups (r01: 35 us for the decoder's linear2 at M = 64).  Here ONE WAVE owns a 32x32 output block and feeds the MFMA
+// straight from global memory (a lane's 16-byte operand chunk is exactly its fragment: row l31, k-offset 8*hi), eight K-steps of
+// loads in flight ahead of the MFMAs, no LDS, no barrier; N/32 x M/32 single-wave workgroups spread over the CUs.  Same instruction,
+// same k order and the same fp32 epilogue arithmetic as gemm_kernel => bit-identical outputs for K < 1024 (tests).
+template <typename TO, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_skinny_kernel(GemmArgs g) {
+    const p3_gemm_desc& d = g.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tn = blockIdx.x, tm = blockIdx.y;
+    const int ar = min(tm * 32 + l31, d.M - 1), wr = min(tn * 32 + l31, d.N - 1);
+    const bf16_t* ap = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)ar * d.lda + 8 * hi;
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (int64_t)wr * d.ldb + 8 * hi;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 8;
+    const int nk_all = d.K / 16;
+    // SPLIT > 1 (K >= 1024: the decoder's linear2): the waves of the workgroup take consecutive K ranges - a single wave cannot keep
+    // enough loads in flight to stream 32 x 4 KB of weights at memory latency (r01: 28 us at K = 2048) - and the partial sums are
+    // added in wave order through LDS (deterministic; fp32 rounding differs from the one-pass order in the last bits)
+    const int per = (nk_all + SPLIT - 1) / SPLIT;
+    const int kbeg = SPLIT > 1 ? wave * per : 0;
+    const int nk = SPLIT > 1 ? min(nk_all, kbeg + per) : nk_all;
+    uint4 a[2][U], b[2][U];
+    auto load = [&](int set, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < nk) {
+                a[set][u] = *reinterpret_cast<const uint4*>(ap + (k0 + u) * 16);
+                b[set][u] = *reinterpret_cast<const uint4*>(wp + (k0 + u) * 16);
+            }
+        }
+    };
+    auto mma = [&](int set, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < nk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), a[set][u]),
+                                                              __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), b[set][u]), acc, 0, 0, 0);
+        }
+    };
+    load(0, kbeg);
+    for (int k0 = kbeg; k0 < nk; k0 += 2 * U) {
+        load(1, k0 + U);
+        mma(0, k0);
+        load(0, k0 + 2 * U);
+        mma(1, k0 + U);
+    }
+    if constexpr (SPLIT > 1) {
+        __shared__ float part[SPLIT - 1][16][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < SPLIT - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += part[w][r][lane];
+    }
+    const int col = tn * 32 + l31;
+    if (col >= d.N) return;
+    const float bias = d.bias ? d.bias[col] : 0.f;
+    TO* C = reinterpret_cast<TO*>(g.C);
+    const bool res_bf = d.dtype_res == P3_BF16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tm * 32 + crow32(r, hi);
+        if (row >= d.M) continue;
+        float v = acc[r] + bias;
+        if (d.act == P3_ACT_GELU) v = gelu_erf(v);
+        else if (d.act == P3_ACT_RELU) v = fmaxf(v, 0.f);
+        if (d.residual) {
+            const int64_t ri = (int64_t)row * d.ldr + col;
+            v += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
+        }
+        C[(int64_t)row * d.ldc + col] = Cvt<TO>::from_f(v);
+    }
+}
+
 template <typename T, typename TO, int BKSEL, bool STATS>
 int launch_bk2(const GemmArgs& g, hipStream_t s) {
     const int ntiles = g.tiles_m * g.tiles_n;
@@ -470,6 +555,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     if (d->a_mode == P3_A_CONV3X3 || d->a_mode == P3_A_CONV3X3_AFFINE_RELU) {
         P3_CHECK(d->conv_C > 0 && d->conv_C % bk == 0 && d->K == 9 * d->conv_C, P3_ESHAPE, "p3_gemm: conv3x3 needs K == 9*C, C % BK == 0");
         P3_CHECK(d->M % (d->conv_H * d->conv_W) == 0, P3_ESHAPE, "p3_gemm: conv3x3 needs M == B*H*W");
+        P3_CHECK(!d->conv_pad || d->a_mode == P3_A_CONV3X3, P3_EINVAL, "p3_gemm: conv_pad goes with P3_A_CONV3X3 (the border must already hold zeros)");
     }
     if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU || d->a_mode == P3_A_CONV3X3_AFFINE_RELU)
         P3_CHECK(d->a_scale && d->a_shift, P3_EINVAL, "p3_gemm: affine mode needs a_scale/a_shift");
@@ -489,6 +575,21 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
+    static int no_skinny = -1;                        // P3_NO_SKINNY=1: A/B switch
+    if (no_skinny < 0) { const char* e = getenv("P3_NO_SKINNY"); no_skinny = (e && e[0] == '1') ? 1 : 0; }
+    if (!no_skinny && d->dtype_in == P3_BF16 && d->M <= 128 && d->a_mode == P3_A_PLAIN && !d->colsum && !d->aux && !d->bwd_saved &&
+        !(d->drop.seed && d->drop.p > 0.f)) {
+        dim3 grid(p3_ceil_div(d->N, 32), p3_ceil_div(d->M, 32));
+        if (d->K >= 1024) {
+            if (d->dtype_out == P3_BF16) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, 8>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<float, 8>), grid, dim3(512), 0, s, g);
+        } else {
+            if (d->dtype_out == P3_BF16) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, 1>), grid, dim3(64), 0, s, g);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<float, 1>), grid, dim3(64), 0, s, g);
+        }
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     if (d->dtype_in == P3_BF16) return d->dtype_out == P3_BF16 ? launch_mode<bf16_t, bf16_t>(g, s) : launch_mode<bf16_t, float>(g, s);
     return d->dtype_out == P3_BF16 ? launch_mode<float, bf16_t>(g, s) : launch_mode<float, float>(g, s);
 }

@@ -97,12 +97,12 @@ class GemmDesc(Structure):
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
                 ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout),
-                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int)]
+                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int), ("conv_pad", c_int)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False):
+         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p)."""
     _dev(a)
     N, K = w.shape
@@ -134,6 +134,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         d.aux_mode = 1 if aux_grad else 0          # aux receives act'(pre) instead of the pre-activation
     if conv is not None:
         d.conv_H, d.conv_W, d.conv_C = conv[1], conv[2], conv[3]
+        d.conv_pad = 1 if conv_pad else 0
     if a_scale is not None:
         d.a_scale, d.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
     if pair_v is not None:
@@ -428,6 +429,32 @@ def assignment(scores, maximize=True, want_perm=True):
     check(lib().p3_assignment(ptr(sc), c_int(B), c_int(N), c_int(1 if maximize else 0), ptr(col), ptr(perm), ptr(status), stream()),
           "p3_assignment")
     return col, perm, status
+
+
+def image_prepare(src_u8, group=None, sub=(0.0, 0.0, 0.0), mul=(1.0 / 255.0,) * 3, out=None):
+    """u8 [B,H,W,C] -> f32 [B,C,H,W] = ToTensorV2(Normalize(D4_group(img)));  group int32 [B] (0..7) or None."""
+    _dev(src_u8)
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4:
+        raise P3Error(f"image_prepare: expected uint8 [B,H,W,C], got {src_u8.dtype} {tuple(src_u8.shape)}")
+    B, H, W, C = src_u8.shape
+    src = src_u8.contiguous()
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+    subc = (c_float * 4)(*([float(v) for v in sub] + [0.0] * 4)[:4])
+    mulc = (c_float * 4)(*([float(v) for v in mul] + [1.0] * 4)[:4])
+    check(lib().p3_image_prepare(ptr(src), ptr(group), ptr(out), c_int(B), c_int(H), c_int(W), c_int(C), ctypes.cast(subc, c_void_p),
+                                 ctypes.cast(mulc, c_void_p), stream()), "p3_image_prepare")
+    return out
+
+
+def points_d4_(values, offsets, group, cx, cy):
+    """in-place D4 of a jagged point list (values [T,3] f32, offsets int64 [B+1]) around (cx, cy); group int32 [B]."""
+    _dev(values)
+    if values.dtype != torch.float32 or not values.is_contiguous() or values.shape[-1] != 3:
+        raise P3Error("points_d4_: values must be contiguous float32 [T, 3]")
+    check(lib().p3_points_d4(ptr(values), ptr(offsets), ptr(group), c_int(offsets.numel() - 1), c_int64(values.shape[0]), c_float(cx),
+                             c_float(cy), stream()), "p3_points_d4")
+    return values
 
 
 def cast(a, dtype):

@@ -1,0 +1,163 @@
+"""Host -> device input pipeline.
+
+The reference prepares every sample on CPU workers (datasets/p3_coco.py:340-436 -> albumentations D4 + Normalize + ToTensorV2,
+datasets/build_datasets.py:53-75; apply_d4_augmentations_to_lidar, p3_coco.py:115-164; collate_fn_pix2poly,
+datasets/collate_funcs.py:68-116) and ships fp32 NCHW images.  Here the host only decodes files and packs bytes:
+
+  host   : uint8 HWC tiles and the untransformed jagged point list go into one of two PINNED staging sets (a quarter of the image bytes
+           of the fp32 path over PCIe), the D4 element of every tile is drawn on the host (it also has to move the vertex
+           coordinates the tokenizer sees: `d4_keypoints`, the same pixel permutation as the image)
+  device : on a copy stream, overlapped with the previous step's compute: H2D, then `p3_image_prepare` (D4 + Normalize + HWC->CHW in
+           one pass) and `p3_points_d4` (the reference's fp32 point arithmetic); an event hands the batch to the compute stream.
+
+No CPU fallback: the kernels come from libp3hip.so, `prepare_images` / `d4_points_` raise without it.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+D4_ELEMENTS = ("e", "r90", "r180", "r270", "v", "hvt", "h", "t")      # albumentations' D4 group, index = the kernels' group id
+
+
+def normalize_constants(mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0):
+    """albumentations.Normalize's fp32 constants: sub = mean * max_pixel_value, mul = reciprocal(std * max_pixel_value)."""
+    m = np.array(mean, dtype=np.float32) * np.float32(max_pixel_value)
+    s = np.array(std, dtype=np.float32) * np.float32(max_pixel_value)
+    return m, np.reciprocal(s, dtype=np.float32)
+
+
+def prepare_images(images_u8, groups=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0, out=None):
+    """uint8 [B,H,W,C] on the device -> fp32 [B,C,H,W] = ToTensorV2(Normalize(D4(img))) (build_datasets.py:55-75 with the reference's
+    encoder config: mean 0, std 1, max 255).  groups: int32 [B] device tensor of D4 element ids, None = no augmentation."""
+    C = images_u8.shape[-1]
+    sub, mul = normalize_constants(mean[:C], std[:C], max_pixel_value)
+    return hip.image_prepare(images_u8, groups, sub.tolist(), mul.tolist(), out=out)
+
+
+def d4_points_(values, offsets, groups, in_width=224, in_height=224):
+    """apply_d4_augmentations_to_lidar (p3_coco.py:115-164) on the whole jagged batch, in place, on the device."""
+    return hip.points_d4_(values, offsets, groups, float(in_width // 2), float(in_height // 2))
+
+
+def d4_keypoints(coords_yx, element, height, width):
+    """Where D4 `element` moves integer pixel coordinates (y, x) - the image permutation of `p3_image_prepare` applied to vertex
+    coordinates (albumentations does this for the `keypoints=` of p3_coco.py:424 in 'yx' format).  Host side, numpy: <= 192 vertices."""
+    c = np.asarray(coords_yx)
+    if c.size == 0:
+        return c.copy()
+    y, x = c[..., 0], c[..., 1]
+    n_y, n_x = height - 1, width - 1
+    g = D4_ELEMENTS.index(element) if isinstance(element, str) else int(element)
+    ny, nx = {0: (y, x), 1: (n_x - x, y), 2: (n_y - y, n_x - x), 3: (x, n_y - y), 4: (n_y - y, x), 5: (n_x - x, n_y - y), 6: (y, n_x - x),
+              7: (x, y)}[g]
+    return np.stack([ny, nx], axis=-1)
+
+
+def pack_lidar(clouds, values_out=None, offsets_out=None):
+    """list of [n_i, 3] float32 arrays / tensors -> (values [sum n_i, 3], offsets int64 [B+1]) - the (values, offsets) pair of the
+    nested jagged tensor collate_fn_pix2poly builds (collate_funcs.py:110-112); writes into the given (pinned) buffers when passed."""
+    lens = [int(c.shape[0]) for c in clouds]
+    total = sum(lens)
+    offsets = torch.zeros(len(clouds) + 1, dtype=torch.int64) if offsets_out is None else offsets_out[: len(clouds) + 1]
+    offsets[0] = 0
+    offsets[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0)
+    if values_out is None:
+        values = torch.empty((total, 3), dtype=torch.float32)
+    else:
+        if values_out.shape[0] < total:
+            raise hip.P3Error(f"pack_lidar: staging buffer holds {values_out.shape[0]} points, batch has {total}")
+        values = values_out[:total]
+    o = 0
+    for c, n in zip(clouds, lens):
+        values[o:o + n].copy_(torch.as_tensor(c, dtype=torch.float32))
+        o += n
+    return values, offsets
+
+
+class DevicePrefetcher:
+    """Double-buffered host->device feeder.  Wraps an iterable of HOST batches (dicts):
+         "image"  uint8 [B,H,W,C] tensor / array (optional)       "lidar"  list of [n_i,3] float32 clouds (optional)
+         "group"  D4 element ids, int [B] (optional: augmentation)  anything else: tensors copied as they are (tokens, perm matrices)
+       and yields DEVICE batches {"image": fp32 [B,C,H,W], "lidar_values", "lidar_offsets", ...} ready for the model.
+       While batch k computes, batch k+1 is packed into the other pinned set, copied and prepared on `self.stream`."""
+
+    def __init__(self, batches, device, max_points=1 << 20, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0,
+                 in_width=224, in_height=224):
+        self.it = iter(batches)
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.norm = (mean, std, max_pixel_value)
+        self.size = (in_width, in_height)
+        self.max_points = max_points
+        self.sets = [dict(), dict()]
+        self.k = 0
+        self.next = None
+        self._preload()
+
+    def _pinned(self, s, key, shape, dtype):
+        buf = s.get(key)
+        if buf is None or buf.dtype != dtype or any(a < b for a, b in zip(buf.shape, shape)) or buf.dim() != len(shape):
+            buf = torch.empty(shape, dtype=dtype).pin_memory()
+            s[key] = buf
+        return buf[tuple(slice(0, n) for n in shape)]
+
+    def _preload(self):
+        try:
+            host = next(self.it)
+        except StopIteration:
+            self.next = None
+            return
+        s = self.sets[self.k]
+        self.k ^= 1
+        ev = s.get("_free")
+        if ev is not None:
+            ev.synchronize()                     # the copies that last read this pinned set are done
+        staged = {}
+        if host.get("image") is not None:
+            img = torch.as_tensor(host["image"])
+            staged["image"] = self._pinned(s, "image", tuple(img.shape), torch.uint8)
+            staged["image"].copy_(img)
+        if host.get("lidar") is not None:
+            vals = self._pinned(s, "lidar_values", (self.max_points, 3), torch.float32)
+            offs = self._pinned(s, "lidar_offsets", (len(host["lidar"]) + 1,), torch.int64)
+            staged["lidar_values"], staged["lidar_offsets"] = pack_lidar(host["lidar"], vals, offs)
+        if host.get("group") is not None:
+            g = torch.as_tensor(host["group"], dtype=torch.int32)
+            staged["group"] = self._pinned(s, "group", tuple(g.shape), torch.int32)
+            staged["group"].copy_(g)
+        for k, v in host.items():
+            if k in ("image", "lidar", "group") or v is None:
+                continue
+            t = torch.as_tensor(v)
+            staged[k] = self._pinned(s, k, tuple(t.shape), t.dtype)
+            staged[k].copy_(t)
+        out = {}
+        with torch.cuda.stream(self.stream):
+            dev = {k: v.to(self.device, non_blocking=True) for k, v in staged.items()}
+            grp = dev.get("group")
+            if "image" in dev:
+                out["image"] = prepare_images(dev["image"], grp, *self.norm)
+            if "lidar_values" in dev:
+                out["lidar_values"], out["lidar_offsets"] = dev["lidar_values"], dev["lidar_offsets"]
+                if grp is not None:
+                    d4_points_(out["lidar_values"], out["lidar_offsets"], grp, *self.size)
+            for k, v in dev.items():
+                if k not in ("image", "lidar_values", "lidar_offsets", "group"):
+                    out[k] = v
+            s["_free"] = torch.cuda.Event()
+            s["_free"].record(self.stream)
+        self.next = out
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.next is None:
+            raise StopIteration
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        batch = self.next
+        for v in batch.values():
+            v.record_stream(torch.cuda.current_stream(self.device))
+        self._preload()
+        return batch

@@ -264,51 +264,87 @@ class Decoder(nn.Module):
 
 
     @torch.no_grad()
-    def generate_cached(self, encoder_out, steps, bos):
+    def generate_cached(self, encoder_out, steps, bos, graphs=False):
         """Greedy decode with per-layer key/value caches: step t runs the decoder on ONE new position.
 
         Same arithmetic per (position, channel) as `predict`'s full re-run — the decoder is causal, GEMM / LayerNorm rows are
         independent and the attention kernels are lane-local per query — so the token sequence and the returned features are
         bit-identical to `steps` calls of `predict` (tests/test_model_gpu.py), at 1/385 of the decoder FLOPs.
+
+        graphs=True: a step is ~90 tiny launches and the loop is launch bound, so each step is captured ONCE into its own hipGraph
+        over static buffers (caches, token buffer, key-padding bias) and replayed afterwards: the first call with a given (batch,
+        steps, weights) runs eagerly (it also warms the compute-dtype weight copies), the second captures, later calls only replay
+        `steps` graphs.  Same kernels on the same buffers: identical results.  A weight update / reload drops the graphs.
         Returns (tokens [B, steps + 1] incl. BOS, features [B, steps, D])."""
-        cd, D, H = self.cd, self.dim, self.num_heads
+        cd, D = self.cd, self.dim
         B, dev = encoder_out.shape[0], encoder_out.device
         if steps > self.max_len - 1:
             raise hip.P3Error(f"generate: {steps} steps exceed the positional table ({self.max_len - 1})")
-        scale = 1.0 / math.sqrt(D // H)
         layers = self.decoder.layers
+        sig = (B, steps, str(dev), cd, tuple(encoder_out.shape[1:]), ops._epoch[0], tuple(p._version for p in self.parameters()),
+               tuple(p.data_ptr() for p in self.parameters()))
+        st = getattr(self, "_decode_state", None)
+        if st is None or st["sig"] != sig:
+            st = dict(sig=sig, warm=False, graphs=None, steps=steps, bos=bos,
+                      kv_mem=[torch.empty((B, encoder_out.shape[1], 2 * D), dtype=cd, device=dev) for _ in layers],
+                      kv_self=[torch.empty((B, steps, 3 * D), dtype=cd, device=dev) for _ in layers],   # packed q|k|v row per position
+                      kb=torch.zeros((B, steps), dtype=torch.float32, device=dev),
+                      feats=torch.empty((B, steps, D), dtype=cd, device=dev),
+                      preds=torch.empty((B, steps + 1), dtype=torch.long, device=dev))
+            self._decode_state = st if graphs else None      # static buffers are only worth keeping for the graph path
         enc = encoder_out if encoder_out.dtype == cd else hip.cast(encoder_out.contiguous(), cd)
         mem = hip.add_pos(enc.contiguous(), self.encoder_pos_embed.detach().reshape(-1, D))
-        kv_mem = [ops.linear(mem, l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias, cd=cd, rows=(D, 3 * D)) for l in layers]
-        kv_self = [torch.empty((B, steps, 2 * D), dtype=cd, device=dev) for _ in layers]
-        kb = torch.zeros((B, steps), dtype=torch.float32, device=dev)
-        feats = torch.empty((B, steps, D), dtype=cd, device=dev)
-        preds = torch.full((B, steps + 1), self.pad_idx, dtype=torch.long, device=dev)
-        preds[:, 0] = bos
+        for li, l in enumerate(layers):
+            st["kv_mem"][li].copy_(ops.linear(mem, l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias, cd=cd, rows=(D, 3 * D)))
+        st["preds"].fill_(self.pad_idx)
+        st["preds"][:, 0] = bos
+        st["kb"].zero_()
+        if not graphs or not st["warm"]:
+            for t in range(steps):
+                self._decode_step(st, t)
+            st["warm"] = True
+        else:
+            if st["graphs"] is None:
+                torch.cuda.synchronize()
+                pool, gs = torch.cuda.graph_pool_handle(), []
+                for t in range(steps):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        self._decode_step(st, t)
+                    gs.append(g)
+                st["graphs"] = gs
+            for g in st["graphs"]:
+                g.replay()
+        if graphs:
+            return st["preds"].clone(), st["feats"].clone()
+        return st["preds"], st["feats"]
+
+    def _decode_step(self, st, t):
+        cd, D, H = self.cd, self.dim, self.num_heads
+        scale = 1.0 / math.sqrt(D // H)
+        preds, kb, kv_self, kv_mem, feats = st["preds"], st["kb"], st["kv_self"], st["kv_mem"], st["feats"]
         emb = self.embedding.weight.detach()
         pos = self.decoder_pos_embed.detach().reshape(-1, D)
-        for t in range(steps):
-            x, kbt = hip.embed_tokens(preds[:, t:t + 1].contiguous(), emb, pos[t:t + 1], self.pad_idx, cd)      # [B,1,D], [B,1]
-            kb[:, t:t + 1] = kbt
-            kbc = kb[:, :t + 1].contiguous()
-            for li, lyr in enumerate(layers):
-                sa, ca = lyr.self_attn, lyr.multihead_attn
-                qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)                                  # [B,1,3D]
-                kv_self[li][:, t] = qkv[:, 0, D:]
-                a = hip.attention(qkv[..., :D], kv_self[li][:, :t + 1, :D], kv_self[li][:, :t + 1, D:], H, scale, key_bias=kbc)
-                y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
-                x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
-                q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
-                a = hip.attention(q, kv_mem[li][..., :D], kv_mem[li][..., D:], H, scale)
-                y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
-                x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
-                y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
-                            out_dtype=torch.float32, cd=cd)
-                x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
-            feats[:, t] = x[:, 0]
-            logits = ops.linear(x[:, 0, :], self.output.weight, self.output.bias, out_dtype=torch.float32, cd=cd)
-            preds[:, t + 1] = hip.argmax(logits)
-        return preds, feats
+        x, kbt = hip.embed_tokens(preds[:, t:t + 1].contiguous(), emb, pos[t:t + 1], self.pad_idx, cd)      # [B,1,D], [B,1]
+        kb[:, t:t + 1] = kbt
+        kbc = kb[:, :t + 1].contiguous()
+        for li, lyr in enumerate(self.decoder.layers):
+            sa, ca = lyr.self_attn, lyr.multihead_attn
+            c = kv_self[li]                                    # the in_proj GEMM writes its [B, 3D] row straight into the cache
+            hip.gemm(x.view(-1, D), ops.shadow(sa.in_proj_weight, cd), bias=sa.in_proj_bias.detach(), out=c[:, t])
+            a = hip.attention(c[:, t:t + 1, :D], c[:, :t + 1, D:2 * D], c[:, :t + 1, 2 * D:], H, scale, key_bias=kbc)
+            y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
+            q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
+            a = hip.attention(q, kv_mem[li][..., :D], kv_mem[li][..., D:], H, scale)
+            y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
+            y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
+                        out_dtype=torch.float32, cd=cd)
+            x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
+        feats[:, t] = x[:, 0]
+        logits = ops.linear(x[:, 0, :], self.output.weight, self.output.bias, out_dtype=torch.float32, cd=cd)
+        preds[:, t + 1] = hip.argmax(logits)
 
 
 # ------------------------------------------------------------------------------------------------ EncoderDecoder
@@ -360,7 +396,7 @@ class EncoderDecoder(nn.Module):
         return scores_to_permutations(self.perm_scores(features))
 
     @torch.no_grad()
-    def generate(self, encoded, steps=None, bos=None, use_cache=True):
+    def generate(self, encoded, steps=None, bos=None, use_cache=True, graphs=False):
         """Greedy decode (predictor_pix2poly.py:188-207 contract: softmax -> argmax).  use_cache=False reproduces the reference's
         loop literally (full `predict` pass per step); the default runs the same arithmetic incrementally over KV caches."""
         tk = self.cfg.experiment.model.tokenizer
@@ -371,7 +407,7 @@ class EncoderDecoder(nn.Module):
             was_training = self.decoder.training
             self.decoder.eval()
             try:
-                return self.decoder.generate_cached(encoded, steps, bos)
+                return self.decoder.generate_cached(encoded, steps, bos, graphs=graphs)
             finally:
                 self.decoder.train(was_training)
         preds = torch.full((B, 1), bos, dtype=torch.long, device=encoded.device)

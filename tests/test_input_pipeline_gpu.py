@@ -1,0 +1,92 @@
+"""f-2: device-side D4 + Normalize + HWC->CHW of the image batch and D4 of the jagged point list are bit-exact against the oracle's
+restatement of the reference's per-sample CPU pipeline; the double-buffered prefetcher yields the same batches."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import p3_oracle as O
+from pixelspointspolygons_amd.input_pipeline import D4_ELEMENTS, DevicePrefetcher, d4_points_, pack_lidar, prepare_images
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tiles(B, n, C, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(B, n, n, C), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("n,C", [(224, 3), (32, 1), (7, 4)])
+def test_image_prepare_all_elements_bit_exact(n, C):
+    img = _tiles(8, n, C, 1)
+    groups = torch.arange(8, dtype=torch.int32)
+    got = prepare_images(torch.from_numpy(img).to(DEV), groups.to(DEV)).cpu()
+    assert got.shape == (8, C, n, n) and got.dtype == torch.float32
+    for b, e in enumerate(D4_ELEMENTS):
+        assert torch.equal(got[b], O.normalize_to_tensor(O.d4_image(img[b], e))), e
+
+
+def test_image_prepare_without_augmentation_and_with_imagenet_constants():
+    img = _tiles(3, 224, 3, 2)
+    got = prepare_images(torch.from_numpy(img).to(DEV)).cpu()
+    for b in range(3):
+        assert torch.equal(got[b], O.normalize_to_tensor(img[b]))
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    got = prepare_images(torch.from_numpy(img).to(DEV), None, mean, std).cpu()
+    want = torch.stack([O.normalize_to_tensor(img[b], mean, std) for b in range(3)])
+    assert torch.equal(got, want)
+    rect = torch.zeros(2, 8, 12, 3, dtype=torch.uint8, device=DEV)
+    assert prepare_images(rect).shape == (2, 3, 8, 12)
+    from pixelspointspolygons_amd._lib import P3Error
+    with pytest.raises(P3Error):
+        prepare_images(rect, torch.zeros(2, dtype=torch.int32, device=DEV))      # D4 needs square tiles
+    with pytest.raises(P3Error):
+        prepare_images(rect.float())
+
+
+def test_points_d4_bit_exact_vs_reference_arithmetic():
+    rng = np.random.default_rng(3)
+    clouds = [(rng.random((n, 3)) * np.array([224.0, 224.0, 100.0])).astype(np.float32) for n in (3000, 0, 1, 2711, 3333, 64, 5, 999)]
+    values, offsets = pack_lidar(clouds)
+    groups = torch.tensor([1, 2, 3, 4, 5, 6, 7, 0], dtype=torch.int32)
+    dv = values.to(DEV)
+    d4_points_(dv, offsets.to(DEV), groups.to(DEV))
+    want = np.concatenate([O.d4_lidar(c, D4_ELEMENTS[int(g)]) for c, g in zip(clouds, groups)])
+    assert np.array_equal(dv.cpu().numpy(), want)
+    empty = torch.zeros(0, 3, device=DEV)
+    d4_points_(empty, torch.zeros(3, dtype=torch.int64, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV))
+
+
+def test_prefetcher_yields_prepared_batches_in_order():
+    rng = np.random.default_rng(4)
+    host = []
+    for k in range(5):
+        B = 4
+        host.append({"image": torch.from_numpy(_tiles(B, 224, 3, 10 + k)),
+                     "lidar": [(rng.random((int(n), 3)) * 224.0).astype(np.float32) for n in rng.integers(1, 3000, size=B)],
+                     "group": rng.integers(0, 8, size=B),
+                     "y": torch.from_numpy(rng.integers(0, 227, size=(B, 386))), "y_perm": torch.rand(B, 192, 192)})
+    got = list(DevicePrefetcher(iter(host), DEV, max_points=16384))
+    assert len(got) == 5
+    for h, d in zip(host, got):
+        torch.cuda.synchronize()
+        for b in range(4):
+            e = D4_ELEMENTS[int(h["group"][b])]
+            assert torch.equal(d["image"][b].cpu(), O.normalize_to_tensor(O.d4_image(h["image"][b].numpy(), e)))
+        want = np.concatenate([O.d4_lidar(c, D4_ELEMENTS[int(g)]) for c, g in zip(h["lidar"], h["group"])])
+        assert np.array_equal(d["lidar_values"].cpu().numpy(), want)
+        assert torch.equal(d["lidar_offsets"].cpu(), pack_lidar(h["lidar"])[1])
+        assert torch.equal(d["y"].cpu(), h["y"]) and torch.equal(d["y_perm"].cpu(), h["y_perm"])
+
+
+def test_prefetched_batch_feeds_the_model():
+    """the prepared batch is what the nn.Module API takes: fp32 NCHW image + (values, offsets) point list."""
+    from tests.test_model_gpu import _model
+    m, cfg = _model("fusion", "bf16", O.make_state_dict("fusion", seed=42))
+    inp = O.make_inputs(2, seed=9)
+    img_u8 = (inp["image"].permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8)
+    clouds = [inp["lidar_values"][inp["lidar_offsets"][b]:inp["lidar_offsets"][b + 1]].numpy() for b in range(2)]
+    batch = next(DevicePrefetcher(iter([{"image": img_u8, "lidar": clouds, "y": inp["y"]}]), DEV, max_points=8192))
+    with torch.no_grad():
+        logits, perm = m(batch["image"], (batch["lidar_values"], batch["lidar_offsets"]), batch["y"][:, :-1])
+        ref_logits, _ = m(prepare_images(img_u8.to(DEV)), (inp["lidar_values"].to(DEV), inp["lidar_offsets"].to(DEV)), inp["y"][:, :-1].to(DEV))
+    assert torch.equal(logits, ref_logits) and torch.isfinite(perm).all()

@@ -258,6 +258,29 @@ def test_kv_cached_generate_full_model(precision):
         assert torch.equal(toks[:, :13].cpu(), ref)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replayed_decode_equals_eager_decode(precision):
+    """generate(graphs=True): call 1 eager, call 2 captures one hipGraph per step, call 3+ only replays — tokens and features equal
+    the eager KV-cache path on every call, also when the encoder features change between calls and after a weight update."""
+    sd = O.make_state_dict("image", seed=42)
+    m, cfg = _model("image", precision, sd)
+    steps = 40
+    with torch.no_grad():
+        encs = [m.encoder(O.make_inputs(3, seed=s)["image"].to(DEV)) for s in (1, 2, 3, 4)]
+        want = [m.generate(e, steps=steps) for e in encs]
+        want = [(t.clone(), f.clone()) for t, f in want]
+        for call, e in enumerate(encs):
+            toks, feats = m.generate(e, steps=steps, graphs=True)
+            assert torch.equal(toks, want[call][0]) and torch.equal(feats, want[call][1]), call
+        assert m.decoder._decode_state["graphs"] is not None and len(m.decoder._decode_state["graphs"]) == steps
+        b1 = m.decoder.decoder.layers[0].linear1.bias
+        b1.data.add_(torch.randn_like(b1) * 0.5)                                            # weights changed: graphs must go
+        ref = m.generate(encs[0], steps=steps)
+        got = m.generate(encs[0], steps=steps, graphs=True)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert not torch.equal(ref[1], want[0][1])
+
+
 def test_lidar_only_model_accepts_all_three_lidar_input_forms():
     """nested jagged tensor (the reference's collate output), (values, offsets) pair (bench.py) and dense [B, N, 3]."""
     sd = O.make_state_dict("lidar", seed=42)

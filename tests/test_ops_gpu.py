@@ -207,3 +207,50 @@ def test_attention_dropout_bits_path_equals_hash_path():
     ones = sum(int(((w >> j) & 1).sum()) for j in range(32))
     frac = ones / (B * H * Lq * ((Lk + 31) // 32) * 32)
     assert abs(frac - 0.75) < 0.02
+
+
+# ------------------------------------------------------------------ decode-step kernels (M <= 128 GEMM, 1-query attention)
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (64, 768, 256), (64, 2048, 256), (64, 256, 2048), (3, 227, 256), (128, 96, 32), (33, 40, 1536)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_skinny_gemm_is_bit_identical_to_the_tiled_kernel(M, N, K, out_dtype):
+    """p3_gemm takes the one-wave-per-32x32-block kernel for M <= 128; same MFMA, same k order, same epilogue arithmetic as the
+    128x128 kernel (K < 1024; above, K is split over 8 waves), which is what the SAME rows give inside a taller problem."""
+    h = _h()
+    a = _rand(M, K, seed=11).to(DEV).bfloat16()
+    w = (_rand(N, K, seed=12, scale=0.2)).to(DEV).bfloat16()
+    bias = _rand(N, seed=13).to(DEV)
+    tall = torch.cat([a, a, a, _rand(129, K, seed=14).to(DEV).bfloat16()], 0)
+    for act in (h.ACT_NONE, h.ACT_RELU, h.ACT_GELU):
+        for res_dtype in (None, torch.float32, torch.bfloat16):
+            res = _rand(M, N, seed=15).to(DEV).to(res_dtype) if res_dtype is not None else None
+            res_tall = torch.cat([res, res, res, torch.zeros(129, N, device=DEV, dtype=res_dtype)], 0) if res is not None else None
+            got = h.gemm(a, w, bias=bias, act=act, residual=res, out_dtype=out_dtype)
+            want = h.gemm(tall, w, bias=bias, act=act, residual=res_tall, out_dtype=out_dtype)[:M]
+            if K < 1024:
+                assert torch.equal(got, want), (act, res_dtype)
+            else:                                   # K >= 1024: 8-way split over K, partial sums added in wave order
+                assert rel_err(got.float(), want.float()) < (1e-5 if out_dtype == torch.float32 else 8e-3), (act, res_dtype)
+    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    assert rel_err(h.gemm(a, w, bias=bias, out_dtype=torch.float32).cpu(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,D,Lk,bias", [(64, 8, 32, 784, False), (64, 8, 32, 1, True), (5, 8, 32, 385, True), (3, 6, 64, 785, False),
+                                            (2, 8, 32, 257, True), (1, 1, 32, 4000, False)])
+def test_decode_attention_one_query_vs_fp32_reference(B, H, D, Lk, bias):
+    """Lq = 1 (KV-cached decode step) takes attn_decode_kernel: fp32 softmax over bf16 Q/K/V, against torch in fp32."""
+    h = _h()
+    E = H * D
+    q = _rand(B, 1, E, seed=21).to(DEV).bfloat16()
+    kv = _rand(B, Lk, 2 * E, seed=22).to(DEV).bfloat16()
+    kb = (torch.rand(B, Lk, generator=torch.Generator().manual_seed(23)) < 0.2).float().to(DEV) if bias else None
+    scale = 1.0 / math.sqrt(D)
+    out = h.attention(q, kv[..., :E], kv[..., E:], H, scale, key_bias=kb)
+    qf = q.float().view(B, 1, H, D).transpose(1, 2)
+    kf = kv[..., :E].float().reshape(B, Lk, H, D).transpose(1, 2)
+    vf = kv[..., E:].float().reshape(B, Lk, H, D).transpose(1, 2)
+    sc = qf @ kf.transpose(-1, -2) * scale
+    if kb is not None:
+        sc = sc + kb[:, None, None, :]
+    ref = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B, 1, E)
+    assert out.shape == (B, 1, E) and out.dtype == torch.bfloat16
+    assert rel_err(out.float().cpu(), ref.cpu()) < 8e-3          # bf16 output rounding
