@@ -475,8 +475,9 @@ def d4_image(img_hwc, element):
 def normalize_to_tensor(img_hwc_u8, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0):
     """A.Normalize + ToTensorV2: ((x - mean*max) * reciprocal(std*max)) in fp32, HWC -> CHW."""
     C = img_hwc_u8.shape[-1]
-    m = np.array(mean[:C], dtype=np.float32) * np.float32(max_pixel_value)
-    d = np.reciprocal(np.array(std[:C], dtype=np.float32) * np.float32(max_pixel_value), dtype=np.float32)
+    mean, std = (tuple(mean) + (0.0,) * C)[:C], (tuple(std) + (1.0,) * C)[:C]
+    m = np.array(mean, dtype=np.float32) * np.float32(max_pixel_value)
+    d = np.reciprocal(np.array(std, dtype=np.float32) * np.float32(max_pixel_value), dtype=np.float32)
     x = img_hwc_u8.astype(np.float32)
     x -= m
     x *= d

@@ -256,6 +256,38 @@ __global__ void pad_nhwc_kernel(const T* __restrict__ src, int ld_src, const flo
     }
 }
 
+// bf16, 8-channel (16-byte) form: one pass over the WHOLE destination, every element written once (zero border, interior, zero channel
+// padding) - the scalar form above pays a 2 GB memset plus 2-byte accesses on the bs-64 FFL maps (1.5 ms; this one moves 3.7 GB)
+__global__ __launch_bounds__(256) void pad_nhwc_vec_kernel(const bf16_t* __restrict__ src, int ld_src, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                           int c_aff, int C, int Cp, bf16_t* __restrict__ dst, int B, int H, int W) {
+    const int Cq = Cp / 8, P = W + 2;
+    const int64_t total = (int64_t)B * (H + 2) * P * Cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cq) * 8;
+        const int64_t pp = i / Cq;
+        const int xp = (int)(pp % P), yp = (int)((pp / P) % (H + 2));
+        const int64_t b = pp / ((int64_t)P * (H + 2));
+        uint4 out = make_uint4(0, 0, 0, 0);
+        if (xp >= 1 && xp <= W && yp >= 1 && yp <= H && c < C) {
+            const int64_t pix = (b * H + (yp - 1)) * W + (xp - 1);
+            out = *reinterpret_cast<const uint4*>(src + pix * ld_src + c);
+            if (sc && c < c_aff) {
+                const uint32_t w[4] = {out.x, out.y, out.z, out.w};
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+                const float4 s0 = *reinterpret_cast<const float4*>(sc + c), s1 = *reinterpret_cast<const float4*>(sc + c + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(sh + c), h1 = *reinterpret_cast<const float4*>(sh + c + 4);
+                const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * ss[k] + hh[k], 0.f);
+                out = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            }
+        }
+        *reinterpret_cast<uint4*>(dst + i * 8) = out;
+    }
+}
+
 // Adjoint of upsample_bilinear, separable: pass X folds the W output columns onto the w source columns, pass Y the H rows onto h.
 // Exactly the forward's index / weight rule, gathered per source cell (deterministic, no atomics).
 __device__ __forceinline__ float bilinear_weight(int o, int srcn, int outn, int cell) {
@@ -393,6 +425,14 @@ extern "C" int p3_pad_nhwc(const void* src, int ld_src, int dtype, const float* 
     P3_CHECK((scale == nullptr) == (shift == nullptr), P3_EINVAL, "p3_pad_nhwc: scale and shift go together");
     P3_CHECK(dtype == P3_BF16 || dtype == P3_F32, P3_EUNSUP, "p3_pad_nhwc: dtype");
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == P3_BF16 && C % 8 == 0 && c_aff % 8 == 0 && Cp % 8 == 0 && ld_src % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
+        (!scale || (((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0))) {
+        const int64_t tot = (int64_t)B * (H + 2) * (W + 2) * (Cp / 8);
+        int64_t g = (tot + 255) / 256; if (g > 65536) g = 65536;
+        hipLaunchKernelGGL(pad_nhwc_vec_kernel, dim3((int)g), dim3(256), 0, s, (const bf16_t*)src, ld_src, scale, shift, c_aff, C, Cp, (bf16_t*)dst, B, H, W);
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     const size_t es = dtype == P3_BF16 ? 2 : 4;
     hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * (H + 2) * (W + 2) * Cp * es, s);
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }

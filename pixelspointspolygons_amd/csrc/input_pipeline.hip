@@ -45,8 +45,7 @@ __global__ __launch_bounds__(256) void points_d4_kernel(float* __restrict__ valu
     if (t >= total) return;
     int lo = 0, hi = B;                                   // tile b with offsets[b] <= t < offsets[b + 1]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= t) lo = mid; else hi = mid; }
-    const int g = group[lo];
-    if (g == 0) return;
+    const int g = group[lo];                             // 'e' still takes the centre round trip, (x - c) + c, as the reference does
     float x = values[t * 3] - cx, y = values[t * 3 + 1] - cy;
     float nx = x, ny = y;
     switch (g) {                                          // p3_coco.py:135-158

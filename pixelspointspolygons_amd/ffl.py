@@ -2,9 +2,10 @@
 models/{vision_transformer/vit_cnn.py, pointpillars/pointpillars_vit_cnn.py, fusion_layers/early_fusion_vit_cnn.py}.
 
 Data flow on the device (never the reference's NCHW round trips): LN'd ViT tokens -> bilinear x8 upsample written as an NHWC map ->
-3x3 conv as implicit GEMM (BatchNorm statistics in the epilogue) into a [B*H*W, 320]-strided feature buffer whose channel 256 later
-receives the detached seg map (the reference's torch.cat(features, seg)); the BN+ReLU of every producer is folded into the A-tile loader
-of its consumer (P3_A_CONV3X3_AFFINE_RELU), so no post-activation map is ever materialised.
+3x3 conv as implicit GEMM (BatchNorm statistics in the epilogue) -> ONE zero-bordered NHWC image of relu(bn(.)) with row stride LDF whose
+channel 256 later receives the detached seg map (the reference's torch.cat(features, seg)).  Both head convolutions gather from that
+image without bounds checks (p3_gemm conv_pad) and the backward's weight-gradient GEMMs read the same image; the heads' own BN + ReLU
+is folded into the 1x1 head kernels.
 Training: `_FFLTail` (autograd.Function) covers tokens -> {seg, crossfield} with a hand-written backward (head / BatchNorm / 3x3 conv
 weight + input gradients on the MFMA GEMMs / adjoint of the bilinear upsample); the encoders' own NCHW `forward` stays forward-only.
 """
@@ -17,7 +18,8 @@ from .fusion_layers import EarlyFusionViT
 from .pointpillars import PointPillarsViT
 from .vision_transformer import ViT, compute_dtype
 
-LDF = 320   # feature buffer row stride: 256 features + 1 seg channel, padded to a multiple of the GEMM's 64-wide K slice
+import os
+LDF = int(os.environ.get("P3_FFL_LDF", "320"))   # row stride of the padded conv-input image: 256 features + 1 seg channel, padded to a multiple of the GEMM's K slice (A/B: 288)
 
 
 def _khwc(w, cpad=None):
@@ -57,7 +59,7 @@ class _CNNTailMixin:
             raise NotImplementedError("HIP FFL heads are specialised for in_feature_dim = 256 (config/model/ffl.yaml at 224 px)")
 
     def features_nhwc(self, tokens, keep=None):
-        """LN'd tokens [B, 1+g*g, D] -> (buf [B*H*W, LDF] with the PRE-BatchNorm conv output in channels 0..255, scale, shift).
+        """LN'd tokens [B, 1+g*g, D] -> (buf [B*H*W, 256] = the PRE-BatchNorm conv output, scale, shift).
         keep (dict): also store what the backward needs (upsampled map, BatchNorm mean / rstd)."""
         B, _, D = tokens.shape
         H = W = self.out_size
@@ -66,11 +68,10 @@ class _CNNTailMixin:
         training = self.training
         up = torch.empty((B, H, W, D), dtype=cd, device=tokens.device)
         hip.upsample_bilinear(tokens.contiguous(), B, self.grid, self.grid, H, W, up)
-        buf = torch.empty((B * H * W, LDF), dtype=cd, device=tokens.device)
-        buf[:, 256:].zero_()
+        buf = torch.empty((B * H * W, 256), dtype=cd, device=tokens.device)
         w2 = ops.shadow(conv.weight, cd, key="khwc", fn=_khwc)
         sums = torch.zeros(512, dtype=torch.float32, device=tokens.device) if training else None
-        hip.gemm(up.view(-1, D), w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, W, D), lda=D, out=buf[:, :256],
+        hip.gemm(up.view(-1, D), w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, W, D), lda=D, out=buf,
                  colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
         if keep is not None:
             sc, sh, mean, rstd = _bn_affine(sums, float(B * H * W), bn, training, save=True)
@@ -82,7 +83,7 @@ class _CNNTailMixin:
     def _nchw(self, tokens):
         buf, sc, sh = self.features_nhwc(tokens)
         B, H = tokens.shape[0], self.out_size
-        return hip.nhwc_to_nchw(buf, LDF, sc, sh, B, 256, H * H).view(B, 256, H, H)
+        return hip.nhwc_to_nchw(buf, 256, sc, sh, B, 256, H * H).view(B, 256, H, H)
 
 
 class ViTCNN(ViT, _CNNTailMixin):
@@ -179,8 +180,7 @@ class _FFLTail(torch.autograd.Function):
         zeros = lambda t: torch.zeros_like(t)
         dseg = zeros(k["seg_out"]) if dseg is None else dseg.contiguous().float()
         dcf = zeros(k["cf_out"]) if dcf is None else dcf.contiguous().float()
-        # zero-bordered image of the conv inputs: channels 0..255 relu(bn(P)), channel 256 the (detached) seg map
-        Xpad = hip.pad_nhwc(buf, LDF, scP, shP, 256, 257, LDF, B, H, H)
+        Xpad = k["xpad"]          # zero-bordered image of the conv inputs (forward): channels 0..255 relu(bn(P)), channel 256 the seg map
         # ---- crossfield branch
         dC1, acc = hip.head1x1_bwd(C1, scC, shC, mC, chead.weight.detach().reshape(4, 256).contiguous(), k["cf_out"], dcf, 1, 2.0, B, HW)
         g_chw, g_chb = acc[512:512 + 1024].view(4, 256, 1, 1), acc[1536:1540]
@@ -202,10 +202,10 @@ class _FFLTail(torch.autograd.Function):
         g_sconv_w = dWs.permute(0, 3, 1, 2).contiguous()
         del dS1, Xpad
         # ---- through BatchNorm + ReLU of proj, then the proj conv and the upsample
-        dP, acc = hip.affine_relu_bwd256(dA, buf, LDF, scP, shP, mP, R)
+        dP, acc = hip.affine_relu_bwd256(dA, buf, 256, scP, shP, mP, R)
         g_pbn_w, g_pbn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], pbn.weight.detach(), mP, rP, cnt, training)
         if training:
-            hip.affine_fix(dP, buf, a_, b_, ldh=LDF)
+            hip.affine_fix(dP, buf, a_, b_, ldh=256)
         g_pconv_b = ops.bias_grad_before_bn(dP, training)
         Upad = hip.pad_nhwc(up, D, None, None, 0, D, D, B, H, H)
         dWp, dUp = _conv3x3_bwd(dP, Upad, D, D, pconv.weight, cd, B, H, D, "flipT")
@@ -246,25 +246,28 @@ class EncoderDecoder(nn.Module):
         outputs = {}
         cnt = float(B * HW)
         save = keep is not None
+        # the conv input of both heads, materialised ONCE: zero-bordered image [B, H+2, H+2, LDF] of relu(bn(P)) (channels 0..255), the
+        # detached seg map (channel 256, filled in below) and zero padding up to LDF.  The heads' implicit-GEMM gathers then read plain
+        # bf16 without bounds checks (folding BN + ReLU into the gather cost 2.2x per conv: 10.0 vs 4.5 ms at bs 64, r01) and the
+        # backward's shifted-row weight-gradient GEMMs reuse the same image.
+        xpad = hip.pad_nhwc(buf, 256, sc, sh, 256, 256, LDF, B, H, H)
         if self.cfg.experiment.model.compute_seg:
             conv, bn, head = self.seg_module[0], self.seg_module[1], self.seg_module[3]
             w2 = ops.shadow(conv.weight, cd, key="khwc", fn=_khwc)
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
-            s1 = hip.gemm(buf, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3_AFFINE_RELU, conv=(B, H, H, 256), lda=LDF, a_scale=sc, a_shift=sh,
+            s1 = hip.gemm(xpad, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, H, 256), lda=LDF, conv_pad=True, M=B * HW,
                           out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
             bnS = _bn_affine(sums, cnt, bn, training, save=save)
-            seg = hip.head1x1(s1, 256, bnS[0], bnS[1], head.weight.detach().reshape(1, 256).contiguous(), head.bias.detach(), 0, 1.0, B, HW,
-                              copy_dst=buf[:, 256:], copy_ld=LDF)           # seg.clone().detach() -> channel 256 (torch.cat, model_ffl.py:87-89)
+            seg = hip.head1x1(s1, 256, bnS[0], bnS[1], head.weight.detach().reshape(1, 256).contiguous(), head.bias.detach(), 0, 1.0, B, HW)
+            xpad[:, 1:H + 1, 1:H + 1, 256] = seg.view(B, H, H)             # seg.clone().detach() -> channel 256 (torch.cat, model_ffl.py:87-89)
             outputs["seg"] = seg.view(B, 1, H, H)
             if save:
                 keep.update(S1=s1, bnS=bnS, seg_out=seg)
         if self.cfg.experiment.model.compute_crossfield:
             conv, bn, head = self.crossfield_module[0], self.crossfield_module[1], self.crossfield_module[3]
             w2 = ops.shadow(conv.weight, cd, key="khwc320", fn=lambda t: _khwc(t, LDF))
-            sc320 = torch.cat([sc, torch.ones(LDF - 256, device=dev)])
-            sh320 = torch.cat([sh, torch.zeros(LDF - 256, device=dev)])
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
-            c1 = hip.gemm(buf, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3_AFFINE_RELU, conv=(B, H, H, LDF), lda=LDF, a_scale=sc320, a_shift=sh320,
+            c1 = hip.gemm(xpad, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, H, LDF), lda=LDF, conv_pad=True, M=B * HW,
                           out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
             bnC = _bn_affine(sums, cnt, bn, training, save=save)
             cf = hip.head1x1(c1, 256, bnC[0], bnC[1], head.weight.detach().reshape(4, 256).contiguous(), head.bias.detach(), 1, 2.0, B, HW)
@@ -272,7 +275,7 @@ class EncoderDecoder(nn.Module):
             if save:
                 keep.update(C1=c1, bnC=bnC, cf_out=cf)
         if save:
-            keep.update(buf=buf)
+            keep.update(buf=buf, xpad=xpad)
         return outputs
 
     def _tail_params(self):

@@ -31,7 +31,8 @@ def prepare_images(images_u8, groups=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 
     """uint8 [B,H,W,C] on the device -> fp32 [B,C,H,W] = ToTensorV2(Normalize(D4(img))) (build_datasets.py:55-75 with the reference's
     encoder config: mean 0, std 1, max 255).  groups: int32 [B] device tensor of D4 element ids, None = no augmentation."""
     C = images_u8.shape[-1]
-    sub, mul = normalize_constants(mean[:C], std[:C], max_pixel_value)
+    mean, std = (tuple(mean) + (0.0,) * C)[:C], (tuple(std) + (1.0,) * C)[:C]      # channels beyond the given constants: mean 0, std 1
+    sub, mul = normalize_constants(mean, std, max_pixel_value)
     return hip.image_prepare(images_u8, groups, sub.tolist(), mul.tolist(), out=out)
 
 
