@@ -516,6 +516,85 @@ def d4_lidar(points, element, in_width=224, in_height=224):
     return lidar
 
 
+# ----------------------------------------------------------------------------------------------
+# FFL losses (f-3): models/ffl/losses.py:220-461 + frame_field_utils.py:9-40 for the shipped config/model/ffl.yaml
+# (seg: interior only, crossfield on; use_freq / use_dist / use_size off; seg.type "bool").
+# ----------------------------------------------------------------------------------------------
+FFL_LOSS_NAMES = ("seg", "crossfield_align", "crossfield_align90", "crossfield_smooth", "seg_interior_crossfield")
+FFL_LOSS_WEIGHTS = {"seg": 1.0, "crossfield_align": 1.0, "crossfield_align90": 0.5, "crossfield_smooth": 0.005,
+                    "seg_interior_crossfield": [0.0, 0.0, 0.2]}
+FFL_EPOCH_THRESHOLDS = (0.0, 5.0, 10.0)
+SCHARR = (47.0 / 512.0, 162.0 / 512.0)      # torch_lydorn scharr 3x3 / sum|k| (kornia normalize_kernel2d)
+
+
+def ffl_weight(name, epoch, weights=None, thresholds=FFL_EPOCH_THRESHOLDS):
+    """MultiLoss weight (losses.py:84-141): scalars as they are; lists interpolated over epoch_thresholds (scipy interp1d, clamped),
+    and used un-interpolated (the interp1d object itself would be multiplied) only when epoch is None - the reference's trainer
+    always passes the epoch, so None is refused here."""
+    w = (weights or FFL_LOSS_WEIGHTS)[name]
+    if isinstance(w, (list, tuple)):
+        if epoch is None:
+            raise ValueError("epoch is required for interpolated loss weights")
+        return float(np.interp(float(epoch), np.asarray(thresholds, dtype=np.float64), np.asarray(w, dtype=np.float64)))
+    return float(w)
+
+
+def _cmul(a, b):
+    return torch.stack([a[:, 0] * b[:, 0] - a[:, 1] * b[:, 1], a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0]], 1)
+
+
+def framefield_align_error(c0, c2, z):
+    """frame_field_utils.py:9-21 with complex_dim=1: |z^4 + c2 z^2 + c0|^2."""
+    z2 = _cmul(z, z)
+    f = _cmul(z2, z2) + _cmul(c2, z2) + c0
+    return f[:, 0] ** 2 + f[:, 1] ** 2
+
+
+def scharr_gradient_ij(seg):
+    """torch_lydorn SpatialGradient(mode="scharr", coord="ij", normalized=True): replicate padding, cross-correlation;
+    -> [B, C, 2, H, W] (d/di = rows, d/dj = columns)."""
+    b, c, h, w = seg.shape
+    a, m = SCHARR
+    kx = seg.new_tensor([[-a, 0.0, a], [-m, 0.0, m], [-a, 0.0, a]])
+    k = torch.stack([kx.t(), kx])[:, None]                      # "ij": (kernel_y, kernel_x)
+    x = F.pad(seg.reshape(b * c, 1, h, w), (1, 1, 1, 1), mode="replicate")
+    return F.conv2d(x, k).view(b, c, 2, h, w)
+
+
+def ffl_losses(seg, crossfield, gt_polygons_image, gt_crossfield_angle, epoch=0, norms=None, weights=None, bce_coef=1.0, dice_coef=0.2):
+    """build_combined_loss(cfg)(pred_batch, gt_batch, normalize=True, epoch) for the shipped FFL config -> (total, {name: loss / norm})."""
+    norms = norms or {}
+    gt = gt_polygons_image
+    # --- SegLoss (losses.py:318-365): dice on the float target, BCE on (gt > 0.98); seg_loss_weights == 1
+    gt_seg = gt[:, :1]
+    num = 2 * torch.sum(gt_seg * seg, dim=(-1, -2))
+    den = torch.sum(gt_seg, dim=(-1, -2)) + torch.sum(seg, dim=(-1, -2))
+    dice = torch.mean(1 - (num + 1) / (den + 1 + 1e-7))
+    bce = F.binary_cross_entropy(seg, (gt_seg > 0.98).to(torch.float32), weight=torch.ones_like(seg), reduction="mean")
+    out = {"seg": bce_coef * bce + dice_coef * dice}
+    # --- crossfield losses (:368-419)
+    c0, c2 = crossfield[:, :2], crossfield[:, 2:]
+    z = torch.cat([torch.cos(gt_crossfield_angle), torch.sin(gt_crossfield_angle)], dim=1)
+    edges, vertices = gt[:, 1], gt[:, 2]
+    out["crossfield_align"] = torch.mean(framefield_align_error(c0, c2, z) * edges)
+    z90 = torch.cat((-z[:, 1:2], z[:, 0:1]), dim=1)
+    out["crossfield_align90"] = torch.mean(framefield_align_error(c0, c2, z90) * (edges - vertices).clamp(0, 1))
+    lap = torch.tensor([[0.5, 1.0, 0.5], [1.0, -6.0, 1.0], [0.5, 1.0, 0.5]], dtype=crossfield.dtype) / 12
+    pen = torch.abs(F.conv2d(crossfield, lap[None, None].expand(4, -1, -1, -1), padding=1, groups=4))
+    out["crossfield_smooth"] = torch.mean(pen * (1 - edges)[:, None])
+    # --- seg interior <-> crossfield coupling (:220-235, :422-444)
+    grads = 2 * scharr_gradient_ij(seg)
+    gnorm = grads.norm(dim=2)
+    gn = grads / (gnorm[:, :, None] + 1e-6)
+    out["seg_interior_crossfield"] = torch.mean(framefield_align_error(c0, c2, gn[:, 0]) * gnorm[:, 0].detach())
+    total = 0.0
+    normed = {}
+    for name in FFL_LOSS_NAMES:
+        normed[name] = out[name] / float(norms.get(name, 1.0))
+        total = total + ffl_weight(name, epoch, weights) * normed[name]
+    return total, normed
+
+
 def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
     x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
     return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))

@@ -63,6 +63,11 @@ def make_config(encoder="early_fusion_vit", model="pix2poly", *, in_size=224, pa
         sinkhorn_iterations=sinkhorn_iterations, vertex_loss_weight=1.0, perm_loss_weight=10.0,
         batch_size=batch_size, learning_rate=3e-4, weight_decay=1e-4, num_epochs=200,
         compute_seg=True, compute_crossfield=True, seg=dict(compute_interior=True, compute_edge=False, compute_vertex=False),
+        # config/model/ffl.yaml `loss:` (the FFL criterion, ffl_losses.build_combined_loss)
+        loss=dict(multi=dict(epoch_thresholds=[0, 5, 10],
+                             weights=dict(seg=1, crossfield_align=1, crossfield_align90=0.5, crossfield_smooth=0.005,
+                                          seg_interior_crossfield=[0, 0, 0.2], seg_edge_crossfield=[0, 0, 0.2], seg_edge_interior=[0, 0, 0.2])),
+                  seg=dict(bce_coef=1.0, dice_coef=0.2, use_freq=False, use_dist=False, use_size=False, w0=50, sigma=10, type="bool")),
     )
     return AttrDict.wrap(dict(
         experiment=dict(encoder=enc, model=mdl, lidar_dropout=lidar_dropout),

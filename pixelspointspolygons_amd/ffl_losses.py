@@ -1,0 +1,121 @@
+"""FFL loss — mirror of pixelspointspolygons/models/ffl/losses.py (build_combined_loss -> MultiLoss) for the shipped
+config/model/ffl.yaml, on ONE fused HIP forward + gradient call (`p3_ffl_loss`).
+
+Same call contract as the reference's trainer uses (models/ffl/losses.py:84-141):
+    criterion = build_combined_loss(cfg)
+    total, individual_losses, extra = criterion(pred_batch, gt_batch, normalize=True, epoch=epoch)
+    criterion.reset_norm(); criterion.update_norm(pred_batch, gt_batch, nums); criterion.sync(world_size)
+`individual_losses[name]` are the normalised losses (loss / norm) as detached device scalars; `total` carries the gradient
+(d total / d seg, d total / d crossfield come out of the same kernels as the value).  `extra` has the reference's keys with empty
+dicts: the visualisation tensors (gt_field, seg_slice_grads) are not produced.
+Unsupported configurations (edge / vertex seg channels, frequency / distance / size pixel weights, seg.type "float") raise.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+LOSS_NAMES = ("seg", "crossfield_align", "crossfield_align90", "crossfield_smooth", "seg_interior_crossfield")
+
+
+class _FFLLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, crossfield, gt, angle, coef, bce_coef, dice_coef):
+        need = seg.requires_grad or crossfield.requires_grad
+        losses, dseg, dcf = hip.ffl_loss(seg.detach(), crossfield.detach(), gt, angle, coef, bce_coef, dice_coef, need_grad=need)
+        ctx.save_for_backward(dseg, dcf)
+        ctx.shapes = (seg.shape, seg.dtype, crossfield.shape, crossfield.dtype)
+        ctx.mark_non_differentiable(losses)
+        return losses[5].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g, _g_losses):
+        dseg, dcf = ctx.saved_tensors
+        ss, sd, cs, cdt = ctx.shapes
+        return (dseg * g).view(ss).to(sd), (dcf * g).view(cs).to(cdt), None, None, None, None, None
+
+
+class MultiLoss(torch.nn.Module):
+    """MultiLoss (losses.py:72-147) over the five losses build_combined_loss assembles for the shipped config."""
+
+    def __init__(self, weights, epoch_thresholds, bce_coef, dice_coef):
+        super().__init__()
+        self.names = LOSS_NAMES
+        self.weights = [list(w) if isinstance(w, (list, tuple)) else float(w) for w in weights]
+        self.epoch_thresholds = [float(t) for t in epoch_thresholds]
+        self.bce_coef, self.dice_coef = float(bce_coef), float(dice_coef)
+        self.norm = torch.nn.Parameter(torch.ones(len(LOSS_NAMES)), requires_grad=False)     # Loss.norm of every loss_func (losses.py:31)
+        self._norm_host = [1.0] * len(LOSS_NAMES)
+
+    # ---- norms (Loss.reset_norm / update_norm / sync, losses.py:36-52) ----
+    def reset_norm(self):
+        self._norm_host = [1.0] * len(LOSS_NAMES)
+        self.norm.data.fill_(1.0)
+
+    @torch.no_grad()
+    def update_norm(self, pred_batch, gt_batch, nums):
+        """the reference sets norm = AverageMeter.val, i.e. the LAST un-normalised loss value (losses.py:40-43)"""
+        raw = self._raw(pred_batch, gt_batch).cpu().tolist()
+        self._norm_host = [float(v) for v in raw[:5]]
+        self.norm.data.copy_(torch.tensor(self._norm_host))
+
+    def sync(self, world_size):
+        dist.all_reduce(self.norm.data)
+        self.norm.data /= world_size
+        self._norm_host = self.norm.data.cpu().tolist()
+
+    def current_weights(self, epoch):
+        out = []
+        for w in self.weights:
+            if isinstance(w, list):
+                if epoch is None:
+                    raise ValueError("MultiLoss: epoch is required for the interpolated loss weights (the reference's trainer passes it)")
+                out.append(float(np.interp(float(epoch), self.epoch_thresholds, w)))
+            else:
+                out.append(w)
+        return out
+
+    def _inputs(self, pred_batch, gt_batch):
+        gt = gt_batch["gt_polygons_image"]
+        if gt.shape[1] != 3:
+            raise ValueError("gt_polygons_image should have 3 channels for interior, edges and vertices")
+        return pred_batch["seg"], pred_batch["crossfield"], gt.float(), gt_batch["gt_crossfield_angle"].float()
+
+    def _raw(self, pred_batch, gt_batch):
+        seg, cf, gt, angle = self._inputs(pred_batch, gt_batch)
+        return hip.ffl_loss(seg.detach(), cf.detach(), gt, angle, [0.0] * 5, self.bce_coef, self.dice_coef, need_grad=False)[0]
+
+    def forward(self, pred_batch, gt_batch, normalize=True, epoch=None):
+        seg, cf, gt, angle = self._inputs(pred_batch, gt_batch)
+        norms = self._norm_host if normalize else [1.0] * 5
+        if normalize and min(norms) <= 1e-9:
+            raise AssertionError("self.norm[0] <= 1e-9 -> this might lead to numerical instabilities.")
+        w = self.current_weights(epoch)
+        coef = [wi / ni for wi, ni in zip(w, norms)]
+        total, losses = _FFLLossFn.apply(seg, cf, gt, angle, coef, self.bce_coef, self.dice_coef)
+        inv = torch.tensor([1.0 / n for n in norms], dtype=torch.float32, device=losses.device)
+        normed = losses[:5] * inv
+        individual = {name: normed[i] for i, name in enumerate(LOSS_NAMES)}
+        return total, individual, {name: {} for name in LOSS_NAMES}
+
+    def __repr__(self):
+        return "MultiLoss:\n\t" + "\n\t".join(f"{n} (norm={v:0.06})" for n, v in zip(LOSS_NAMES, self._norm_host))
+
+
+def build_combined_loss(cfg):
+    """models/ffl/losses.py:237-316 for the configuration the HIP kernels cover (config/model/ffl.yaml as shipped)."""
+    m = cfg.experiment.model
+    if not (m.compute_seg and m.compute_crossfield):
+        raise NotImplementedError("p3hip FFL loss needs compute_seg and compute_crossfield")
+    if not m.seg.compute_interior or m.seg.compute_edge or m.seg.compute_vertex:
+        raise NotImplementedError("p3hip FFL loss covers the shipped seg head (interior channel only)")
+    ls = m.loss.seg
+    if ls.use_freq or ls.use_dist or ls.use_size:
+        raise NotImplementedError("p3hip FFL loss: pixel weights (use_freq / use_dist / use_size) are off in the shipped config and not built")
+    if ls.type != "bool":
+        raise NotImplementedError("p3hip FFL loss: loss.seg.type must be 'bool' (shipped config)")
+    w = m.loss.multi.weights
+    seq = lambda v: list(v) if hasattr(v, "__iter__") else v
+    weights = [seq(w.seg), seq(w.crossfield_align), seq(w.crossfield_align90), seq(w.crossfield_smooth), seq(w.seg_interior_crossfield)]
+    return MultiLoss(weights, list(m.loss.multi.epoch_thresholds), ls.bce_coef, ls.dice_coef).to(cfg.host.device)

@@ -457,6 +457,25 @@ def points_d4_(values, offsets, group, cx, cy):
     return values
 
 
+def ffl_loss(seg, crossfield, gt_polygons_image, gt_crossfield_angle, coef, bce_coef, dice_coef, need_grad=True):
+    """fused FFL loss: -> (losses fp32 [6] = five raw losses + total, dseg | None, dcrossfield | None)."""
+    _dev(seg)
+    B, _, H, W = seg.shape
+    ts = [t.contiguous().float() for t in (seg, crossfield, gt_polygons_image, gt_crossfield_angle)]
+    if ts[0].shape != (B, 1, H, W) or ts[1].shape != (B, 4, H, W) or ts[2].shape != (B, 3, H, W) or ts[3].numel() != B * H * W:
+        raise P3Error(f"ffl_loss: shapes seg {tuple(seg.shape)} crossfield {tuple(crossfield.shape)} gt {tuple(gt_polygons_image.shape)} "
+                      f"angle {tuple(gt_crossfield_angle.shape)}")
+    lib().p3_ffl_loss_workspace_bytes.restype = c_int64
+    ws = workspace(int(lib().p3_ffl_loss_workspace_bytes(c_int(B), c_int(H), c_int(W))), seg.device, "ffl_loss")
+    losses = torch.empty(6, dtype=torch.float32, device=seg.device)
+    dseg = torch.empty_like(ts[0]) if need_grad else None
+    dcf = torch.empty_like(ts[1]) if need_grad else None
+    cc = (c_float * 5)(*[float(v) for v in coef])
+    check(lib().p3_ffl_loss(ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), c_int(B), c_int(H), c_int(W), ctypes.cast(cc, c_void_p),
+                            c_float(bce_coef), c_float(dice_coef), ptr(losses), ptr(dseg), ptr(dcf), ptr(ws), stream()), "p3_ffl_loss")
+    return losses, dseg, dcf
+
+
 def cast(a, dtype):
     out = torch.empty(a.shape, dtype=dtype, device=a.device)
     check(lib().p3_cast(ptr(a.contiguous()), c_int(dt(a)), ptr(out), c_int(dt(out)), c_int64(a.numel()), stream()), "p3_cast")
