@@ -184,3 +184,29 @@ def test_smoke_configuration_loads_the_oracle_weights():
     cfg = make_config("early_fusion_vit", vit_depth=2, precision="fp32", device="cpu")
     m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
     m.load_state_dict(sd, strict=True)
+
+
+def test_checkpoint_interchange_matches_the_reference_loader_rules(tmp_path):
+    """misc/shared_utils.py:66-117: exact match, 'module.' on either side, encoder.model. -> encoder.vit.; report + strict load."""
+    from pixelspointspolygons_amd import checkpoint as C
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    cfg = _cfg("vit")
+    m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+    sd = O.make_state_dict("image", seed=5)
+    ddp = {"module." + k.replace("encoder.vit.", "encoder.model."): v for k, v in sd.items()}     # a DDP-wrapped, old-name checkpoint
+    rep = C.compare(m, ddp)
+    assert not rep.missing and not rep.shape_mismatch and not rep.unused and len(rep.matched) == len(sd)
+    C.smart_load_state_dict(m, ddp, strict=True)
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    path = tmp_path / "ckpt.pth"
+    torch.save({"state_dict": C.export_state_dict(m), "epoch": 3}, path)
+    m2 = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+    C.load_checkpoint(m2, str(path))
+    assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+    partial = {k: v for k, v in sd.items() if not k.startswith("scorenet2.")}
+    partial["extra.unused"] = torch.zeros(1)
+    rep = C.compare(m, partial)
+    assert rep.unused == ["extra.unused"] and all(k.startswith("scorenet2.") for k in rep.missing) and rep.missing
+    with pytest.raises(RuntimeError):
+        C.smart_load_state_dict(m, partial, strict=True)
+    C.smart_load_state_dict(m, partial, strict=False)
