@@ -57,8 +57,8 @@ def make_cfg(args, dev):
     return cfg
 
 
-def synth_batch(O, args, rank, step, dev, kind):
-    inp = O.make_inputs(args.batch, seed=1234 + 1000 * rank + step, n_points=args.points, jitter=args.points // 10)
+def synth_batch(S, args, rank, step, dev, kind):
+    inp = S.make_inputs(args.batch, seed=1234 + 1000 * rank + step, n_points=args.points, jitter=args.points // 10)
     b = {"y": inp["y"].to(dev), "y_perm": inp["y_perm"].to(dev)}
     if kind != "lidar":
         b["image"] = inp["image"].to(dev)
@@ -148,7 +148,7 @@ class Stepper:
         return self.fwd_out
 
 
-def host_feed_leg(O, args, st, dev, kind, rank):
+def host_feed_leg(S, args, st, dev, kind, rank):
     """PCIe-inclusive rate (never `value`): the same train step fed from HOST memory through pixelspointspolygons_amd.input_pipeline -
     uint8 HWC tiles + untransformed point lists + a D4 element per tile packed into pinned staging, H2D + D4/Normalize kernels on a
     copy stream overlapped with the previous step."""
@@ -156,7 +156,7 @@ def host_feed_leg(O, args, st, dev, kind, rank):
     from pixelspointspolygons_amd.input_pipeline import DevicePrefetcher
     host_pool = []
     for s_ in range(args.pool):
-        inp = O.make_inputs(args.batch, seed=1234 + 1000 * rank + s_, n_points=args.points, jitter=args.points // 10)
+        inp = S.make_inputs(args.batch, seed=1234 + 1000 * rank + s_, n_points=args.points, jitter=args.points // 10)
         hb = {"y": inp["y"], "y_perm": inp["y_perm"], "group": np.random.default_rng(s_).integers(0, 8, size=args.batch)}
         if kind != "lidar":
             hb["image"] = (inp["image"].permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8).contiguous()
@@ -180,8 +180,10 @@ def host_feed_leg(O, args, st, dev, kind, rank):
             "what": "uint8 HWC tiles + jagged points + tokens from pinned host memory, D4 + Normalize + HWC->CHW on the device, double buffered"}
 
 
-def cpu_baseline(O, args, kind):
-    """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(args, kind):
+    """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload.
+    The only place bench.py touches oracle/."""
+    from oracle import p3_oracle as O
     import torch.nn.functional as F  # noqa: F401
     B = 2
     cfgv = O.VIT_S8 if args.workload != "image_b16" else O.VIT_B16
@@ -245,7 +247,7 @@ def main():
             dist.init_process_group("nccl", init_method="env://", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend, init_method="env://")
-    from oracle import p3_oracle as O       # synthetic-input generator + cpu_baseline leg only (never on the product path)
+    from pixelspointspolygons_amd import synthetic as S        # synthetic-input generator (oracle/ is imported by the cpu_baseline leg only)
     from pixelspointspolygons_amd import hip
     from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
     from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer
@@ -273,7 +275,7 @@ def main():
                     direct_grad=bool(args.graph) or world == 1 or sync_bn)   # hook-driven overlap needs autograd's AccumulateGrad
     opt.set_linear_schedule(200 * 1000)
     reducer = GradBucketReducer(opt, overlap=not args.graph and not sync_bn)   # hooks (overlap) only on the plain eager path
-    pool = [synth_batch(O, args, rank, s, dev, kind) for s in range(args.pool)]
+    pool = [synth_batch(S, args, rank, s, dev, kind) for s in range(args.pool)]
     st = Stepper(model, opt, reducer, pool, kind, bool(args.graph))
 
     for i in range(max(args.warmup, 3 if args.graph else 0)):   # 2 eager steps + the capture step stay untimed
@@ -324,7 +326,7 @@ def main():
 
     feed = None
     if world == 1 and not args.no_host_feed and not args.no_fwd:
-        feed = host_feed_leg(O, args, st, dev, kind, rank)
+        feed = host_feed_leg(S, args, st, dev, kind, rank)
 
     # dominant-kernel timing with HIP events on the launch stream (instrumented steps, after the timed region)
     roofline = None
@@ -380,7 +382,7 @@ def main():
         if feed is not None:
             line["pcie_inclusive"] = feed
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the host cores are shared by the ranks otherwise)
-            line["cpu_baseline"] = cpu_baseline(O, args, kind)
+            line["cpu_baseline"] = cpu_baseline(args, kind)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                                    # rank 0 runs the instrumented leg alone: leave together

@@ -210,3 +210,29 @@ def test_checkpoint_interchange_matches_the_reference_loader_rules(tmp_path):
     with pytest.raises(RuntimeError):
         C.smart_load_state_dict(m, partial, strict=True)
     C.smart_load_state_dict(m, partial, strict=False)
+
+
+def test_product_synthetic_generator_equals_the_oracles():
+    """bench.py / tools feed on pixelspointspolygons_amd.synthetic (oracle/ stays test infrastructure); same seed -> same batch."""
+    from pixelspointspolygons_amd import synthetic as S
+    a, b = S.make_inputs(3, seed=77, n_points=500, jitter=50), O.make_inputs(3, seed=77, n_points=500, jitter=50)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    assert (S.NUM_BINS, S.BOS, S.EOS, S.PAD) == (O.NUM_BINS, O.BOS, O.EOS, O.PAD)
+
+
+def test_only_checkers_import_the_oracle():
+    """the product package, bench.py outside its cpu_baseline leg, and tools/ never import oracle/."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    offenders = []
+    for d in ("pixelspointspolygons_amd", "tools"):
+        for dp, _, fs in os.walk(os.path.join(root, d)):
+            for f in fs:
+                if f.endswith(".py") and pat.search(open(os.path.join(dp, f)).read()):
+                    offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
+    src = open(os.path.join(root, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(src)]
+    body = src[src.index("def cpu_baseline("):src.index("def pmc_traffic(")]
+    assert len(hits) == 1 and pat.search(body)

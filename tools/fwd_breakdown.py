@@ -4,7 +4,7 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
-from oracle import p3_oracle as O  # noqa: E402  (synthetic inputs only)
+from pixelspointspolygons_amd import synthetic as O  # noqa: E402  (product-side synthetic inputs)
 from pixelspointspolygons_amd import hip  # noqa: E402
 from pixelspointspolygons_amd.config import make_config  # noqa: E402
 from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer  # noqa: E402

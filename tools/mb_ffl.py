@@ -1,7 +1,7 @@
 """FFL (early_fusion_vit_cnn) inference forward throughput on synthetic tiles (BASELINE configs[4] shape, forward only)."""
 import sys, time, torch
 sys.path.insert(0, ".")
-from oracle import p3_oracle as O
+from pixelspointspolygons_amd import synthetic as O  # noqa: E402  (product-side synthetic inputs)
 from pixelspointspolygons_amd.config import make_config
 from pixelspointspolygons_amd.ffl import FFLModel
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
