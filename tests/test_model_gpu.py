@@ -281,6 +281,25 @@ def test_graph_replayed_decode_equals_eager_decode(precision):
         assert not torch.equal(ref[1], want[0][1])
 
 
+def test_lidar_feature_dropout_zeroes_the_whole_batch():
+    """SURVEY §9-8 (early_fusion_vit.py:113-119): one draw per BATCH; p = 1.0 (what validation sets) zeroes every tile's LiDAR
+    features before the fusion conv, p = 0.0 never fires.  Checked against the oracle with the LiDAR map scaled by 0."""
+    sd = O.make_state_dict("fusion", seed=42)
+    inp = O.make_inputs(3, seed=21)
+    d = _to_dev(inp)
+    lidar = (d["lidar_values"], d["lidar_offsets"])
+    with torch.no_grad():
+        m1, _ = _model("fusion", "fp32", sd, lidar_dropout=1.0)
+        got = m1.encoder(d["image"], lidar)
+        ref = O.encoder_fusion(inp["image"], inp["lidar_values"], inp["lidar_offsets"], sd, lidar_scale=0.0)
+        assert rel_err(got.float().cpu(), ref) < TOL32
+        m0, _ = _model("fusion", "fp32", sd, lidar_dropout=0.0)
+        mn, _ = _model("fusion", "fp32", sd)
+        torch.manual_seed(0)
+        a, b = m0.encoder(d["image"], lidar), mn.encoder(d["image"], lidar)
+        assert torch.equal(a, b) and not torch.equal(a, got)
+
+
 def test_lidar_only_model_accepts_all_three_lidar_input_forms():
     """nested jagged tensor (the reference's collate output), (values, offsets) pair (bench.py) and dense [B, N, 3]."""
     sd = O.make_state_dict("lidar", seed=42)
