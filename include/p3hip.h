@@ -379,6 +379,16 @@ int p3_ffl_loss(const float* seg, const float* crossfield, const float* gt_polyg
                 void* stream);
 int64_t p3_ffl_loss_workspace_bytes(int B, int H, int W);
 
+/* ------------------------------------------------------------------------------------------
+ * HiSup attraction field map (the reference's only native kernel: models/hisup/afm_module/afm_op/cuda/afm.cu:29-112,
+ * bound as afm(lines, shape_info, height, width) in models/hisup/model_hisup.py:95).
+ * lines [L,4] fp32 (x1, y1, x2, y2 in source pixels), shape_info [B,4] int32 = (first line, one past the last line, source height,
+ * source width) per tile -> afmap [B,2,height,width] fp32 = -sgn(a) log(|a| / size + 1e-6) of the offset a to the closest segment
+ * point, aflabel [B,1,height,width] int32 = index of that segment inside the tile (first of equally close ones); tiles without
+ * segments get zeros.
+ * ------------------------------------------------------------------------------------------ */
+int p3_afm(const float* lines, const int32_t* shape_info, int B, int height, int width, float* afmap, int32_t* aflabel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -595,6 +595,20 @@ def ffl_losses(seg, crossfield, gt_polygons_image, gt_crossfield_angle, epoch=0,
     return total, normed
 
 
+def afm(lines, shape_info, height, width):
+    """HiSup attraction field map (afm_op/cuda/afm.cu:29-112) through the C restatement oracle/afm.c.
+    lines float32 [L,4], shape_info int32 [B,4] = (start, end, src_h, src_w) -> (afmap [B,2,H,W] f32, aflabel [B,1,H,W] i32)."""
+    lib = _oracle_lib()
+    ln = np.ascontiguousarray(lines.detach().cpu().numpy(), dtype=np.float32)
+    si = np.ascontiguousarray(shape_info.detach().cpu().numpy(), dtype=np.int32)
+    B = si.shape[0]
+    afmap = np.zeros((B, 2, height, width), dtype=np.float32)
+    lab = np.zeros((B, 1, height, width), dtype=np.int32)
+    lib.p3o_afm(ln.ctypes.data_as(ctypes.c_void_p), si.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(B), ctypes.c_int(height), ctypes.c_int(width),
+                afmap.ctypes.data_as(ctypes.c_void_p), lab.ctypes.data_as(ctypes.c_void_p))
+    return torch.from_numpy(afmap), torch.from_numpy(lab)
+
+
 def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
     x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
     return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))

@@ -476,6 +476,18 @@ def ffl_loss(seg, crossfield, gt_polygons_image, gt_crossfield_angle, coef, bce_
     return losses, dseg, dcf
 
 
+def afm(lines, shape_info, height, width):
+    """attraction field map of line segments (HiSup afm op): -> (afmap f32 [B,2,H,W], aflabel i32 [B,1,H,W])."""
+    _dev(shape_info)
+    si = shape_info.to(torch.int32).contiguous()
+    ln = lines.float().contiguous() if lines is not None and lines.numel() else None
+    B = si.shape[0]
+    afmap = torch.empty((B, 2, height, width), dtype=torch.float32, device=si.device)
+    lab = torch.empty((B, 1, height, width), dtype=torch.int32, device=si.device)
+    check(lib().p3_afm(ptr(ln), ptr(si), c_int(B), c_int(height), c_int(width), ptr(afmap), ptr(lab), stream()), "p3_afm")
+    return afmap, lab
+
+
 def cast(a, dtype):
     out = torch.empty(a.shape, dtype=dtype, device=a.device)
     check(lib().p3_cast(ptr(a.contiguous()), c_int(dt(a)), ptr(out), c_int(dt(out)), c_int64(a.numel()), stream()), "p3_cast")
