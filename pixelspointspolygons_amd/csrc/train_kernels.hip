@@ -1,4 +1,6 @@
 // p3hip training-step kernels: Sinkhorn backward (single launch), CE / BCE losses (forward + backward), fused AdamW.
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -8,12 +10,14 @@ namespace {
 // the reference, model_pix2poly.py:35-66,261-264).  One 1024-thread workgroup per sample: Z stays in LDS, the gradient dZ
 // lives in registers with a fixed (row = wave + 16k, col = lane + 64c) ownership; the LSE terms are recovered from the saved
 // dual iterates (u_t, v_t):  softmax_i(Z + u_t)[i,j] = exp(Z_ij + u_t[i] + v_t[j] - log_nu[j]), etc. - no re-reduction.
-constexpr int SK_MAXK = 13, SK_MAXC = 4;   // rows <= 16*13 = 208, cols <= 256  (reference: 193 x 193)
+constexpr int SK_MAXC = 4;   // rows <= 208, cols <= 256  (reference: 193 x 193)
 
-__global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
+template <bool FAST, int NW>
+__global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                             int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
                                                             const float* __restrict__ dperm, float* __restrict__ dscores,
-                                                            float* __restrict__ dalpha) {
+                                                            float* __restrict__ dalpha, int* __restrict__ tile_flags) {
+    constexpr int NT = 64 * NW, MAXK = 208 / NW;             // rows w, w + NW, ...: 16 waves x 13 or 8 waves x 26 register-resident dZ rows
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1;
     float* Z = sm;                   // [M1][N1]
@@ -23,26 +27,57 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
     float* du = vp + N1;             // [M1]
     float* dv = du + M1;             // [N1]
     float* dvn = dv + N1;            // [N1] next dv (accumulated with LDS atomics)
+    float* rmax = dvn + N1;          // [M1] row maxima of Z        } linear-domain path (see sinkhorn.hip): Z holds E = exp(Z - rmax_i),
+    float* Ai = rmax + M1;           // [M1] exp(u_t + rmax)        } every exp(Z + u + v - c) below becomes E_ij * (row factor) * (column factor)
+    float* Di = Ai + M1;             // [M1] Ai / mu_i * du_i
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Two launches per call: the linear-domain kernel (FAST) decides per tile whether it may run (tile_flags[b] = 0) or leaves the
+    // tile to the log-domain kernel that follows it (tile_flags[b] = 1).  One kernel holding both loops spilled 40 more registers.
+    if (!FAST && tile_flags[b] == 0) return;
+    const int forced = FAST ? (tile_flags[b] != 0) : 0;      // host request (P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel
     const float alpha = alpha_p[0];
-    for (int i = tid; i < M1 * N1; i += 1024) {
+    for (int i = tid; i < M1 * N1; i += NT) {
         const int r = i / N1, c = i - r * N1;
         Z[i] = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
     }
-    for (int i = tid; i < N1; i += 1024) { dv[i] = 0.f; dvn[i] = 0.f; }
-    for (int i = tid; i < M1; i += 1024) du[i] = 0.f;
+    for (int i = tid; i < N1; i += NT) { dv[i] = 0.f; dvn[i] = 0.f; }
+    for (int i = tid; i < M1; i += NT) du[i] = 0.f;
     const float norm = -logf((float)(m + n));
     const float a_last = logf((float)n) + norm, b_last = logf((float)m) + norm;
-    float dZ[SK_MAXK][SK_MAXC];
+    float dZ[MAXK][SK_MAXC];
 #pragma unroll
-    for (int k = 0; k < SK_MAXK; ++k)
+    for (int k = 0; k < MAXK; ++k)
 #pragma unroll
         for (int c = 0; c < SK_MAXC; ++c) dZ[k][c] = 0.f;
     __syncthreads();
+    // same test as the forward kernel: every row's spread below 60 -> no E_ij underflows
+    if constexpr (FAST) {
+    int wide = 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int i = w + NW * k;
+        if (i < M1) {
+            float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+            for (int c = 0; c < SK_MAXC; ++c) {
+                const int j = lane + 64 * c;
+                if (j < N1) { const float x = Z[i * N1 + j]; mx = fmaxf(mx, x); mn = fminf(mn, x); }
+            }
+            mx = wave_max(mx); mn = -wave_max(-mn);
+            if (lane == 0) rmax[i] = mx;
+            wide |= !(mx - mn < 60.f);
+        }
+    }
+    const bool wide_tile = __syncthreads_or(wide | forced);
+    if (tid == 0) tile_flags[b] = wide_tile ? 1 : 0;
+    if (wide_tile) return;
+    for (int i = tid; i < M1 * N1; i += NT) { const int r = i / N1; Z[i] = __expf(Z[i] - rmax[r]); }
+    __syncthreads();
+    }
     // ---- softmax backward: G = perm * (dperm - rowdot); dZ += G; dv[j] = sum_i G ----
 #pragma unroll
-    for (int k = 0; k < SK_MAXK; ++k) {
-        const int i = w + 16 * k;
+    for (int k = 0; k < MAXK; ++k) {
+        const int i = w + NW * k;
         float pv[SK_MAXC], gv[SK_MAXC];
         float dot = 0.f;
 #pragma unroll
@@ -66,13 +101,66 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
     for (int t = iters; t >= 1; --t) {
         const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
         const float* hp = t > 1 ? h - (M1 + N1) : nullptr;
-        for (int i = tid; i < M1; i += 1024) ut[i] = h[i];
-        for (int i = tid; i < N1; i += 1024) { vt[i] = h[M1 + i]; vp[i] = hp ? hp[M1 + i] : 0.f; }
+        for (int i = tid; i < M1; i += NT) ut[i] = h[i];
+        for (int i = tid; i < N1; i += NT) { vt[i] = h[M1 + i]; vp[i] = hp ? hp[M1 + i] : 0.f; }
         __syncthreads();
+        if constexpr (FAST) {
+            const float inv_mu = (float)(m + n), inv_mu_last = (float)(m + n) / (float)n;      // 1 / exp(log_mu)
+            float Bv[SK_MAXC], Cj[SK_MAXC];
+#pragma unroll
+            for (int c = 0; c < SK_MAXC; ++c) {
+                const int j = lane + 64 * c;
+                Bv[c] = j < N1 ? __expf(vt[j] - (j < n ? norm : b_last)) * dv[j] : 0.f;
+                Cj[c] = j < N1 ? __expf(vp[j]) : 0.f;
+            }
+            if (tid < M1) Ai[tid] = __expf(ut[tid] + rmax[tid]);
+            __syncthreads();
+            // pass A: q = softmax_i(Z + u_t)[i,j] * dv[j] = E_ij * Ai * Bv
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k) {
+                const int i = w + NW * k;
+                float acc = 0.f;
+                if (i < M1) {
+                    const float ai = Ai[i];
+#pragma unroll
+                    for (int c = 0; c < SK_MAXC; ++c) {
+                        const int j = lane + 64 * c;
+                        if (j < N1) {
+                            const float q = Z[i * N1 + j] * ai * Bv[c];
+                            dZ[k][c] -= q; acc += q;
+                        }
+                    }
+                }
+                acc = wave_sum(acc);
+                if (lane == 0 && i < M1) { du[i] = -acc; Di[i] = Ai[i] * (i < m ? inv_mu : inv_mu_last) * -acc; }
+            }
+            __syncthreads();
+            // pass B: r = softmax_j(Z + v_{t-1})[i,j] * du[i] = E_ij * Cj * Di
+#pragma unroll
+            for (int c = 0; c < SK_MAXC; ++c) {
+                const int j = lane + 64 * c;
+                float acc = 0.f;
+                if (j < N1) {
+#pragma unroll
+                    for (int k = 0; k < MAXK; ++k) {
+                        const int i = w + NW * k;
+                        if (i < M1) {
+                            const float r = Z[i * N1 + j] * Cj[c] * Di[i];
+                            dZ[k][c] -= r; acc += r;
+                        }
+                    }
+                    atomicAdd(&dvn[j], -acc);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < N1; i += NT) { dv[i] = dvn[i]; dvn[i] = 0.f; }
+            __syncthreads();
+            continue;
+        }
         // pass A: v_t = log_nu - LSE_i(Z + u_t):  q = softmax_i * dv[j];  dZ -= q;  du[i] = -sum_j q
 #pragma unroll
-        for (int k = 0; k < SK_MAXK; ++k) {
-            const int i = w + 16 * k;
+        for (int k = 0; k < MAXK; ++k) {
+            const int i = w + NW * k;
             float acc = 0.f;
             if (i < M1) {
                 const float ui = ut[i];
@@ -97,8 +185,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
             if (j < N1) {
                 const float vj = vp[j];
 #pragma unroll
-                for (int k = 0; k < SK_MAXK; ++k) {
-                    const int i = w + 16 * k;
+                for (int k = 0; k < MAXK; ++k) {
+                    const int i = w + NW * k;
                     if (i < M1) {
                         const float r = __expf(Z[i * N1 + j] + vj + ut[i] - (i < m ? norm : a_last)) * du[i];
                         dZ[k][c] -= r; acc += r;
@@ -108,13 +196,13 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        for (int i = tid; i < N1; i += 1024) { dv[i] = dvn[i]; dvn[i] = 0.f; }
+        for (int i = tid; i < N1; i += NT) { dv[i] = dvn[i]; dvn[i] = 0.f; }
         __syncthreads();
     }
     float da = 0.f;
 #pragma unroll
-    for (int k = 0; k < SK_MAXK; ++k) {
-        const int i = w + 16 * k;
+    for (int k = 0; k < MAXK; ++k) {
+        const int i = w + NW * k;
 #pragma unroll
         for (int c = 0; c < SK_MAXC; ++c) {
             const int j = lane + 64 * c;
@@ -219,19 +307,26 @@ inline int grid_for(int64_t work) {
 }  // namespace
 
 extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
-                               const float* uv_hist, const float* dperm, float* dscores, float* dalpha, void* stream) {
-    P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
-    P3_CHECK(m + 1 <= 16 * SK_MAXK && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
-    const size_t lds = ((size_t)(m + 1) * (n + 1) + 2 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
-    P3_CHECK(lds <= 160 * 1024, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
+                               const float* uv_hist, const float* dperm, float* dscores, float* dalpha, int32_t* tile_flags, void* stream) {
+    P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && tile_flags && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
+    P3_CHECK(m + 1 <= 208 && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
+    const size_t lds = ((size_t)(m + 1) * (n + 1) + 5 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
+    P3_CHECK(lds <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
+    static int force_log = -1;                        // P3_SINKHORN_LOG=1: log-domain loop only (A/B, tests of the fallback)
+    if (force_log < 0) { const char* e = getenv("P3_SINKHORN_LOG"); force_log = (e && e[0] == '1') ? 1 : 0; }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, alpha, m, n, iters, perm, uv_hist, dperm,
-                       dscores, dalpha);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t me = hipMemsetAsync(tile_flags, force_log ? 1 : 0, sizeof(int32_t) * (size_t)B, s);
+    if (me != hipSuccess) { p3_set_error(hipGetErrorString(me)); return (int)me; }
+    // 16 waves per tile (8 waves x 26 register rows measured slower: 1.94 vs 1.49 ms at 64 x 192 x 192, r01)
+    hipLaunchKernelGGL((sinkhorn_bwd_kernel<true, 16>), dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
+    hipLaunchKernelGGL((sinkhorn_bwd_kernel<false, 16>), dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -116,6 +116,32 @@ def test_sinkhorn_backward_vs_autograd():
         assert abs(float(ad.grad.cpu()) - float(alpha.grad)) < 2e-3 * max(1.0, abs(float(alpha.grad)))
 
 
+def test_sinkhorn_wide_range_scores_take_the_log_domain_path():
+    """Rows whose scores span more than 60 (exp(Z - rowmax) would underflow) fall back to the log-domain loop; tiles below the
+    threshold run the linear-domain iterations: both against the oracle's log_optimal_transport, values and gradients."""
+    from pixelspointspolygons_amd import ops
+    m, iters = 40, 100
+    s = _rand(4, m, m, seed=9) * 2
+    s[0, 3, :] *= 30.0                      # spread ~ 200 in one row of tile 0 -> fallback for tile 0 only
+    s[1] = s[1] * 12.0                      # spread ~ 90 everywhere in tile 1
+    s[2, :, 5] -= 120.0                     # one column far below everything
+    s = s.requires_grad_(True)
+    alpha = torch.tensor(1.3, requires_grad=True)
+    z = O.log_optimal_transport(s, alpha, iters)
+    perm = torch.softmax(z[:, :m, :m], -1)
+    g = _rand(4, m, m, seed=19)
+    perm.backward(g)
+    sd, ad = s.detach().to(DEV).requires_grad_(True), alpha.detach().to(DEV).requires_grad_(True)
+    pd = ops.sinkhorn_softmax(sd, ad, iters)
+    pd.backward(g.to(DEV))
+    assert torch.isfinite(pd).all() and torch.isfinite(sd.grad).all()
+    assert rel_err(pd.detach().cpu(), perm.detach()) < 1e-4
+    assert rel_err(sd.grad.cpu(), s.grad) < 2e-3
+    import pixelspointspolygons_amd.hip as h
+    _, zf, _ = h.sinkhorn(s.detach().to(DEV), alpha.detach().to(DEV).reshape(1), iters, want_perm=False, want_z=True)
+    assert rel_err(zf.cpu(), z.detach()) < 1e-5
+
+
 def test_losses_forward_backward():
     from pixelspointspolygons_amd.training import pix2poly_loss
     inp = O.make_inputs(3, seed=5)
