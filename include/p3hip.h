@@ -277,9 +277,11 @@ int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dty
 int p3_pool_pos_bwd(const void* dout, int dtype_dout, void* dy, int dtype_dy, int B, int np, int Din, int Dout, void* stream);
 int p3_pair_mean_bwd(const float* dF, void* dfeats, int dtype, int B, int L, int N, int D, int accumulate, void* stream);
 /* reverse-mode through all Sinkhorn iterations + slice + softmax in one launch (uv_hist from p3_sinkhorn) */
-/* tile_flags: int32 [B] device scratch (which tiles ran the linear-domain iterations, which fell back to the log domain) */
+/* workspace: p3_sinkhorn_bwd_workspace_bytes(B, m, n, iters) bytes of device scratch (per-tile path flags + the per-iteration
+ * row / column factor vectors of the linear-domain sweep) */
 int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
-                    const float* uv_hist, const float* dperm, float* dscores, float* dalpha, int32_t* tile_flags, void* stream);
+                    const float* uv_hist, const float* dperm, float* dscores, float* dalpha, void* workspace, void* stream);
+int64_t p3_sinkhorn_bwd_workspace_bytes(int B, int m, int n, int iters);
 /* nn.CrossEntropyLoss(ignore_index) / nn.BCELoss (trainer_pix2poly.py:91-93): acc[0] = loss sum, acc[1] = #valid rows;
  * backward kernels read the upstream gradient x loss weight from the device scalar `gscale` (no host sync) */
 int p3_ce_loss_fwd(const float* logits, int ld, const int64_t* targets, int R, int V, int ignore_index, float* row_lse, float* acc, void* stream);

@@ -10,14 +10,12 @@ namespace {
 // the reference, model_pix2poly.py:35-66,261-264).  One 1024-thread workgroup per sample: Z stays in LDS, the gradient dZ
 // lives in registers with a fixed (row = wave + 16k, col = lane + 64c) ownership; the LSE terms are recovered from the saved
 // dual iterates (u_t, v_t):  softmax_i(Z + u_t)[i,j] = exp(Z_ij + u_t[i] + v_t[j] - log_nu[j]), etc. - no re-reduction.
-constexpr int SK_MAXC = 4;   // rows <= 208, cols <= 256  (reference: 193 x 193)
+constexpr int SK_MAXK = 13, SK_MAXC = 4;   // rows <= 16*13 = 208, cols <= 256  (reference: 193 x 193)
 
-template <bool FAST, int NW>
-__global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
+__global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                             int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
                                                             const float* __restrict__ dperm, float* __restrict__ dscores,
-                                                            float* __restrict__ dalpha, int* __restrict__ tile_flags) {
-    constexpr int NT = 64 * NW, MAXK = 208 / NW;             // rows w, w + NW, ...: 16 waves x 13 or 8 waves x 26 register-resident dZ rows
+                                                            float* __restrict__ dalpha, const int* __restrict__ tile_flags) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1;
     float* Z = sm;                   // [M1][N1]
@@ -27,57 +25,27 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __re
     float* du = vp + N1;             // [M1]
     float* dv = du + M1;             // [N1]
     float* dvn = dv + N1;            // [N1] next dv (accumulated with LDS atomics)
-    float* rmax = dvn + N1;          // [M1] row maxima of Z        } linear-domain path (see sinkhorn.hip): Z holds E = exp(Z - rmax_i),
-    float* Ai = rmax + M1;           // [M1] exp(u_t + rmax)        } every exp(Z + u + v - c) below becomes E_ij * (row factor) * (column factor)
-    float* Di = Ai + M1;             // [M1] Ai / mu_i * du_i
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // Two launches per call: the linear-domain kernel (FAST) decides per tile whether it may run (tile_flags[b] = 0) or leaves the
-    // tile to the log-domain kernel that follows it (tile_flags[b] = 1).  One kernel holding both loops spilled 40 more registers.
-    if (!FAST && tile_flags[b] == 0) return;
-    const int forced = FAST ? (tile_flags[b] != 0) : 0;      // host request (P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel
+    if (tile_flags[b] == 0) return;       // this tile was done by sinkhorn_bwd_fast_kernel (linear domain)
     const float alpha = alpha_p[0];
-    for (int i = tid; i < M1 * N1; i += NT) {
+    for (int i = tid; i < M1 * N1; i += 1024) {
         const int r = i / N1, c = i - r * N1;
         Z[i] = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
     }
-    for (int i = tid; i < N1; i += NT) { dv[i] = 0.f; dvn[i] = 0.f; }
-    for (int i = tid; i < M1; i += NT) du[i] = 0.f;
+    for (int i = tid; i < N1; i += 1024) { dv[i] = 0.f; dvn[i] = 0.f; }
+    for (int i = tid; i < M1; i += 1024) du[i] = 0.f;
     const float norm = -logf((float)(m + n));
     const float a_last = logf((float)n) + norm, b_last = logf((float)m) + norm;
-    float dZ[MAXK][SK_MAXC];
+    float dZ[SK_MAXK][SK_MAXC];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k)
+    for (int k = 0; k < SK_MAXK; ++k)
 #pragma unroll
         for (int c = 0; c < SK_MAXC; ++c) dZ[k][c] = 0.f;
     __syncthreads();
-    // same test as the forward kernel: every row's spread below 60 -> no E_ij underflows
-    if constexpr (FAST) {
-    int wide = 0;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-        const int i = w + NW * k;
-        if (i < M1) {
-            float mx = -INFINITY, mn = INFINITY;
-#pragma unroll
-            for (int c = 0; c < SK_MAXC; ++c) {
-                const int j = lane + 64 * c;
-                if (j < N1) { const float x = Z[i * N1 + j]; mx = fmaxf(mx, x); mn = fminf(mn, x); }
-            }
-            mx = wave_max(mx); mn = -wave_max(-mn);
-            if (lane == 0) rmax[i] = mx;
-            wide |= !(mx - mn < 60.f);
-        }
-    }
-    const bool wide_tile = __syncthreads_or(wide | forced);
-    if (tid == 0) tile_flags[b] = wide_tile ? 1 : 0;
-    if (wide_tile) return;
-    for (int i = tid; i < M1 * N1; i += NT) { const int r = i / N1; Z[i] = __expf(Z[i] - rmax[r]); }
-    __syncthreads();
-    }
     // ---- softmax backward: G = perm * (dperm - rowdot); dZ += G; dv[j] = sum_i G ----
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-        const int i = w + NW * k;
+    for (int k = 0; k < SK_MAXK; ++k) {
+        const int i = w + 16 * k;
         float pv[SK_MAXC], gv[SK_MAXC];
         float dot = 0.f;
 #pragma unroll
@@ -101,66 +69,13 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __re
     for (int t = iters; t >= 1; --t) {
         const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
         const float* hp = t > 1 ? h - (M1 + N1) : nullptr;
-        for (int i = tid; i < M1; i += NT) ut[i] = h[i];
-        for (int i = tid; i < N1; i += NT) { vt[i] = h[M1 + i]; vp[i] = hp ? hp[M1 + i] : 0.f; }
+        for (int i = tid; i < M1; i += 1024) ut[i] = h[i];
+        for (int i = tid; i < N1; i += 1024) { vt[i] = h[M1 + i]; vp[i] = hp ? hp[M1 + i] : 0.f; }
         __syncthreads();
-        if constexpr (FAST) {
-            const float inv_mu = (float)(m + n), inv_mu_last = (float)(m + n) / (float)n;      // 1 / exp(log_mu)
-            float Bv[SK_MAXC], Cj[SK_MAXC];
-#pragma unroll
-            for (int c = 0; c < SK_MAXC; ++c) {
-                const int j = lane + 64 * c;
-                Bv[c] = j < N1 ? __expf(vt[j] - (j < n ? norm : b_last)) * dv[j] : 0.f;
-                Cj[c] = j < N1 ? __expf(vp[j]) : 0.f;
-            }
-            if (tid < M1) Ai[tid] = __expf(ut[tid] + rmax[tid]);
-            __syncthreads();
-            // pass A: q = softmax_i(Z + u_t)[i,j] * dv[j] = E_ij * Ai * Bv
-#pragma unroll
-            for (int k = 0; k < MAXK; ++k) {
-                const int i = w + NW * k;
-                float acc = 0.f;
-                if (i < M1) {
-                    const float ai = Ai[i];
-#pragma unroll
-                    for (int c = 0; c < SK_MAXC; ++c) {
-                        const int j = lane + 64 * c;
-                        if (j < N1) {
-                            const float q = Z[i * N1 + j] * ai * Bv[c];
-                            dZ[k][c] -= q; acc += q;
-                        }
-                    }
-                }
-                acc = wave_sum(acc);
-                if (lane == 0 && i < M1) { du[i] = -acc; Di[i] = Ai[i] * (i < m ? inv_mu : inv_mu_last) * -acc; }
-            }
-            __syncthreads();
-            // pass B: r = softmax_j(Z + v_{t-1})[i,j] * du[i] = E_ij * Cj * Di
-#pragma unroll
-            for (int c = 0; c < SK_MAXC; ++c) {
-                const int j = lane + 64 * c;
-                float acc = 0.f;
-                if (j < N1) {
-#pragma unroll
-                    for (int k = 0; k < MAXK; ++k) {
-                        const int i = w + NW * k;
-                        if (i < M1) {
-                            const float r = Z[i * N1 + j] * Cj[c] * Di[i];
-                            dZ[k][c] -= r; acc += r;
-                        }
-                    }
-                    atomicAdd(&dvn[j], -acc);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < N1; i += NT) { dv[i] = dvn[i]; dvn[i] = 0.f; }
-            __syncthreads();
-            continue;
-        }
         // pass A: v_t = log_nu - LSE_i(Z + u_t):  q = softmax_i * dv[j];  dZ -= q;  du[i] = -sum_j q
 #pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            const int i = w + NW * k;
+        for (int k = 0; k < SK_MAXK; ++k) {
+            const int i = w + 16 * k;
             float acc = 0.f;
             if (i < M1) {
                 const float ui = ut[i];
@@ -185,8 +100,8 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __re
             if (j < N1) {
                 const float vj = vp[j];
 #pragma unroll
-                for (int k = 0; k < MAXK; ++k) {
-                    const int i = w + NW * k;
+                for (int k = 0; k < SK_MAXK; ++k) {
+                    const int i = w + 16 * k;
                     if (i < M1) {
                         const float r = __expf(Z[i * N1 + j] + vj + ut[i] - (i < m ? norm : a_last)) * du[i];
                         dZ[k][c] -= r; acc += r;
@@ -196,18 +111,189 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_bwd_kernel(const float* __re
             }
         }
         __syncthreads();
-        for (int i = tid; i < N1; i += NT) { dv[i] = dvn[i]; dvn[i] = 0.f; }
+        for (int i = tid; i < N1; i += 1024) { dv[i] = dvn[i]; dvn[i] = 0.f; }
         __syncthreads();
     }
     float da = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-        const int i = w + NW * k;
+    for (int k = 0; k < SK_MAXK; ++k) {
+        const int i = w + 16 * k;
 #pragma unroll
         for (int c = 0; c < SK_MAXC; ++c) {
             const int j = lane + 64 * c;
             if (i < m && j < n) dscores[((int64_t)b * m + i) * n + j] = dZ[k][c];
             else if (i < M1 && j < N1) da += dZ[k][c];
+        }
+    }
+    da = wave_sum(da);
+    if (lane == 0 && da != 0.f) atomicAdd(dalpha, da);
+}
+
+// ---- linear-domain backward (tiles whose row spread allows E = exp(Z - rowmax), see sinkhorn.hip) -------------------------------
+// With E fixed, every exp(Z + u + v - c) of the reverse sweep factorises: q_ij = E_ij A_i B_j, r_ij = E_ij D_i C_j.  The dual
+// gradients therefore need only two matrix-vector products per iteration (du = -A (E B), dv' = -C (E^T D)) - the same loop shape
+// as the forward kernel - and the 37 k-element gradient dZ = G - E (sum_t A^t B^t^T + D^t C^t^T) is accumulated ONCE at the end
+// from the per-iteration vectors (kept in a global scratch slab, 309 KB per tile, L2 resident) instead of being read-modify-written
+// in registers twice per iteration (r01: 1.49 ms for that form, 1.72 ms for the log-domain one, 64 x 192 x 192 x 100).
+__global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
+                                                                 int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
+                                                                 const float* __restrict__ dperm, float* __restrict__ dscores,
+                                                                 float* __restrict__ dalpha, int* __restrict__ tile_flags, float* __restrict__ vecs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int M1 = m + 1, N1 = n + 1, VS = 2 * (M1 + N1);
+    float* E = sm;                   // [M1][N1]
+    float* rmax = sm + M1 * N1;      // [M1]
+    float* Ai = rmax + M1;           // [M1] exp(u_t + rmax)
+    float* Di = Ai + M1;             // [M1] Ai / mu_i * du_i
+    float* Bj = Di + M1;             // [N1] exp(v_t - log_nu) * dv
+    float* Cj = Bj + N1;             // [N1] exp(v_{t-1})
+    float* dv = Cj + N1;             // [N1]
+    float* pm = dv + N1;             // [1024] partials
+    float* ps = pm + 1024;           // [1024] partials
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int idx = tid & 255, part = tid >> 8;
+    const int chj = (N1 + 3) / 4, chi = (M1 + 3) / 4;
+    const int forced = tile_flags[b] != 0;                   // host request (P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel
+    const float alpha = alpha_p[0];
+    for (int i = tid; i < M1 * N1; i += 1024) {
+        const int r = i / N1, c = i - r * N1;
+        E[i] = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
+    }
+    for (int i = tid; i < N1; i += 1024) dv[i] = 0.f;
+    const float norm = -logf((float)(m + n));
+    const float b_last = logf((float)m) + norm;
+    const float inv_mu = (float)(m + n), inv_mu_last = (float)(m + n) / (float)n;      // 1 / exp(log_mu)
+    __syncthreads();
+    {   // row maxima / spread test (same rule as the forward kernel)
+        float mx = -INFINITY, mn = INFINITY;
+        if (idx < M1) {
+            const int c0 = part * chj, c1 = min(N1, c0 + chj);
+            const float* zr = E + idx * N1;
+            for (int c = c0; c < c1; ++c) { const float x = zr[c]; mx = fmaxf(mx, x); mn = fminf(mn, x); }
+        }
+        pm[part * 256 + idx] = mx; ps[part * 256 + idx] = mn;
+    }
+    __syncthreads();
+    int wide = forced;
+    if (tid < M1) {
+        const float mm = fmaxf(fmaxf(pm[tid], pm[256 + tid]), fmaxf(pm[512 + tid], pm[768 + tid]));
+        const float nn = fminf(fminf(ps[tid], ps[256 + tid]), fminf(ps[512 + tid], ps[768 + tid]));
+        rmax[tid] = mm;
+        wide |= !(mm - nn < 60.f);
+    }
+    const bool wide_tile = __syncthreads_or(wide);
+    if (tid == 0) tile_flags[b] = wide_tile ? 1 : 0;
+    if (wide_tile) return;
+    for (int i = tid; i < M1 * N1; i += 1024) { const int r = i / N1; E[i] = __expf(E[i] - rmax[r]); }
+    // ---- softmax backward: G = perm * (dperm - rowdot); dv[j] = sum_i G_ij (G itself is rebuilt in the last phase)
+    for (int i = w; i < m; i += 16) {
+        float pv[SK_MAXC], gv[SK_MAXC];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = j < n;
+            pv[c] = ok ? perm[((int64_t)b * m + i) * n + j] : 0.f;
+            gv[c] = ok ? dperm[((int64_t)b * m + i) * n + j] : 0.f;
+            dot += pv[c] * gv[c];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const float G = pv[c] * (gv[c] - dot);
+            if (j < n && G != 0.f) atomicAdd(&dv[j], G);
+        }
+    }
+    __syncthreads();
+    float* vt_all = vecs + (int64_t)b * iters * VS;
+    for (int t = iters; t >= 1; --t) {
+        const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
+        float* vs = vt_all + (int64_t)(t - 1) * VS;            // [A (M1) | D (M1) | B (N1) | C (N1)] of this iteration
+        if (tid < M1) { const float a = __expf(h[tid] + rmax[tid]); Ai[tid] = a; vs[tid] = a; }
+        if (tid < N1) {
+            const float bj = __expf(h[M1 + tid] - (tid < n ? norm : b_last)) * dv[tid];
+            const float cj = t > 1 ? __expf(h[M1 + tid - (M1 + N1)]) : 1.f;                        // v_0 = 0
+            Bj[tid] = bj; Cj[tid] = cj; vs[2 * M1 + tid] = bj; vs[2 * M1 + N1 + tid] = cj;
+        }
+        __syncthreads();
+        {   // s_i = sum_j E_ij B_j
+            float sacc = 0.f;
+            if (idx < M1) {
+                const int c0 = part * chj, c1 = min(N1, c0 + chj);
+                const float* er = E + idx * N1;
+                for (int c = c0; c < c1; ++c) sacc = fmaf(er[c], Bj[c], sacc);
+            }
+            ps[part * 256 + idx] = sacc;
+        }
+        __syncthreads();
+        if (tid < M1) {
+            const float du = -Ai[tid] * ((ps[tid] + ps[256 + tid]) + (ps[512 + tid] + ps[768 + tid]));
+            const float d = Ai[tid] * (tid < m ? inv_mu : inv_mu_last) * du;
+            Di[tid] = d; vs[M1 + tid] = d;
+        }
+        __syncthreads();
+        {   // w_j = sum_i E_ij D_i
+            float sacc = 0.f;
+            if (idx < N1) {
+                const int r0 = part * chi, r1 = min(M1, r0 + chi);
+                for (int r = r0; r < r1; ++r) sacc = fmaf(E[r * N1 + idx], Di[r], sacc);
+            }
+            pm[part * 256 + idx] = sacc;
+        }
+        __syncthreads();
+        if (tid < N1) dv[tid] = -Cj[tid] * ((pm[tid] + pm[256 + tid]) + (pm[512 + tid] + pm[768 + tid]));
+        // no barrier needed here: dv[tid] is read by the same thread next iteration; Ai/Bj/Cj/Di writes of the next iteration come
+        // after this iteration's last reads of them (before the barrier above) except Cj, read just now by its own writer thread
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- dZ = G - E * sum_t (A^t_i B^t_j + D^t_i C^t_j); rows w, w + 16, ..., columns lane, lane + 64, ...
+    float acc[13][SK_MAXC];
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) acc[k][c] = 0.f;
+    for (int t = 0; t < iters; ++t) {
+        const float* vs = vt_all + (int64_t)t * VS;
+        float bb[SK_MAXC], cc[SK_MAXC];
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            bb[c] = j < N1 ? vs[2 * M1 + j] : 0.f;
+            cc[c] = j < N1 ? vs[2 * M1 + N1 + j] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            const int i = w + 16 * k;
+            const float a = i < M1 ? vs[i] : 0.f, d = i < M1 ? vs[M1 + i] : 0.f;
+#pragma unroll
+            for (int c = 0; c < SK_MAXC; ++c) acc[k][c] = fmaf(a, bb[c], fmaf(d, cc[c], acc[k][c]));
+        }
+    }
+    float da = 0.f;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = w + 16 * k;
+        float pv[SK_MAXC], gv[SK_MAXC];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = i < m && j < n;
+            pv[c] = ok ? perm[((int64_t)b * m + i) * n + j] : 0.f;
+            gv[c] = ok ? dperm[((int64_t)b * m + i) * n + j] : 0.f;
+            dot += pv[c] * gv[c];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            if (i < M1 && j < N1) {
+                const float dz = pv[c] * (gv[c] - dot) - E[i * N1 + j] * acc[k][c];
+                if (i < m && j < n) dscores[((int64_t)b * m + i) * n + j] = dz;
+                else da += dz;
+            }
         }
     }
     da = wave_sum(da);
@@ -306,27 +392,35 @@ inline int grid_for(int64_t work) {
 
 }  // namespace
 
+extern "C" int64_t p3_sinkhorn_bwd_workspace_bytes(int B, int m, int n, int iters) {
+    return 256 + ((int64_t)B * 4 + 255) / 256 * 256 + (int64_t)B * iters * 2 * (m + n + 2) * 4;
+}
+
 extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
-                               const float* uv_hist, const float* dperm, float* dscores, float* dalpha, int32_t* tile_flags, void* stream) {
-    P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && tile_flags && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
-    P3_CHECK(m + 1 <= 208 && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
-    const size_t lds = ((size_t)(m + 1) * (n + 1) + 5 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
-    P3_CHECK(lds <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
+                               const float* uv_hist, const float* dperm, float* dscores, float* dalpha, void* workspace, void* stream) {
+    P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && workspace && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
+    P3_CHECK(m + 1 <= 16 * SK_MAXK && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
+    const size_t lds = ((size_t)(m + 1) * (n + 1) + 2 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
+    const size_t lds_fast = ((size_t)(m + 1) * (n + 1) + 3 * (size_t)(m + 1) + 3 * (size_t)(n + 1) + 2048) * sizeof(float);
+    P3_CHECK(lds <= 160 * 1024 && lds_fast <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
     static int force_log = -1;                        // P3_SINKHORN_LOG=1: log-domain loop only (A/B, tests of the fallback)
     if (force_log < 0) { const char* e = getenv("P3_SINKHORN_LOG"); force_log = (e && e[0] == '1') ? 1 : 0; }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sinkhorn_bwd_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
+    int* tile_flags = reinterpret_cast<int*>(workspace);
+    float* vecs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * 4 + 255) / 256 * 256);
     hipError_t me = hipMemsetAsync(tile_flags, force_log ? 1 : 0, sizeof(int32_t) * (size_t)B, s);
     if (me != hipSuccess) { p3_set_error(hipGetErrorString(me)); return (int)me; }
-    // 16 waves per tile (8 waves x 26 register rows measured slower: 1.94 vs 1.49 ms at 64 x 192 x 192, r01)
-    hipLaunchKernelGGL((sinkhorn_bwd_kernel<true, 16>), dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
-    hipLaunchKernelGGL((sinkhorn_bwd_kernel<false, 16>), dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
+    // two launches: the linear-domain kernel takes every tile whose row spread allows it and flags the others for the log-domain
+    // kernel, which returns at once for the tiles already done (one kernel holding both loops spilled 40 more registers)
+    hipLaunchKernelGGL(sinkhorn_bwd_fast_kernel, dim3(B), dim3(1024), lds_fast, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags, vecs);
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -602,9 +602,10 @@ def sinkhorn_bwd(scores, alpha, perm, hist, dperm, iters):
     B, m, n = scores.shape
     dscores = torch.empty_like(scores)
     dalpha = torch.zeros(1, dtype=torch.float32, device=scores.device)
-    flags = torch.empty(B, dtype=torch.int32, device=scores.device)
+    lib().p3_sinkhorn_bwd_workspace_bytes.restype = c_int64
+    ws = workspace(int(lib().p3_sinkhorn_bwd_workspace_bytes(c_int(B), c_int(m), c_int(n), c_int(iters))), scores.device, "sinkhorn_bwd")
     check(lib().p3_sinkhorn_bwd(ptr(scores), ptr(alpha), c_int(B), c_int(m), c_int(n), c_int(iters), ptr(perm), ptr(hist), ptr(dperm),
-                                ptr(dscores), ptr(dalpha), ptr(flags), stream()), "p3_sinkhorn_bwd")
+                                ptr(dscores), ptr(dalpha), ptr(ws), stream()), "p3_sinkhorn_bwd")
     return dscores, dalpha
 
 
