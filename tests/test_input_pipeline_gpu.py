@@ -90,3 +90,19 @@ def test_prefetched_batch_feeds_the_model():
         logits, perm = m(batch["image"], (batch["lidar_values"], batch["lidar_offsets"]), batch["y"][:, :-1])
         ref_logits, _ = m(prepare_images(img_u8.to(DEV)), (inp["lidar_values"].to(DEV), inp["lidar_offsets"].to(DEV)), inp["y"][:, :-1].to(DEV))
     assert torch.equal(logits, ref_logits) and torch.isfinite(perm).all()
+
+
+def test_prefetcher_single_modality_batches_and_no_augmentation():
+    """image-only and lidar-only host batches, no D4 group: validation / prediction feeding."""
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy(_tiles(2, 224, 3, 31))
+    clouds = [(rng.random((n, 3)) * 224.0).astype(np.float32) for n in (10, 2000)]
+    b = next(DevicePrefetcher(iter([{"image": img}]), DEV))
+    assert set(b) == {"image"} and torch.equal(b["image"][1].cpu(), O.normalize_to_tensor(img[1].numpy()))
+    b = next(DevicePrefetcher(iter([{"lidar": clouds, "image": None}]), DEV, max_points=4096))
+    assert set(b) == {"lidar_values", "lidar_offsets"}
+    assert np.array_equal(b["lidar_values"].cpu().numpy(), np.concatenate(clouds)) and b["lidar_offsets"].tolist() == [0, 10, 2010]
+    from pixelspointspolygons_amd._lib import P3Error
+    with pytest.raises(P3Error):
+        DevicePrefetcher(iter([{"lidar": clouds}]), DEV, max_points=100)          # staging buffer too small: loud
+    assert list(DevicePrefetcher(iter([]), DEV)) == []

@@ -281,6 +281,20 @@ def test_graph_replayed_decode_equals_eager_decode(precision):
         assert not torch.equal(ref[1], want[0][1])
 
 
+def test_graph_replayed_decode_single_tile_and_step_limit():
+    sd = O.make_state_dict("image", seed=42)
+    m, cfg = _model("image", "bf16", sd)
+    with torch.no_grad():
+        enc = m.encoder(O.make_inputs(1, seed=2)["image"].to(DEV))
+        ref = m.generate(enc, steps=6)
+        for _ in range(3):
+            got = m.generate(enc, steps=6, graphs=True)
+            assert got[0].shape == (1, 7) and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        from pixelspointspolygons_amd._lib import P3Error
+        with pytest.raises(P3Error):
+            m.generate(enc, steps=386)
+
+
 def test_lidar_feature_dropout_zeroes_the_whole_batch():
     """SURVEY §9-8 (early_fusion_vit.py:113-119): one draw per BATCH; p = 1.0 (what validation sets) zeroes every tile's LiDAR
     features before the fusion conv, p = 0.0 never fires.  Checked against the oracle with the LiDAR map scaled by 0."""
