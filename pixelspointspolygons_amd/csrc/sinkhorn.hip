@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
         rmax[tid] = mm;
         wide = !(mm - nn < 60.f);              // also catches NaN / inf scores
     }
-    const bool fast = !__syncthreads_or(wide) && !force_log;
+    const bool fast = !__syncthreads_or(wide) && !force_log && iters > 0;     // iters == 0: u = v = 0 stay log-domain quantities
     if (fast) {
         for (int i = tid; i < M1 * N1; i += 1024) { const int r = i / N1; Z[i] = __expf(Z[i] - rmax[r]); }
         for (int i = tid; i < N1; i += 1024) v[i] = 1.f;

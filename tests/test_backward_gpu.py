@@ -142,6 +142,15 @@ def test_sinkhorn_wide_range_scores_take_the_log_domain_path():
     assert rel_err(zf.cpu(), z.detach()) < 1e-5
 
 
+def test_sinkhorn_zero_iterations_is_plain_softmax_with_dustbins():
+    import pixelspointspolygons_amd.hip as h
+    s = _rand(2, 9, 9, seed=4)
+    alpha = torch.tensor([0.3])
+    perm, z, _ = h.sinkhorn(s.to(DEV), alpha.to(DEV), 0, want_perm=True, want_z=True)
+    zr = O.log_optimal_transport(s, alpha[0], 0)
+    assert rel_err(z.cpu(), zr) < 1e-6 and rel_err(perm.cpu(), torch.softmax(zr[:, :9, :9], -1)) < 1e-6
+
+
 def test_losses_forward_backward():
     from pixelspointspolygons_amd.training import pix2poly_loss
     inp = O.make_inputs(3, seed=5)
