@@ -609,6 +609,43 @@ def afm(lines, shape_info, height, width):
     return torch.from_numpy(afmap), torch.from_numpy(lab)
 
 
+# ----------------------------------------------------------------------------------------------
+# Predictor post-processing (predict/predictor_pix2poly.py:213-305), restated for the parity tests; pinned by tests/golden/postprocess.npz
+# (outputs of the reference's own methods).
+# ----------------------------------------------------------------------------------------------
+def predictor_postprocess(batch_preds, decode, eos_code=EOS, token_mode=2):
+    """:284-305: first EOS per row; rows whose EOS index fails (idx - 1) % token_mode == 0 (or have none) yield None."""
+    eos_idx = (batch_preds == eos_code).float().argmax(dim=-1)
+    eos_idx[((eos_idx - 1) % token_mode != 0).nonzero().view(-1)] = 0
+    return [None if e == 0 else decode(batch_preds[i, :e + 1]) for i, e in enumerate(eos_idx.tolist())]
+
+
+def permutation_polygons(perm_b):
+    """:213-250 for one tile: vertex index chains of the non-diagonal part of a permutation matrix.  The reference merges the pairs
+    (i, argmax row i) head-to-tail; for a permutation that is each cycle, starting at its smallest index and closed by repeating it,
+    cycles ordered by smallest index.  Returned indices address the restricted (non-diagonal) vertex list."""
+    n = perm_b.shape[0]
+    idx = [i for i in range(n) if perm_b[i, i] == 0]
+    if not idx:
+        return idx, []
+    sub = perm_b[idx][:, idx]
+    pairs = [[i, int(sub[i].argmax())] for i in range(len(idx))]
+    polys, used = [], set()
+    for s, (a, nxt) in enumerate(pairs):
+        if s in used:
+            continue
+        chain = [a, nxt]
+        used.add(s)
+        while True:
+            t = next((k for k in range(len(pairs)) if k not in used and pairs[k][0] == chain[-1]), None)
+            if t is None:
+                break
+            used.add(t)
+            chain.append(pairs[t][1])
+        polys.append(chain)
+    return idx, polys
+
+
 def conv_bn_relu(x, sd, pre_conv, pre_bn, training=False):
     x = F.conv2d(x, sd[pre_conv + ".weight"], sd[pre_conv + ".bias"], padding=1)
     return F.relu(_bn(x, sd, pre_bn, training, 1e-5, 0.1, dims=(0, 2, 3)))
