@@ -7,7 +7,7 @@ channel 256 later receives the detached seg map (the reference's torch.cat(featu
 image without bounds checks (p3_gemm conv_pad) and the backward's weight-gradient GEMMs read the same image; the heads' own BN + ReLU
 is folded into the 1x1 head kernels.
 Training: `_FFLTail` (autograd.Function) covers tokens -> {seg, crossfield} with a hand-written backward (head / BatchNorm / 3x3 conv
-weight + input gradients on the MFMA GEMMs / adjoint of the bilinear upsample); the encoders' own NCHW `forward` stays forward-only.
+weight + input gradients on the MFMA GEMMs / adjoint of the bilinear upsample); `_CNNFeatures` does the same for the encoders' own NCHW `forward`.
 """
 import torch
 import torch.nn as nn
@@ -38,11 +38,6 @@ def _bn_affine(sums, count, bn, training, save=False):
     if training:
         bn.num_batches_tracked += 1
     return r
-
-
-def _no_grad_only(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("p3hip round 1: the FFL / *CNN tails are forward-only (run under torch.no_grad()); see DESIGN.md §8")
 
 
 class _CNNTailMixin:
@@ -81,6 +76,11 @@ class _CNNTailMixin:
         return buf, sc, sh
 
     def _nchw(self, tokens):
+        """tokens -> relu(bn(conv(upsample))) as the reference's NCHW fp32 feature map; differentiable (`_CNNFeatures`)."""
+        conv, bn = self.proj[1], self.proj[2]
+        needs_grad = torch.is_grad_enabled() and (tokens.requires_grad or conv.weight.requires_grad)
+        if needs_grad:
+            return _CNNFeatures.apply(tokens, self, conv.weight, conv.bias, bn.weight, bn.bias)
         buf, sc, sh = self.features_nhwc(tokens)
         B, H = tokens.shape[0], self.out_size
         return hip.nhwc_to_nchw(buf, 256, sc, sh, B, 256, H * H).view(B, 256, H, H)
@@ -97,7 +97,6 @@ class ViTCNN(ViT, _CNNTailMixin):
         return self.vit(x_image)
 
     def forward(self, x):
-        _no_grad_only(x, self.proj[1].weight)
         return self._nchw(self.vit(x))
 
 
@@ -112,7 +111,6 @@ class PointPillarsViTCNN(PointPillarsViT, _CNNTailMixin):
         return self.vit(x_lidar if x_lidar is not None else x_image)
 
     def forward(self, x):
-        _no_grad_only(self.proj[1].weight)
         return self._nchw(self.vit(x))
 
 
@@ -128,7 +126,6 @@ class EarlyFusionViTCNN(EarlyFusionViT, _CNNTailMixin):
         return self.fused_tokens(x_image, x_lidar)
 
     def forward(self, x_image, x_lidar):
-        _no_grad_only(x_image, self.proj[1].weight)
         return self._nchw(self.fused_tokens(x_image, x_lidar))
 
 
@@ -151,6 +148,40 @@ def _conv3x3_bwd(dY, Xpad, ldx, cin, w, cd, B, H, ci_dx, key, residual=None):
     wf = ops.shadow(w, cd, key=key, fn=lambda t_: t_[:, :ci_dx].flip(2, 3).permute(1, 2, 3, 0).reshape(ci_dx, -1))
     dX = hip.gemm(dY, wf, a_mode=hip.A_CONV3X3, conv=(B, H, H, Co), lda=Co, out_dtype=cd, residual=residual)
     return dW2.view(Co, 3, 3, cin), dX
+
+
+class _CNNFeatures(torch.autograd.Function):
+    """Stand-alone `*CNN` encoder tail (early_fusion_vit_cnn.py:96-104): LN'd tokens -> NCHW fp32 relu(bn(conv3x3(upsample(tokens)))),
+    backward through BatchNorm + ReLU, the 3x3 convolution (weight / input gradients on the MFMA GEMMs) and the bilinear upsample."""
+
+    @staticmethod
+    def forward(ctx, tokens, enc, *params):
+        keep = {}
+        buf, sc, sh = enc.features_nhwc(tokens.detach(), keep)
+        B, H = tokens.shape[0], enc.out_size
+        ctx.enc, ctx.keep, ctx.meta = enc, dict(keep, buf=buf), (tokens.shape, tokens.dtype)
+        return hip.nhwc_to_nchw(buf, 256, sc, sh, B, 256, H * H).view(B, 256, H, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc, k = ctx.enc, ctx.keep
+        (B, L, D), cd = ctx.meta
+        H, g = enc.out_size, enc.grid
+        R, training = B * H * H, enc.training
+        buf, up = k["buf"], k["up"]
+        scP, shP, mP, rP = k["bnP"]
+        pconv, pbn = enc.proj[1], enc.proj[2]
+        dA = dout.permute(0, 2, 3, 1).reshape(R, 256).to(cd).contiguous()          # NCHW fp32 -> NHWC compute dtype
+        dP, acc = hip.affine_relu_bwd256(dA, buf, 256, scP, shP, mP, R)
+        g_bn_w, g_bn_b, a_, b_ = ops.bn_backward_coeffs(acc[:256], acc[256:512], pbn.weight.detach(), mP, rP, float(R), training)
+        if training:
+            hip.affine_fix(dP, buf, a_, b_, ldh=256)
+        g_conv_b = ops.bias_grad_before_bn(dP, training)
+        Upad = hip.pad_nhwc(up, D, None, None, 0, D, D, B, H, H)
+        dW, dUp = _conv3x3_bwd(dP, Upad, D, D, pconv.weight, cd, B, H, D, "flipT")
+        dtok = hip.upsample_bilinear_bwd(dUp.view(B, H, H, D), B, g, g, H, H)
+        ctx.keep = None
+        return dtok, None, dW.permute(0, 3, 1, 2).contiguous(), g_conv_b, g_bn_w, g_bn_b
 
 
 class _FFLTail(torch.autograd.Function):

@@ -71,11 +71,39 @@ def test_ffl_single_modality(encoder, kind):
     assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < 1e-3
 
 
-def test_cnn_encoder_nchw_forward_refuses_grad():
-    """The *CNN encoders' own NCHW forward is inference-only; training goes through FFLModel (hand-written backward)."""
-    m, sd, cfg = _model("vit_cnn", "bf16", "image", SMALL, vit_depth=2)
-    with pytest.raises(NotImplementedError):
-        m.encoder(torch.rand(1, 3, 224, 224, device="cuda"))
+@pytest.mark.parametrize("training", [True, False])
+def test_cnn_encoder_standalone_forward_is_differentiable(training):
+    """ViTCNN.forward (vit_cnn.py:45-57) on its own: NCHW features and the gradients of every encoder parameter + the input image
+    for a random linear functional, vs float64 autograd of the oracle (encoder tokens -> vitcnn_tail)."""
+    from oracle import p3_oracle as O
+    from helpers import l2_err
+    m, sd, cfg = _model("vit_cnn", "fp32", "image", SMALL, vit_depth=2)
+    enc = m.encoder.train(training)
+    img = O.make_inputs(1, seed=12)["image"]
+    gen = torch.Generator().manual_seed(5)
+    g = torch.randn(1, 256, 224, 224, generator=gen)
+    p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+         for k, v in sd.items()}
+    x = O.patch_embed(img.double(), p, "encoder.vit.patch_embed.", SMALL["patch"]).flatten(2).transpose(1, 2)
+    tok = O.vit_blocks(x, p, "encoder.vit.", SMALL["depth"], SMALL["heads"], SMALL["eps"])
+    ref = O.vitcnn_tail(tok, p, "encoder.", 224, training)
+    (ref * g.double()).sum().backward()
+    xin = img.cuda().requires_grad_(True)
+    out = enc(xin)
+    assert out.shape == (1, 256, 224, 224) and out.dtype == torch.float32
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-3
+    (out * g.cuda()).sum().backward()
+    gnorm = max(float(v.grad.norm()) for k, v in p.items() if k.startswith("encoder.") and v.is_floating_point() and v.requires_grad and v.grad is not None)
+    bad = {}
+    for k, prm in enc.named_parameters():
+        r = p["encoder." + k].grad
+        if r is None:
+            continue
+        assert prm.grad is not None, k
+        e = l2_err(prm.grad.float().cpu(), r, floor=1e-3 * gnorm)
+        if not e < 1.5e-2:
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
 @pytest.mark.parametrize("training", [True, False])
