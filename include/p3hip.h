@@ -374,12 +374,13 @@ int p3_points_d4(float* values, const int64_t* offsets, const int32_t* group, in
  *   0 seg (bce_coef * BCE(seg, gt0 > 0.98) + dice_coef * dice(seg, gt0), :318-365)   1 crossfield_align (:368-386)
  *   2 crossfield_align90 (:389-406)   3 crossfield_smooth (:409-419)   4 seg_interior_crossfield (:220-235, :422-444)
  * seg [B,1,H,W], crossfield [B,4,H,W], gt_polygons_image [B,3,H,W] (interior, edge, vertex), gt_crossfield_angle [B,1,H,W]: fp32 NCHW.
+ * seg_weights [B,1,H,W] or NULL: the per-pixel BCE weights of compute_seg_loss_weigths (:150-205; all ones in the shipped config).
  * coef[5] (host) = weight_i(epoch) / norm_i.  losses[6] (device) = the five RAW losses and total = sum coef_i * loss_i.
  * dseg / dcrossfield (both or neither): d total / d input.  workspace: p3_ffl_loss_workspace_bytes(B, H, W) bytes of device scratch.
  * ------------------------------------------------------------------------------------------ */
-int p3_ffl_loss(const float* seg, const float* crossfield, const float* gt_polygons_image, const float* gt_crossfield_angle, int B, int H,
-                int W, const float* coef, float bce_coef, float dice_coef, float* losses, float* dseg, float* dcrossfield, void* workspace,
-                void* stream);
+int p3_ffl_loss(const float* seg, const float* crossfield, const float* gt_polygons_image, const float* gt_crossfield_angle,
+                const float* seg_weights, int B, int H, int W, const float* coef, float bce_coef, float dice_coef, float* losses, float* dseg,
+                float* dcrossfield, void* workspace, void* stream);
 int64_t p3_ffl_loss_workspace_bytes(int B, int H, int W);
 
 /* ------------------------------------------------------------------------------------------

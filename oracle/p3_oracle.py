@@ -561,7 +561,23 @@ def scharr_gradient_ij(seg):
     return F.conv2d(x, k).view(b, c, 2, h, w)
 
 
-def ffl_losses(seg, crossfield, gt_polygons_image, gt_crossfield_angle, epoch=0, norms=None, weights=None, bce_coef=1.0, dice_coef=0.2):
+def ffl_seg_loss_weights(gt_polygons_image, class_freq, distances, sizes, use_freq, use_dist, use_size, w0=50.0, sigma=10.0, height=224, width=224):
+    """compute_seg_loss_weigths (losses.py:150-205): per-pixel BCE weights [B,3,H,W]; ones, replaced by 1/class frequency (use_freq),
+    plus the U-Net distance term (use_dist), times the size term (use_size)."""
+    w = torch.ones_like(gt_polygons_image)
+    if use_freq:
+        mask = (0 < gt_polygons_image).float()
+        bg = 1 - torch.sum(class_freq, dim=1)
+        w = 1 / (mask * class_freq[:, :, None, None] + (1 - mask) * bg[:, None, None, None])
+    if use_dist:
+        w = w + w0 * torch.exp(-((distances * (height + width)) ** 2) / (sigma ** 2))
+    if use_size:
+        w = w * (1 + 1 / (math.sqrt(height * width) / 2 * sizes))
+    return w
+
+
+def ffl_losses(seg, crossfield, gt_polygons_image, gt_crossfield_angle, epoch=0, norms=None, weights=None, bce_coef=1.0, dice_coef=0.2,
+               seg_weights=None):
     """build_combined_loss(cfg)(pred_batch, gt_batch, normalize=True, epoch) for the shipped FFL config -> (total, {name: loss / norm})."""
     norms = norms or {}
     gt = gt_polygons_image
@@ -570,7 +586,8 @@ def ffl_losses(seg, crossfield, gt_polygons_image, gt_crossfield_angle, epoch=0,
     num = 2 * torch.sum(gt_seg * seg, dim=(-1, -2))
     den = torch.sum(gt_seg, dim=(-1, -2)) + torch.sum(seg, dim=(-1, -2))
     dice = torch.mean(1 - (num + 1) / (den + 1 + 1e-7))
-    bce = F.binary_cross_entropy(seg, (gt_seg > 0.98).to(torch.float32), weight=torch.ones_like(seg), reduction="mean")
+    bce = F.binary_cross_entropy(seg, (gt_seg > 0.98).to(torch.float32), weight=torch.ones_like(seg) if seg_weights is None else seg_weights[:, :1],
+                                 reduction="mean")
     out = {"seg": bce_coef * bce + dice_coef * dice}
     # --- crossfield losses (:368-419)
     c0, c2 = crossfield[:, :2], crossfield[:, 2:]

@@ -60,7 +60,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // acc (double): [0] bce sum, [1] align, [2] align90, [3] smooth, [4] couple, then per tile b: [5 + 3b + {0,1,2}] = sum y*p, sum y, sum p
 __global__ __launch_bounds__(256) void ffl_loss_sums_kernel(const float* __restrict__ seg, const float* __restrict__ cf, const float* __restrict__ gt,
-                                                            const float* __restrict__ angle, int B, int H, int W, double* __restrict__ acc) {
+                                                            const float* __restrict__ angle, const float* __restrict__ segw, int B, int H, int W,
+                                                            double* __restrict__ acc) {
     __shared__ float red[4];
     const int HW = H * W;
     const int b = blockIdx.y;
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void ffl_loss_sums_kernel(const float* __restr
         const float pr = sg[p], y0 = g[p], ed = g[HW + p], vx = g[2 * HW + p];
         const float yb = y0 > 0.98f ? 1.f : 0.f;
         v[0] = -(yb * fmaxf(logf(pr), -100.f) + (1.f - yb) * fmaxf(logf(1.f - pr), -100.f));      // F.binary_cross_entropy's clamped logs
+        if (segw) v[0] *= segw[(int64_t)b * HW + p];                                                // seg_loss_weights (losses.py:150-205)
         v[5] = y0 * pr; v[6] = y0; v[7] = pr;
         const float c0r = c[p], c0i = c[HW + p], c2r = c[2 * HW + p], c2i = c[3 * HW + p];
         float sn, cs; sincosf(angle[(int64_t)b * HW + p], &sn, &cs);
@@ -119,7 +121,8 @@ __device__ __forceinline__ void align_grad_c(float fr, float fi, float z2r, floa
 }
 
 __global__ __launch_bounds__(256) void ffl_loss_point_kernel(const float* __restrict__ seg, const float* __restrict__ cf, const float* __restrict__ gt,
-                                                             const float* __restrict__ angle, int B, int H, int W, const double* __restrict__ acc, LossCoef k,
+                                                             const float* __restrict__ angle, const float* __restrict__ segw, int B, int H, int W,
+                                                             const double* __restrict__ acc, LossCoef k,
                                                              float* __restrict__ dseg, float* __restrict__ dcf, float* __restrict__ dG, float* __restrict__ sL) {
     const int HW = H * W;
     const int b = blockIdx.y;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void ffl_loss_point_kernel(const float* __rest
     // ---- seg: BCE (torch's backward: (p - y) / max((1 - p) p, 1e-12)) + dice
     const float yb = y0 > 0.98f ? 1.f : 0.f;
     float ds = k.seg * k.bce_coef * inv_n * (pr - yb) / fmaxf((1.f - pr) * pr, 1e-12f);
+    if (segw) ds *= segw[(int64_t)b * HW + p];
     {
         const float num = 2.f * (float)acc[5 + 3 * b] + 1.f, den = (float)acc[5 + 3 * b + 1] + (float)acc[5 + 3 * b + 2] + 1.f + 1e-7f;
         ds += k.seg * k.dice_coef * (1.f / (float)B) * -((2.f * y0 * den - num) / (den * den));
@@ -210,9 +214,9 @@ __global__ __launch_bounds__(256) void ffl_loss_stencil_kernel(int B, int H, int
 
 }  // namespace
 
-extern "C" int p3_ffl_loss(const float* seg, const float* crossfield, const float* gt_polygons_image, const float* gt_crossfield_angle, int B,
-                           int H, int W, const float* coef, float bce_coef, float dice_coef, float* losses, float* dseg, float* dcrossfield,
-                           void* workspace, void* stream) {
+extern "C" int p3_ffl_loss(const float* seg, const float* crossfield, const float* gt_polygons_image, const float* gt_crossfield_angle,
+                           const float* seg_weights, int B, int H, int W, const float* coef, float bce_coef, float dice_coef, float* losses,
+                           float* dseg, float* dcrossfield, void* workspace, void* stream) {
     P3_CHECK(seg && crossfield && gt_polygons_image && gt_crossfield_angle && coef && losses && workspace, P3_EINVAL, "p3_ffl_loss: null pointer");
     P3_CHECK(B > 0 && H > 1 && W > 1, P3_ESHAPE, "p3_ffl_loss: bad sizes");
     P3_CHECK((dseg == nullptr) == (dcrossfield == nullptr), P3_EINVAL, "p3_ffl_loss: dseg and dcrossfield go together");
@@ -225,10 +229,10 @@ extern "C" int p3_ffl_loss(const float* seg, const float* crossfield, const floa
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     LossCoef k; k.seg = coef[0]; k.align = coef[1]; k.align90 = coef[2]; k.smooth = coef[3]; k.couple = coef[4]; k.bce_coef = bce_coef; k.dice_coef = dice_coef;
     dim3 grid((unsigned)((HW + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(ffl_loss_sums_kernel, grid, block, 0, s, seg, crossfield, gt_polygons_image, gt_crossfield_angle, B, H, W, acc);
+    hipLaunchKernelGGL(ffl_loss_sums_kernel, grid, block, 0, s, seg, crossfield, gt_polygons_image, gt_crossfield_angle, seg_weights, B, H, W, acc);
     hipLaunchKernelGGL(ffl_loss_finalize_kernel, dim3(1), dim3(64), 0, s, acc, B, H, W, k, losses);
     if (dseg) {
-        hipLaunchKernelGGL(ffl_loss_point_kernel, grid, block, 0, s, seg, crossfield, gt_polygons_image, gt_crossfield_angle, B, H, W, acc, k, dseg, dcrossfield, dG, sL);
+        hipLaunchKernelGGL(ffl_loss_point_kernel, grid, block, 0, s, seg, crossfield, gt_polygons_image, gt_crossfield_angle, seg_weights, B, H, W, acc, k, dseg, dcrossfield, dG, sL);
         hipLaunchKernelGGL(ffl_loss_stencil_kernel, grid, block, 0, s, B, H, W, dG, sL, dseg, dcrossfield);
     }
     P3_LAUNCH_CHECK();

@@ -8,7 +8,9 @@ Same call contract as the reference's trainer uses (models/ffl/losses.py:84-141)
 `individual_losses[name]` are the normalised losses (loss / norm) as detached device scalars; `total` carries the gradient
 (d total / d seg, d total / d crossfield come out of the same kernels as the value).  `extra` has the reference's keys with empty
 dicts: the visualisation tensors (gt_field, seg_slice_grads) are not produced.
-Unsupported configurations (edge / vertex seg channels, frequency / distance / size pixel weights, seg.type "float") raise.
+The frequency / distance / size pixel weights of `compute_seg_loss_weigths` (off in the shipped config) are honoured: a few torch
+elementwise ops build the weight plane the kernel multiplies into the BCE term.  Unsupported configurations (edge / vertex seg
+channels, seg.type "float") raise.
 """
 import numpy as np
 import torch
@@ -21,9 +23,10 @@ LOSS_NAMES = ("seg", "crossfield_align", "crossfield_align90", "crossfield_smoot
 
 class _FFLLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, seg, crossfield, gt, angle, coef, bce_coef, dice_coef):
+    def forward(ctx, seg, crossfield, gt, angle, coef, bce_coef, dice_coef, seg_weights):
         need = seg.requires_grad or crossfield.requires_grad
-        losses, dseg, dcf = hip.ffl_loss(seg.detach(), crossfield.detach(), gt, angle, coef, bce_coef, dice_coef, need_grad=need)
+        losses, dseg, dcf = hip.ffl_loss(seg.detach(), crossfield.detach(), gt, angle, coef, bce_coef, dice_coef, need_grad=need,
+                                         seg_weights=seg_weights)
         ctx.save_for_backward(dseg, dcf)
         ctx.shapes = (seg.shape, seg.dtype, crossfield.shape, crossfield.dtype)
         ctx.mark_non_differentiable(losses)
@@ -33,14 +36,15 @@ class _FFLLossFn(torch.autograd.Function):
     def backward(ctx, g, _g_losses):
         dseg, dcf = ctx.saved_tensors
         ss, sd, cs, cdt = ctx.shapes
-        return (dseg * g).view(ss).to(sd), (dcf * g).view(cs).to(cdt), None, None, None, None, None
+        return (dseg * g).view(ss).to(sd), (dcf * g).view(cs).to(cdt), None, None, None, None, None, None
 
 
 class MultiLoss(torch.nn.Module):
     """MultiLoss (losses.py:72-147) over the five losses build_combined_loss assembles for the shipped config."""
 
-    def __init__(self, weights, epoch_thresholds, bce_coef, dice_coef):
+    def __init__(self, weights, epoch_thresholds, bce_coef, dice_coef, pixel_weights=None):
         super().__init__()
+        self.pixel_weights = pixel_weights           # None, or dict(use_freq, use_dist, use_size, w0, sigma, height, width) (losses.py:150-205)
         self.names = LOSS_NAMES
         self.weights = [list(w) if isinstance(w, (list, tuple)) else float(w) for w in weights]
         self.epoch_thresholds = [float(t) for t in epoch_thresholds]
@@ -82,9 +86,36 @@ class MultiLoss(torch.nn.Module):
             raise ValueError("gt_polygons_image should have 3 channels for interior, edges and vertices")
         return pred_batch["seg"], pred_batch["crossfield"], gt.float(), gt_batch["gt_crossfield_angle"].float()
 
+    def seg_loss_weights(self, gt_batch):
+        """compute_seg_loss_weigths (losses.py:150-205) for the interior channel -> [B,1,H,W] or None (all ones: the shipped config).
+        A handful of elementwise torch ops on ground-truth tensors; the result multiplies the BCE term inside the fused kernel."""
+        pw = self.pixel_weights
+        if not pw or not (pw["use_freq"] or pw["use_dist"] or pw["use_size"]):
+            return None
+        gt = gt_batch["gt_polygons_image"].float()
+        w = torch.ones_like(gt[:, :1])
+        if pw["use_freq"]:
+            cf = gt_batch["class_freq"].float()
+            mask = (0 < gt[:, :1]).float()
+            bg = 1 - torch.sum(cf, dim=1)
+            freq = mask * cf[:, :1, None, None] + (1 - mask) * bg[:, None, None, None]
+            if float(freq.min()) == 0:
+                raise ZeroDivisionError("pixel_class_freq has some zero values, can't divide by zero!")
+            w = 1 / freq
+        if pw["use_dist"]:
+            d = gt_batch["distances"].float() * (pw["height"] + pw["width"])
+            w = w + pw["w0"] * torch.exp(-(d ** 2) / (pw["sigma"] ** 2))
+        if pw["use_size"]:
+            sizes = gt_batch["sizes"].float()
+            if float(sizes.min()) == 0:
+                raise ZeroDivisionError("sizes tensor has zero values, can't divide by zero!")
+            w = w * (1 + 1 / ((pw["height"] * pw["width"]) ** 0.5 / 2 * sizes))
+        return w.contiguous()
+
     def _raw(self, pred_batch, gt_batch):
         seg, cf, gt, angle = self._inputs(pred_batch, gt_batch)
-        return hip.ffl_loss(seg.detach(), cf.detach(), gt, angle, [0.0] * 5, self.bce_coef, self.dice_coef, need_grad=False)[0]
+        return hip.ffl_loss(seg.detach(), cf.detach(), gt, angle, [0.0] * 5, self.bce_coef, self.dice_coef, need_grad=False,
+                            seg_weights=self.seg_loss_weights(gt_batch))[0]
 
     def forward(self, pred_batch, gt_batch, normalize=True, epoch=None):
         seg, cf, gt, angle = self._inputs(pred_batch, gt_batch)
@@ -93,7 +124,7 @@ class MultiLoss(torch.nn.Module):
             raise AssertionError("self.norm[0] <= 1e-9 -> this might lead to numerical instabilities.")
         w = self.current_weights(epoch)
         coef = [wi / ni for wi, ni in zip(w, norms)]
-        total, losses = _FFLLossFn.apply(seg, cf, gt, angle, coef, self.bce_coef, self.dice_coef)
+        total, losses = _FFLLossFn.apply(seg, cf, gt, angle, coef, self.bce_coef, self.dice_coef, self.seg_loss_weights(gt_batch))
         inv = torch.tensor([1.0 / n for n in norms], dtype=torch.float32, device=losses.device)
         normed = losses[:5] * inv
         individual = {name: normed[i] for i, name in enumerate(LOSS_NAMES)}
@@ -111,11 +142,12 @@ def build_combined_loss(cfg):
     if not m.seg.compute_interior or m.seg.compute_edge or m.seg.compute_vertex:
         raise NotImplementedError("p3hip FFL loss covers the shipped seg head (interior channel only)")
     ls = m.loss.seg
-    if ls.use_freq or ls.use_dist or ls.use_size:
-        raise NotImplementedError("p3hip FFL loss: pixel weights (use_freq / use_dist / use_size) are off in the shipped config and not built")
     if ls.type != "bool":
         raise NotImplementedError("p3hip FFL loss: loss.seg.type must be 'bool' (shipped config)")
     w = m.loss.multi.weights
     seq = lambda v: list(v) if hasattr(v, "__iter__") else v
     weights = [seq(w.seg), seq(w.crossfield_align), seq(w.crossfield_align90), seq(w.crossfield_smooth), seq(w.seg_interior_crossfield)]
-    return MultiLoss(weights, list(m.loss.multi.epoch_thresholds), ls.bce_coef, ls.dice_coef).to(cfg.host.device)
+    enc = cfg.experiment.encoder
+    pixel = dict(use_freq=bool(ls.use_freq), use_dist=bool(ls.use_dist), use_size=bool(ls.use_size), w0=float(ls.w0), sigma=float(ls.sigma),
+                 height=int(enc.in_height), width=int(enc.in_width))
+    return MultiLoss(weights, list(m.loss.multi.epoch_thresholds), ls.bce_coef, ls.dice_coef, pixel).to(cfg.host.device)

@@ -457,7 +457,7 @@ def points_d4_(values, offsets, group, cx, cy):
     return values
 
 
-def ffl_loss(seg, crossfield, gt_polygons_image, gt_crossfield_angle, coef, bce_coef, dice_coef, need_grad=True):
+def ffl_loss(seg, crossfield, gt_polygons_image, gt_crossfield_angle, coef, bce_coef, dice_coef, need_grad=True, seg_weights=None):
     """fused FFL loss: -> (losses fp32 [6] = five raw losses + total, dseg | None, dcrossfield | None)."""
     _dev(seg)
     B, _, H, W = seg.shape
@@ -471,7 +471,10 @@ def ffl_loss(seg, crossfield, gt_polygons_image, gt_crossfield_angle, coef, bce_
     dseg = torch.empty_like(ts[0]) if need_grad else None
     dcf = torch.empty_like(ts[1]) if need_grad else None
     cc = (c_float * 5)(*[float(v) for v in coef])
-    check(lib().p3_ffl_loss(ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), c_int(B), c_int(H), c_int(W), ctypes.cast(cc, c_void_p),
+    sw = seg_weights.contiguous().float() if seg_weights is not None else None
+    if sw is not None and sw.numel() != B * H * W:
+        raise P3Error(f"ffl_loss: seg_weights must hold one weight per pixel of the seg channel, got {tuple(seg_weights.shape)}")
+    check(lib().p3_ffl_loss(ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), ptr(sw), c_int(B), c_int(H), c_int(W), ctypes.cast(cc, c_void_p),
                             c_float(bce_coef), c_float(dice_coef), ptr(losses), ptr(dseg), ptr(dcf), ptr(ws), stream()), "p3_ffl_loss")
     return losses, dseg, dcf
 

@@ -65,12 +65,12 @@ def ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
-def make_cfg():
+def make_cfg(use_freq=False, use_dist=False, use_size=False):
     """the fields build_combined_loss reads, with config/model/ffl.yaml's values"""
     loss = ns(multi=ns(epoch_thresholds=[0, 5, 10],
                        weights=ns(seg=1, crossfield_align=1, crossfield_align90=0.5, crossfield_smooth=0.005,
                                   seg_interior_crossfield=[0, 0, 0.2], seg_edge_crossfield=[0, 0, 0.2], seg_edge_interior=[0, 0, 0.2])),
-              seg=ns(bce_coef=1.0, dice_coef=0.2, use_freq=False, use_dist=False, use_size=False, w0=50, sigma=10, type="bool"))
+              seg=ns(bce_coef=1.0, dice_coef=0.2, use_freq=use_freq, use_dist=use_dist, use_size=use_size, w0=50, sigma=10, type="bool"))
     model = ns(compute_seg=True, compute_crossfield=True, seg=ns(compute_interior=True, compute_edge=False, compute_vertex=False), loss=loss)
     return ns(experiment=ns(model=model, encoder=ns(in_height=224, in_width=224)), host=ns(device="cpu"))
 
@@ -108,6 +108,22 @@ def main():
                        f"{tag}::angle": angle.numpy(), f"{tag}::epoch": np.float64(epoch), f"{tag}::norms": np.array(norms or [1.0] * len(names)),
                        f"{tag}::total": total.detach().numpy(), f"{tag}::losses": np.array([float(ind[n]) for n in names]),
                        f"{tag}::dseg": seg.grad.numpy(), f"{tag}::dcf": cf.grad.numpy()})
+    # pixel-weighted BCE (use_freq + use_dist + use_size), reference pre-process compute_seg_loss_weigths
+    critw = L.build_combined_loss(make_cfg(True, True, True))
+    seg, cf, gt, angle = make_case(2, 24, 9)
+    g = torch.Generator().manual_seed(99)
+    dist = torch.rand(2, 1, 24, 24, generator=g) * 0.05
+    sizes = 0.01 + torch.rand(2, 1, 24, 24, generator=g) * 0.2
+    cfreq = torch.tensor([[0.3, 0.1, 0.02], [0.2, 0.05, 0.01]])
+    seg.requires_grad_(True)
+    cf.requires_grad_(True)
+    total, ind, _ = critw({"seg": seg, "crossfield": cf}, {"gt_polygons_image": gt, "gt_crossfield_angle": angle, "distances": dist, "sizes": sizes,
+                                                          "class_freq": cfreq}, normalize=True, epoch=6.0)
+    total.backward()
+    arrays.update({"w24::seg": seg.detach().numpy(), "w24::crossfield": cf.detach().numpy(), "w24::gt": gt.numpy(), "w24::angle": angle.numpy(),
+                   "w24::distances": dist.numpy(), "w24::sizes": sizes.numpy(), "w24::class_freq": cfreq.numpy(), "w24::epoch": np.float64(6.0),
+                   "w24::total": total.detach().numpy(), "w24::losses": np.array([float(ind[n]) for n in names]),
+                   "w24::dseg": seg.grad.numpy(), "w24::dcf": cf.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, "ffl_loss.npz"), **arrays)
     print("wrote ffl_loss.npz", names, os.path.getsize(os.path.join(HERE, "ffl_loss.npz")))
 

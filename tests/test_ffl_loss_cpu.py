@@ -38,6 +38,22 @@ def test_oracle_matches_reference_losses_and_gradients(tag):
     assert rel_err(cf.grad, torch.from_numpy(d["dcf"])) < 1e-5
 
 
+def test_oracle_pixel_weighted_bce_matches_reference():
+    """use_freq + use_dist + use_size (compute_seg_loss_weigths, losses.py:150-205) against the reference's own run."""
+    z = np.load(os.path.join(GOLD, "ffl_loss.npz"))
+    d = {k.split("::")[1]: z[k] for k in z.files if k.startswith("w24::")}
+    names = [str(n) for n in z["names"]]
+    gt = torch.from_numpy(d["gt"])
+    w = O.ffl_seg_loss_weights(gt, torch.from_numpy(d["class_freq"]), torch.from_numpy(d["distances"]), torch.from_numpy(d["sizes"]), True, True, True)
+    seg = torch.from_numpy(d["seg"]).requires_grad_(True)
+    cf = torch.from_numpy(d["crossfield"]).requires_grad_(True)
+    total, ind = O.ffl_losses(seg, cf, gt, torch.from_numpy(d["angle"]), epoch=float(d["epoch"]), seg_weights=w)
+    total.backward()
+    assert abs(float(total) - float(d["total"])) <= 1e-6 * abs(float(d["total"]))
+    assert abs(float(ind["seg"]) - d["losses"][names.index("seg")]) <= 1e-6 * abs(d["losses"][names.index("seg")])
+    assert rel_err(seg.grad, torch.from_numpy(d["dseg"])) < 1e-5 and rel_err(cf.grad, torch.from_numpy(d["dcf"])) < 1e-5
+
+
 def test_weight_interpolation_follows_epoch_thresholds():
     assert O.ffl_weight("seg_interior_crossfield", 0) == 0.0 and O.ffl_weight("seg_interior_crossfield", 5) == 0.0
     assert abs(O.ffl_weight("seg_interior_crossfield", 7.5) - 0.1) < 1e-12 and O.ffl_weight("seg_interior_crossfield", 50) == 0.2
@@ -53,9 +69,11 @@ def test_host_mirror_refuses_configurations_the_kernels_do_not_cover():
     crit = build_combined_loss(cfg)
     assert crit.names == O.FFL_LOSS_NAMES and crit.current_weights(7.5)[4] == pytest.approx(0.1)
     cfg.experiment.model.loss.seg.use_dist = True
+    assert build_combined_loss(cfg).pixel_weights["use_dist"] is True
+    cfg.experiment.model.loss.seg.type = "float"
     with pytest.raises(NotImplementedError):
         build_combined_loss(cfg)
-    cfg.experiment.model.loss.seg.use_dist = False
+    cfg.experiment.model.loss.seg.type = "bool"
     cfg.experiment.model.seg.compute_edge = True
     with pytest.raises(NotImplementedError):
         build_combined_loss(cfg)

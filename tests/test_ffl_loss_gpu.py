@@ -42,6 +42,32 @@ def test_reference_golden_values_and_gradients(tag):
     assert rel_err(cf.grad.cpu(), torch.from_numpy(d["dcf"])) < TOL * 5
 
 
+def test_pixel_weighted_bce_matches_reference_golden():
+    """use_freq + use_dist + use_size: the host mirror builds the weight plane (compute_seg_loss_weigths), the kernel applies it."""
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.ffl_losses import build_combined_loss
+    z = np.load(os.path.join(GOLD, "ffl_loss.npz"))
+    d = {k.split("::")[1]: z[k] for k in z.files if k.startswith("w24::")}
+    names = [str(n) for n in z["names"]]
+    cfg = make_config("early_fusion_vit_cnn", model="ffl", device=DEV)
+    ls = cfg.experiment.model.loss.seg
+    ls.use_freq = ls.use_dist = ls.use_size = True
+    crit = build_combined_loss(cfg)
+    seg = torch.from_numpy(d["seg"]).to(DEV).requires_grad_(True)
+    cf = torch.from_numpy(d["crossfield"]).to(DEV).requires_grad_(True)
+    gtb = {k: torch.from_numpy(d[v]).to(DEV) for k, v in (("gt_polygons_image", "gt"), ("gt_crossfield_angle", "angle"), ("distances", "distances"),
+                                                            ("sizes", "sizes"), ("class_freq", "class_freq"))}
+    total, ind, _ = crit({"seg": seg, "crossfield": cf}, gtb, normalize=True, epoch=float(d["epoch"]))
+    total.backward()
+    assert abs(float(total) - float(d["total"])) <= TOL * abs(float(d["total"]))
+    for i, n in enumerate(names):
+        assert abs(float(ind[n]) - d["losses"][i]) <= TOL * max(abs(d["losses"][i]), 1e-9), n
+    assert rel_err(seg.grad.cpu(), torch.from_numpy(d["dseg"])) < TOL * 5 and rel_err(cf.grad.cpu(), torch.from_numpy(d["dcf"])) < TOL * 5
+    gtb["sizes"] = torch.zeros_like(gtb["sizes"])
+    with pytest.raises(ZeroDivisionError):
+        crit({"seg": seg, "crossfield": cf}, gtb, epoch=1.0)
+
+
 def _inputs(B, H, seed):
     g = torch.Generator().manual_seed(seed)
     seg = torch.sigmoid(torch.randn(B, 1, H, H, generator=g) * 2.0)
