@@ -367,6 +367,13 @@ int p3_image_prepare(const uint8_t* src, const int32_t* group, float* dst, int B
 /* in-place D4 of the jagged point list values [total,3] (x, y, z) / offsets [B+1] around the centre (cx, cy) = (in_width // 2,
  * in_height // 2): subtract centre, swap / negate as p3_coco.py:135-158, add centre - fp32, same operation order */
 int p3_points_d4(float* values, const int64_t* offsets, const int32_t* group, int B, int64_t total, float cx, float cy, void* stream);
+/* FFL ground truth of a batch (datasets/p3_coco.py:254-296 + apply_augmentations_to_ffl_crossfield_angle :166-205), every input optional:
+ * gt_polygons_u8 [B,H,W,3] -> out_gt f32 [B,3,H,W] = clamp(u8 / 255, 0, 1); crossfield_angle_u8 [B,H,W] -> out_angle f32 [B,1,H,W] =
+ * ((u8 * pi / 255 + pi/2) % pi) rotated / mirrored with the tile; distances / sizes f32 [B,H,W] -> [B,1,H,W] permuted only.
+ * group[b] = the tile's D4 element (NULL: none). */
+int p3_ffl_targets_prepare(const uint8_t* gt_polygons_u8, const uint8_t* crossfield_angle_u8, const float* distances, const float* sizes,
+                           const int32_t* group, int B, int H, int W, float* out_gt, float* out_angle, float* out_distances, float* out_sizes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FFL frame-field loss, forward + gradients: build_combined_loss / MultiLoss of models/ffl/losses.py:84-141,237-316 with

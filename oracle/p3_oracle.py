@@ -484,6 +484,33 @@ def normalize_to_tensor(img_hwc_u8, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), m
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
 
+def ffl_angle_from_u8(angle_u8, element=None):
+    """datasets/p3_coco.py:283-292 + apply_augmentations_to_ffl_crossfield_angle (:166-205) on a float32 mask: u8 -> radians,
+    normals -> tangents, then the D4 element's rotation / mirroring of the angle VALUES (the mask itself is permuted by d4_image)."""
+    a = angle_u8.astype(np.float32) * np.float32(np.pi) / np.float32(255.0)
+    a = (a + np.float32(np.pi / 2)) % np.float32(np.pi)
+    if element is None or element == "e":
+        return a
+    pi = np.float32(np.pi)
+    if element == "r90":
+        a = (a + np.float32(np.pi / 2)) % pi
+    elif element == "r180":
+        a = (a + pi) % pi
+    elif element == "r270":
+        a = (a + np.float32(3 * np.pi / 2)) % pi
+    elif element == "v":
+        a = (pi - a) % pi
+    elif element == "hvt":
+        a = (np.float32(3 * np.pi / 2) - a) % pi
+    elif element == "h":
+        a = (-a) % pi
+    elif element == "t":
+        a = (np.float32(np.pi / 2) - a) % pi
+    else:
+        raise ValueError(f"Unknown group element {element}")
+    return a
+
+
 def d4_lidar(points, element, in_width=224, in_height=224):
     """apply_d4_augmentations_to_lidar (datasets/p3_coco.py:127-164), statement for statement, on a float32 [n,3] array."""
     lidar = np.array(points, dtype=np.float32, copy=True)

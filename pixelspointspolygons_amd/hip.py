@@ -447,6 +447,28 @@ def image_prepare(src_u8, group=None, sub=(0.0, 0.0, 0.0), mul=(1.0 / 255.0,) * 
     return out
 
 
+def ffl_targets_prepare(gt_u8=None, angle_u8=None, distances=None, sizes=None, group=None):
+    """FFL ground-truth masks of a batch -> dict of fp32 NCHW tensors (gt_polygons_image, gt_crossfield_angle, distances, sizes)."""
+    ref = next(t for t in (gt_u8, angle_u8, distances, sizes) if t is not None)
+    _dev(ref)
+    B, H, W = ref.shape[0], ref.shape[1], ref.shape[2]
+    dev = ref.device
+    if gt_u8 is not None and (gt_u8.dtype != torch.uint8 or tuple(gt_u8.shape) != (B, H, W, 3)):
+        raise P3Error(f"ffl_targets_prepare: gt_polygons_image must be uint8 [B,H,W,3], got {gt_u8.dtype} {tuple(gt_u8.shape)}")
+    if angle_u8 is not None and (angle_u8.dtype != torch.uint8 or tuple(angle_u8.shape) != (B, H, W)):
+        raise P3Error(f"ffl_targets_prepare: gt_crossfield_angle must be uint8 [B,H,W], got {angle_u8.dtype} {tuple(angle_u8.shape)}")
+    c = lambda t: t.contiguous() if t is not None else None
+    gt_u8, angle_u8 = c(gt_u8), c(angle_u8)
+    distances = c(distances.float()) if distances is not None else None
+    sizes = c(sizes.float()) if sizes is not None else None
+    mk = lambda t, ch: torch.empty((B, ch, H, W), dtype=torch.float32, device=dev) if t is not None else None
+    o_gt, o_an, o_di, o_si = mk(gt_u8, 3), mk(angle_u8, 1), mk(distances, 1), mk(sizes, 1)
+    check(lib().p3_ffl_targets_prepare(ptr(gt_u8), ptr(angle_u8), ptr(distances), ptr(sizes), ptr(group), c_int(B), c_int(H), c_int(W), ptr(o_gt),
+                                       ptr(o_an), ptr(o_di), ptr(o_si), stream()), "p3_ffl_targets_prepare")
+    out = {"gt_polygons_image": o_gt, "gt_crossfield_angle": o_an, "distances": o_di, "sizes": o_si}
+    return {k: v for k, v in out.items() if v is not None}
+
+
 def points_d4_(values, offsets, group, cx, cy):
     """in-place D4 of a jagged point list (values [T,3] f32, offsets int64 [B+1]) around (cx, cy); group int32 [B]."""
     _dev(values)

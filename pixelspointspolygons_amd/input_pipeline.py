@@ -41,6 +41,14 @@ def d4_points_(values, offsets, groups, in_width=224, in_height=224):
     return hip.points_d4_(values, offsets, groups, float(in_width // 2), float(in_height // 2))
 
 
+def prepare_ffl_targets(gt_polygons_u8=None, crossfield_angle_u8=None, distances=None, sizes=None, groups=None):
+    """FFL ground truth of a batch on the device (datasets/p3_coco.py:254-296): uint8 [B,H,W,3] polygon masks -> fp32 [B,3,H,W] in
+    [0, 1]; uint8 [B,H,W] crossfield angle -> radians, normals -> tangents, rotated / mirrored with the tile; `distances` / `sizes`
+    fp32 [B,H,W] -> [B,1,H,W]; all through the tile's D4 permutation (groups int32 [B], None = no augmentation).
+    Returns the gt_batch entries the FFL criterion reads."""
+    return hip.ffl_targets_prepare(gt_polygons_u8, crossfield_angle_u8, distances, sizes, groups)
+
+
 def d4_keypoints(coords_yx, element, height, width):
     """Where D4 `element` moves integer pixel coordinates (y, x) - the image permutation of `p3_image_prepare` applied to vertex
     coordinates (albumentations does this for the `keypoints=` of p3_coco.py:424 in 'yx' format).  Host side, numpy: <= 192 vertices."""
@@ -80,6 +88,8 @@ class DevicePrefetcher:
     """Double-buffered host->device feeder.  Wraps an iterable of HOST batches (dicts):
          "image"  uint8 [B,H,W,C] tensor / array (optional)       "lidar"  list of [n_i,3] float32 clouds (optional)
          "group"  D4 element ids, int [B] (optional: augmentation)  anything else: tensors copied as they are (tokens, perm matrices)
+         "gt_polygons_image" uint8 [B,H,W,3] (+ "gt_crossfield_angle" uint8 [B,H,W], "distances" / "sizes" float [B,H,W]): FFL ground
+                  truth as stored on disk -> the fp32 NCHW gt_batch entries of the FFL criterion (`prepare_ffl_targets`)
        and yields DEVICE batches {"image": fp32 [B,C,H,W], "lidar_values", "lidar_offsets", ...} ready for the model.
        While batch k computes, batch k+1 is packed into the other pinned set, copied and prepared on `self.stream`."""
 
@@ -143,8 +153,11 @@ class DevicePrefetcher:
                 out["lidar_values"], out["lidar_offsets"] = dev["lidar_values"], dev["lidar_offsets"]
                 if grp is not None:
                     d4_points_(out["lidar_values"], out["lidar_offsets"], grp, *self.size)
+            ffl_keys = ("gt_polygons_image", "gt_crossfield_angle", "distances", "sizes")
+            if "gt_polygons_image" in dev and dev["gt_polygons_image"].dtype == torch.uint8:       # FFL ground truth as stored (uint8 masks)
+                out.update(prepare_ffl_targets(dev["gt_polygons_image"], dev.get("gt_crossfield_angle"), dev.get("distances"), dev.get("sizes"), grp))
             for k, v in dev.items():
-                if k not in ("image", "lidar_values", "lidar_offsets", "group"):
+                if k not in ("image", "lidar_values", "lidar_offsets", "group") and k not in out:
                     out[k] = v
             s["_free"] = torch.cuda.Event()
             s["_free"].record(self.stream)

@@ -106,3 +106,48 @@ def test_prefetcher_single_modality_batches_and_no_augmentation():
     with pytest.raises(P3Error):
         DevicePrefetcher(iter([{"lidar": clouds}]), DEV, max_points=100)          # staging buffer too small: loud
     assert list(DevicePrefetcher(iter([]), DEV)) == []
+
+
+def test_ffl_targets_prepare_bit_exact_for_all_elements():
+    """polygon masks, crossfield angle (value rotation + mask permutation), distances / sizes vs the oracle's float32 restatement."""
+    from pixelspointspolygons_amd.input_pipeline import prepare_ffl_targets
+    rng = np.random.default_rng(12)
+    B, n = 8, 56
+    gt = rng.integers(0, 256, size=(B, n, n, 3), dtype=np.uint8)
+    ang = rng.integers(0, 256, size=(B, n, n), dtype=np.uint8)
+    ang[:, 0, :4] = [0, 255, 127, 128]                                   # modulo edge values
+    dist = rng.random((B, n, n)).astype(np.float32)
+    sizes = rng.random((B, n, n)).astype(np.float32) + 0.01
+    groups = torch.arange(8, dtype=torch.int32)
+    out = prepare_ffl_targets(torch.from_numpy(gt).to(DEV), torch.from_numpy(ang).to(DEV), torch.from_numpy(dist).to(DEV),
+                              torch.from_numpy(sizes).to(DEV), groups.to(DEV))
+    assert out["gt_polygons_image"].shape == (B, 3, n, n) and out["gt_crossfield_angle"].shape == (B, 1, n, n)
+    for b, e in enumerate(D4_ELEMENTS):
+        want_gt = np.clip(O.d4_image(gt[b], e).astype(np.float32) / np.float32(255), 0, 1).transpose(2, 0, 1)
+        assert np.array_equal(out["gt_polygons_image"][b].cpu().numpy(), want_gt), e
+        want_ang = O.ffl_angle_from_u8(O.d4_image(ang[b][..., None], e)[..., 0], e)
+        assert np.array_equal(out["gt_crossfield_angle"][b, 0].cpu().numpy(), want_ang), e
+        assert np.array_equal(out["distances"][b, 0].cpu().numpy(), O.d4_image(dist[b][..., None], e)[..., 0]), e
+        assert np.array_equal(out["sizes"][b, 0].cpu().numpy(), O.d4_image(sizes[b][..., None], e)[..., 0]), e
+    plain = prepare_ffl_targets(torch.from_numpy(gt).to(DEV), torch.from_numpy(ang).to(DEV))
+    assert set(plain) == {"gt_polygons_image", "gt_crossfield_angle"}
+    assert np.array_equal(plain["gt_crossfield_angle"][3, 0].cpu().numpy(), O.ffl_angle_from_u8(ang[3]))
+    a = plain["gt_crossfield_angle"]
+    assert float(a.min()) >= 0.0 and float(a.max()) < np.pi + 1e-6
+
+
+def test_prefetcher_prepares_ffl_ground_truth():
+    rng = np.random.default_rng(13)
+    B, n = 3, 224
+    gt = rng.integers(0, 256, size=(B, n, n, 3), dtype=np.uint8)
+    ang = rng.integers(0, 256, size=(B, n, n), dtype=np.uint8)
+    grp = np.array([5, 0, 3])
+    host = {"image": torch.from_numpy(_tiles(B, n, 3, 40)), "gt_polygons_image": torch.from_numpy(gt), "gt_crossfield_angle": torch.from_numpy(ang),
+            "group": grp, "class_freq": torch.rand(B, 3)}
+    b = next(DevicePrefetcher(iter([host]), DEV))
+    assert b["gt_polygons_image"].shape == (B, 3, n, n) and b["gt_polygons_image"].dtype == torch.float32
+    for i in range(B):
+        e = D4_ELEMENTS[int(grp[i])]
+        assert np.array_equal(b["gt_crossfield_angle"][i, 0].cpu().numpy(), O.ffl_angle_from_u8(O.d4_image(ang[i][..., None], e)[..., 0], e))
+        assert torch.equal(b["image"][i].cpu(), O.normalize_to_tensor(O.d4_image(host["image"][i].numpy(), e)))
+    assert torch.equal(b["class_freq"].cpu(), host["class_freq"])
