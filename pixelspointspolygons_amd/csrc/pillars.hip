@@ -190,6 +190,66 @@ __device__ __forceinline__ void pfn_l0(const float* __restrict__ pts, const VoxT
     cnt_out = cnt; valid_out = valid;
 }
 
+
+// ---- quad layout for max_points <= 64 ------------------------------------------------------------------------------------------
+// A wave per pillar with lane == slot leaves most lanes idle (3 k points over 784 pillars: ~4 points per pillar) and makes every lane
+// evaluate all 32 layer-0 channels from LDS-resident weights (256 LDS reads + 256 FMAs + 32 full-wave max reductions per pillar; r01:
+// 0.58 ms for pfn_l1_apply).  Here a lane is (slot s = lane & 15, channel group cg = lane >> 4): it keeps the 8 x 8 weights of its 8
+// channels in registers, a pass covers 16 slots (one pass for almost every pillar) and the per-channel max is a 16-lane butterfly.
+// The point loads and the pillar mean stay in the 64-lane layout (one load per slot, same summation order as before), the slot's
+// coordinates reach its four lanes by shuffle.  Same per-element arithmetic as pfn_l0: identical h, xmax and rows.
+struct QuadCtx { float w[8][8]; float sc[8], sh[8]; };
+
+__device__ __forceinline__ void quad_init(QuadCtx& q, const float* __restrict__ w1s, const float* __restrict__ ss, int cg) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q.w[c][k] = w1s[(cg * 8 + c) * 8 + k];
+        q.sc[c] = ss ? ss[cg * 8 + c] : 1.f;
+        q.sh[c] = ss ? ss[C1 + cg * 8 + c] : 0.f;
+    }
+}
+
+struct QuadPillar { float x, y, z, mx, my, mz, ccx, ccy; int cnt; };
+
+__device__ __forceinline__ QuadPillar quad_pillar(const float* __restrict__ pts, const VoxTab& t, int v, int lane, const PillarGeom& g) {
+    QuadPillar p;
+    p.cnt = t.cnt[v];
+    p.x = 0.f; p.y = 0.f; p.z = 0.f;
+    if (lane < p.cnt) { const float* q = pts + 3 * (int64_t)t.sorted[t.start[v] + lane]; p.x = q[0]; p.y = q[1]; p.z = q[2]; }
+    p.mx = wave_sum(p.x) / (float)p.cnt; p.my = wave_sum(p.y) / (float)p.cnt; p.mz = wave_sum(p.z) / (float)p.cnt;   // sum over slots, then divide
+    const int xy = t.xy[v] & 0xffffff;
+    const int cx = xy % g.nx, cy = xy / g.nx;
+    p.ccx = (float)cx * g.vx + 0.5f * g.vx; p.ccy = (float)cy * g.vy + 0.5f * g.vy;
+    return p;
+}
+
+// layer-0 pre-activation of this lane's 8 channels for slot `slot` (0 for padded slots) and the slot's decorated features
+__device__ __forceinline__ void quad_l0(const QuadCtx& q, const QuadPillar& p, int slot, bool valid, float (&h)[8], float (&f)[8]) {
+    const float x = __shfl(p.x, slot & 63, 64), y = __shfl(p.y, slot & 63, 64), z = __shfl(p.z, slot & 63, 64);
+    const float ff[8] = {x, y, z, x - p.mx, y - p.my, z - p.mz, x - p.ccx, y - p.ccy};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += q.w[c][k] * ff[k];
+        h[c] = valid ? a : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = valid ? ff[k] : 0.f;
+}
+
+__device__ __forceinline__ float quad_max16(float v) {      // over the 16 slots of a pass (lanes that share cg)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float quad_sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 template <bool MULTI>
 __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
                                                            int nslots, const float* __restrict__ w1, float* __restrict__ sums /*[2*C1]*/) {
@@ -197,13 +257,16 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
     for (int i = threadIdx.x; i < C1 * 8; i += 256) w1s[i] = w1[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    float s1[C1], s2[C1];
+    const int qs = lane & 15, qcg = lane >> 4;
+    QuadCtx qc;
+    if constexpr (!MULTI) quad_init(qc, w1s, nullptr, qcg);
+    float s1[MULTI ? C1 : 8], s2[MULTI ? C1 : 8];
 #pragma unroll
-    for (int c = 0; c < C1; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    for (int c = 0; c < (MULTI ? C1 : 8); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
-        float h[C1]; int cnt; bool valid; float f8[8];
         if constexpr (MULTI) {
+            float h[C1]; int cnt; bool valid; float f8[8];
             float mx, my, mz;
             pfn_mean(pts, t, v, lane, mx, my, mz);
             const int cn = t.cnt[v];
@@ -213,17 +276,29 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
                 for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
             }
         } else {
-            pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
+            const QuadPillar qp = quad_pillar(pts, t, v, lane, g);
+            for (int s0 = 0; s0 < qp.cnt; s0 += 16) {
+                float hq[8], fq[8];
+                quad_l0(qc, qp, s0 + qs, s0 + qs < qp.cnt, hq, fq);
 #pragma unroll
-            for (int c = 0; c < C1; ++c) { s1[c] += h[c]; s2[c] += h[c] * h[c]; }
+                for (int c = 0; c < 8; ++c) { s1[c] += hq[c]; s2[c] += hq[c] * hq[c]; }
+            }
         }
     }
     // block-level reduction first: one atomic per channel per block (8k waves hammering 64 addresses cost 3 ms)
     __shared__ float red[4][2 * C1];
+    if constexpr (MULTI) {
 #pragma unroll
-    for (int c = 0; c < C1; ++c) {
-        const float a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
-        if (lane == 0) { red[threadIdx.x >> 6][c] = a; red[threadIdx.x >> 6][C1 + c] = b2; }
+        for (int c = 0; c < C1; ++c) {
+            const float a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+            if (lane == 0) { red[threadIdx.x >> 6][c] = a; red[threadIdx.x >> 6][C1 + c] = b2; }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float a = quad_sum16(s1[c]), b2 = quad_sum16(s2[c]);
+            if (qs == 0) { red[threadIdx.x >> 6][qcg * 8 + c] = a; red[threadIdx.x >> 6][C1 + qcg * 8 + c] = b2; }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2 * C1) atomicAdd(sums + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
@@ -289,10 +364,13 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
     if (threadIdx.x < C1) { ss[threadIdx.x] = scale[threadIdx.x]; ss[C1 + threadIdx.x] = shift[threadIdx.x]; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    const int qs = lane & 15, qcg = lane >> 4;
+    QuadCtx qc;
+    if constexpr (!MULTI) quad_init(qc, w1s, ss, qcg);
     for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
-        float h[C1]; int cnt; bool valid; float f8[8];
         if constexpr (MULTI) {
+            float h[C1]; int cnt; bool valid; float f8[8];
             // max_points > 64: pass 1 = per-channel max over all 64-slot chunks, pass 2 = recompute and write the rows
             float mx, my, mz;
             pfn_mean(pts, t, v, lane, mx, my, mz);
@@ -319,22 +397,52 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
             }
             continue;
         }
-        pfn_l0(pts, t, v, lane, g, w1s, h, cnt, valid, f8);
-        const bool has_pad = cnt < max_points;
-        float xm[C1];
+        // quad layout: lane = (slot s0 + qs, channels 8 qcg .. 8 qcg + 7)
+        const QuadPillar qp = quad_pillar(pts, t, v, lane, g);
+        const int cn = qp.cnt;
+        const bool has_pad = cn < max_points;
+        const int last = has_pad ? cn : cn - 1;                  // highest slot that owns a row (the representative padded slot is cn)
+        float xq[8];
 #pragma unroll
-        for (int c = 0; c < C1; ++c) {
-            h[c] = fmaxf(h[c] * ss[c] + ss[C1 + c], 0.f);          // padded slots: relu(shift)
-            float m = wave_max(valid ? h[c] : -INFINITY);
-            if (has_pad) m = fmaxf(m, fmaxf(ss[C1 + c], 0.f));
-            xm[c] = m;
+        for (int c = 0; c < 8; ++c) xq[c] = -INFINITY;
+        for (int s0 = 0; s0 < cn; s0 += 16) {                    // pass 1: per-channel max over the real slots
+            float hq[8], fq[8];
+            const bool ok = s0 + qs < cn;
+            quad_l0(qc, qp, s0 + qs, ok, hq, fq);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xq[c] = fmaxf(xq[c], ok ? fmaxf(hq[c] * qc.sc[c] + qc.sh[c], 0.f) : -INFINITY);
         }
-        // rows: lane < cnt -> real slot; lane == cnt (if has_pad) -> the representative padded slot
-        if (valid || (has_pad && lane == cnt)) {
-            const int64_t row = (int64_t)t.row[v] + lane;
-            // training path: per-row pillar id / BN weight / decorated features (padded representative: zeros, weight P - cnt)
-            row_vox[row] = v; row_w[row] = valid ? 1.f : (float)(max_points - cnt);
-            store_row<T>(F8 + row * 8, X2 + row * K2, f8, h, xm);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            xq[c] = quad_max16(xq[c]);
+            if (has_pad) xq[c] = fmaxf(xq[c], fmaxf(qc.sh[c], 0.f));     // padded slots: relu(shift)
+        }
+        for (int s0 = 0; s0 <= last; s0 += 16) {                 // pass 2: rows
+            float hq[8], fq[8];
+            const int slot = s0 + qs;
+            const bool ok = slot < cn;
+            quad_l0(qc, qp, slot, ok, hq, fq);
+            if (ok || (has_pad && slot == cn)) {
+                const int64_t row = (int64_t)t.row[v] + slot;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) hq[c] = fmaxf(hq[c] * qc.sc[c] + qc.sh[c], 0.f);
+                if (qcg == 0) {
+                    // training path: per-row pillar id / BN weight / decorated features (padded representative: zeros, weight P - cnt)
+                    row_vox[row] = v; row_w[row] = ok ? 1.f : (float)(max_points - cn);
+                    *reinterpret_cast<float4*>(F8 + row * 8) = make_float4(fq[0], fq[1], fq[2], fq[3]);
+                    *reinterpret_cast<float4*>(F8 + row * 8 + 4) = make_float4(fq[4], fq[5], fq[6], fq[7]);
+                }
+                T* dst = X2 + row * K2 + qcg * 8;
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(hq[0], hq[1]), pack_bf2(hq[2], hq[3]), pack_bf2(hq[4], hq[5]), pack_bf2(hq[6], hq[7]));
+                    *reinterpret_cast<uint4*>(dst + C1) = make_uint4(pack_bf2(xq[0], xq[1]), pack_bf2(xq[2], xq[3]), pack_bf2(xq[4], xq[5]), pack_bf2(xq[6], xq[7]));
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(hq[0], hq[1], hq[2], hq[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(hq[4], hq[5], hq[6], hq[7]);
+                    *reinterpret_cast<float4*>(dst + C1) = make_float4(xq[0], xq[1], xq[2], xq[3]);
+                    *reinterpret_cast<float4*>(dst + C1 + 4) = make_float4(xq[4], xq[5], xq[6], xq[7]);
+                }
+            }
         }
     }
 }
