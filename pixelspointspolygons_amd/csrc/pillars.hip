@@ -19,6 +19,7 @@ namespace {
 
 constexpr int C1 = 32;      // PFN layer-0 units (feat_channels[0] / 2)
 constexpr int K2 = 64;      // layer-1 input = [x | xmax]
+constexpr int L2R_BLOCKS = 2048;   // pfn_l2_reduce grid cap (512 with per-wave atomics: 0.38 ms; see the kernel)
 constexpr int SORT_THREADS = 1024, SORT_WAVES = 16;
 constexpr int MAX_CELLS = 1900;
 // layer-0 backward accumulators: S_dyf[32][8] | S_xf[32][8] | S_f[8] | dbeta[32] | dgamma[32]
@@ -479,9 +480,18 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict_
         }
     }
     if (sums) {
+        // block-level fold first (4 waves -> 1): the grid can then be 4x larger (8 waves / SIMD for this latency-bound walk) at the same
+        // number of same-address atomics
+        __shared__ float red[4][2 * 64 * MAXJ];
+        const int wv = threadIdx.x >> 6;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) { atomicAdd(sums + lane + 64 * j, s1[j]); atomicAdd(sums + C + lane + 64 * j, s2[j]); }
+            if (j < nj) { red[wv][lane + 64 * j] = s1[j]; red[wv][64 * MAXJ + lane + 64 * j] = s2[j]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(sums + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+            atomicAdd(sums + C + c, (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]));
+        }
     }
 }
 
@@ -787,9 +797,9 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     if (rc != P3_OK) return rc;
     float* sums2 = d->training ? w.sums2 : nullptr;
     if (d->dtype == P3_BF16)
-        hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     else
-        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     P3_LAUNCH_CHECK();
     }
     if (phases & 4) {
