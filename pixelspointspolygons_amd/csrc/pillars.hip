@@ -555,9 +555,17 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max
             }
         }
     }
+    // block-level fold first, so that the grid can be 4x larger at the same number of same-address atomics (cf. pfn_l2_reduce_kernel)
+    __shared__ float red[4][2 * 64 * MAXJ];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) { atomicAdd(dbeta + lane + 64 * j, s1[j]); atomicAdd(dgamma + lane + 64 * j, s2[j]); }
+        if (j < nj) { red[wv][lane + 64 * j] = s1[j]; red[wv][64 * MAXJ + lane + 64 * j] = s2[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dbeta + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        atomicAdd(dgamma + c, (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]));
+    }
 }
 
 // step 2: H2 rows -> dH2 rows in place:  gamma*rstd * (g [first arg-max row] - w_row * (dbeta + xhat * dgamma) / n)
@@ -857,9 +865,9 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     const bool bf = d->dtype == P3_BF16;
     if (phases & 1) {
     if (bf)
-        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     else
-        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     P3_LAUNCH_CHECK();
     }
     if (phases & 2) {
