@@ -4,7 +4,11 @@ keys and shapes, so a published `.pth` loads as it is; this module mirrors the r
   smart_load_state_dict(model, checkpoint_state_dict, logger=None, strict=True)    misc/shared_utils.py:66-117
       "encoder.model." -> "encoder.vit." rename, exact key match first, then suffix match in either direction (DDP's "module."
       prefix on one side or the other); loads the matched tensors, returns the model
-  load_checkpoint(model, path_or_dict, ...)       accepts the trainer's {"state_dict": ...} files and bare state dicts
+  load_checkpoint(model, path_or_dict, ...)       the trainer's files {"cfg", "model", "optimizer", "lr_scheduler", "epoch", ...}
+                                                  (train/trainer.py:114-122; read back at :166-190 and predict/predictor.py:73-93 after
+                                                  renaming "*_state_dict" -> "*"), older {"model_state_dict": ...} / {"state_dict": ...}
+                                                  files and bare state dicts; return_extras=True also hands back the other entries
+  normalize_checkpoint(obj)                       that key normalisation alone
   compare(model, checkpoint_state_dict)           -> Report(matched, missing, unused, shape_mismatch) without touching the model
   export_state_dict(model)                        reference-keyed CPU fp32 state dict (for torch.save), whatever the compute dtype
 """
@@ -60,11 +64,31 @@ def smart_load_state_dict(model, checkpoint_state_dict, logger=None, strict=True
     return model
 
 
-def load_checkpoint(model, path_or_dict, logger=None, strict=True, map_location="cpu"):
+def normalize_checkpoint(obj):
+    """-> (model state dict, dict of the remaining entries).  Key handling of the reference's readers: every top-level key has
+    "_state_dict" removed ("model_state_dict" -> "model", "optimizer_state_dict" -> "optimizer", trainer.py:169-175), then the model
+    weights are checkpoint["model"].  A file that holds nothing but tensors is taken as the state dict itself."""
+    if not isinstance(obj, dict):
+        raise TypeError(f"checkpoint must be a dict, got {type(obj).__name__}")
+    if obj and all(torch.is_tensor(v) for v in obj.values()):
+        return obj, {}
+    renamed = {}
+    for k, v in obj.items():
+        renamed[k.replace("_state_dict", "") if isinstance(k, str) else k] = v
+    for key in ("model", "state_dict"):
+        sd = renamed.get(key)
+        if isinstance(sd, dict) and sd and all(torch.is_tensor(v) for v in sd.values()):
+            rest = {k: v for k, v in renamed.items() if k != key}
+            return sd, rest
+    raise KeyError(f"no model state dict in checkpoint (top-level keys: {sorted(map(str, obj.keys()))})")
+
+
+def load_checkpoint(model, path_or_dict, logger=None, strict=True, map_location="cpu", return_extras=False):
     obj = torch.load(path_or_dict, map_location=map_location, weights_only=False) if isinstance(path_or_dict, (str, bytes)) or hasattr(path_or_dict, "read") \
         else path_or_dict
-    sd = obj["state_dict"] if isinstance(obj, dict) and "state_dict" in obj and not torch.is_tensor(obj["state_dict"]) else obj
-    return smart_load_state_dict(model, sd, logger=logger, strict=strict)
+    sd, rest = normalize_checkpoint(obj)
+    model = smart_load_state_dict(model, sd, logger=logger, strict=strict)
+    return (model, rest) if return_extras else model
 
 
 def export_state_dict(model):

@@ -19,66 +19,65 @@ from .vision_transformer import ViT, compute_dtype
 
 # ------------------------------------------------------------------------------------------------ Tokenizer
 class Tokenizer:
-    """models/pix2poly/tokenizer.py:4-97 (host-side integer bookkeeping; identical constants and behaviour)."""
+    """Sequence codec of Pix2Poly: polygon vertices <-> bin indices framed by BOS / EOS (behaviour of the reference's
+    models/pix2poly/tokenizer.py:4-97, pinned by tests/golden/tokenizer.npz).
+
+    Vocabulary layout: [0, num_bins) coordinate bins, then BOS, EOS, PAD.  A vertex contributes `token_mode` = 2 tokens (x, y)."""
+
+    token_mode = 2
 
     def __init__(self, cfg, num_classes=1):
-        self.num_classes = num_classes
-        self.cfg = cfg
-        self.token_mode = 2
-        self.num_bins = self.cfg.experiment.model.tokenizer.num_bins
-        self.width = self.cfg.experiment.encoder.in_width
-        self.height = self.cfg.experiment.encoder.in_height
-        self.max_len = self.cfg.experiment.model.tokenizer.max_num_vertices * self.token_mode + 2
-        self.BOS_code = self.num_bins
-        self.EOS_code = self.BOS_code + 1
-        self.PAD_code = self.EOS_code + 1
-        self.vocab_size = self.num_bins + 3
-        self.cfg.experiment.model.tokenizer.pad_idx = self.PAD_code
-        self.cfg.experiment.model.tokenizer.max_len = self.max_len
-        self.cfg.experiment.model.tokenizer.generation_steps = self.cfg.experiment.model.tokenizer.max_num_vertices * self.token_mode + 1
+        tcfg, enc = cfg.experiment.model.tokenizer, cfg.experiment.encoder
+        self.cfg, self.num_classes = cfg, num_classes
+        self.num_bins = tcfg.num_bins
+        self.width, self.height = enc.in_width, enc.in_height
+        self.BOS_code, self.EOS_code, self.PAD_code = (self.num_bins + i for i in range(3))
+        self.vocab_size = self.PAD_code + 1
+        body = tcfg.max_num_vertices * self.token_mode
+        self.max_len = body + 2                       # BOS + body + EOS
+        # collate function and predictor read these three from the config (tokenizer.py:25-27)
+        tcfg.pad_idx, tcfg.max_len, tcfg.generation_steps = self.PAD_code, self.max_len, body + 1
 
     def quantize(self, x):
-        return (x * (self.num_bins - 1)).round(0).astype("int")
+        """[0, 1] -> bin index (round half to even, like ndarray.round)."""
+        return np.rint(np.asarray(x) * (self.num_bins - 1)).astype("int")
 
     def dequantize(self, x):
-        return x.astype("float32") / (self.num_bins - 1)
+        return np.asarray(x).astype("float32") / (self.num_bins - 1)
+
+    def _extent(self, like):
+        return np.asarray([self.width, self.height], dtype=like.dtype if np.issubdtype(like.dtype, np.floating) else np.float64)
 
     def __call__(self, coords, shuffle=True):
+        """coords [n, 2] pixel vertices -> (token list, the vertex order used).  As in the reference the caller's array is
+        normalised IN PLACE, at most max_len vertices are kept, and the order is reversed (run_type 'debug') or drawn from
+        numpy's global generator."""
         if len(coords) > 0:
-            coords[:, 0] = coords[:, 0] / self.width
-            coords[:, 1] = coords[:, 1] / self.height
-        coords = self.quantize(coords)[: self.max_len]
-        rand_idxs = np.arange(0, len(coords))
-        if shuffle:
-            rand_idxs = np.arange(0, len(coords))
-            if self.cfg.run_type.name == "debug":
-                rand_idxs = rand_idxs[::-1]
-            else:
-                np.random.shuffle(rand_idxs)
-            coords = coords[rand_idxs]
-        tokenized = [self.BOS_code]
-        for coord in coords:
-            tokenized.extend(list(map(int, list(coord))))
-        tokenized.append(self.EOS_code)
-        return tokenized, rand_idxs
+            coords[:, :2] = coords[:, :2] / self._extent(coords)
+        bins = self.quantize(coords)[: self.max_len]
+        n = len(bins)
+        if not shuffle:
+            order = np.arange(n)
+        elif self.cfg.run_type.name == "debug":
+            order = np.arange(n)[::-1]
+        else:
+            order = np.random.permutation(n)          # same generator draw as shuffling arange(n)
+        body = bins[order].reshape(-1).tolist() if shuffle else bins.reshape(-1).tolist()
+        return [self.BOS_code, *body, self.EOS_code], order
 
     def decode(self, tokens):
-        mask = tokens != self.PAD_code
-        tokens = tokens[mask]
-        tokens = tokens[1:-1]
-        assert len(tokens) % self.token_mode == 0, "Invalid tokens!"
-        coords = np.array(tokens).reshape(-1, self.token_mode)[:, :2]
-        coords = self.dequantize(coords)
-        if len(coords) > 0:
-            coords[:, 0] = coords[:, 0] * self.width
-            coords[:, 1] = coords[:, 1] * self.height
-        return coords
+        """tokens [L] (tensor or array, PAD allowed anywhere) -> [n, 2] float32 pixel coordinates."""
+        tokens = np.asarray(tokens)
+        body = tokens[tokens != self.PAD_code][1:-1]
+        assert body.size % self.token_mode == 0, "Invalid tokens!"
+        xy = self.dequantize(body.reshape(-1, self.token_mode)[:, :2])
+        return xy * self._extent(xy) if len(xy) else xy
 
 
 # ------------------------------------------------------------------------------------------------ mask helpers (API parity)
 def generate_square_subsequent_mask(sz, device):
-    mask = (torch.triu(torch.ones((sz, sz), device=device)) == 1).transpose(0, 1)
-    return mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, float(0.0))
+    """[sz, sz] additive causal mask: 0 on and below the diagonal, -inf above (model_pix2poly.py:12-18)."""
+    return torch.full((sz, sz), float("-inf"), device=device).triu(1)
 
 
 def create_mask(tgt, pad_idx):

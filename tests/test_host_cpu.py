@@ -198,11 +198,26 @@ def test_checkpoint_interchange_matches_the_reference_loader_rules(tmp_path):
     assert not rep.missing and not rep.shape_mismatch and not rep.unused and len(rep.matched) == len(sd)
     C.smart_load_state_dict(m, ddp, strict=True)
     assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    # the file the reference's trainer writes (train/trainer.py:114-122) and its readers open (trainer.py:166-190, predictor.py:73-93):
+    # {"cfg", "model", "optimizer", "lr_scheduler", "epoch", ...}; here from a DDP-wrapped model with the old encoder name
     path = tmp_path / "ckpt.pth"
-    torch.save({"state_dict": C.export_state_dict(m), "epoch": 3}, path)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0)
+    torch.save({"cfg": {"experiment": "p2p_fusion"}, "model": ddp, "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(),
+                "epoch": 3, "best_val_loss": 0.5}, path)
     m2 = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
-    C.load_checkpoint(m2, str(path))
-    assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+    m2b, rest = C.load_checkpoint(m2, str(path), return_extras=True)
+    assert m2b is m2 and all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+    assert rest["epoch"] == 3 and set(rest) == {"cfg", "optimizer", "lr_scheduler", "epoch", "best_val_loss"}
+    # older spellings the reference renames on load ("*_state_dict" -> "*"), this repository's round-1 {"state_dict": ...} files, bare dicts
+    for wrapper in ({"model_state_dict": C.export_state_dict(m), "optimizer_state_dict": {}, "epochs_run": 7}, {"state_dict": C.export_state_dict(m)},
+                    C.export_state_dict(m)):
+        m3 = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+        _, rest3 = C.load_checkpoint(m3, wrapper, return_extras=True)
+        assert all(torch.equal(m3.state_dict()[k], sd[k]) for k in sd)
+        assert "optimizer_state_dict" not in rest3 and ("optimizer" in rest3) == ("optimizer_state_dict" in wrapper)
+    with pytest.raises(KeyError):
+        C.load_checkpoint(m2, {"cfg": 1, "optimizer": {}})
     partial = {k: v for k, v in sd.items() if not k.startswith("scorenet2.")}
     partial["extra.unused"] = torch.zeros(1)
     rep = C.compare(m, partial)
