@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the Pix2Poly hot path on MI355X.
+"""Headline benchmark of the Pix2Poly / FFL hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
@@ -8,10 +8,17 @@ in HBM: forward (encoder + fusion + decoder + 2x ScoreNet + Sinkhorn) -> 1.0*CE 
 Metric (BASELINE.json): training tiles/s, whole job; `fwd_ms_per_tile` is reported in the same line.
 Default workload = the configuration the metric is quoted on ("224px img + 3k-pt lidar"): early-fusion Pix2Poly
 (ViT-S/8 + PointPillars stem, mnv = 64), 64 tiles per GPU, bf16 storage / fp32 accumulate.
+`--workload ffl_fusion` = BASELINE configs[4]: FFL early_fusion_vit_cnn, step = forward + FFL criterion + backward + AdamW.
+
+Extra objects in the JSON line (N = 1): `roofline` (dominant kernel, HIP events on the launch stream; step-level traffic from the
+committed PMC passes), `fp32_parity_mode` (the same step in the precision all 1e-3 parity claims are made in), `predict` (BASELINE
+configs[0]: image-only model, batch 1, 385-step greedy decode of the demo tile), `pcie_inclusive` (host-fed step, never `value`),
+`cpu_baseline` (the oracle on this box's host cores).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -21,8 +28,14 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# forward GFLOP per tile of the dense reference formulation (SURVEY §8d / BASELINE.md §2)
-GFLOP_FWD = {"fusion_s8": 85.2, "image_s8": 80.9, "image_b16": 35.13 + 10.7 + 25.4, "lidar_s8": 80.9 - 0.116 + 0.149}
+# Forward GFLOP per tile that the kernels EXECUTE: dense reference count minus the ScoreNet layer-1 work that the
+# separable formulation skips (2 x ScoreNet: 12.688 -> 3.074 GMAC).  The dense reference counts ride along for comparison only.
+_SCORENET_SKIPPED = 2.0 * (12.688 - 3.074)
+GFLOP_FWD_DENSE = {"fusion_s8": 85.2, "image_s8": 80.9, "image_b16": 35.13 + 10.7 + 25.4, "lidar_s8": 80.9 - 0.116 + 0.149, "ffl_fusion": 259.0}
+GFLOP_FWD = {k: (v if k == "ffl_fusion" else round(v - _SCORENET_SKIPPED, 2)) for k, v in GFLOP_FWD_DENSE.items()}
+# algorithmic HBM bytes of one train step at 64 tiles: 1.14 MB/tile of inputs + outputs, AdamW 16 B per parameter
+STEP_ALGO_BYTES = {"fusion_s8": 64 * 1.14e6 + 16 * 34.6e6}
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -30,36 +43,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fusion_s8", choices=["fusion_s8", "image_s8", "image_b16", "lidar_s8"])
+    ap.add_argument("--workload", default="fusion_s8", choices=["fusion_s8", "image_s8", "image_b16", "lidar_s8", "ffl_fusion"])
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--points", type=int, default=3000)
-    ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph (single-GPU)")
-    ap.add_argument("--sync-bn", type=int, default=1, help="N > 1: SyncBatchNorm like the reference's convert_sync_batchnorm (step runs eagerly)")
+    ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph")
+    ap.add_argument("--sync-bn", type=int, default=1, help="N > 1: SyncBatchNorm like the reference's convert_sync_batchnorm")
     ap.add_argument("--no-dropout", action="store_true", help="A/B only: decoder dropout off (the headline run keeps the reference's rates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs)")
+    ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency legs (profiling runs)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 parity-mode timed leg")
+    ap.add_argument("--no-predict", action="store_true", help="skip the configs[0] predict leg (image-only, batch 1, 385-step decode)")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive leg (host uint8 tiles + point lists through the device input pipeline)")
-    return ap.parse_args()
+    ap.add_argument("--lean", action="store_true", help="timed loop only (= all --no-* switches; profiling / A-B runs)")
+    a = ap.parse_args()
+    if a.lean:
+        a.no_cpu_baseline = a.no_kernel_timing = a.no_fwd = a.no_fp32_leg = a.no_predict = a.no_host_feed = True
+    return a
 
 
-def make_cfg(args, dev):
+KIND = {"fusion_s8": "fusion", "image_s8": "image", "image_b16": "image", "lidar_s8": "lidar", "ffl_fusion": "fusion"}
+
+
+def make_cfg(args, dev, precision=None, workload=None, batch=None):
     from pixelspointspolygons_amd.config import make_config
-    enc = {"fusion_s8": "early_fusion_vit", "image_s8": "vit", "image_b16": "vit", "lidar_s8": "pointpillars_vit"}[args.workload]
+    wl = workload or args.workload
+    prec = precision or args.precision
+    if wl == "ffl_fusion":
+        return make_config("early_fusion_vit_cnn", model="ffl", precision=prec, device=dev, batch_size=batch or args.batch)
+    enc = {"fusion_s8": "early_fusion_vit", "image_s8": "vit", "image_b16": "vit", "lidar_s8": "pointpillars_vit"}[wl]
     kw = {}
-    if args.workload == "image_b16":
+    if wl == "image_b16":
         kw = dict(patch_size=16, patch_feature_dim=768, vit_heads=12)
-    cfg = make_config(enc, precision=args.precision, device=dev, batch_size=args.batch, **kw)
-    if args.workload == "image_b16":
+    cfg = make_config(enc, precision=prec, device=dev, batch_size=batch or args.batch, **kw)
+    if wl == "image_b16":
         cfg.experiment.encoder.type = cfg.experiment.encoder.vit.type = "vit_base_patch16_224.dino"
     return cfg
 
 
-def synth_batch(S, args, rank, step, dev, kind):
+def synth_batch(S, args, rank, step, dev, kind, ffl=False):
     inp = S.make_inputs(args.batch, seed=1234 + 1000 * rank + step, n_points=args.points, jitter=args.points // 10)
-    b = {"y": inp["y"].to(dev), "y_perm": inp["y_perm"].to(dev)}
+    b = {}
+    if ffl:
+        b.update({k: v.to(dev) for k, v in S.make_ffl_targets(args.batch, seed=4321 + 1000 * rank + step).items()})
+    else:
+        b.update({"y": inp["y"].to(dev), "y_perm": inp["y_perm"].to(dev)})
     if kind != "lidar":
         b["image"] = inp["image"].to(dev)
     if kind != "image":
@@ -68,18 +98,18 @@ def synth_batch(S, args, rank, step, dev, kind):
 
 
 class Stepper:
-    """Static input buffers + (optionally) one captured hipGraph of forward + loss + backward + AdamW."""
+    """Static input buffers + (optionally) one captured hipGraph of forward + loss + backward (+ bucketed all-reduce launches) + AdamW."""
 
-    def __init__(self, model, opt, reducer, pool, kind, use_graph):
+    def __init__(self, model, opt, reducer, pool, kind, use_graph, criterion=None):
         from pixelspointspolygons_amd import ops
         from pixelspointspolygons_amd.training import pix2poly_loss
         self.ops = ops
         self.model, self.opt, self.reducer, self.kind = model, opt, reducer, kind
-        self.loss_fn = pix2poly_loss
+        self.loss_fn, self.criterion = pix2poly_loss, criterion
         cap = max(int(b["lidar_values"].shape[0]) for b in pool) if kind != "image" else 0
         self.static = {k: torch.empty_like(v) for k, v in pool[0].items() if k not in ("lidar_values",)}
         if kind != "image":
-            self.static["lidar_values"] = torch.zeros((cap, 3), dtype=torch.float32, device=pool[0]["y"].device)
+            self.static["lidar_values"] = torch.zeros((cap, 3), dtype=torch.float32, device=next(iter(pool[0].values())).device)
         self.graph = None
         self.eager_done = 0
         self.use_graph = use_graph
@@ -87,18 +117,35 @@ class Stepper:
 
     def load(self, b):
         for k, v in b.items():
+            if k not in self.static:
+                continue
             if k == "lidar_values":
                 self.static[k][: v.shape[0]].copy_(v, non_blocking=True)
             else:
                 self.static[k].copy_(v, non_blocking=True)
 
+    def _lidar(self):
+        s = self.static
+        return (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
+
+    def _forward(self):
+        s = self.static
+        if self.criterion is not None:       # FFL: dict batch in, {"seg", "crossfield"} out (model_ffl.py:99-104)
+            lidar = self._lidar()
+            nt = torch.nested.nested_tensor_from_jagged(lidar[0], lidar[1]) if lidar is not None else None
+            return self.model({"image": s.get("image"), "lidar": nt})
+        return self.model(s.get("image"), self._lidar(), s["y"][:, :-1])
+
     def _fwd_bwd(self):
         s = self.static
-        y = s["y"]
-        self.ops.advance_rng(y.device)           # new decoder dropout masks every step (device counter: replays with the graph)
-        lidar = (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
-        logits, perm = self.model(s.get("image"), lidar, y[:, :-1])
-        loss, ce, bce = self.loss_fn(logits, perm, y[:, 1:], s["y_perm"], 1.0, 10.0, 226)
+        dev = next(iter(s.values())).device
+        self.ops.advance_rng(dev)               # new decoder dropout masks every step (device counter: replays with the graph)
+        out = self._forward()
+        if self.criterion is not None:
+            loss = self.criterion(out, {"gt_polygons_image": s["gt_polygons_image"], "gt_crossfield_angle": s["gt_crossfield_angle"]},
+                                  normalize=True, epoch=10.0)[0]
+        else:
+            loss = self.loss_fn(out[0], out[1], s["y"][:, 1:], s["y_perm"], 1.0, 10.0, 226)[0]
         self.opt.zero_grad()
         loss.backward()
         return loss.detach()
@@ -106,18 +153,15 @@ class Stepper:
     def step(self, b):
         self.load(b)
         self.opt.prepare_step()
-        if self.use_graph and self.eager_done >= 2:
-            single = self.reducer.world == 1
+        capturable = self.reducer.world == 1 or self.reducer.graph_safe
+        if self.use_graph and capturable and self.eager_done >= 2:
             if self.graph is None:
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self.out = self._fwd_bwd()
-                    if single:
-                        self.opt.apply(1.0)
+                    self.opt.apply(self.reducer.finish())
             self.graph.replay()
-            if not single:                       # N > 1: graph = forward + backward; bucketed RCCL all-reduce + AdamW stay eager
-                self.opt.apply(self.reducer.finish())
         else:
             self.out = self._fwd_bwd()
             self.opt.apply(self.reducer.finish())
@@ -127,12 +171,10 @@ class Stepper:
     def forward_only(self, b, use_graph=True):
         """train-mode forward (batch statistics) without autograd; captured in its own hipGraph after two eager passes."""
         self.load(b)
-        s = self.static
-        lidar = (s["lidar_values"], s["lidar_offsets"]) if self.kind != "image" else None
 
         def run():
             with torch.no_grad():
-                return self.model(s.get("image"), lidar, s["y"][:, :-1])
+                return self._forward()
         if not (use_graph and self.use_graph):
             return run()
         self.fwd_eager = getattr(self, "fwd_eager", 0)
@@ -148,10 +190,34 @@ class Stepper:
         return self.fwd_out
 
 
+def timed_steps(st, pool, steps, warmup, world, dev):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    for i in range(warmup):
+        st.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = st.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(out)
+
+
 def host_feed_leg(S, args, st, dev, kind, rank):
     """PCIe-inclusive rate (never `value`): the same train step fed from HOST memory through pixelspointspolygons_amd.input_pipeline -
-    uint8 HWC tiles + untransformed point lists + a D4 element per tile packed into pinned staging, H2D + D4/Normalize kernels on a
-    copy stream overlapped with the previous step."""
+    uint8 HWC tiles + untransformed point lists + a D4 element per tile packed into pinned staging by a feeder thread, H2D + D4 /
+    Normalize kernels on a copy stream, persistent device staging (no allocation inside the loop).  Median of 3 repeats."""
     import numpy as np
     from pixelspointspolygons_amd.input_pipeline import DevicePrefetcher
     host_pool = []
@@ -164,70 +230,190 @@ def host_feed_leg(S, args, st, dev, kind, rank):
             off = inp["lidar_offsets"].tolist()
             hb["lidar"] = [inp["lidar_values"][off[b]:off[b + 1]].numpy() for b in range(args.batch)]
         host_pool.append(hb)
-    n_warm, n = 3, max(5, min(args.steps, 20))
-    pf = DevicePrefetcher((host_pool[i % len(host_pool)] for i in range(n_warm + n)), dev, max_points=int(args.batch * args.points * 1.5))
-    t0 = None
+    n_warm, n, reps = 6, max(5, min(args.steps, 20)), 3
+    pf = DevicePrefetcher((host_pool[i % len(host_pool)] for i in range(n_warm + reps * n)), dev, max_points=int(args.batch * args.points * 1.5))
+    times, t0 = [], None
     for i, b in enumerate(pf):
-        if i == n_warm:
+        if i >= n_warm and (i - n_warm) % n == 0:
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            now = time.perf_counter()
+            if t0 is not None:
+                times.append(now - t0)
+            t0 = now
         st.step(b)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     img_mb = args.batch * 224 * 224 * 3 / 1e6 if kind != "lidar" else 0.0
-    return {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
+    return {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n, "repeats": len(times),
+            "ms_per_step_all": [round(t / n * 1e3, 3) for t in times],
             "host_bytes_per_step_mb": round(img_mb + (args.batch * args.points * 12 / 1e6 if kind != "image" else 0.0) + args.batch * (386 * 8 + 192 * 192 * 4) / 1e6, 1),
-            "what": "uint8 HWC tiles + jagged points + tokens from pinned host memory, D4 + Normalize + HWC->CHW on the device, double buffered"}
+            "what": "uint8 HWC tiles + jagged points + tokens from pinned host memory (packed by a feeder thread), D4 + Normalize + HWC->CHW on the "
+                    "device, persistent triple-buffered staging; median of the repeats"}
+
+
+def _stats(samples):
+    return {"min": round(min(samples), 4), "median": round(statistics.median(samples), 4), "n": len(samples)}
 
 
 def cpu_baseline(args, kind):
-    """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload.
-    The only place bench.py touches oracle/."""
+    """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload
+    (SURVEY §8d protocol: B in {1, 8}, 3 warm-up + up to 10 timed iterations, min and median; forward ms/tile, train-step tiles/s and
+    s/tile of the literal 385-step greedy decode).  Every leg stops at a wall-clock budget so that the whole baseline stays within
+    ~1-2 minutes on a small host; the number of iterations that ran is reported.  The only place bench.py touches oracle/."""
     from oracle import p3_oracle as O
-    import torch.nn.functional as F  # noqa: F401
-    B = 2
     cfgv = O.VIT_S8 if args.workload != "image_b16" else O.VIT_B16
-    sd = O.make_state_dict({"fusion_s8": "fusion", "image_s8": "image", "image_b16": "image", "lidar_s8": "lidar"}[args.workload], cfgv, seed=42)
+    okind = {"fusion": "fusion", "image": "image", "lidar": "lidar"}[kind]
+    sd = O.make_state_dict(okind, cfgv, seed=42)
+
+    def inputs(B):
+        inp = O.make_inputs(B, seed=1234, n_points=args.points, jitter=args.points // 10)
+        img = inp["image"] if kind != "lidar" else None
+        lidar = (inp["lidar_values"], inp["lidar_offsets"]) if kind != "image" else None
+        return inp, img, lidar
+
+    def run(fn, warm, max_n, budget):
+        for _ in range(warm):
+            fn()
+        ts, t_end = [], time.time() + budget
+        while len(ts) < max_n and (len(ts) < 2 or time.time() < t_end):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return ts
+
+    fwd, train = {}, {}
+    for B in (1, 8):
+        inp, img, lidar = inputs(B)
+        with torch.no_grad():
+            ts = run(lambda: O.pix2poly_forward(sd, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=False), 3 if B == 1 else 1, 10, 10.0)
+        fwd[f"B{B}_ms_per_tile"] = _stats([t * 1e3 / B for t in ts])
     p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     params = [v for v in p.values() if v.is_floating_point() and v.requires_grad]
     opt = torch.optim.AdamW(params, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95))
-    inp = O.make_inputs(B, seed=1234, n_points=args.points, jitter=args.points // 10)
-    img = inp["image"] if kind != "lidar" else None
-    lidar = (inp["lidar_values"], inp["lidar_offsets"]) if kind != "image" else None
+    best = 0.0
+    for B in (1, 8):
+        inp, img, lidar = inputs(B)
 
-    def one():
-        logits, perm = O.pix2poly_forward(p, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=True)
-        loss, _, _ = O.pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-    one()
-    t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < 12 and n < 6):
-        one()
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle train step (fwd+CE+10*BCE+bwd+AdamW, fp32), batch {B}, {n} timed steps after 1 warm-up, host CPU"}
+        def one():
+            logits, perm = O.pix2poly_forward(p, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=True)
+            loss, _, _ = O.pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        ts = run(one, 1, 10, 15.0 if B == 1 else 25.0)
+        train[f"B{B}_tiles_per_s"] = {"max": round(B / min(ts), 4), "median": round(B / statistics.median(ts), 4), "n": len(ts)}
+        best = max(best, B / statistics.median(ts))
+    # literal greedy decode (Decoder.predict re-runs the whole padded sequence every step, model_pix2poly.py:187-219): every step costs
+    # the same, so a bounded number of steps is timed and scaled to the 385 steps of one tile
+    inp, img, lidar = inputs(1)
+    with torch.no_grad():
+        enc = O.encoder_fusion(img, lidar[0], lidar[1], sd, cfg=cfgv) if kind == "fusion" else (
+            O.encoder_vit(img, sd, cfg=cfgv) if kind == "image" else O.encoder_lidar(lidar[0], lidar[1], sd, cfg=cfgv))
+        n_dec = 12
+        t0 = time.time()
+        O.greedy_generate(enc, sd, steps=n_dec)
+        dec_s = (time.time() - t0) / n_dec * (O.MAX_LEN - 1)
+    return {"value": round(best, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "oracle (fp32 torch CPU restatement): train step fwd+CE+10*BCE+bwd+AdamW at B = 1 and 8 (value = best median), forward at B = 1 and 8, "
+                      f"literal greedy decode ({n_dec} of {O.MAX_LEN - 1} steps timed at B = 1, scaled); wall-clock bounded legs, iteration counts in `n`",
+            "forward": fwd, "train": train, "decode_s_per_tile": round(dec_s, 2)}
 
 
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
-    runs of `bench.py --graph 0`; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE as reported; tools/pmc_traffic.py).
-    bench.py cannot collect counters on itself, so this is the number of the same kernel on the same workload from profiles/."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or not kernel_label.startswith("gemm_kernel<bf16,plain"):
-        return None, None
-    with open(path) as fh:
-        t = json.load(fh)
+def pmc_step_traffic():
+    """HBM bytes per train step and per launch of each kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE,
+    separate runs of `bench.py --graph 0`; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md; tools/pmc_traffic.py).  bench.py cannot
+    collect counters on itself: these are the numbers of the same kernels on the same workload from profiles/."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh), f"profiles/{name}"
+    return None, None
+
+
+def kernel_traffic(table, label):
+    if table is None:
+        return None
     tot = n = 0.0
-    for k, v in t.items():
+    for k, v in table.items():
+        if not isinstance(v, dict) or "launches" not in v:
+            continue
         parts = [x.strip() for x in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
-        if k.startswith("gemm_kernel<unsigned short,") and len(parts) >= 3 and parts[2] == "0":   # bf16 in, bf16 / f32 out, plain A
+        hit = False
+        if label.startswith("gemm_kernel<bf16,plain"):
+            hit = k.startswith("gemm_kernel<unsigned short,") and len(parts) >= 3 and parts[2] == "0"
+        elif label.startswith("rp_gemm"):
+            hit = k.startswith("rp_gemm")
+        if hit:
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
-    return (round(tot / n) if n else None), "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, mean per launch over the train step)"
+    return round(tot / n) if n else None
+
+
+def roofline_leg(args, st, pool, hip, peak_tf):
+    """dominant-kernel timing with HIP events on the launch stream (instrumented forward passes, after the timed region)"""
+    from pixelspointspolygons_amd import ops as _ops
+    was_sync, _ops.SYNC_BN[0] = _ops.SYNC_BN[0], False     # rank-0-only leg: no collectives here
+    hip.KTIMER.enable()
+    for i in range(3):
+        st.forward_only(pool[i % len(pool)], use_graph=False)
+    torch.cuda.synchronize()
+    kt = hip.KTIMER.summary()
+    hip.KTIMER.disable()
+    _ops.SYNC_BN[0] = was_sync
+    if not kt:
+        return None
+    name, rec = max(kt.items(), key=lambda kv: kv[1]["ms"])
+    peak_gb = 8000.0
+    sec = rec["ms"] * 1e-3
+    ach_tf = rec["flop"] / sec / 1e12
+    ach_gb = rec["bytes"] / sec / 1e9 if rec["bytes"] else 0.0
+    ai = rec["flop"] / rec["bytes"] if rec["bytes"] else float("inf")
+    ridge = peak_tf * 1e12 / (peak_gb * 1e9)
+    table, tsrc = pmc_step_traffic()
+    step_traffic = table.get("_step_total_bytes") if table else None
+    common = {"kernel": name, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+              "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3),
+              "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+              "traffic": kernel_traffic(table, name), "traffic_source": tsrc,
+              "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]), "algorithmic_flop_per_launch": round(rec["flop"] / rec["n"]),
+              "step_traffic_bytes": step_traffic, "step_algorithmic_bytes": round(STEP_ALGO_BYTES.get(args.workload, 0)) or None}
+    # the bound is the one the launch mix sits under (ridge = 2.5 PF / 8 TB/s = 312 FLOP/B for bf16); both fractions are reported
+    if ai < ridge:
+        return {"bound": "hbm", "achieved": round(ach_gb, 1), "peak": peak_gb, "unit": "GB/s", "frac": round(ach_gb / peak_gb, 4),
+                "mfma_achieved_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak_tf, 4), **common}
+    return {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
+            "hbm_achieved_gbs": round(ach_gb, 1), "hbm_frac": round(ach_gb / peak_gb, 4), **common}
+
+
+def build(args, dev, local, precision, S, rank, world, sync_bn):
+    """model + optimizer + reducer + synthetic pool + stepper for one precision"""
+    from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer
+    from pixelspointspolygons_amd.vision_transformer import compute_dtype
+    kind = KIND[args.workload]
+    cfg = make_cfg(args, dev, precision=precision)
+    torch.manual_seed(42)                    # reference seed (train/trainer.py:214); random-init weights (no checkpoints offline)
+    criterion = None
+    if args.workload == "ffl_fusion":
+        from pixelspointspolygons_amd.ffl import FFLModel
+        from pixelspointspolygons_amd.ffl_losses import build_combined_loss
+        model = FFLModel(cfg, local)
+        criterion = build_combined_loss(cfg)
+    else:
+        from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+        model = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, local)
+        if args.no_dropout:
+            model.decoder.set_dropout(0.0)
+        # decoder dropout stays at the reference's training defaults (0.1 in nn.TransformerDecoderLayer incl. the attention
+        # probabilities, 0.05 on both positional sums, model_pix2poly.py:136-143): fused into the GEMM epilogues / attention kernels
+    model.train()
+    opt = FlatAdamW(model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=compute_dtype(cfg), direct_grad=True)
+    opt.set_linear_schedule(200 * 1000)
+    reducer = GradBucketReducer(opt)         # N > 1: bucket all-reduces launched from backward as buckets complete (side stream)
+    pool = [synth_batch(S, args, rank, s, dev, kind, ffl=criterion is not None) for s in range(args.pool)]
+    st = Stepper(model, opt, reducer, pool, kind, bool(args.graph), criterion=criterion)
+    return cfg, model, opt, reducer, pool, st
 
 
 def main():
@@ -248,58 +434,18 @@ def main():
         else:
             dist.init_process_group(backend, init_method="env://")
     from pixelspointspolygons_amd import synthetic as S        # synthetic-input generator (oracle/ is imported by the cpu_baseline leg only)
-    from pixelspointspolygons_amd import hip
-    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
-    from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer
-    from pixelspointspolygons_amd.vision_transformer import compute_dtype
+    from pixelspointspolygons_amd import hip, ops
 
-    kind = {"fusion_s8": "fusion", "image_s8": "image", "image_b16": "image", "lidar_s8": "lidar"}[args.workload]
-    cfg = make_cfg(args, dev)
-    torch.manual_seed(42)                    # reference seed (train/trainer.py:214); random-init weights (no checkpoints offline)
-    tk = Tokenizer(cfg)
-    model = Pix2PolyModel(cfg, tk.vocab_size, local)
-    model.train()
-    if args.no_dropout:
-        model.decoder.set_dropout(0.0)
-    # decoder dropout stays at the reference's training defaults (0.1 in nn.TransformerDecoderLayer incl. the attention
-    # probabilities, 0.05 on both positional sums, model_pix2poly.py:136-143): fused into the GEMM epilogues / attention kernels
-    # N > 1 with SyncBatchNorm (the reference's DDP setup, model_pix2poly.py:326-328): the 18 small statistic all-reduces sit inside
-    # forward/backward, so the step runs eagerly (measured on one GPU: eager == graph within 0.3 %, the step is GPU-bound); gradients
-    # go straight into the flat arena and are all-reduced bucket by bucket after backward.
+    kind = KIND[args.workload]
+    # N > 1 = the reference's DDP setup (model_pix2poly.py:324-328, model_ffl.py:161-163): SyncBatchNorm in every BatchNorm site (statistics
+    # packed into one buffer per module group) + gradient buckets all-reduced on a side stream while backward continues
     sync_bn = world > 1 and bool(args.sync_bn)
-    if sync_bn:
-        from pixelspointspolygons_amd import ops
-        ops.SYNC_BN[0] = True
-        args.graph = 0
-    opt = FlatAdamW(model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=compute_dtype(cfg),
-                    direct_grad=bool(args.graph) or world == 1 or sync_bn)   # hook-driven overlap needs autograd's AccumulateGrad
-    opt.set_linear_schedule(200 * 1000)
-    reducer = GradBucketReducer(opt, overlap=not args.graph and not sync_bn)   # hooks (overlap) only on the plain eager path
-    pool = [synth_batch(S, args, rank, s, dev, kind) for s in range(args.pool)]
-    st = Stepper(model, opt, reducer, pool, kind, bool(args.graph))
+    ops.SYNC_BN[0] = sync_bn
+    cfg, model, opt, reducer, pool, st = build(args, dev, local, args.precision, S, rank, world, sync_bn)
+    dt, loss_val = timed_steps(st, pool, args.steps, max(args.warmup, 3 if st.use_graph else 0), world, dev)   # 2 eager steps + the capture stay untimed
 
-    for i in range(max(args.warmup, 3 if args.graph else 0)):   # 2 eager steps + the capture step stay untimed
-        st.step(pool[i % len(pool)])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = st.step(pool[i % len(pool)])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    loss_val = float(out)
-
-    # forward-only latency (eval of the same model state, no grad)
-    fwd_ms = float("nan")
+    # forward-only latency (train-mode forward of the same model state, no grad; hipGraph)
+    fwd_ms = fwd_eval_ms = float("nan")
     if not args.no_fwd:
         for i in range(4):
             st.forward_only(pool[0])
@@ -310,9 +456,7 @@ def main():
             st.forward_only(pool[i % len(pool)])
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / nf * 1e3
-    # inference forward: model.eval() (running BatchNorm statistics, no dropout), eager launches, same batch shape
-    fwd_eval_ms = float("nan")
-    if not args.no_fwd:
+        # inference forward: model.eval() (running BatchNorm statistics, no dropout), eager launches, same batch shape
         model.eval()
         for i in range(3):
             st.forward_only(pool[0], use_graph=False)
@@ -324,64 +468,71 @@ def main():
         fwd_eval_ms = (time.perf_counter() - t1) / 5 * 1e3
         model.train()
 
+    single = world == 1
+    graph_used = st.graph is not None
     feed = None
-    if world == 1 and not args.no_host_feed and not args.no_fwd:
+    if single and not args.no_host_feed and args.workload != "ffl_fusion":
         feed = host_feed_leg(S, args, st, dev, kind, rank)
 
-    # dominant-kernel timing with HIP events on the launch stream (instrumented steps, after the timed region)
+    peak_tf = 2500.0 if args.precision == "bf16" else 157.3
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
-        from pixelspointspolygons_amd import ops as _ops
-        was_sync, _ops.SYNC_BN[0] = _ops.SYNC_BN[0], False     # rank-0-only leg: no collectives here
-        hip.KTIMER.enable()
-        for i in range(3):
-            st.forward_only(pool[i % len(pool)], use_graph=False)
-        torch.cuda.synchronize()
-        kt = hip.KTIMER.summary()
-        hip.KTIMER.disable()
-        _ops.SYNC_BN[0] = was_sync
-        if kt:
-            name, rec = max(kt.items(), key=lambda kv: kv[1]["ms"])
-            peak_tf = 2500.0 if args.precision == "bf16" else 157.3
-            peak_gb = 8000.0
-            sec = rec["ms"] * 1e-3
-            ach_tf = rec["flop"] / sec / 1e12
-            ach_gb = rec["bytes"] / sec / 1e9 if rec["bytes"] else 0.0
-            ai = rec["flop"] / rec["bytes"] if rec["bytes"] else float("inf")
-            ridge = peak_tf * 1e12 / (peak_gb * 1e9)
-            traffic, tsrc = pmc_traffic(name)
-            common = {"kernel": name, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
-                      "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3),
-                      "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
-                      "traffic": traffic, "traffic_source": tsrc,
-                      "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]), "algorithmic_flop_per_launch": round(rec["flop"] / rec["n"])}
-            # the bound is the one the launch mix sits under: K = 384 GEMMs with fp32 residual / bf16 outputs move 77-290 FLOP per
-            # byte, below the 312 FLOP/B ridge of MI355X (2.5 PF / 8 TB/s) -> HBM bound; both fractions are reported
-            if ai < ridge:
-                roofline = {"bound": "hbm", "achieved": round(ach_gb, 1), "peak": peak_gb, "unit": "GB/s", "frac": round(ach_gb / peak_gb, 4),
-                            "mfma_achieved_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak_tf, 4), **common}
-            else:
-                roofline = {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
-                            "hbm_achieved_gbs": round(ach_gb, 1), "hbm_frac": round(ach_gb / peak_gb, 4), **common}
+        roofline = roofline_leg(args, st, pool, hip, peak_tf)
+
+    # the same step in the precision the 1e-3 parity claims hold in (every matmul on the exact fp32 MFMA path)
+    fp32_leg = None
+    if single and not args.no_fp32_leg and args.precision == "bf16":
+        del st, reducer
+        opt.close()
+        del opt, model
+        torch.cuda.empty_cache()
+        _, model32, opt32, _, pool32, st32 = build(args, dev, local, "fp32", S, rank, world, False)
+        n32 = max(3, min(args.steps, 6))
+        dt32, loss32 = timed_steps(st32, pool32, n32, 3, 1, dev)
+        fp32_leg = {"value": round(args.batch * n32 / dt32, 2), "unit": "tiles/s", "ms_per_step": round(dt32 / n32 * 1e3, 3), "steps": n32, "warmup": 3,
+                    "dtype": "f32", "frac_of_157.3TF_fp32_mfma": round(3 * GFLOP_FWD[args.workload] * args.batch / (dt32 / n32) / 1e3 / 157.3, 4),
+                    "final_loss": round(loss32, 4),
+                    "what": "precision='fp32': v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains), the mode tests/ hold to 1e-3 against the oracle"}
+        opt32.close()
+        del st32, opt32, model32, pool32
+        torch.cuda.empty_cache()
+
+    predict = None
+    if single and rank == 0 and not args.no_predict and args.workload != "ffl_fusion":
+        try:
+            from pixelspointspolygons_amd.predict_demo import predict_leg
+            predict = predict_leg(dev)
+        except ImportError:
+            predict = None
 
     if rank == 0:
         tiles = args.batch * world * args.steps
+        gf = GFLOP_FWD[args.workload]
+        step_s = dt / args.steps
         line = {
             "metric": "training tiles/sec (224px img + 3k-pt lidar)", "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"pix2poly_{args.workload}_bs{args.batch}x{world}", "tiles_per_gpu": args.batch, "points_per_tile": args.points,
-                       "hip_graph": bool(args.graph), "sync_bn": sync_bn, "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
-                       "step": "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
+            "config": {"workload": f"{'ffl' if args.workload == 'ffl_fusion' else 'pix2poly'}_{args.workload}_bs{args.batch}x{world}", "tiles_per_gpu": args.batch,
+                       "points_per_tile": args.points, "hip_graph": graph_used, "sync_bn": sync_bn,
+                       "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
+                       "step": "fwd+FFL criterion+bwd+AdamW" if args.workload == "ffl_fusion" else "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
             "fwd_ms_per_tile": round(fwd_ms / args.batch, 4), "fwd_ms_per_batch": round(fwd_ms, 3),
             "fwd_eval_ms_per_tile": round(fwd_eval_ms / args.batch, 4),
-            "fwd_mfma_frac_of_2.5PF": round(GFLOP_FWD[args.workload] * args.batch / (fwd_ms * 1e-3) / 1e3 / 2500.0, 4) if args.precision == "bf16" else None,
+            "gflop_fwd_per_tile_executed": gf, "gflop_fwd_per_tile_dense_reference": GFLOP_FWD_DENSE[args.workload],
+            "fwd_mfma_frac": round(gf * args.batch / (fwd_ms * 1e-3) / 1e3 / peak_tf, 4) if fwd_ms == fwd_ms else None,
+            "step_mfma_frac": round(3 * gf * args.batch / step_s / 1e3 / peak_tf, 4),
+            "mfma_peak_tflops": peak_tf,
             "final_loss": round(loss_val, 4),
             "roofline": roofline,
         }
+        if fp32_leg is not None:
+            line["fp32_parity_mode"] = fp32_leg
+        if predict is not None:
+            line["predict"] = predict
         if feed is not None:
             line["pcie_inclusive"] = feed
-        if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the host cores are shared by the ranks otherwise)
+        if not args.no_cpu_baseline and single and args.workload != "ffl_fusion":   # N = 1 only (the ranks would share the host cores)
             line["cpu_baseline"] = cpu_baseline(args, kind)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -289,6 +289,12 @@ int p3_ce_loss_bwd(const float* logits, int ld, const int64_t* targets, int R, i
                    const float* acc, const float* gscale, void* dlogits, int dtype_out, int ld_out, int Vpad, void* stream);
 int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float* acc, void* stream);
 int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gscale, float* dp, void* stream);
+/* Device-side step counter + learning-rate schedule of the optimizer (torch.optim.AdamW bias corrections, and the reference's
+ * transformers.get_linear_schedule_with_warmup, train/trainer_pix2poly.py:62-77): reads step[0] = s (optimizer steps done), writes
+ * hyper = {base_lr * lambda(s), 1 - beta1^(s+1), 1 - beta2^(s+1)} and step[0] = s + 1.  kind 0 = constant, 1 = linear warm-up / decay.
+ * Launch it right before p3_adamw on the same stream (inside the captured step graph). */
+int p3_adamw_schedule(long long* step, float* hyper, float base_lr, int kind, int warmup_steps, int total_steps, float beta1, float beta2,
+                      void* stream);
 /* torch.optim.AdamW step over a flat parameter arena; hyper = {lr, 1-beta1^t, 1-beta2^t} on the device; optional bf16 shadow */
 int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1,
              float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow, void* stream);

@@ -385,6 +385,25 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Step counter and schedule live on the device: one thread advances the counter and writes {lr, 1 - beta1^t, 1 - beta2^t} for the
+// update kernel that follows it in the stream, so a captured graph (or a host that runs many steps ahead of the GPU) can never pair
+// step t's update with another step's bias corrections.  kind 0: constant lr; kind 1: linear warm-up then linear decay to zero
+// (transformers.get_linear_schedule_with_warmup, the reference's scheduler: train/trainer_pix2poly.py:62-77).
+__global__ void adamw_schedule_kernel(long long* __restrict__ step, float* __restrict__ hyper, float base_lr, int kind, int warmup, int total,
+                                      float beta1, float beta2) {
+    const long long s = step[0];
+    double lam = 1.0;
+    if (kind == 1) {
+        if (s < warmup) lam = (double)s / (double)(warmup > 1 ? warmup : 1);
+        else { const int den = total - warmup; lam = (double)(total - s) / (double)(den > 1 ? den : 1); if (lam < 0.0) lam = 0.0; }
+    }
+    const double t = (double)(s + 1);
+    hyper[0] = (float)((double)base_lr * lam);
+    hyper[1] = (float)(1.0 - pow((double)beta1, t));
+    hyper[2] = (float)(1.0 - pow((double)beta2, t));
+    step[0] = s + 1;
+}
+
 inline int grid_for(int64_t work) {
     int64_t g = (work + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -456,6 +475,15 @@ extern "C" int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float*
 extern "C" int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gscale, float* dp, void* stream) {
     P3_CHECK(p && y && gscale && dp && n > 0, P3_EINVAL, "p3_bce_loss_bwd: bad arguments");
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, gscale, dp);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+extern "C" int p3_adamw_schedule(long long* step, float* hyper, float base_lr, int kind, int warmup_steps, int total_steps, float beta1,
+                                 float beta2, void* stream) {
+    P3_CHECK(step && hyper && (kind == 0 || kind == 1), P3_EINVAL, "p3_adamw_schedule: bad arguments");
+    hipLaunchKernelGGL(adamw_schedule_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, hyper, base_lr, kind, warmup_steps, total_steps, beta1,
+                       beta2);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -252,13 +252,22 @@ class PillarDesc(Structure):
 
 
 _ws_cache = {}
+_ws_retired = []     # superseded buffers: a captured hipGraph may still hold their addresses, so they are never handed back
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag): avoids allocator traffic inside the step / graph capture."""
+    """Grow-only scratch buffer per (device, tag): avoids allocator traffic inside the step / graph capture.  A buffer that has to
+    grow is replaced, and the old one is kept alive for the life of the process (a graph captured at the smaller size replays into
+    it; freeing it would let the caching allocator hand that memory to other tensors).  Growing DURING a capture would allocate
+    from the graph's private pool and leave eager callers with a pointer the graph owns: refused."""
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise P3Error(f"workspace '{tag}' must grow from {buf.numel()} to {nbytes} bytes while a hipGraph is being captured: run the "
+                          "largest shape once eagerly before capturing")
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -662,6 +671,11 @@ def bce_loss_bwd(p, y, gscale):
     dp = torch.empty_like(p)
     check(lib().p3_bce_loss_bwd(ptr(p), ptr(y), c_int64(p.numel()), ptr(gscale), ptr(dp), stream()), "p3_bce_loss_bwd")
     return dp
+
+
+def adamw_schedule(step, hyper, base_lr, kind, warmup, total, beta1, beta2):
+    check(lib().p3_adamw_schedule(ptr(step), ptr(hyper), c_float(base_lr), c_int(kind), c_int(warmup), c_int(total), c_float(beta1),
+                                  c_float(beta2), stream()), "p3_adamw_schedule")
 
 
 def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, shadow=None):

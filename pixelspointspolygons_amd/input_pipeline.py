@@ -85,45 +85,56 @@ def pack_lidar(clouds, values_out=None, offsets_out=None):
 
 
 class DevicePrefetcher:
-    """Double-buffered host->device feeder.  Wraps an iterable of HOST batches (dicts):
+    """Triple-buffered host->device feeder.  Wraps an iterable of HOST batches (dicts):
          "image"  uint8 [B,H,W,C] tensor / array (optional)       "lidar"  list of [n_i,3] float32 clouds (optional)
          "group"  D4 element ids, int [B] (optional: augmentation)  anything else: tensors copied as they are (tokens, perm matrices)
          "gt_polygons_image" uint8 [B,H,W,3] (+ "gt_crossfield_angle" uint8 [B,H,W], "distances" / "sizes" float [B,H,W]): FFL ground
                   truth as stored on disk -> the fp32 NCHW gt_batch entries of the FFL criterion (`prepare_ffl_targets`)
        and yields DEVICE batches {"image": fp32 [B,C,H,W], "lidar_values", "lidar_offsets", ...} ready for the model.
-       While batch k computes, batch k+1 is packed into the other pinned set, copied and prepared on `self.stream`."""
+
+    A feeder thread packs batch k+1 / k+2 into pinned staging and queues the H2D copies + prepare kernels on `self.stream` while the
+    caller's thread launches step k, so neither the host packing nor the copies sit on the step's critical path.  Every staging
+    set owns its pinned buffers AND its device buffers for the life of the feeder (shape-stable batches allocate nothing after the
+    first `depth` batches; round 1 allocated ~60 MB of device tensors per step on the side stream, which on a fresh box fell through
+    to hipMalloc inside the timed loop).  Hand-over is by events: `ready` (copy stream -> consumer stream), `consumed` (consumer stream
+    -> copy stream, recorded when the caller asks for the next batch).  A yielded batch stays valid until the next call of next();
+    work already enqueued on the consumer's stream at that moment is safe."""
 
     def __init__(self, batches, device, max_points=1 << 20, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), max_pixel_value=255.0,
-                 in_width=224, in_height=224):
+                 in_width=224, in_height=224, depth=3):
+        import queue
+        import threading
         self.it = iter(batches)
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.norm = (mean, std, max_pixel_value)
         self.size = (in_width, in_height)
         self.max_points = max_points
-        self.sets = [dict(), dict()]
-        self.k = 0
-        self.next = None
-        self._preload()
+        self.free, self.ready = queue.Queue(), queue.Queue()
+        for _ in range(max(2, depth)):
+            self.free.put({"pin": {}, "dev": {}, "copied": None, "consumed": None})
+        self.current = None
+        self._stop = False
+        self.thread = threading.Thread(target=self._feed, name="p3-feeder", daemon=True)
+        self.thread.start()
 
-    def _pinned(self, s, key, shape, dtype):
-        buf = s.get(key)
-        if buf is None or buf.dtype != dtype or any(a < b for a, b in zip(buf.shape, shape)) or buf.dim() != len(shape):
-            buf = torch.empty(shape, dtype=dtype).pin_memory()
-            s[key] = buf
+    # ---- persistent buffers of one staging set
+    @staticmethod
+    def _buf(store, key, shape, dtype, make):
+        buf = store.get(key)
+        if buf is None or buf.dtype != dtype or buf.dim() != len(shape) or any(a < b for a, b in zip(buf.shape, shape)):
+            buf = make(shape, dtype)
+            store[key] = buf
         return buf[tuple(slice(0, n) for n in shape)]
 
-    def _preload(self):
-        try:
-            host = next(self.it)
-        except StopIteration:
-            self.next = None
-            return
-        s = self.sets[self.k]
-        self.k ^= 1
-        ev = s.get("_free")
-        if ev is not None:
-            ev.synchronize()                     # the copies that last read this pinned set are done
+    def _pinned(self, s, key, shape, dtype):
+        return self._buf(s["pin"], key, shape, dtype, lambda sh, dt: torch.empty(sh, dtype=dt).pin_memory())
+
+    def _device(self, s, key, shape, dtype):
+        return self._buf(s["dev"], key, shape, dtype, lambda sh, dt: torch.empty(sh, dtype=dt, device=self.device))
+
+    def _stage(self, s, host):
+        """host batch -> pinned staging of set `s` (CPU work of the feeder thread)"""
         staged = {}
         if host.get("image") is not None:
             img = torch.as_tensor(host["image"])
@@ -143,35 +154,74 @@ class DevicePrefetcher:
             t = torch.as_tensor(v)
             staged[k] = self._pinned(s, k, tuple(t.shape), t.dtype)
             staged[k].copy_(t)
+        return staged
+
+    def _upload(self, s, staged):
+        """pinned staging -> device buffers of set `s` + prepare kernels, all on the copy stream; returns the device batch"""
         out = {}
         with torch.cuda.stream(self.stream):
-            dev = {k: v.to(self.device, non_blocking=True) for k, v in staged.items()}
+            if s["consumed"] is not None:
+                self.stream.wait_event(s["consumed"])          # the consumer's kernels that read this set's last batch are done
+            dev = {}
+            for k, v in staged.items():
+                d = self._device(s, "raw_" + k, tuple(v.shape), v.dtype)
+                d.copy_(v, non_blocking=True)
+                dev[k] = d
+            s["copied"] = torch.cuda.Event()
+            s["copied"].record(self.stream)
             grp = dev.get("group")
             if "image" in dev:
-                out["image"] = prepare_images(dev["image"], grp, *self.norm)
+                B, H, W, C = dev["image"].shape
+                out["image"] = prepare_images(dev["image"], grp, *self.norm, out=self._device(s, "image", (B, C, H, W), torch.float32))
             if "lidar_values" in dev:
                 out["lidar_values"], out["lidar_offsets"] = dev["lidar_values"], dev["lidar_offsets"]
                 if grp is not None:
                     d4_points_(out["lidar_values"], out["lidar_offsets"], grp, *self.size)
-            ffl_keys = ("gt_polygons_image", "gt_crossfield_angle", "distances", "sizes")
             if "gt_polygons_image" in dev and dev["gt_polygons_image"].dtype == torch.uint8:       # FFL ground truth as stored (uint8 masks)
                 out.update(prepare_ffl_targets(dev["gt_polygons_image"], dev.get("gt_crossfield_angle"), dev.get("distances"), dev.get("sizes"), grp))
             for k, v in dev.items():
                 if k not in ("image", "lidar_values", "lidar_offsets", "group") and k not in out:
                     out[k] = v
-            s["_free"] = torch.cuda.Event()
-            s["_free"].record(self.stream)
-        self.next = out
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return out, ready
+
+    def _feed(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for host in self.it:
+                s = self.free.get()
+                if self._stop:
+                    return
+                if s["copied"] is not None:
+                    s["copied"].synchronize()                  # the H2D copies that last read this set's pinned buffers are done
+                out, ready = self._upload(s, self._stage(s, host))
+                self.ready.put((s, out, ready, None))
+            self.ready.put((None, None, None, StopIteration()))
+        except BaseException as e:                             # surface feeder errors in the consumer's thread
+            self.ready.put((None, None, None, e))
+
+    def close(self):
+        self._stop = True
+        self.free.put({"pin": {}, "dev": {}, "copied": None, "consumed": None})
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        if self.next is None:
-            raise StopIteration
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        batch = self.next
-        for v in batch.values():
-            v.record_stream(torch.cuda.current_stream(self.device))
-        self._preload()
-        return batch
+        cur = torch.cuda.current_stream(self.device)
+        if self.current is not None:                           # hand the previous set back: its consumers are enqueued by now
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.current["consumed"] = ev
+            self.free.put(self.current)
+            self.current = None
+        s, out, ready, err = self.ready.get()
+        if err is not None:
+            self.ready.put((None, None, None, err))            # stay exhausted / keep raising
+            if isinstance(err, StopIteration):
+                raise StopIteration
+            raise err
+        cur.wait_event(ready)
+        self.current = s
+        return out

@@ -11,31 +11,52 @@ import torch
 
 from . import hip
 
-_shadow_cache = {}
-_registered = {}     # id(param) -> (param, bf16 view of the optimizer's shadow arena; refreshed by the AdamW kernel itself)
-_epoch = [0]         # bumped by the optimizer: parameters changed behind autograd's back (flat arena update)
+_shadow_cache = {}   # (id(param), dtype, key) -> _Derived
+_registered = {}     # id(param) -> (param, bf16 view of the optimizer's shadow arena, owning optimizer); the AdamW kernel rewrites the view
+_epoch = [0]         # bumped by invalidate_derived(): parameters of NO arena changed behind autograd's back
 DIRECT_GRAD = [False]   # set by FlatAdamW: weight / bias / LayerNorm gradients are accumulated straight into the flat gradient
                         # arena by the split-M atomics of the TN GEMM / colsum kernels (no zero-fill, no AccumulateGrad add pass)
+
+
+GRAD_READY = [None]     # callable(param) installed by GradBucketReducer: the kernels that accumulate into param.grad are enqueued
+
+
+def _grad_ready(*params):
+    cb = GRAD_READY[0]
+    if cb is not None:
+        for p in params:
+            if p is not None:
+                cb(p)
 
 
 SYNC_BN = [False]       # set by the model factories when cfg.host.multi_gpu (nn.SyncBatchNorm.convert_sync_batchnorm, model_pix2poly.py:326)
 
 
+SYNC_CALLS = [0]        # collectives issued by sync_stats (tests / DESIGN: one per BatchNorm site and direction)
+
+
 def sync_stats(*tensors):
-    """SyncBatchNorm: SUM the per-rank statistic buffers (BatchNorm sums, counts, backward sums) across ranks, in place.
+    """SyncBatchNorm: SUM the per-rank statistic buffers (BatchNorm sums, counts, backward sums) across ranks, in place - ONE
+    collective per call: several buffers are packed into one flat message (xGMI all-reduce latency is per message, the payload is a few
+    hundred bytes).  Device tensors go to the process group as they are (RCCL; gloo stages through the host by itself).
     Returns the world size the batch count must be multiplied by (1 when SyncBatchNorm is off / single process)."""
     if not SYNC_BN[0]:
         return 1
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 1
-    for t in tensors:
-        if dist.get_backend() == "gloo" and t.is_cuda:     # test rigs (world-2 on one GPU): gloo reduces through the host
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ts = [t for t in tensors if t is not None]
+    SYNC_CALLS[0] += 1
+    if len(ts) == 1 and ts[0].is_contiguous():
+        dist.all_reduce(ts[0], op=dist.ReduceOp.SUM)
+        return dist.get_world_size()
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in ts])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    o = 0
+    for t in ts:
+        n = t.numel()
+        t.copy_(flat[o:o + n].view(t.shape))
+        o += n
     return dist.get_world_size()
 
 
@@ -91,43 +112,80 @@ def advance_rng(device):
 _registered_T = {}   # id(param) -> (param, bf16 [in, out] transposed copy kept fresh by the optimizer (hip.transpose_many))
 
 
-def register_shadow(p, view):
-    _registered[id(p)] = (p, view)
+def register_shadow(p, view, owner=None):
+    _registered[id(p)] = (p, view, owner)
 
 
 def register_shadow_T(p, view_t):
     _registered_T[id(p)] = (p, view_t)
 
 
+def unregister(params):
+    """optimizer teardown: forget the arena views (and the cached copies derived from them) of these parameters."""
+    ids = {id(p) for p in params}
+    for i in ids:
+        _registered.pop(i, None)
+        _registered_T.pop(i, None)
+    for k in [k for k in _shadow_cache if k[0] in ids]:
+        del _shadow_cache[k]
+
+
 def invalidate_derived():
     _epoch[0] += 1
+
+
+class _Derived:
+    """one cached compute-dtype / re-laid-out copy of a parameter"""
+    __slots__ = ("p", "out", "fn", "dtype", "ver", "arena")
+
+    def __init__(self, p, out, fn, dtype, ver, arena):
+        self.p, self.out, self.fn, self.dtype, self.ver, self.arena = p, out, fn, dtype, ver, arena
+
+
+def refresh_derived(params=None):
+    """Re-derive IN PLACE every cached re-laid-out copy that hangs off an optimizer arena (conv weights in (ky, kx, c) order, padded
+    transposes, ...).  The optimizer calls this right after its update kernel - inside the captured step graph too - so the copies
+    are fresh whether the next forward is a graph replay or an eager call, and tensors / graph-captured pointers stay valid.  (Round 1
+    invalidated by a Python-side counter instead, which a graph replay never advances: an eager evaluation after replayed training
+    steps read copies that were one update old.)"""
+    ids = None if params is None else {id(p) for p in params}
+    for k, ent in _shadow_cache.items():
+        if not ent.arena or (ids is not None and k[0] not in ids):
+            continue
+        reg = _registered.get(k[0])
+        if reg is None or reg[0] is not ent.p:
+            continue
+        if ent.out.untyped_storage().data_ptr() == reg[1].untyped_storage().data_ptr():
+            continue                             # a view of the arena itself (e.g. a reshape): fresh by construction
+        src = ent.fn(reg[1]) if ent.fn is not None else reg[1]
+        ent.out.copy_(src)                       # strided gather + (no-op) cast in one pass, into the buffer everyone already holds
 
 
 def shadow(p, dtype, key=None, fn=None):
     """compute-dtype (and optionally re-laid-out) copy of parameter `p`, cached until the parameter changes."""
     if dtype == torch.float32 and fn is None:
         return p.detach()
+    reg = _registered.get(id(p))
+    arena = reg is not None and reg[0] is p and dtype == torch.bfloat16
+    if arena and reg[2] is not None:
+        reg[2].check_fresh(p)                    # parameter written outside the optimizer (load_state_dict, init): resync the arenas
     if key == "T" and dtype == torch.bfloat16:
         rt = _registered_T.get(id(p))
         if rt is not None and rt[0] is p:
             return rt[1]
-    reg = _registered.get(id(p))
-    if reg is not None and reg[0] is p and dtype == torch.bfloat16:
-        if fn is None:
-            return reg[1]
-        base = reg[1]            # derive re-laid-out copies from the bf16 arena (no fp32 -> bf16 cast pass)
-    else:
-        base = None
+    if arena and fn is None:
+        return reg[1]
     k = (id(p), dtype, key)
     ent = _shadow_cache.get(k)
-    ver = (p._version, _epoch[0])
-    if ent is not None and ent[0] == ver and ent[2] is p:
-        return ent[1]
-    src = base if base is not None else p.detach()
+    # arena copies are kept fresh in place by refresh_derived(); everything else is versioned by autograd's counter + the epoch
+    ver = None if arena else (p._version, _epoch[0])
+    if ent is not None and ent.p is p and ent.ver == ver and ent.arena == arena:
+        return ent.out
+    src = reg[1] if arena else p.detach()        # derive from the bf16 arena when there is one (no fp32 -> bf16 cast pass)
     if fn is not None:
         src = fn(src)
     out = hip.cast(src, dtype) if src.dtype != dtype else src.contiguous()
-    _shadow_cache[k] = (ver, out, p)
+    _shadow_cache[k] = _Derived(p, out, fn, dtype, ver, arena)
     return out
 
 
@@ -217,6 +275,7 @@ class _Linear(torch.autograd.Function):
                     hip.colsum(dpre, out=bias_p.grad[r0:r1])
                 else:
                     db = hip.colsum(dpre)
+            _grad_ready(weight, bias_p if ctx.has_bias else None)
             return dx, None, db, dres, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
@@ -251,6 +310,7 @@ def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
                 hip.colsum(dpre, out=bias.grad)
             else:
                 db = hip.colsum(dpre)
+        _grad_ready(weight, bias)
         return dw, db
     if need_w:
         dw = hip.gemm_tn(dpre, x2)
@@ -331,6 +391,7 @@ class _LayerNorm(torch.autograd.Function):
         beta = ctx.beta_param
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad)
+            _grad_ready(gamma, beta)
             return dx, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
@@ -364,6 +425,7 @@ class _LayerNormFork(torch.autograd.Function):
             dres = dres.to(x.dtype)
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres)
+            _grad_ready(gamma, beta)
             return dx, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)

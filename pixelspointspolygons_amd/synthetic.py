@@ -30,3 +30,24 @@ def make_inputs(batch, seed=1234, n_points=3000, jitter=300, n_vertices=192, img
         rest = torch.arange(n, n_vertices)
         perm[b, rest, rest] = 1.0
     return dict(image=img, lidar_values=vals, lidar_offsets=offsets, y=y, y_perm=perm)
+
+
+def make_ffl_targets(batch, seed=1234, img_size=224):
+    """Ground truth of an FFL step in the layout the reference's dataset hands the criterion (datasets/p3_coco.py:254-296):
+    gt_polygons_image [B, 3, H, W] in [0, 1] (interior, edge, vertex channels) and gt_crossfield_angle [B, 1, H, W] in radians.
+    Axis-aligned-ish building blobs: a handful of filled rectangles per tile, their outlines as the edge channel."""
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.zeros(batch, 3, img_size, img_size)
+    angle = torch.zeros(batch, 1, img_size, img_size)
+    for b in range(batch):
+        for _ in range(int(torch.randint(3, 9, (1,), generator=g))):
+            h, w = (int(v) for v in torch.randint(12, 70, (2,), generator=g))
+            y0, x0 = int(torch.randint(0, img_size - h, (1,), generator=g)), int(torch.randint(0, img_size - w, (1,), generator=g))
+            gt[b, 0, y0:y0 + h, x0:x0 + w] = 1.0
+            gt[b, 1, y0:y0 + h, x0] = gt[b, 1, y0:y0 + h, x0 + w - 1] = 1.0
+            gt[b, 1, y0, x0:x0 + w] = gt[b, 1, y0 + h - 1, x0:x0 + w] = 1.0
+            gt[b, 2, [y0, y0, y0 + h - 1, y0 + h - 1], [x0, x0 + w - 1, x0, x0 + w - 1]] = 1.0
+            a = float(torch.rand(1, generator=g)) * 3.14159265
+            angle[b, 0, y0:y0 + h, x0] = angle[b, 0, y0:y0 + h, x0 + w - 1] = a
+            angle[b, 0, y0, x0:x0 + w] = angle[b, 0, y0 + h - 1, x0:x0 + w] = a + 1.57079633
+    return dict(gt_polygons_image=gt, gt_crossfield_angle=angle)

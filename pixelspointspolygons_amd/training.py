@@ -65,22 +65,33 @@ class FlatAdamW:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        if any(isinstance(m, torch.nn.parallel.DistributedDataParallel) for m in model.modules()) and direct_grad:
+            raise hip.P3Error("FlatAdamW(direct_grad=True) writes gradients past autograd's AccumulateGrad nodes, so torch DDP's reducer "
+                              "hooks never fire: pass the bare module (GradBucketReducer does the all-reduce) or direct_grad=False")
         for p, o in zip(params, offs):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
             if self.shadow is not None:
-                ops.register_shadow(p, self.shadow[o:o + n].view(p.shape))
+                ops.register_shadow(p, self.shadow[o:o + n].view(p.shape), self)
         if self.shadow is not None:
             self.shadow.copy_(self.flat)
         self._build_transposes(params, offs, dev)
+        self._versions = [p._version for p in params]
+        self._index = {id(p): i for i, p in enumerate(params)}
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         ops.DIRECT_GRAD[0] = bool(direct_grad)   # kernels accumulate parameter gradients in place in the arena
-        self.step_count = 0
+        # Step counter, schedule and bias corrections live on the device (p3_adamw_schedule runs right before the update kernel, inside
+        # a captured graph as well): the host may run any number of steps ahead.  A custom Python lr_lambda switches to host-fed
+        # scalars through a ring of pinned slots, each guarded by an event.
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(3)
-        self.lr_lambda = lambda step: 1.0
+        self.step_count = 0                      # host mirror of step_dev (logging / lr queries); prepare_step() advances it
+        self._sched = (0, 0, 0)                  # (kind, warm-up steps, total steps): constant learning rate
+        self._lr_lambda = lambda step: 1.0
+        self._host_fed = False
+        self._slots = None
         # gradient buckets for the data-parallel all-reduce (in arena order)
         nb = max(1, int(bucket_mb * (1 << 20) // 4))
         self.buckets, start = [], 0          # whole parameters per bucket: a bucket is complete when its parameters are
@@ -89,6 +100,26 @@ class FlatAdamW:
             if end - start >= nb or i + 1 == len(offs):
                 self.buckets.append((start, end))
                 start = end
+
+    # ---- freshness of the arenas when somebody else writes the parameters (load_state_dict after construction, re-initialisation)
+    def check_fresh(self, p):
+        i = self._index.get(id(p))
+        if i is not None and p._version != self._versions[i]:
+            self.resync()
+
+    def resync(self):
+        """bf16 shadow, transposed copies and derived layouts <- the fp32 parameters as they are now (eager; not inside a capture)."""
+        if self.shadow is not None:
+            self.shadow.copy_(self.flat)
+            if self.shadow_T is not None:
+                hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
+            ops.refresh_derived(self.params)
+        self._versions = [p._version for p in self.params]
+
+    def close(self):
+        """teardown: drop this optimizer's entries from the process-wide registries (they hold strong references to the arenas)."""
+        ops.unregister(self.params)
+        ops.DIRECT_GRAD[0] = False
 
     def _build_transposes(self, params, offs, dev):
         """bf16 W^T copies ([in, out]) of every 2-D weight whose dX GEMM reads the plain transpose (out % 64 == 0): one arena, one
@@ -118,33 +149,58 @@ class FlatAdamW:
         hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
 
     def set_linear_schedule(self, num_training_steps, warmup_frac=0.05):
-        """transformers.get_linear_schedule_with_warmup as used at trainer_pix2poly.py:62-77."""
+        """transformers.get_linear_schedule_with_warmup as used at trainer_pix2poly.py:62-77 (evaluated on the device)."""
         nw = int(warmup_frac * num_training_steps)
 
         def lam(step):
             if step < nw:
                 return float(step) / float(max(1, nw))
             return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - nw)))
-        self.lr_lambda = lam
+        self._lr_lambda, self._sched, self._host_fed = lam, (1, nw, int(num_training_steps)), False
+
+    @property
+    def lr_lambda(self):
+        return self._lr_lambda
+
+    @lr_lambda.setter
+    def lr_lambda(self, fn):
+        """arbitrary Python schedule: the scalars are computed on the host and fed through event-guarded pinned slots"""
+        self._lr_lambda, self._host_fed = fn, True
 
     def zero_grad(self):
         self.grad.zero_()
 
     def prepare_step(self):
-        """host side of the step: schedule + bias corrections -> device scalar (outside any captured graph)."""
-        lr = self.lr * self.lr_lambda(self.step_count)
+        """Host side of a step, outside any captured graph.  Device schedule (default): bookkeeping only.  Host-fed schedule: writes
+        {lr, 1 - beta1^t, 1 - beta2^t} into the next pinned slot (waiting for the copy that last used the slot) and queues its copy."""
+        lr = self.lr * self._lr_lambda(self.step_count)
         self.step_count += 1
-        t = self.step_count
-        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = lr, 1.0 - self.betas[0] ** t, 1.0 - self.betas[1] ** t
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        if self._host_fed:
+            t = self.step_count
+            if self._slots is None:
+                pin = torch.cuda.is_available()
+                self._slots = [[torch.zeros(3).pin_memory() if pin else torch.zeros(3), None] for _ in range(4)]
+            slot = self._slots[t % len(self._slots)]
+            if slot[1] is not None:
+                slot[1].synchronize()            # the H2D copy issued from this slot four steps ago has been consumed
+            slot[0][0], slot[0][1], slot[0][2] = lr, 1.0 - self.betas[0] ** t, 1.0 - self.betas[1] ** t
+            self.hyper.copy_(slot[0], non_blocking=True)
+            if self.hyper.is_cuda:
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
         return lr
 
     def apply(self, grad_scale=1.0):
-        """device side (capturable): one fused kernel over the arena, also refreshes the bf16 shadow."""
+        """device side (capturable): schedule kernel + one fused update kernel over the arena (which also refreshes the bf16 shadow),
+        then the transposed / re-laid-out weight copies are rewritten in place."""
+        if not self._host_fed:
+            kind, nw, nt = self._sched
+            hip.adamw_schedule(self.step_dev, self.hyper, self.lr, kind, nw, nt, self.betas[0], self.betas[1])
         hip.adamw(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
                   grad_scale=grad_scale, shadow=self.shadow)
         if self.shadow_T is not None:
             hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
+        ops.refresh_derived(self.params)
         ops.invalidate_derived()
 
     def step(self, grad_scale=1.0):
@@ -154,52 +210,93 @@ class FlatAdamW:
 
 # ------------------------------------------------------------------------------------------------ data parallel
 class GradBucketReducer:
-    """Overlapped gradient all-reduce over the flat arena (the DDP reducer of model_pix2poly.py:326-328, re-designed for xGMI).
+    """Overlapped gradient all-reduce over the flat arena (the DDP reducer of model_pix2poly.py:324-328, re-designed for xGMI: a few
+    large buckets, because a ring over point-to-point links is per-link bound).
 
-    Parameters are laid out in registration order, which is roughly forward order; backward therefore completes the LAST
-    bucket first.  A post-accumulate hook per parameter counts completions; when a bucket is full its all-reduce is issued
-    asynchronously (RCCL runs it on its own stream) while backward continues.
-    """
+    A bucket is all-reduced as soon as the LAST kernel that writes into it has been enqueued, while backward keeps running: the
+    collective is issued with async_op=True, so RCCL orders it after the work already on the compute stream and runs it on its own
+    stream.  "Last writer enqueued" is known in both gradient paths:
+      * autograd's AccumulateGrad (BatchNorm / conv / embedding parameters ...): a post-accumulate hook per parameter;
+      * direct accumulation into the arena by the weight-gradient GEMM / LayerNorm kernels (FlatAdamW(direct_grad=True), which bypasses
+        AccumulateGrad): the operators report through ops.GRAD_READY.
+    Some parameters are reported more than once per step (the packed in_proj weight of cross-attention gets its q rows and its k|v
+    rows from two GEMMs), so the trigger is positional: the FIRST backward of a model records the sequence of reports and reduces
+    everything in finish(); from the second step on, bucket b is launched when the report stream reaches the position of b's last
+    report.  The stream is checked against the recording while it arrives; the first deviation (a different graph: frozen layers,
+    another branch) stops early launches for that step, finish() reduces what is left, and the next step re-records.
+    SyncBatchNorm's small statistic collectives interleave with these on the same process group in program order, which is the same
+    on every rank.  The collectives are never captured into a hipGraph (`graph_safe` False): N > 1 steps run eagerly."""
+
+    graph_safe = False
 
     def __init__(self, opt: FlatAdamW, process_group=None, overlap=True):
-        """overlap=False: no hooks; `finish()` reduces all buckets after backward (used when backward runs inside a hipGraph)."""
+        """overlap=False: no early launches; `finish()` reduces all buckets after backward."""
         self.opt, self.pg = opt, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.handles = []
-        self.bucket_of, self.expect = [], [0] * len(opt.buckets)
-        for p, o in zip(opt.params, opt.offs):
-            b = min(range(len(opt.buckets)), key=lambda i: 0 if opt.buckets[i][0] <= o < opt.buckets[i][1] else 1)
-            self.bucket_of.append(b)
-            self.expect[b] += 1
-        self.count = [0] * len(opt.buckets)
         self.overlap = overlap
+        nb = len(opt.buckets)
+        self.bucket_of = []
+        for o in opt.offs:
+            self.bucket_of.append(next(i for i, (s, e) in enumerate(opt.buckets) if s <= o < e))
+        self._index = {id(p): i for i, p in enumerate(opt.params)}
+        self.handles, self.launched = [], [False] * nb
+        self.ref, self.trigger = None, None       # recorded report sequence, {position -> buckets complete after it}
+        self.seq, self.pos, self.following = [], 0, True
+        self.early_launches = 0                   # buckets reduced before finish() over the life of the reducer (tests, DESIGN)
         if self.world > 1 and overlap:
             for i, p in enumerate(opt.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._report(i))
+            ops.GRAD_READY[0] = self._report_param
 
-    def _make_hook(self, i):
-        def hook(_p):
-            b = self.bucket_of[i]
-            self.count[b] += 1
-            if self.count[b] == self.expect[b]:
+    def _report_param(self, p):
+        i = self._index.get(id(p))
+        if i is not None:
+            self._report(i)
+
+    def _report(self, i):
+        if self.ref is None:                      # recording step
+            self.seq.append(i)
+            return
+        if not self.following:
+            return
+        if self.pos < len(self.ref) and self.ref[self.pos] == i:
+            for b in self.trigger.get(self.pos, ()):
                 self._launch(b)
-        return hook
+                self.early_launches += 1
+            self.pos += 1
+        else:
+            self.following = False
 
     def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
         s, e = self.opt.buckets[b]
         self.handles.append(dist.all_reduce(self.opt.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
-        """call after backward: flush buckets whose parameters got no gradient, wait, return the 1/world scale for AdamW."""
+        """call after backward: reduce the buckets that are still open, wait, return the 1/world scale for AdamW."""
         if self.world > 1:
-            for b in range(len(self.count)):
-                if not self.overlap or self.count[b] != self.expect[b]:
-                    self._launch(b)
+            if self.overlap and self.ref is None:                    # first backward: turn the recording into triggers
+                last = {}
+                for pos, i in enumerate(self.seq):
+                    last[self.bucket_of[i]] = pos
+                self.ref, self.trigger = list(self.seq), {}
+                for b, pos in last.items():
+                    self.trigger.setdefault(pos, []).append(b)
+            elif self.overlap and (not self.following or self.pos != len(self.ref)):
+                self.ref, self.trigger = None, None                  # the graph changed: record again on the next step
+            for b in range(len(self.launched)):
+                self._launch(b)
             for h in self.handles:
                 h.wait()
-        self.handles = []
-        self.count = [0] * len(self.count)
+        self.handles, self.launched = [], [False] * len(self.launched)
+        self.seq, self.pos, self.following = [], 0, True
         return 1.0 / self.world
+
+    def close(self):
+        if ops.GRAD_READY[0] == self._report_param:
+            ops.GRAD_READY[0] = None
 
 
 def sync_bn_sums(sums):

@@ -186,6 +186,118 @@ def test_adamw_matches_torch():
         assert rel_err(pm.detach().cpu(), pr.detach()) < 1e-6
 
 
+def test_adamw_device_schedule_under_graph_replay_matches_torch():
+    """The step counter, the linear warm-up / decay factor and the bias corrections are computed on the device by a kernel inside the
+    captured graph: 40 replays queued without any host wait (the host runs far ahead of the GPU: big arena) == torch AdamW + LambdaLR."""
+    from transformers import get_linear_schedule_with_warmup
+    from pixelspointspolygons_amd.training import FlatAdamW
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(1024, 2048)
+    mine = torch.nn.Linear(1024, 2048)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95))
+    sch = get_linear_schedule_with_warmup(opt_ref, num_warmup_steps=10, num_training_steps=200)
+    opt = FlatAdamW(mine, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), compute_dtype=torch.float32, direct_grad=False)
+    opt.set_linear_schedule(200)
+    assert opt._sched == (1, 10, 200)
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.randn(p.shape, generator=g) for p in ref.parameters()]
+    for pm, gr in zip(mine.parameters(), grads):
+        pm.grad.copy_(gr.to(DEV))
+    for _ in range(2):                       # eager steps first (the allocator settles), then capture
+        opt.step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.apply(1.0)
+    n = 40
+    for _ in range(n):
+        opt.prepare_step()
+        graph.replay()
+    for _ in range(2 + n):
+        for pr, gr in zip(ref.parameters(), grads):
+            pr.grad = gr.clone()
+        opt_ref.step()
+        sch.step()
+    torch.cuda.synchronize()
+    assert int(opt.step_dev.item()) == 2 + n == opt.step_count
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        assert rel_err(pm.detach().cpu(), pr.detach()) < 2e-6
+    # a custom Python schedule goes through the event-guarded pinned slots
+    opt.lr_lambda = lambda step: 0.5
+    for pg in opt_ref.param_groups:
+        pg["lr"] = 3e-4 * 0.5
+    for _ in range(6):
+        for pr, gr in zip(ref.parameters(), grads):
+            pr.grad = gr.clone()
+        opt_ref.step()
+        opt.step()
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        assert rel_err(pm.detach().cpu(), pr.detach()) < 2e-6
+    opt.close()
+
+
+def test_derived_weight_layouts_stay_fresh_across_graph_replays_and_external_writes():
+    """Train by graph replay, evaluate eagerly twice: the re-laid-out weight copies (fusion conv in (ky, kx, c) order, transposes) are
+    rewritten in place after every optimizer step, so the eager forward equals a model rebuilt from the current state_dict; a
+    load_state_dict AFTER the optimizer was built resyncs the bf16 arenas."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import FlatAdamW, pix2poly_loss
+    cfg = make_config("early_fusion_vit", vit_depth=1, precision="bf16", device=DEV, batch_size=2)
+    torch.manual_seed(3)
+    m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+    opt = FlatAdamW(m, lr=1e-2, compute_dtype=torch.bfloat16)
+    inp = {k: v.to(DEV) for k, v in O.make_inputs(2, seed=9, n_points=400, jitter=40).items()}
+    lidar = (inp["lidar_values"], inp["lidar_offsets"])
+
+    def fwd_bwd():
+        logits, perm = m(inp["image"], lidar, inp["y"][:, :-1])
+        loss, _, _ = pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])
+        opt.zero_grad()
+        loss.backward()
+
+    def evaluate(model):
+        model.eval()
+        with torch.no_grad():
+            out = model(inp["image"], lidar, inp["y"][:, :-1])[0].float().clone()
+        model.train()
+        return out
+
+    m.train()
+    for _ in range(2):
+        fwd_bwd()
+        opt.step()
+    e0 = evaluate(m)                          # caches the derived copies eagerly
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fwd_bwd()
+        opt.apply(1.0)
+    for _ in range(3):
+        opt.prepare_step()
+        graph.replay()
+    e1, e2 = evaluate(m), evaluate(m)
+    assert torch.equal(e1, e2) and not torch.equal(e0, e1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg2 = make_config("early_fusion_vit", vit_depth=1, precision="bf16", device=DEV, batch_size=2)
+    fresh = Pix2PolyModel(cfg2, Tokenizer(cfg2).vocab_size, 0)
+    fresh.load_state_dict(sd)
+    ref = evaluate(fresh)                     # no optimizer: every copy derived from the fp32 parameters right now
+    assert rel_err(e1, ref) < 2e-2, rel_err(e1, ref)      # bf16(fp32 weights) on both sides; the arena copy was rounded by the update kernel
+    stale_gap = rel_err(e0, ref)
+    assert rel_err(e1, ref) < 0.2 * stale_gap, (rel_err(e1, ref), stale_gap)
+    # external write after the optimizer exists
+    sd0 = {k: (v * 0.5 if v.is_floating_point() and v.dim() > 1 else v) for k, v in sd.items()}
+    m.load_state_dict(sd0)
+    fresh.load_state_dict(sd0)
+    assert rel_err(evaluate(m), evaluate(fresh)) < 2e-2
+    opt.close()
+    assert not ops._registered and not ops.DIRECT_GRAD[0]
+
+
 def _oracle_grads(sd, inp, kind="fusion"):
     """float64 autograd of the oracle = ground truth (fp32 CPU sums over 10^5 rows are themselves ~1e-3 noisy)."""
     p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))

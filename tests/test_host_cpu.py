@@ -120,14 +120,24 @@ def _ddp_worker(rank, world, port, out):
     red = GradBucketReducer(opt)
     g = torch.Generator().manual_seed(100 + rank)                            # each rank sees its own shard of the batch
     x = torch.randn(4, 16, generator=g)
+    for step in range(3):        # step 0 records the order in which parameters report, steps 1.. launch buckets from inside backward
+        opt.zero_grad()
+        net(x).pow(2).mean().backward()
+        early = red.early_launches
+        scale = red.finish()
+    assert early >= len(opt.buckets) - 1 and red.ref is not None, (early, len(opt.buckets))
+    grads = (opt.grad * scale).clone()
+    # a different autograd graph (first layer frozen): the report stream deviates, nothing is reduced early that is not complete
+    net[0].weight.requires_grad_(False)
     opt.zero_grad()
     net(x).pow(2).mean().backward()
-    scale = red.finish()
-    grads = (opt.grad * scale).clone()
+    red.finish()
+    net[0].weight.requires_grad_(True)
+    frozen_ok = red.ref is None                                              # re-records on the next step
     sums = torch.tensor([1.0 + rank, 2.0 * (rank + 1)])
     w = sync_bn_sums(sums)
     if rank == 0:
-        torch.save({"grads": grads, "sums": sums, "w": w, "nb": len(opt.buckets)}, out)
+        torch.save({"grads": grads, "sums": sums, "w": w, "nb": len(opt.buckets), "frozen_ok": frozen_ok}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -138,7 +148,7 @@ def test_bucketed_allreduce_and_syncbn_sums_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
-    assert r["nb"] >= 3 and r["w"] == 2
+    assert r["nb"] >= 3 and r["w"] == 2 and r["frozen_ok"]
     assert torch.allclose(r["sums"], torch.tensor([3.0, 6.0]))
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
@@ -249,5 +259,5 @@ def test_only_checkers_import_the_oracle():
     assert not offenders, offenders
     src = open(os.path.join(root, "bench.py")).read()
     hits = [m.start() for m in pat.finditer(src)]
-    body = src[src.index("def cpu_baseline("):src.index("def pmc_traffic(")]
+    body = src[src.index("def cpu_baseline("):src.index("def pmc_step_traffic(")]
     assert len(hits) == 1 and pat.search(body)

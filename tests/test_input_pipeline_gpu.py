@@ -65,9 +65,9 @@ def test_prefetcher_yields_prepared_batches_in_order():
                      "lidar": [(rng.random((int(n), 3)) * 224.0).astype(np.float32) for n in rng.integers(1, 3000, size=B)],
                      "group": rng.integers(0, 8, size=B),
                      "y": torch.from_numpy(rng.integers(0, 227, size=(B, 386))), "y_perm": torch.rand(B, 192, 192)})
-    got = list(DevicePrefetcher(iter(host), DEV, max_points=16384))
-    assert len(got) == 5
-    for h, d in zip(host, got):
+    n = 0
+    for h, d in zip(host, DevicePrefetcher(iter(host), DEV, max_points=16384)):      # a batch is valid until the next one is requested
+        n += 1
         torch.cuda.synchronize()
         for b in range(4):
             e = D4_ELEMENTS[int(h["group"][b])]
@@ -76,6 +76,31 @@ def test_prefetcher_yields_prepared_batches_in_order():
         assert np.array_equal(d["lidar_values"].cpu().numpy(), want)
         assert torch.equal(d["lidar_offsets"].cpu(), pack_lidar(h["lidar"])[1])
         assert torch.equal(d["y"].cpu(), h["y"]) and torch.equal(d["y_perm"].cpu(), h["y_perm"])
+    assert n == 5
+
+
+def test_prefetcher_reuses_its_staging_sets_without_allocating():
+    """20 shape-stable batches through 3 staging sets: the consumer copies each batch into its own static buffers (what a graph-
+    replayed step does) while the feeder thread overwrites the sets behind it - every batch arrives intact, device memory stays flat."""
+    rng = np.random.default_rng(5)
+    B = 8
+    host = [{"image": torch.from_numpy(_tiles(B, 224, 3, 100 + k)), "lidar": [(rng.random((1500, 3)) * 224.0).astype(np.float32) for _ in range(B)],
+             "y_perm": torch.rand(B, 192, 192)} for k in range(20)]
+    static = None
+    sums, mem = [], []
+    for d in DevicePrefetcher(iter(host), DEV, max_points=B * 1500):
+        if static is None:
+            static = {k: torch.empty_like(v) for k, v in d.items()}
+        for k, v in d.items():
+            static[k].copy_(v, non_blocking=True)
+        sums.append((static["image"].sum(dtype=torch.float64), static["lidar_values"].sum(dtype=torch.float64), static["y_perm"].sum(dtype=torch.float64)))
+        mem.append(torch.cuda.memory_allocated())
+    torch.cuda.synchronize()
+    assert len(sums) == 20 and max(mem[6:]) == min(mem[6:])
+    for h, (a, b, c) in zip(host, sums):
+        assert abs(float(a) - float(h["image"].double().sum())) < 1e-6 * float(a)
+        assert abs(float(b) - float(np.concatenate(h["lidar"]).astype(np.float64).sum())) < 1e-6 * float(b)
+        assert abs(float(c) - float(h["y_perm"].double().sum())) < 1e-6 * float(c)
 
 
 def test_prefetched_batch_feeds_the_model():
@@ -104,7 +129,7 @@ def test_prefetcher_single_modality_batches_and_no_augmentation():
     assert np.array_equal(b["lidar_values"].cpu().numpy(), np.concatenate(clouds)) and b["lidar_offsets"].tolist() == [0, 10, 2010]
     from pixelspointspolygons_amd._lib import P3Error
     with pytest.raises(P3Error):
-        DevicePrefetcher(iter([{"lidar": clouds}]), DEV, max_points=100)          # staging buffer too small: loud
+        next(DevicePrefetcher(iter([{"lidar": clouds}]), DEV, max_points=100))    # staging buffer too small: loud (raised in the consumer's thread)
     assert list(DevicePrefetcher(iter([]), DEV)) == []
 
 
