@@ -372,7 +372,10 @@ def roofline_leg(args, st, pool, hip, peak_tf):
     ai = rec["flop"] / rec["bytes"] if rec["bytes"] else float("inf")
     ridge = peak_tf * 1e12 / (peak_gb * 1e9)
     table, tsrc = pmc_step_traffic()
-    step_traffic = table.get("_step_total_bytes") if table else None
+    step_traffic = None
+    if table:       # sum over all kernels of (FETCH x 2 + WRITE) x launches / profiled train steps (r01 passes: 2 warm-up + 4 timed = 6 steps)
+        tot = sum((v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"] for v in table.values() if isinstance(v, dict) and "launches" in v)
+        step_traffic = round(tot / float(table.get("_steps", 6)))
     common = {"kernel": name, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
               "share_of_fwd_kernel_time": round(rec["ms"] / sum(r["ms"] for r in kt.values()), 3),
               "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),

@@ -106,6 +106,8 @@ class DevicePrefetcher:
         import threading
         self.it = iter(batches)
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device)
         self.norm = (mean, std, max_pixel_value)
         self.size = (in_width, in_height)

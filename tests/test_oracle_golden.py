@@ -127,3 +127,24 @@ def test_pool_pairs_pattern():
     y = O.pool_channels(x, 256)[0, 0]
     exp = torch.tensor([(3 * (c // 2) + (c % 2)) + 0.5 for c in range(256)])
     assert torch.equal(y, exp)
+
+
+def test_demo_tile_fixture_is_consistent_with_the_oracle():
+    """configs[0] fixture: planted decoder tensors + seeded model -> the oracle's teacher-forced argmax reproduces the stored tokens up
+    to the EOS (one full decoder pass: cheap), the stored permutation is the scipy assignment of the stored scores."""
+    import os
+    from tests.helpers import GOLD
+    fx = np.load(os.path.join(GOLD, "demo_tile.npz"))
+    sd = O.make_state_dict("image", O.VIT_S8, seed=42)
+    for k in fx.files:
+        if k.startswith("planted."):
+            sd[k[len("planted."):]] = torch.from_numpy(fx[k])
+    img = torch.from_numpy(fx["image_u8"]).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    toks = torch.from_numpy(fx["tokens"])
+    with torch.no_grad():
+        enc = O.encoder_vit(img, sd, cfg=O.VIT_S8)
+        logits, _ = O.decoder_forward(enc, toks[:, :-1], sd)
+    eos = int((toks[0] == O.EOS).nonzero()[0])
+    assert torch.equal(logits[0, :eos].argmax(-1), toks[0, 1:eos + 1])        # causal decoder: teacher forcing == the greedy loop's choices
+    assert torch.equal(O.scores_to_permutations(torch.from_numpy(fx["scores"])), torch.from_numpy(fx["perm"]).float())
+    assert fx["image_u8"].shape == (224, 224, 3) and fx["poly_len"].sum() == len(fx["poly_flat"])

@@ -1,0 +1,54 @@
+"""BASELINE configs[0] end to end on the HIP path: the reference's demo tile (pixel bytes committed as a fixture), image-only Pix2Poly,
+batch 1, 385-step greedy decode, Hungarian assignment, polygons - against the oracle's outputs for the same seeded model with a
+planted (CPU-fitted) output layer: sharp, trained-like logits, a real EOS, non-trivial polygons (tests/golden/make_demo_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import p3_oracle as O
+from tests.helpers import GOLD
+
+DEV = "cuda"
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixture():
+    import os
+    return np.load(os.path.join(GOLD, "demo_tile.npz"))
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_demo_tile_predict_matches_the_oracle(graphs):
+    from pixelspointspolygons_amd.predict_demo import demo_model, predict_tile
+    fx = _fixture()
+    model, tk = demo_model(DEV, "fp32", state_dict=O.make_state_dict("image", O.VIT_S8, seed=42), fixture=fx)
+    want = torch.from_numpy(fx["tokens"])
+    margins = fx["margins"]
+    eos = int((want[0] == O.EOS).nonzero()[0])
+    assert eos == fx["target"].shape[1] - 1 and want[0, :eos + 1].tolist() == fx["target"][0].tolist()
+    for rep in range(3 if graphs else 1):                  # graphs: eager pass, capture pass, replay pass
+        polys, tokens = predict_tile(model, tk, fx["image_u8"], graphs=graphs)
+        assert tokens.shape == want.shape
+        # bit-exact token indices: everything up to the EOS (margins >> fp32 noise), and the free-running tail for as long as the
+        # oracle's own argmax margin stays above fp32 rounding
+        assert torch.equal(tokens[0, :eos + 1], want[0, :eos + 1])
+        low = np.nonzero(margins < 1e-4)[0]
+        upto = int(low[0]) + 1 if len(low) else want.shape[1]
+        assert torch.equal(tokens[0, :upto], want[0, :upto]), (upto, int((tokens[0] != want[0]).nonzero()[0]))
+        if torch.equal(tokens, want):                      # same sequence -> same decoder features -> same assignment -> same polygons
+            flat = np.concatenate([p.numpy() for p in polys]) if polys else np.zeros((0, 2), np.float32)
+            assert [len(p) for p in polys] == fx["poly_len"].tolist()
+            assert np.array_equal(flat, fx["poly_flat"])
+    assert len(fx["poly_len"]) > 0
+
+
+def test_demo_tile_bf16_reproduces_the_planted_sequence():
+    """throughput mode: the trained-like (sharp) part of the sequence - every token up to the EOS - survives bf16 storage"""
+    from pixelspointspolygons_amd.predict_demo import demo_model, predict_tile
+    fx = _fixture()
+    model, tk = demo_model(DEV, "bf16", state_dict=O.make_state_dict("image", O.VIT_S8, seed=42), fixture=fx)
+    polys, tokens = predict_tile(model, tk, fx["image_u8"], graphs=False)
+    n = fx["target"].shape[1]
+    agree = float((tokens[0, :n] == torch.from_numpy(fx["target"][0])).float().mean())
+    assert agree >= 0.9, agree
