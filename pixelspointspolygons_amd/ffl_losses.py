@@ -39,6 +39,15 @@ class _FFLLossFn(torch.autograd.Function):
         return (dseg * g).view(ss).to(sd), (dcf * g).view(cs).to(cdt), None, None, None, None, None, None
 
 
+class _LossSlot(torch.nn.Module):
+    """parameter container of one loss: `norm` [1] like the reference's Loss (losses.py:26-34)"""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+        self.norm = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+
+
 class MultiLoss(torch.nn.Module):
     """MultiLoss (losses.py:72-147) over the five losses build_combined_loss assembles for the shipped config."""
 
@@ -49,25 +58,44 @@ class MultiLoss(torch.nn.Module):
         self.weights = [list(w) if isinstance(w, (list, tuple)) else float(w) for w in weights]
         self.epoch_thresholds = [float(t) for t in epoch_thresholds]
         self.bce_coef, self.dice_coef = float(bce_coef), float(dice_coef)
-        self.norm = torch.nn.Parameter(torch.ones(len(LOSS_NAMES)), requires_grad=False)     # Loss.norm of every loss_func (losses.py:31)
-        self._norm_host = [1.0] * len(LOSS_NAMES)
+        # one sub-module per loss with its own `norm` parameter of shape [1]: the reference's state_dict keys `loss_funcs.{i}.norm`
+        # (Loss.norm, losses.py:31-33; saved / restored as checkpoint["loss_func"], train/trainer.py:193-194)
+        self.loss_funcs = torch.nn.ModuleList([_LossSlot(n) for n in LOSS_NAMES])
+        self._host_cache = (None, None)
+
+    @property
+    def norm(self):
+        """the five norms as one [5] tensor (a copy; the parameters are loss_funcs[i].norm)"""
+        return torch.cat([lf.norm.detach().reshape(1) for lf in self.loss_funcs])
+
+    @property
+    def _norm_host(self):
+        """host floats of the norms (they enter the fused kernel as coefficients); re-read whenever a norm parameter was written -
+        reset / update / sync below, load_state_dict, .to(device)"""
+        key = tuple((lf.norm._version, lf.norm.data_ptr()) for lf in self.loss_funcs)
+        if self._host_cache[0] != key:
+            self._host_cache = (key, [float(v) for v in self.norm.cpu().tolist()])
+        return self._host_cache[1]
+
+    def _set_norms(self, values):
+        with torch.no_grad():
+            for lf, v in zip(self.loss_funcs, values):
+                lf.norm.fill_(float(v))
 
     # ---- norms (Loss.reset_norm / update_norm / sync, losses.py:36-52) ----
     def reset_norm(self):
-        self._norm_host = [1.0] * len(LOSS_NAMES)
-        self.norm.data.fill_(1.0)
+        self._set_norms([1.0] * len(LOSS_NAMES))
 
     @torch.no_grad()
     def update_norm(self, pred_batch, gt_batch, nums):
         """the reference sets norm = AverageMeter.val, i.e. the LAST un-normalised loss value (losses.py:40-43)"""
         raw = self._raw(pred_batch, gt_batch).cpu().tolist()
-        self._norm_host = [float(v) for v in raw[:5]]
-        self.norm.data.copy_(torch.tensor(self._norm_host))
+        self._set_norms(raw[:5])
 
     def sync(self, world_size):
-        dist.all_reduce(self.norm.data)
-        self.norm.data /= world_size
-        self._norm_host = self.norm.data.cpu().tolist()
+        packed = self.norm
+        dist.all_reduce(packed)
+        self._set_norms((packed / world_size).cpu().tolist())
 
     def current_weights(self, epoch):
         out = []

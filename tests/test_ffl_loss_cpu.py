@@ -77,3 +77,18 @@ def test_host_mirror_refuses_configurations_the_kernels_do_not_cover():
     cfg.experiment.model.seg.compute_edge = True
     with pytest.raises(NotImplementedError):
         build_combined_loss(cfg)
+
+
+def test_multiloss_state_dict_uses_the_reference_key_layout():
+    """checkpoint["loss_func"] of the reference (train/trainer.py:193-194): keys loss_funcs.{i}.norm of shape [1] (losses.py:31-33);
+    loading one changes the norms the next forward uses."""
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.ffl_losses import build_combined_loss
+    crit = build_combined_loss(make_config("vit_cnn", model="ffl", device="cpu"))
+    sd = crit.state_dict()
+    assert sorted(sd) == [f"loss_funcs.{i}.norm" for i in range(5)] and all(v.shape == (1,) for v in sd.values())
+    ref_sd = {f"loss_funcs.{i}.norm": torch.tensor([0.5 + i]) for i in range(5)}        # what the reference's MultiLoss.state_dict() holds
+    crit.load_state_dict(ref_sd, strict=True)
+    assert crit._norm_host == [0.5, 1.5, 2.5, 3.5, 4.5] and crit.norm.tolist() == [0.5, 1.5, 2.5, 3.5, 4.5]
+    crit.reset_norm()
+    assert crit._norm_host == [1.0] * 5 and all(float(v) == 1.0 for v in crit.state_dict().values())
