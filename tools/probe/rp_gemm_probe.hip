@@ -6,6 +6,18 @@
 // tile.  The product is formed transposed (W fragment = MFMA A operand, X fragment = B operand), so a lane owns one token row of
 // the result and the epilogue is row-per-lane with 16-byte stores after a v_permlane32_swap pairing.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 rp_gemm_probe.hip -o rp_gemm_probe
+//
+// Round-2 findings on MI355X (M = 50240, K = 384, N = 1152; the production 128x128 kernel takes 72 us on this shape), kept here because
+// they decide what a successor has to do differently:
+//   * correct and 69-73 us as written; no variant beat the production kernel, so it is NOT wired into the library;
+//   * pieces in isolation: LDS-DMA stream + X load 23 us, MFMA / LDS loop alone 44-46 us (SQ_LDS_BANK_CONFLICT = 0 with the source-side
+//     swizzle; hand-scheduled asm reads two MFMA groups ahead did not move it: the loop is bounded by per-step barrier + first-read
+//     latency with both workgroups of a CU phase-locked, and by the epilogue's bias loads), row-per-lane 16-byte stores + 19 us
+//     (32 rows x 32 B per instruction = 4x the L1 transactions of a coalesced store: the epilogue must be staged through LDS);
+//   * counting epilogue stores in s_waitcnt vmcnt(N) RACES (VAR & 8): loads and stores retire out of order with respect to each other
+//     on gfx950; only loads issued after the awaited DMA may be counted, stores have to be issued before the next DMA instead;
+//   * hipcc's own global_load_lds builtin makes it wait vmcnt(0) before the next ds_read (LDS-DMA alias tracking): the DMA has to be
+//     inline asm; fragments carried ACROSS asm statements while their ds_read is in flight are moved / spilled by the compiler.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
