@@ -193,6 +193,89 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
     atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
 }
 
+// bf16 form with 16-byte accesses (r02: the 8-byte form above ran at 1.4 TB/s on the 1.2 GB of dA; 8-byte accesses reach 0.54-0.70x the
+// rate of 16-byte ones on this chip): a lane owns EIGHT channels, the two half-waves take the two halves of the block's IC rows i, the
+// dV partial sums of the halves are paired with v_permlane32_swap so that the atomic count per dV element stays N / IC.
+template <int IC>
+__global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ U, const bf16_t* __restrict__ V,
+                                                         const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
+                                                         float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C) {
+    constexpr int IH = IC / 2;
+    __shared__ float red[4][IC + 2][256];     // C == 256; rows IC, IC+1: (dscale, dshift) partials
+    const int b = blockIdx.y, i0 = blockIdx.x * IC;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5, c0 = l31 * 8;
+    float s[8], h[8], mu[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = sc[c0 + k]; h[k] = sh[c0 + k]; mu[k] = mean[c0 + k]; }
+    auto unpack8 = [](const uint4& raw, float (&v)[8]) __attribute__((always_inline)) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    };
+    uint4 upk[IH];                            // U rows stay packed (bf16 pairs): unpacked per use, 32 registers instead of 64
+    float au[IH][8];
+    const int ib = i0 + half * IH;
+#pragma unroll
+    for (int i = 0; i < IH; ++i) {
+        upk[i] = (ib + i < N) ? *reinterpret_cast<const uint4*>(U + ((int64_t)b * N + ib + i) * C + c0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) au[i][k] = 0.f;
+    }
+    float a_sc[8], a_sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a_sc[k] = 0.f; a_sh[k] = 0.f; }
+    for (int j = grp; j < N; j += 4) {
+        float v[8], av[8];
+        unpack8(*reinterpret_cast<const uint4*>(V + ((int64_t)b * N + j) * C + c0), v);
+        uint4 graw[IH];
+#pragma unroll
+        for (int i = 0; i < IH; ++i)
+            graw[i] = (ib + i < N) ? *reinterpret_cast<const uint4*>(dA + (((int64_t)b * N + ib + i) * N + j) * C + c0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) av[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < IH; ++i) {
+            float g[8], ui[8];
+            unpack8(graw[i], g);
+            asm volatile("" : "+v"(upk[i].x), "+v"(upk[i].y), "+v"(upk[i].z), "+v"(upk[i].w));   // keep the unpack inside the loop (no hoisting)
+            unpack8(upk[i], ui);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float p = ui[k] + v[k];
+                const float dz = (p * s[k] + h[k] > 0.f) ? g[k] : 0.f;
+                a_sc[k] += dz * (p - mu[k]); a_sh[k] += dz;
+                au[i][k] += dz * s[k]; av[k] += dz * s[k];
+            }
+        }
+        // both halves hold partial dV[b, j, c0 .. c0+7] sums over their rows i: pair them, half 0 adds channels 0..3, half 1 channels 4..7
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(av[k]), __float_as_uint(av[k + 4]), false, false);
+            // lo lane: r2[0] = own av[k], r2[1] = hi's av[k];  hi lane: r2[0] = lo's av[k+4], r2[1] = own av[k+4]
+            atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k + 4 * half, __uint_as_float(r2[0]) + __uint_as_float(r2[1]));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IH; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[grp][half * IH + i][c0 + k] = au[i][k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {            // the halves hold the same channels for different rows: fold, half 0 writes
+        a_sc[k] += __shfl_xor(a_sc[k], 32, 64); a_sh[k] += __shfl_xor(a_sh[k], 32, 64);
+        if (half == 0) { red[grp][IC][c0 + k] = a_sc[k]; red[grp][IC + 1][c0 + k] = a_sh[k]; }
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    for (int i = 0; i < IC; ++i)
+        if (i0 + i < N) dU[((int64_t)b * N + i0 + i) * C + c] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
+    atomicAdd(acc + c, (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]));
+    atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
+}
+
+// (r02, measured and dropped: accumulating dU in LDS with ds_add_f32 over IC = 48 rows per block to cut the dV atomics to N / 48 per
+// element ran 4x slower, 3.0 ms - LDS fp32 atomics retire far below the LDS load / store rate.  The register form stays bound by its
+// ~50 M global fp32 atomics per launch (~87 G atomics/s on this chip); per-block dV slabs reduced by pair_stats_bwd are the next step.)
+
 // BN1 statistics were closed-form in U, V: dU[b,i] += N*a + b1*(N*U[b,i] + sum_j V[b,j]), dV symmetric
 template <typename T>
 __global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restrict__ V, const float* __restrict__ a, const float* __restrict__ bco,
@@ -278,6 +361,15 @@ extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const f
     if (ic_env < 0) { const char* e = getenv("P3_PAIR_IC"); ic_env = e ? atoi(e) : 0; }
     const int ic = ic_env > 0 ? ic_env : 16;     // rows i per block: dV gets N/IC atomic adds per element (same-box sweep r01: 4 -> 60.2 ms, 8 -> 58.0, 12 -> 57.7, 16 -> 57.6)
 #define PB(T, IC) hipLaunchKernelGGL((pair_bwd_kernel<T, IC>), dim3((N + IC - 1) / IC, B), dim3(256), 0, s, (const T*)dA, (const T*)U, (const T*)V, scale, shift, mean, dU, dV, acc, N, C)
+    static int wide = -1;                             // P3_PAIR_WIDE=0: the 8-byte form (A/B switch)
+    if (wide < 0) { const char* e = getenv("P3_PAIR_WIDE"); wide = e ? atoi(e) : 1; }   // 0: 8-byte form
+    if (dtype == P3_BF16 && wide && ic_env <= 0) {
+        // IC = 12 rows i per block (6 per half-wave): the register budget of two waves per SIMD without spills (IC = 16 spills 270 B / lane)
+        hipLaunchKernelGGL((pair_bwd_kernel16<12>), dim3((N + 11) / 12, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
+                           mean, dU, dV, acc, N, C);
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     if (dtype == P3_BF16) { if (ic == 16) PB(bf16_t, 16); else if (ic == 12) PB(bf16_t, 12); else if (ic == 4) PB(bf16_t, 4); else PB(bf16_t, 8); }
     else PB(float, 8);
 #undef PB
