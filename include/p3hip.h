@@ -324,6 +324,11 @@ int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a, const flo
 /* pair grid: dA [B*N*N, C] -> dU (written), dV (+=, zero-filled by the caller) [B*N, C] fp32, acc = [dscale(C) | dshift(C)] */
 int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
                 int B, int N, int C, int dtype, void* stream);
+/* same with a scratch of p3_pair_bwd_workspace_bytes(B, N, C) bytes: the per-block dV partial rows are stored there and summed by a second
+ * kernel instead of being added with global fp32 atomics (bf16 path; other dtypes ignore the workspace) */
+int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C);
+int p3_pair_bwd_ws(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV,
+                   float* acc, int B, int N, int C, int dtype, void* workspace, void* stream);
 int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
                       void* stream);
 

@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
 template <int IC>
 __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ U, const bf16_t* __restrict__ V,
                                                          const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
-                                                         float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C) {
+                                                         float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C,
+                                                         float* __restrict__ slab) {
+    // slab != NULL: the block's dV partial rows go to slab[b][blockIdx.x][N][C] with plain 16-byte stores and pair_dv_reduce_kernel sums
+    // the N / IC slabs afterwards - no global atomics at all (r02: ~50 M fp32 atomics per launch bound this kernel at ~87 G atomics/s).
     constexpr int IH = IC / 2;
     __shared__ float red[4][IC + 2][256];     // C == 256; rows IC, IC+1: (dscale, dshift) partials
     const int b = blockIdx.y, i0 = blockIdx.x * IC;
@@ -248,11 +251,18 @@ __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __rest
             }
         }
         // both halves hold partial dV[b, j, c0 .. c0+7] sums over their rows i: pair them, half 0 adds channels 0..3, half 1 channels 4..7
+        float pr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(av[k]), __float_as_uint(av[k + 4]), false, false);
             // lo lane: r2[0] = own av[k], r2[1] = hi's av[k];  hi lane: r2[0] = lo's av[k+4], r2[1] = own av[k+4]
-            atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k + 4 * half, __uint_as_float(r2[0]) + __uint_as_float(r2[1]));
+            pr[k] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+        }
+        if (slab) {
+            *reinterpret_cast<float4*>(slab + (((int64_t)b * gridDim.x + blockIdx.x) * N + j) * C + c0 + 4 * half) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k + 4 * half, pr[k]);
         }
     }
 #pragma unroll
@@ -270,6 +280,17 @@ __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __rest
         if (i0 + i < N) dU[((int64_t)b * N + i0 + i) * C + c] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
     atomicAdd(acc + c, (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]));
     atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
+}
+
+// dV[b, j, :] += sum over the nblk slabs of a tile (16-byte accesses, one thread per 4 channels)
+__global__ void pair_dv_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dV, int nblk, int64_t per_tile /* N*C/4 */, int64_t total /* B*N*C/4 */) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_tile, r = i - b * per_tile;
+        const float4* src = reinterpret_cast<const float4*>(slab) + b * nblk * per_tile + r;
+        float4 a = reinterpret_cast<float4*>(dV)[i];
+        for (int k = 0; k < nblk; ++k) { const float4 v = src[(int64_t)k * per_tile]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        reinterpret_cast<float4*>(dV)[i] = a;
+    }
 }
 
 // (r02, measured and dropped: accumulating dU in LDS with ds_add_f32 over IC = 48 rows per block to cut the dV atomics to N / 48 per
@@ -352,8 +373,23 @@ extern "C" int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a
     return P3_OK;
 }
 
+extern "C" int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C) { return (int64_t)B * ((N + 11) / 12) * N * C * 4; }
+
+static int pair_bwd_impl(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
+                         int B, int N, int C, int dtype, float* slab, void* stream);
+
 extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
                            int B, int N, int C, int dtype, void* stream) {
+    return pair_bwd_impl(dA, U, V, scale, shift, mean, dU, dV, acc, B, N, C, dtype, nullptr, stream);
+}
+
+extern "C" int p3_pair_bwd_ws(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
+                              int B, int N, int C, int dtype, void* workspace, void* stream) {
+    return pair_bwd_impl(dA, U, V, scale, shift, mean, dU, dV, acc, B, N, C, dtype, (float*)workspace, stream);
+}
+
+static int pair_bwd_impl(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
+                         int B, int N, int C, int dtype, float* slab, void* stream) {
     P3_CHECK(dA && U && V && scale && shift && mean && dU && dV && acc && B > 0, P3_EINVAL, "p3_pair_bwd: bad arguments");
     P3_CHECK(C == 256, P3_EUNSUP, "p3_pair_bwd: ScoreNet conv1 width must be 256 (model_pix2poly.py:74)");
     hipStream_t s = (hipStream_t)stream;
@@ -365,9 +401,15 @@ extern "C" int p3_pair_bwd(const void* dA, const void* U, const void* V, const f
     if (wide < 0) { const char* e = getenv("P3_PAIR_WIDE"); wide = e ? atoi(e) : 1; }   // 0: 8-byte form
     if (dtype == P3_BF16 && wide && ic_env <= 0) {
         // IC = 12 rows i per block (6 per half-wave): the register budget of two waves per SIMD without spills (IC = 16 spills 270 B / lane)
-        hipLaunchKernelGGL((pair_bwd_kernel16<12>), dim3((N + 11) / 12, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
-                           mean, dU, dV, acc, N, C);
+        const int nblk = (N + 11) / 12;
+        hipLaunchKernelGGL((pair_bwd_kernel16<12>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
+                           mean, dU, dV, acc, N, C, slab);
         P3_LAUNCH_CHECK();
+        if (slab) {
+            const int64_t per = (int64_t)N * C / 4, total = (int64_t)B * per;
+            hipLaunchKernelGGL(pair_dv_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, slab, dV, nblk, per, total);
+            P3_LAUNCH_CHECK();
+        }
         return P3_OK;
     }
     if (dtype == P3_BF16) { if (ic == 16) PB(bf16_t, 16); else if (ic == 12) PB(bf16_t, 12); else if (ic == 4) PB(bf16_t, 4); else PB(bf16_t, 8); }

@@ -726,7 +726,15 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
     C = U.shape[1]
     dU = torch.empty((B * N, C), dtype=torch.float32, device=U.device)
     dV = torch.zeros((B * N, C), dtype=torch.float32, device=U.device)
-    check(lib().p3_pair_bwd(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),
+    L = lib()
+    import os
+    if dt(U) == BF16 and os.environ.get("P3_PAIR_SLAB", "1") != "0":       # dV partials through a scratch slab instead of global atomics
+        L.p3_pair_bwd_workspace_bytes.restype = c_int64
+        ws = workspace(L.p3_pair_bwd_workspace_bytes(c_int(B), c_int(N), c_int(C)), U.device, "pair_bwd")
+        check(L.p3_pair_bwd_ws(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),
+                               c_int(dt(U)), ptr(ws), stream()), "p3_pair_bwd_ws")
+    else:
+        check(L.p3_pair_bwd(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),
                             c_int(dt(U)), stream()), "p3_pair_bwd")
     return dU, dV
 

@@ -18,8 +18,7 @@ def _criterion(norms=None):
     from pixelspointspolygons_amd.ffl_losses import build_combined_loss
     crit = build_combined_loss(make_config("early_fusion_vit_cnn", model="ffl", device=DEV))
     if norms is not None:
-        crit._norm_host = [float(v) for v in norms]
-        crit.norm.data.copy_(torch.tensor(crit._norm_host))
+        crit.load_state_dict({f"loss_funcs.{i}.norm": torch.tensor([float(v)]) for i, v in enumerate(norms)})   # the reference's key layout
     return crit
 
 

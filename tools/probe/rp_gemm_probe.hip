@@ -16,6 +16,9 @@
 //     (32 rows x 32 B per instruction = 4x the L1 transactions of a coalesced store: the epilogue must be staged through LDS);
 //   * counting epilogue stores in s_waitcnt vmcnt(N) RACES (VAR & 8): loads and stores retire out of order with respect to each other
 //     on gfx950; only loads issued after the awaited DMA may be counted, stores have to be issued before the next DMA instead;
+//   * a later form with every fix the list above asks for (64-column panels x 128-k slices, LDS-staged 128-B-per-row stores issued one step
+//     late, bias from LDS, DMA pieces spread over the step) reached 68 us with compiler-scheduled MFMAs - parity with the production
+//     kernel, not a win: the 2-workgroups-per-CU row-panel structure itself is bounded near 45-50 us by barrier / first-read bubbles;
 //   * hipcc's own global_load_lds builtin makes it wait vmcnt(0) before the next ds_read (LDS-DMA alias tracking): the DMA has to be
 //     inline asm; fragments carried ACROSS asm statements while their ds_read is in flight are moved / spilled by the compiler.
 #include <hip/hip_runtime.h>
