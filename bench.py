@@ -139,6 +139,7 @@ class Stepper:
     def _fwd_bwd(self):
         s = self.static
         dev = next(iter(s.values())).device
+        self.opt.zero_grad()
         self.ops.advance_rng(dev)               # new decoder dropout masks every step (device counter: replays with the graph)
         out = self._forward()
         if self.criterion is not None:
@@ -146,7 +147,6 @@ class Stepper:
                                   normalize=True, epoch=10.0)[0]
         else:
             loss = self.loss_fn(out[0], out[1], s["y"][:, 1:], s["y_perm"], 1.0, 10.0, 226)[0]
-        self.opt.zero_grad()
         loss.backward()
         return loss.detach()
 

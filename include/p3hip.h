@@ -119,6 +119,11 @@ int p3_layernorm(const void* x, const float* gamma, const float* beta, void* y, 
 int p3_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                          void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                          void* stream);
+/* dx_lo (optional, bf16 [rows, cols], needs cols % 128 == 0 and an fp32 dx): a bf16 copy of dx written in the same pass - what the
+ * GEMMs of the sublayer below read, instead of a separate cast pass over the fp32 residual-gradient stream */
+int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                        void* dx, void* dx_lo, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
+                        void* stream);
 int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                      void* stream);

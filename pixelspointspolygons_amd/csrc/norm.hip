@@ -150,6 +150,87 @@ __global__ __launch_bounds__(256, (NV == 4 ? 2 : 4)) void ln_bwd_kernel(const TD
     }
 }
 
+// Half-wave-per-row form for cols % 128 == 0 (the path's 256 / 384 / 768): 32 lanes x CPL float4 chunks cover a row exactly (the one-wave-
+// per-row form leaves a quarter of the lanes idle at 384 columns and keeps ONE row per wave in flight: 3.6 TB/s, 91 % of the wave time
+// waiting, r01 SQ counters), so a wave carries two rows at once, gamma stays in registers for the whole block, and an optional bf16
+// copy of dx (`dx_lo`) is written from the same registers - the residual-gradient stream is fp32, but the GEMMs of the sublayer
+// below consume it in bf16: this saves their separate cast pass (a 77 MB read + a launch per sublayer).
+template <typename TDY, typename TX, typename TDX, int CPL>
+__global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const TDX* __restrict__ dres, TDX* __restrict__ dx, bf16_t* __restrict__ dx_lo,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block) {
+    constexpr int cols = CPL * 128;
+    __shared__ float sg[8][cols], sb[8][cols];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    float g[CPL][4], ag[CPL][4], ab[CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        load4<float>(gamma + (l31 + 32 * c) * 4, g[c]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+    }
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    int64_t rend = rbeg + rows_per_block;
+    if (rend > rows) rend = rows;
+    for (int64_t r0 = rbeg + w * 2; r0 < rend; r0 += 8) {
+        const int64_t row = r0 + half;
+        const bool ok = row < rend;
+        const int64_t rr = ok ? row : rend - 1;
+        const float mu = mean[rr], rs = rstd[rr];
+        float xh[CPL][4], d[CPL][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int64_t o = rr * cols + (l31 + 32 * c) * 4;
+            float xv[4];
+            load4<TX>(x + o, xv);
+            load4<TDY>(dy + o, d[c]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[c][i] = (xv[i] - mu) * rs;
+                const float gd = g[c][i] * d[c][i];
+                s1 += gd; s2 += gd * xh[c][i];
+                if (ok) { ag[c][i] += d[c][i] * xh[c][i]; ab[c][i] += d[c][i]; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }   // within the 32-lane half
+        s1 *= 1.f / (float)cols; s2 *= 1.f / (float)cols;
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int64_t o = row * cols + (l31 + 32 * c) * 4;
+                float ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = rs * (g[c][i] * d[c][i] - s1 - xh[c][i] * s2);
+                if (dres) {
+                    float rv[4];
+                    load4<TDX>(dres + o, rv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ov[i] += rv[i];
+                }
+                store4<TDX>(dx + o, ov);
+                if (dx_lo) store4<bf16_t>(dx_lo + o, ov);
+            }
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sg[w * 2 + half][(l31 + 32 * c) * 4 + i] = ag[c][i]; sb[w * 2 + half][(l31 + 32 * c) * 4 + i] = ab[c][i]; }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < cols; cidx += 256) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a += sg[q][cidx]; b += sb[q][cidx]; }
+            atomicAdd(dgamma + cidx, a);
+            atomicAdd(dbeta + cidx, b);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int p3_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int cols, int ldx,
@@ -180,7 +261,14 @@ extern "C" int p3_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                                     void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
                                     int dtype_dx, void* stream) {
+    return p3_layernorm_bwd_lo(dy, x, gamma, mean, rstd, dres, dx, nullptr, dgamma, dbeta, rows, cols, dtype_dy, dtype_x, dtype_dx, stream);
+}
+
+extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                   void* dx, void* dx_lo, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
+                                   int dtype_dx, void* stream) {
     P3_CHECK(dy && x && gamma && mean && rstd && dx, P3_EINVAL, "p3_layernorm_bwd: null pointer");
+    P3_CHECK(!dx_lo || (cols % 128 == 0 && dtype_dx == P3_F32), P3_EUNSUP, "p3_layernorm_bwd: the bf16 copy needs cols % 128 == 0 and an fp32 dx");
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
     if (rows <= 0) return P3_OK;
@@ -191,6 +279,23 @@ extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* 
     const int rpb = rpb_env > 0 ? rpb_env : 48;
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)
+    if (half_env < 0) { const char* e = getenv("P3_LN_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
+    if ((half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768)) {
+#define LNH_C(TDY, TX, TDX, CPL) \
+    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb)
+#define LNH(TDY, TX, TDX) \
+    do { if (cols == 256) LNH_C(TDY, TX, TDX, 2); else if (cols == 384) LNH_C(TDY, TX, TDX, 3); else LNH_C(TDY, TX, TDX, 6); } while (0)
+        if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNH(float, float, float);
+        else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNH(bf16_t, float, float);
+        else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNH(bf16_t, bf16_t, bf16_t);
+        else if (dtype_dy == P3_F32 && dtype_x == P3_BF16 && dtype_dx == P3_F32) LNH(float, bf16_t, float);
+        else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
+#undef LNH
+#undef LNH_C
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
 #define LNB_NV(TDY, TX, TDX, NV) \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NV>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
 #define LNB(TDY, TX, TDX) \

@@ -188,8 +188,9 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
     return (out, mean, rstd) if save_stats else out
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None):
-    """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False):
+    """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass.
+    want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo)."""
     cols = x.shape[-1]
     dy2, x2 = dy.reshape(-1, cols).contiguous(), x.reshape(-1, cols).contiguous()
     rows = x2.shape[0]
@@ -198,10 +199,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=No
         dres = dres.contiguous()
         if dres.dtype != dx.dtype:
             raise P3Error("layernorm_bwd: dres dtype must equal the dx dtype")
-    check(lib().p3_layernorm_bwd_res(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                     c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
+    lo = None
+    if want_lo and dx.dtype == torch.float32 and cols % 128 == 0:
+        lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().p3_layernorm_bwd_lo(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo), ptr(dgamma), ptr(dbeta),
+                                    c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
           "p3_layernorm_bwd")
-    return dx
+    return (dx, lo) if want_lo else dx
 
 
 class AttnDesc(Structure):

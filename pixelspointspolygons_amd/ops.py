@@ -206,6 +206,37 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
+# ---- bf16 twins of fp32 residual gradients ---------------------------------------------------------------------------------------
+# The ViT residual-gradient stream is fp32; the GEMMs of a sublayer's backward consume it in bf16.  ln_bwd writes that bf16 copy from
+# the registers it already holds (hip.layernorm_bwd(want_lo=True)) and leaves it here for the consumer, which would otherwise run a cast
+# pass over the 77 MB tensor.  An entry keeps a STRONG reference to the fp32 tensor, so its memory cannot be handed to another tensor
+# while the entry exists: a hit on (data_ptr, numel) is the same bytes.  Consumed entries are popped; the rest is dropped at the next
+# optimizer.zero_grad() / apply() (or when the table grows past a few dozen entries in optimizer-less use).
+_twins = {}
+
+
+def _register_twin(t, lo):
+    if lo is not None:
+        if len(_twins) > 48:
+            _twins.clear()
+        _twins[t.data_ptr()] = (t, lo)
+
+
+def clear_twins():
+    _twins.clear()
+
+
+def _to_cd(t2, cd):
+    """gradient `t2` in the compute dtype: the producer's bf16 twin when there is one, a cast pass otherwise"""
+    if t2.dtype == cd:
+        return t2
+    if cd == torch.bfloat16 and t2.dtype == torch.float32:
+        ent = _twins.pop(t2.data_ptr(), None)
+        if ent is not None and ent[1].numel() == t2.numel() and t2.is_contiguous():
+            return ent[1].view(t2.shape)
+    return hip.cast(t2, cd)
+
+
 # ---------------------------------------------------------------------------------------------- Linear
 class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x [.., K] compute dtype; W [N, K] fp32 parameter."""
@@ -246,7 +277,7 @@ class _Linear(torch.autograd.Function):
             if drop is not None:        # same (seed, site, row*N + col) mask as the forward epilogue, regenerated while casting
                 dpre = hip.dropout_apply(dy2, cd, drop)
             else:
-                dpre = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
+                dpre = _to_cd(dy2, cd)
         else:                           # ReLU then dropout: the saved output is already masked, only the 1/(1-p) factor remains
             dpre = hip.act_bwd(dy2, saved, ctx.act, cd, scale=1.0 / (1.0 - drop[2]) if drop is not None else 1.0)
         dx = dw = db = None
@@ -354,7 +385,7 @@ class _Mlp(torch.autograd.Function):
         if drop2 is not None:
             dpre2 = hip.dropout_apply(dy2, cd, drop2)
         else:
-            dpre2 = dy2 if dy2.dtype == cd else hip.cast(dy2, cd)
+            dpre2 = _to_cd(dy2, cd)
         dw2, db2 = _weight_grads(dpre2, h, w2, ctx.b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                       # [hidden, out]
         scale = 1.0 / (1.0 - drop1[2]) if drop1 is not None else 1.0
@@ -389,13 +420,20 @@ class _LayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
+        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] % 128 == 0   # fp32 stream under bf16 GEMMs
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad)
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo)
             _grad_ready(gamma, beta)
+            if lo:
+                _register_twin(*dx)
+                dx = dx[0]
             return dx, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
-        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db)
+        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, want_lo=lo)
+        if lo:
+            _register_twin(*dx)
+            dx = dx[0]
         return dx, dg, db, None, None
 
 
@@ -423,13 +461,20 @@ class _LayerNormFork(torch.autograd.Function):
         beta = ctx.beta_param
         if dres is not None and dres.dtype != x.dtype:
             dres = dres.to(x.dtype)
+        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] % 128 == 0
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres)
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres, want_lo=lo)
             _grad_ready(gamma, beta)
+            if lo:
+                _register_twin(*dx)
+                dx = dx[0]
             return dx, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
-        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, dres=dres)
+        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, dres=dres, want_lo=lo)
+        if lo:
+            _register_twin(*dx)
+            dx = dx[0]
         return dx, dg, db, None, None
 
 

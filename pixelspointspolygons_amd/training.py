@@ -169,6 +169,7 @@ class FlatAdamW:
 
     def zero_grad(self):
         self.grad.zero_()
+        ops.clear_twins()
 
     def prepare_step(self):
         """Host side of a step, outside any captured graph.  Device schedule (default): bookkeeping only.  Host-fed schedule: writes
@@ -202,6 +203,7 @@ class FlatAdamW:
             hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
         ops.refresh_derived(self.params)
         ops.invalidate_derived()
+        ops.clear_twins()
 
     def step(self, grad_scale=1.0):
         self.prepare_step()
@@ -243,10 +245,11 @@ class GradBucketReducer:
         self.ref, self.trigger = None, None       # recorded report sequence, {position -> buckets complete after it}
         self.seq, self.pos, self.following = [], 0, True
         self.early_launches = 0                   # buckets reduced before finish() over the life of the reducer (tests, DESIGN)
+        self._hooks = []
         if self.world > 1 and overlap:
             for i, p in enumerate(opt.params):
-                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._report(i))
-            ops.GRAD_READY[0] = self._report_param
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._report(i)))
+            ops.GRAD_READY[0] = self._report_param      # one reducer per process: the operators report to the most recent one
 
     def _report_param(self, p):
         i = self._index.get(id(p))
@@ -295,6 +298,10 @@ class GradBucketReducer:
         return 1.0 / self.world
 
     def close(self):
+        """detach from the parameters and from the operators' report channel"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         if ops.GRAD_READY[0] == self._report_param:
             ops.GRAD_READY[0] = None
 
@@ -311,10 +318,10 @@ def train_step(model, opt: FlatAdamW, batch, reducer: GradBucketReducer = None, 
     """One reference train step (trainer_pix2poly.py:305-329) -> (loss, ce, bce) device scalars (no host sync)."""
     y = batch["y"]
     pad = model.cfg.experiment.model.tokenizer.pad_idx if hasattr(model, "cfg") else 226
+    opt.zero_grad()
     ops.advance_rng(y.device)        # fresh dropout masks (decoder) for this step
     logits, perm = model(batch.get("image"), batch.get("lidar"), y[:, :-1])
     loss, ce, bce = pix2poly_loss(logits, perm, y[:, 1:], batch["y_perm"], w_vertex, w_perm, pad)
-    opt.zero_grad()
     loss.backward()
     scale = reducer.finish() if reducer is not None else 1.0
     opt.step(scale)

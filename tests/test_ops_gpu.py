@@ -118,6 +118,47 @@ def test_layernorm_fwd_bwd(cols, eps):
     assert rel_err(dg.cpu(), g.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
     o16 = h.layernorm(x.detach().to(DEV), g.detach().to(DEV), b.detach().to(DEV), eps, out_dtype=torch.bfloat16)
     assert rel_err(o16.float().cpu(), y.detach()) < 5e-3
+    # residual-gradient form used by the ViT blocks: bf16 dy, fp32 residual gradient added in the same pass, bf16 twin of dx written too;
+    # the half-wave-per-row kernel (default) against the one-wave-per-row kernel (P3_LN_HALF=0 is read once per process: compare with torch)
+    dres = _rand(777, cols, seed=5)
+    dy16 = dy.bfloat16()
+    x2 = x.detach().clone().requires_grad_(True)
+    F.layer_norm(x2, (cols,), g.detach(), b.detach(), eps).backward(dy16.float())
+    dg.zero_(); db.zero_()
+    dx2, lo = h.layernorm_bwd(dy16.to(DEV), x.detach().to(DEV), g.detach().to(DEV), mean, rstd, dgamma=dg, dbeta=db, dres=dres.to(DEV), want_lo=True)
+    assert rel_err(dx2.cpu(), x2.grad + dres) < 1e-5
+    assert lo.dtype == torch.bfloat16 and torch.equal(lo, dx2.bfloat16())
+
+
+def test_residual_gradient_twin_replaces_the_cast_pass():
+    """ViT-style chain in bf16 mode: the fp32 residual gradient that ln_bwd produces reaches the next Linear's backward together with its
+    bf16 twin (no cast kernel), and the gradients equal the path that casts."""
+    from pixelspointspolygons_amd import ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(384, 384).to(DEV)
+    norm = torch.nn.LayerNorm(384, eps=1e-6).to(DEV)
+    x0 = torch.randn(4, 50, 384, device=DEV)
+
+    def run(use_twin):
+        ops.clear_twins()
+        for p_ in list(lin.parameters()) + list(norm.parameters()):
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = ops.linear(x.bfloat16(), lin.weight, lin.bias, residual=x, out_dtype=torch.float32, cd=torch.bfloat16)     # fp32 stream
+        r, hn = ops.layernorm_fork(y, norm.weight, norm.bias, norm.eps, out_dtype=torch.bfloat16)
+        z = (r * 0.5).sum() + (hn.float() ** 2).sum()
+        if not use_twin:
+            reg, ops._register_twin = ops._register_twin, (lambda t, lo: None)
+        try:
+            z.backward()
+        finally:
+            if not use_twin:
+                ops._register_twin = reg
+        return x.grad.clone(), lin.weight.grad.clone(), len(ops._twins)
+    gx1, gw1, left1 = run(True)
+    gx0, gw0, _ = run(False)
+    assert left1 == 0                                   # the twin was consumed by the Linear's backward
+    assert torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
 
 
 # ------------------------------------------------------------------ attention
