@@ -8,6 +8,8 @@
 // the gradient being accumulated).  Rows >= M contribute zeros.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "p3_common.h"
 
 namespace {
@@ -69,11 +71,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     const int rt = tid / TPR;                       // bf16: row-pair index 0..15 ; f32: row 0..7
     constexpr int NLOAD = BF ? 4 : 2;               // 16-byte loads per operand per step
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[NLOAD], rb[NLOAD];
+    // two staging register sets: the loads of step t+2 are issued while step t is multiplied (a global load gets two MFMA phases to land;
+    // r02 SQ counters: 46 % of the wave time parked on waits with the one-deep pipeline)
+    u32x4 rsa[2][NLOAD], rsb[2][NLOAD];
     const int coln = tn * TN + cv, colk = tk * TK + cv;
     const bool okn = coln < g.N, okk = colk < g.K;  // N, K are multiples of VEC (checked on the host)
 
-    auto load_step = [&](int m0) __attribute__((always_inline)) {
+    auto load_step = [&](auto SET, int m0) __attribute__((always_inline)) {
+        constexpr int ss = decltype(SET)::value;
+        u32x4 (&ra)[NLOAD] = rsa[ss];
+        u32x4 (&rb)[NLOAD] = rsb[ss];
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             int row;
@@ -129,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) csum[q] = 0.f;
     const bool do_cs = g.colsum != nullptr && tk == 0;
-    auto store_step = [&](int buf) __attribute__((always_inline)) {
+    auto store_step = [&](auto SET, int buf) __attribute__((always_inline)) {
+        constexpr int ss = decltype(SET)::value;
+        u32x4 (&ra)[NLOAD] = rsa[ss];
+        u32x4 (&rb)[NLOAD] = rsb[ss];
         if (do_cs) {
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
@@ -160,11 +170,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     };
 
     const int nsteps = (m_end - m_beg + BM - 1) / BM;
-    if (nsteps > 0) { load_step(m_beg); store_step(0); }
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if (nsteps > 0) { load_step(S0{}, m_beg); if (nsteps > 1) load_step(S1{}, m_beg + BM); store_step(S0{}, 0); }
     __syncthreads();
-    for (int t = 0; t < nsteps; ++t) {
+    auto body = [&](auto SET, int t) __attribute__((always_inline)) {
+        // SET = register set that held step t (free now: step t is in LDS); step t+1 sits in the other set
+        constexpr int s0 = decltype(SET)::value;
         const int cur = t & 1;
-        if (t + 1 < nsteps) load_step(m_beg + (t + 1) * BM);
+        if (t + 2 < nsteps) load_step(std::integral_constant<int, s0>{}, m_beg + (t + 2) * BM);
         const T* as = lds + cur * ELEMS;
         const T* bs = lds + (2 + cur) * ELEMS;
         if constexpr (BF) {
@@ -227,8 +241,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (t + 1 < nsteps) store_step(cur ^ 1);
+        if (t + 1 < nsteps) store_step(std::integral_constant<int, s0 ^ 1>{}, cur ^ 1);
         __syncthreads();
+    };
+    for (int t = 0; t < nsteps; t += 2) {
+        body(S0{}, t);
+        if (t + 1 < nsteps) body(S1{}, t + 1);
     }
     if (do_cs) {   // fold the per-thread column partials (threads with equal cv) through the idle LDS, one atomic per column
         float* red = reinterpret_cast<float*>(lds);
