@@ -516,12 +516,12 @@ def main():
             "metric": "training tiles/sec (224px img + 3k-pt lidar)", "value": round(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{'ffl' if args.workload == 'ffl_fusion' else 'pix2poly'}_{args.workload}_bs{args.batch}x{world}", "tiles_per_gpu": args.batch,
+            "config": {"workload": (f"ffl_early_fusion_vit_cnn_bs{args.batch}x{world}" if args.workload == "ffl_fusion" else f"pix2poly_{args.workload}_bs{args.batch}x{world}"), "tiles_per_gpu": args.batch,
                        "points_per_tile": args.points, "hip_graph": graph_used, "sync_bn": sync_bn,
                        "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
                        "step": "fwd+FFL criterion+bwd+AdamW" if args.workload == "ffl_fusion" else "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
-            "fwd_ms_per_tile": round(fwd_ms / args.batch, 4), "fwd_ms_per_batch": round(fwd_ms, 3),
-            "fwd_eval_ms_per_tile": round(fwd_eval_ms / args.batch, 4),
+            "fwd_ms_per_tile": round(fwd_ms / args.batch, 4) if fwd_ms == fwd_ms else None, "fwd_ms_per_batch": round(fwd_ms, 3) if fwd_ms == fwd_ms else None,
+            "fwd_eval_ms_per_tile": round(fwd_eval_ms / args.batch, 4) if fwd_eval_ms == fwd_eval_ms else None,
             "gflop_fwd_per_tile_executed": gf, "gflop_fwd_per_tile_dense_reference": GFLOP_FWD_DENSE[args.workload],
             "fwd_mfma_frac": round(gf * args.batch / (fwd_ms * 1e-3) / 1e3 / peak_tf, 4) if fwd_ms == fwd_ms else None,
             "step_mfma_frac": round(3 * gf * args.batch / step_s / 1e3 / peak_tf, 4),

@@ -153,9 +153,8 @@ class MultiLoss(torch.nn.Module):
         w = self.current_weights(epoch)
         coef = [wi / ni for wi, ni in zip(w, norms)]
         total, losses = _FFLLossFn.apply(seg, cf, gt, angle, coef, self.bce_coef, self.dice_coef, self.seg_loss_weights(gt_batch))
-        inv = torch.tensor([1.0 / n for n in norms], dtype=torch.float32, device=losses.device)
-        normed = losses[:5] * inv
-        individual = {name: normed[i] for i, name in enumerate(LOSS_NAMES)}
+        # host scalars times device scalars: no host->device copy, so the criterion can sit inside a captured hipGraph
+        individual = {name: losses[i] * (1.0 / norms[i]) for i, name in enumerate(LOSS_NAMES)}
         return total, individual, {name: {} for name in LOSS_NAMES}
 
     def __repr__(self):
