@@ -61,6 +61,45 @@ def test_gemm_bf16(M, N, K):
     assert out16.dtype == torch.bfloat16 and rel_err(out16.float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 384, 384), (50240 // 8 + 37, 1152, 384), (4200, 227, 256), (5000, 384, 1536), (4100, 256, 2048)])
+@pytest.mark.parametrize("epi", ["plain", "gelu_aux", "residual_f32", "dropout"])
+def test_gemm_bf16_tall_tiles(M, N, K, epi):
+    """Tall problems (the path's M = 24 640 / 50 240 regime) with every epilogue the path uses: ragged M (last tile partly / mostly empty),
+    N not a multiple of the tile (227), both K-slice depths.  (Written for the 256-row, 8-wave tile variant of round 2, which passed it
+    but lost 2 ms in the step and is not in the tree; kept as coverage of the 128-row kernel at these sizes.)"""
+    h = _h()
+    a = _rand(M, K, seed=1).bfloat16()
+    w = _rand(N, K, seed=2, scale=0.1).bfloat16()
+    b = _rand(N, seed=3)
+    pre = a.float() @ w.float().t() + b
+    A, W_, Bv = a.to(DEV), w.to(DEV), b.to(DEV)
+    if epi == "plain":
+        out = h.gemm(A, W_, bias=Bv, out_dtype=torch.float32).cpu()
+        assert rel_err(out, pre) < 1e-5
+    elif epi == "gelu_aux":
+        if N % 8:
+            pytest.skip("aux rows need 16-byte alignment")
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        out = h.gemm(A, W_, bias=Bv, act=1, aux=aux, aux_grad=True).cpu()
+        assert rel_err(out.float(), F.gelu(pre)) < 6e-3
+        x = pre.clone().requires_grad_(True)
+        F.gelu(x).sum().backward()
+        assert rel_err(aux.float().cpu(), x.grad) < 6e-3
+    elif epi == "residual_f32":
+        r = _rand(M, N, seed=4)
+        out = h.gemm(A, W_, bias=Bv, residual=r.to(DEV), out_dtype=torch.float32).cpu()
+        assert rel_err(out, pre + r) < 1e-5
+    else:
+        seed = torch.full((1,), 1234567, dtype=torch.int64, device=DEV)
+        out = h.gemm(A, W_, bias=Bv, out_dtype=torch.float32, drop=(seed, 7, 0.25)).cpu()
+        keep = out != 0
+        assert 0.70 < float(keep.float().mean()) < 0.80
+        assert rel_err(out[keep], (pre / 0.75)[keep]) < 1e-5
+        # the mask is a function of (seed, site, row, column) only: equal to the elementwise kernel's
+        ref_mask = h.dropout_apply(torch.ones(M, N, device=DEV), torch.float32, (seed, 7, 0.25)).cpu() != 0
+        assert torch.equal(keep | (pre == 0), ref_mask | (pre == 0))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_conv3x3_implicit(dtype):
     h = _h()
