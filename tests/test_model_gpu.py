@@ -326,3 +326,34 @@ def test_lidar_only_model_accepts_all_three_lidar_input_forms():
         b, _ = m(None, (d["lidar_values"], d["lidar_offsets"]), y)
         c, _ = m(None, d["lidar_values"].view(2, 500, 3), y)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_bench_batch_is_batch_independent_and_matches_the_oracle(precision):
+    """BASELINE configs[2] at its FULL size (64 tiles, 3 k points each): in eval mode every tile's logits / permutation rows must not depend
+    on its neighbours in the batch - tile b of the batch of 64 == the same tile run alone, bit for bit (row-independent GEMM / LayerNorm
+    arithmetic, per-(tile, head) attention, per-tile pillar sort / Sinkhorn) - and two of the 64 tiles are checked against the oracle."""
+    sd = O.make_state_dict("fusion", seed=42)
+    m, cfg = _model("fusion", precision, sd, batch_size=64)
+    inp = O.make_inputs(64, seed=1234)
+    d = _to_dev(inp)
+    off = inp["lidar_offsets"]
+    with torch.no_grad():
+        logits, perm = m(d["image"], (d["lidar_values"], d["lidar_offsets"]), d["y"][:, :-1])
+        assert logits.shape == (64, 385, 227) and perm.shape == (64, 192, 192)
+        assert torch.isfinite(logits).all() and torch.isfinite(perm).all()
+        rows = perm.sum(-1)
+        assert float((rows - 1).abs().max()) < 1e-3                       # softmax rows of the Sinkhorn output
+        for b in (0, 17, 63):
+            vals = d["lidar_values"][off[b]:off[b + 1]].contiguous()
+            offs = torch.tensor([0, int(off[b + 1] - off[b])], device=DEV)
+            l1, p1 = m(d["image"][b:b + 1], (vals, offs), d["y"][b:b + 1, :-1])
+            assert torch.equal(l1[0], logits[b]) and torch.equal(p1[0], perm[b]), b
+        tol = TOL32 if precision == "fp32" else TOL16
+        for b in (17, 63):
+            lo, hi = int(off[b]), int(off[b + 1])
+            rl, rp = O.pix2poly_forward({k: v.clone() for k, v in sd.items()}, inp["y"][b:b + 1, :-1], inp["image"][b:b + 1],
+                                        (inp["lidar_values"][lo:hi], torch.tensor([0, hi - lo])))
+            assert rel_err(logits[b:b + 1].float().cpu(), rl) < tol and rel_err(perm[b:b + 1].float().cpu(), rp) < tol * 5
+            if precision == "fp32":
+                assert torch.equal(logits[b:b + 1].float().cpu().argmax(-1), rl.argmax(-1))
