@@ -227,7 +227,7 @@ class _Pool(torch.autograd.Function):
     def backward(ctx, dout):
         yshape, ydt, Dout, has_pos = ctx.meta
         dy = hip.pool_pos_bwd(dout.contiguous(), yshape, ydt)
-        dpos = dout.float().sum(0, keepdim=True) if has_pos else None
+        dpos = hip.batch_sum(dout.contiguous()).unsqueeze(0) if has_pos else None      # HIP column-sum kernel (was an ATen cast + sum)
         return dy, dpos, None, None
 
 
