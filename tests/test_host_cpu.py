@@ -136,8 +136,17 @@ def _ddp_worker(rank, world, port, out):
     frozen_ok = red.ref is None                                              # re-records on the next step
     sums = torch.tensor([1.0 + rank, 2.0 * (rank + 1)])
     w = sync_bn_sums(sums)
+    # SyncBatchNorm statistic exchange of the HIP BatchNorm sites: several buffers of one site travel as ONE packed collective
+    from pixelspointspolygons_amd import ops
+    ops.SYNC_BN[0] = True
+    c0 = ops.SYNC_CALLS[0]
+    t1, t2, t3 = torch.full((3,), 1.0 + rank), torch.arange(4.0).view(2, 2) * (rank + 1), torch.tensor([10.0 * (rank + 1)])
+    w2 = ops.sync_stats(t1, t2[:, :1], t3)                                   # incl. a non-contiguous view
+    packed_ok = (ops.SYNC_CALLS[0] - c0 == 1 and w2 == world and torch.equal(t1, torch.full((3,), 3.0)) and
+                 torch.equal(t2, torch.tensor([[0.0, 1.0], [6.0, 3.0]]) if rank == 0 else torch.tensor([[0.0, 2.0], [6.0, 6.0]])) and float(t3) == 30.0)
+    ops.SYNC_BN[0] = False
     if rank == 0:
-        torch.save({"grads": grads, "sums": sums, "w": w, "nb": len(opt.buckets), "frozen_ok": frozen_ok}, out)
+        torch.save({"grads": grads, "sums": sums, "w": w, "nb": len(opt.buckets), "frozen_ok": frozen_ok, "packed_ok": packed_ok}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,7 +157,7 @@ def test_bucketed_allreduce_and_syncbn_sums_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
-    assert r["nb"] >= 3 and r["w"] == 2 and r["frozen_ok"]
+    assert r["nb"] >= 3 and r["w"] == 2 and r["frozen_ok"] and r["packed_ok"]
     assert torch.allclose(r["sums"], torch.tensor([3.0, 6.0]))
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
