@@ -112,7 +112,11 @@ class Stepper:
             self.static["lidar_values"] = torch.zeros((cap, 3), dtype=torch.float32, device=next(iter(pool[0].values())).device)
         self.graph = None
         self.eager_done = 0
-        self.use_graph = use_graph
+        # No hipGraph capture in a process that issues collectives: the reducer's all-reduces are not capturable (graph_safe False), and
+        # ProcessGroupNCCL's watchdog thread polls its events while ANY stream captures -> hipErrorStreamCaptureUnsupported aborts
+        # the process (measured with a 1-rank RCCL group, tools/rccl_probe.py).  N > 1 steps and forward legs run as plain launches;
+        # at N = 1 graph and eager steps time the same (48.66 vs 48.70 ms, profiles/r02_graph_vs_eager.txt).
+        self.use_graph = use_graph and (not reducer.active or reducer.graph_safe)
         self.out = None
 
     def load(self, b):
@@ -153,8 +157,7 @@ class Stepper:
     def step(self, b):
         self.load(b)
         self.opt.prepare_step()
-        capturable = self.reducer.world == 1 or self.reducer.graph_safe
-        if self.use_graph and capturable and self.eager_done >= 2:
+        if self.use_graph and self.eager_done >= 2:
             if self.graph is None:
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
@@ -192,6 +195,7 @@ class Stepper:
 
 def timed_steps(st, pool, steps, warmup, world, dev):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    world = 2 if (dist.is_available() and dist.is_initialized()) else 1     # a process group (also the forced 1-rank one) => collective bracket
     for i in range(warmup):
         st.step(pool[i % len(pool)])
     torch.cuda.synchronize()
@@ -431,25 +435,33 @@ def main():
     backend = os.environ.get("P3_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    if world > 1:
+    forced = world == 1 and os.environ.get("P3_FORCE_COLLECTIVES") == "1"   # 1-rank RCCL smoke run (ops.SINGLE_RANK_COLLECTIVES)
+    if forced:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29617"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if world > 1 or forced:
         if backend == "nccl":
             dist.init_process_group("nccl", init_method="env://", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend, init_method="env://")
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)                             # communicator set-up (and RCCL's banner) happen here, before anything is timed
+        torch.cuda.synchronize()
+        _flush_c_stdio()
     from pixelspointspolygons_amd import synthetic as S        # synthetic-input generator (oracle/ is imported by the cpu_baseline leg only)
     from pixelspointspolygons_amd import hip, ops
 
     kind = KIND[args.workload]
     # N > 1 = the reference's DDP setup (model_pix2poly.py:324-328, model_ffl.py:161-163): SyncBatchNorm in every BatchNorm site (statistics
     # packed into one buffer per module group) + gradient buckets all-reduced on a side stream while backward continues
-    sync_bn = world > 1 and bool(args.sync_bn)
+    sync_bn = (world > 1 or forced) and bool(args.sync_bn)
     ops.SYNC_BN[0] = sync_bn
     cfg, model, opt, reducer, pool, st = build(args, dev, local, args.precision, S, rank, world, sync_bn)
     dt, loss_val = timed_steps(st, pool, args.steps, max(args.warmup, 3 if st.use_graph else 0), world, dev)   # 2 eager steps + the capture stay untimed
 
     # forward-only latency (train-mode forward of the same model state, no grad; hipGraph)
     fwd_ms = fwd_eval_ms = float("nan")
-    if not args.no_fwd:
+    if not args.no_fwd and not reducer.active:       # N = 1 legs (single-GPU latency figures; no extra collectives in a scaling run)
         for i in range(4):
             st.forward_only(pool[0])
         torch.cuda.synchronize()
@@ -471,7 +483,8 @@ def main():
         fwd_eval_ms = (time.perf_counter() - t1) / 5 * 1e3
         model.train()
 
-    single = world == 1
+    single = world == 1 and not forced
+    opt_buckets, early_launches, sync_calls = list(opt.buckets), reducer.early_launches, ops.SYNC_CALLS[0]
     graph_used = st.graph is not None
     feed = None
     if single and not args.no_host_feed and args.workload != "ffl_fusion":
@@ -518,6 +531,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"ffl_early_fusion_vit_cnn_bs{args.batch}x{world}" if args.workload == "ffl_fusion" else f"pix2poly_{args.workload}_bs{args.batch}x{world}"), "tiles_per_gpu": args.batch,
                        "points_per_tile": args.points, "hip_graph": graph_used, "sync_bn": sync_bn,
+                       **({"collectives": {"backend": dist.get_backend(), "world": world, "forced_single_rank": forced, "grad_buckets": len(opt_buckets),
+                                           "early_bucket_launches": early_launches, "syncbn_collectives": sync_calls}} if (world > 1 or forced) else {}),
                        "decoder_dropout": "off (A/B run)" if args.no_dropout else "reference defaults (0.1 / 0.05)",
                        "step": "fwd+FFL criterion+bwd+AdamW" if args.workload == "ffl_fusion" else "fwd+CE+10*BCE+bwd+AdamW", "parallelism": f"dp{world}"},
             "fwd_ms_per_tile": round(fwd_ms / args.batch, 4) if fwd_ms == fwd_ms else None, "fwd_ms_per_batch": round(fwd_ms, 3) if fwd_ms == fwd_ms else None,
@@ -537,10 +552,21 @@ def main():
             line["pcie_inclusive"] = feed
         if not args.no_cpu_baseline and single and args.workload != "ffl_fusion":   # N = 1 only (the ranks would share the host cores)
             line["cpu_baseline"] = cpu_baseline(args, kind)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()                                    # rank 0 runs the instrumented leg alone: leave together
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)               # the LAST line of stdout
+
+
+def _flush_c_stdio():
+    """RCCL writes a version banner to the C stdout buffer at init; unflushed it would land AFTER the JSON line at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
 
 
 if __name__ == "__main__":

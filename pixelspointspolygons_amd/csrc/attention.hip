@@ -10,14 +10,16 @@
 //   O^T[d, q] += V^T[d, kv] . P^T[kv, q]  A = V^T from LDS, B = P of the lane's own query, fed straight from the
 //       score registers: the MFMA k-slots are *assigned* to the keys the lane already holds (a sum over keys is
 //       order independent), so no cross-lane shuffle of P is needed; the V^T fragment is read with the same key order.
-//   bf16: v_mfma_f32_32x32x16_bf16, V is transposed while it is staged (pairs of keys packed per dword);
+//   bf16: v_mfma_f32_32x32x16_bf16; K and V tiles are staged as they lie in memory (attn_tile.h: unpadded, XOR-swizzled 16-byte chunks),
+//         the V^T fragments come from the transposing LDS read ds_read_b64_tr_b16;
 //   f32 : v_mfma_f32_32x32x2_f32 (exact fp32), V stays row-major.
 // Masks: keys >= Lk, causal (key > query) -> -inf; key_bias[b, key] is ADDED (reference's float padding mask).
 #include "p3_common.h"
+#include "attn_tile.h"
 
 namespace {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using p3attn::u32x4;
 
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O;
@@ -26,8 +28,8 @@ struct AttnArgs {
 
 template <typename T, int D> struct ATr;
 template <int D> struct ATr<bf16_t, D> {
-    static constexpr int KT = 64, PK = D + 8, PV = KT + 4;  // K [KT][PK] ; V^T [D][PV]
-    static constexpr int K_ELEMS = KT * PK, V_ELEMS = D * PV;
+    static constexpr int KT = 64, PK = D, PV = D;           // K [KT][D] ; V [KT][D], both swizzled (attn_tile.h)
+    static constexpr int K_ELEMS = KT * D, V_ELEMS = KT * D;
 };
 template <int D> struct ATr<float, D> {
     static constexpr int KT = 32, PK = D + 1, PV = D;       // K [KT][PK] ; V [KT][PV]
@@ -41,7 +43,7 @@ __device__ __forceinline__ void attn_load_tile(int t, int tid, const p3_attn_des
     constexpr int KT = TR::KT;
     constexpr bool BF = sizeof(T) == 2;
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;
-    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;
+    constexpr int VITEMS = KV16;
 
         const int kv0 = t * KT;
 #pragma unroll
@@ -58,18 +60,11 @@ __device__ __forceinline__ void attn_load_tile(int t, int tid, const p3_attn_des
         for (int i = 0; i < VPT; ++i) {
             const int item = tid + 256 * i;
             if (VITEMS % 256 == 0 || item < VITEMS) {
-                if constexpr (BF) {
-                    int dg = item % (D / 4), kp = item / (D / 4);
-                    int kva = kv0 + 2 * kp, kvb = kva + 1;
-                    if (kva >= d.Lk) kva = d.Lk - 1;
-                    if (kvb >= d.Lk) kvb = d.Lk - 1;
-                    uint2 ra = *reinterpret_cast<const uint2*>(Vp + (int64_t)kva * d.v_rs + dg * 4);
-                    uint2 rb = *reinterpret_cast<const uint2*>(Vp + (int64_t)kvb * d.v_rs + dg * 4);
-                    vreg[i] = u32x4{ra.x, ra.y, rb.x, rb.y};
-                } else {
-                    int row = item / (D / 4), cv = item % (D / 4);
+                {
+                    constexpr int VPR = D * (int)sizeof(T) / 16;
+                    int row = item / VPR, cv = item % VPR;
                     int kv = kv0 + row; if (kv >= d.Lk) kv = d.Lk - 1;
-                    vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (int64_t)kv * d.v_rs + cv * 4);
+                    vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (int64_t)kv * d.v_rs + cv * (16 / (int)sizeof(T)));
                 }
             }
         }
@@ -81,38 +76,22 @@ __device__ __forceinline__ void attn_store_tile(int tid, T* Ks, T* Vs, const u32
     constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV;
     constexpr bool BF = sizeof(T) == 2;
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;
-    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;
-
+    constexpr int VPR = D * (int)sizeof(T) / 16;      // 16-byte vectors per row
+    static_assert(KPT == VPT, "K and V tiles have the same shape");
+    // bf16: item -> (row, chunk) of the swizzled image; item + 256 is the same lane-constant offset + a multiple of 32 rows
+    const int sbase = BF ? p3attn::img_off<D>(tid / VPR, tid % VPR) : 0;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int item = tid + 256 * i;
             if (KV16 % 256 == 0 || item < KV16) {
-                constexpr int VPR = D * (int)sizeof(T) / 16;
-                int row = item / VPR, cv = item % VPR;
                 if constexpr (BF) {
-                    *reinterpret_cast<u32x4*>(Ks + row * PK + cv * 8) = kreg[i];
+                    *reinterpret_cast<u32x4*>(Ks + sbase + i * (256 / VPR) * D) = kreg[i];
+                    *reinterpret_cast<u32x4*>(Vs + sbase + i * (256 / VPR) * D) = vreg[i];
                 } else {
+                    int row = item / VPR, cv = item % VPR;
                     float* p = reinterpret_cast<float*>(Ks) + row * PK + cv * 4;
                     p[0] = __uint_as_float(kreg[i].x); p[1] = __uint_as_float(kreg[i].y);
                     p[2] = __uint_as_float(kreg[i].z); p[3] = __uint_as_float(kreg[i].w);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int item = tid + 256 * i;
-            if (VITEMS % 256 == 0 || item < VITEMS) {
-                if constexpr (BF) {
-                    int dg = item % (D / 4), kp = item / (D / 4);
-                    // V^T[d][2kp..2kp+1] as one dword: low half = key 2kp, high half = key 2kp+1
-                    uint32_t* p = reinterpret_cast<uint32_t*>(Vs);
-                    const uint32_t a0 = vreg[i].x, a1 = vreg[i].y, b0 = vreg[i].z, b1 = vreg[i].w;
-                    p[((dg * 4 + 0) * PV) / 2 + kp] = (a0 & 0xffffu) | (b0 << 16);
-                    p[((dg * 4 + 1) * PV) / 2 + kp] = (a0 >> 16) | (b0 & 0xffff0000u);
-                    p[((dg * 4 + 2) * PV) / 2 + kp] = (a1 & 0xffffu) | (b1 << 16);
-                    p[((dg * 4 + 3) * PV) / 2 + kp] = (a1 >> 16) | (b1 & 0xffff0000u);
-                } else {
-                    int row = item / (D / 4), cv = item % (D / 4);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(Vs) + row * PV + cv * 4) = vreg[i];
                 }
             }
@@ -172,10 +151,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     // staging registers
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
     constexpr int KPT = (KV16 + 255) / 256;                 // per thread
-    constexpr int VITEMS = BF ? (KT / 2) * (D / 4) : KV16;  // bf16: (key pair, 4 dims) items ; f32: float4 items
-    constexpr int VPT = (VITEMS + 255) / 256;
+    constexpr int VPT = KPT;
     u32x4 kreg[KPT];
-    u32x4 vreg[VPT];  // bf16: {row kv: 8 B, row kv+1: 8 B} ; f32: float4
+    u32x4 vreg[VPT];
+    p3attn::ScoreAddr<BF ? D : 16> sadr;          // bf16: lane-constant offsets into the swizzled K / V images
+    p3attn::TrAddr<BF ? D : 32> tadr;
+    if constexpr (BF) { sadr.init(l31, hi); tadr.init(lane); }
 
     if (ntiles > 0) attn_load_tile<T, D, KPT, VPT>(0, tid, d, Kp, Vp, kreg, vreg);
     for (int t = 0; t < ntiles; ++t) {
@@ -195,12 +176,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) sacc[h2][r] = 0.f;
             if constexpr (BF) {
 #pragma unroll
-                for (int ks = 0; ks < D / 16; ++ks) {
-                    s16x8 kf = *reinterpret_cast<const s16x8*>(Ks + (h2 * 32 + l31) * PK + ks * 16 + 8 * hi);
-                    sacc[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), kf),
-                        __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), qb[ks]), sacc[h2], 0, 0, 0);
-                }
+                for (int ks = 0; ks < D / 16; ++ks)
+                    sacc[h2] = p3attn::mfma_bf16(sadr.frag(reinterpret_cast<const bf16_t*>(Ks), h2, ks), qb[ks], sacc[h2]);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < D / 2; ++ks) {
@@ -299,17 +276,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pw[i] = pack_bf2(sacc[h2][8 * c2 + 2 * i], sacc[h2][8 * c2 + 2 * i + 1]);
                     s16x8 pb = __builtin_bit_cast(s16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-                    const int kvb = h2 * 32 + 16 * c2 + 4 * hi;
 #pragma unroll
-                    for (int j = 0; j < NDJ; ++j) {
-                        const T* vrow = Vs + (j * 32 + l31) * PV + kvb;
-                        uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-                        uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-                        s16x8 vf = __builtin_bit_cast(s16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), vf),
-                            __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), pb), oacc[j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NDJ; ++j)      // V^T[d, keys 4hi + {0..3, 8..11}] of the 16-key group: the keys this lane's P registers hold
+                        oacc[j] = p3attn::mfma_bf16(tadr.frag(reinterpret_cast<const bf16_t*>(Vs), h2 * 32 + 16 * c2, j), pb, oacc[j]);
                 }
         } else {
 #pragma unroll
@@ -439,8 +408,8 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     P3_CHECK(d->head_dim == 32 || d->head_dim == 64, P3_EUNSUP, "p3_attention: head_dim must be 32 or 64");
     P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention: dtype");
     const int al = d->dtype == P3_BF16 ? 8 : 4;
-    P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % 4 == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
-    P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % 4 == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
+    P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
+    P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
     P3_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, P3_EALIGN, "p3_attention: 16-byte base alignment");
     AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d;
     dim3 grid(p3_ceil_div(d->Lq, 128) * d->H * d->B), block(256);

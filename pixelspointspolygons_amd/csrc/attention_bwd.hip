@@ -5,12 +5,13 @@
 // Both reuse the forward's lane-local formulation: a lane owns ONE query (dQ kernel) or ONE key (dK/dV kernel), the
 // score-like products (K.Q^T, V.dO^T / Q.K^T, dO.V^T) put that index on the MFMA column, and the accumulate products
 // (K^T.dS^T / dO^T.P, Q^T.dS) feed P / dS straight from the score registers with the k-slots assigned to the rows the
-// lane already holds.  bf16: transposed LDS images are built while staging (row pairs packed per dword).
+// lane already holds.  bf16: one swizzled row image per tile; the transposed fragments come from ds_read_b64_tr_b16 (attn_tile.h).
 #include "p3_common.h"
+#include "attn_tile.h"
 
 namespace {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using p3attn::u32x4;
 
 struct BwdArgs {
     const void* Q; const void* K; const void* V; const void* O; const void* dO;
@@ -34,96 +35,67 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(BwdArgs a, int D) {
     }
 }
 
-// ---- LDS tile: R rows x D.  Row image [R][PR] (+ bf16 only: transposed image [D][PT], row pairs packed) -------------
+// ---- LDS tile: R rows x D.  bf16: ONE swizzled row image (attn_tile.h) serves both the score products (ds_read_b128) and the
+// accumulate products (transposing ds_read_b64_tr_b16); f32: row image [R][D + 1].
 template <typename T, int D, int R> struct Tile {
     static constexpr bool BF = sizeof(T) == 2;
-    static constexpr int PR = BF ? D + 8 : D + 1;
-    static constexpr int PT = R + 4;
+    static constexpr int PR = BF ? D : D + 1;
     static constexpr int ROW_ELEMS = R * PR;
-    static constexpr int TR_ELEMS = BF ? D * PT : 0;
 };
 
-// Staging of R rows (row0.., clamped to nvalid-1) of a [*, row_stride] tensor is split in two (guide T14): stage_load issues the
-// global loads of tile t+1 into registers BEFORE the MFMAs of tile t, stage_store writes them to LDS after the barrier that retires
+// Staging of R rows (row0.., clamped to nvalid-1) of a [*, row_stride] tensor is split in two (guide T14): load() issues the
+// global loads of tile t+1 into registers BEFORE the MFMAs of tile t, store() writes them to LDS after the barrier that retires
 // tile t's readers.  (PMC r01, synchronous staging: waves parked 47-58 % of their cycles in the dQ / dKV kernels.)
-template <typename T, int D, int R> struct StageRegs {
-    static constexpr bool BF = sizeof(T) == 2;
-    static constexpr int ITEMS = BF ? (R / 2) * (D / 4) : R * (D / 4);
-    static constexpr int N = (ITEMS + 255) / 256;
-    u32x4 v[N];   // bf16: {row 2rp: 8 B, row 2rp+1: 8 B}; f32: one float4
-};
-
-template <typename T, int D, int R>
-__device__ __forceinline__ void stage_load(const T* __restrict__ src, int row0, int nvalid, int row_stride, StageRegs<T, D, R>& rg, int tid) {
-    using SR = StageRegs<T, D, R>;
+template <typename T, int D, int R> struct Stage;
+template <int D, int R> struct Stage<bf16_t, D, R> : p3attn::RowStage<D, R> {};
+template <int D, int R> struct Stage<float, D, R> {
+    static constexpr int ITEMS = R * (D / 4), N = (ITEMS + 255) / 256;
+    u32x4 v[N];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int row0, int nvalid, int64_t row_stride, int tid) {
 #pragma unroll
-    for (int it = 0; it < SR::N; ++it) {
-        const int item = tid + 256 * it;
-        if (SR::ITEMS % 256 == 0 || item < SR::ITEMS) {
-            if constexpr (SR::BF) {
-                const int dg = item % (D / 4), rp = item / (D / 4);
-                int ra = row0 + 2 * rp, rb = ra + 1;
-                if (ra >= nvalid) ra = nvalid - 1;
-                if (rb >= nvalid) rb = nvalid - 1;
-                const uint2 va = *reinterpret_cast<const uint2*>(src + (int64_t)ra * row_stride + dg * 4);
-                const uint2 vb = *reinterpret_cast<const uint2*>(src + (int64_t)rb * row_stride + dg * 4);
-                rg.v[it] = u32x4{va.x, va.y, vb.x, vb.y};
-            } else {
+        for (int it = 0; it < N; ++it) {
+            const int item = tid + 256 * it;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
                 const int cv = item % (D / 4), r = item / (D / 4);
                 int rr = row0 + r; if (rr >= nvalid) rr = nvalid - 1;
-                rg.v[it] = *reinterpret_cast<const u32x4*>(src + (int64_t)rr * row_stride + cv * 4);
+                v[it] = *reinterpret_cast<const u32x4*>(src + (int64_t)rr * row_stride + cv * 4);
             }
         }
     }
-}
-
-template <typename T, int D, int R, bool WANT_ROW, bool WANT_TR>
-__device__ __forceinline__ void stage_store(const StageRegs<T, D, R>& rg, T* rowimg, T* trimg, int tid) {
-    using TL = Tile<T, D, R>;
-    using SR = StageRegs<T, D, R>;
+    __device__ __forceinline__ void store(float* rowimg, int tid) const {
+        constexpr int PR = Tile<float, D, R>::PR;
 #pragma unroll
-    for (int it = 0; it < SR::N; ++it) {
-        const int item = tid + 256 * it;
-        if (SR::ITEMS % 256 == 0 || item < SR::ITEMS) {
-            if constexpr (SR::BF) {
-                const int dg = item % (D / 4), rp = item / (D / 4);
-                const uint2 va = make_uint2(rg.v[it].x, rg.v[it].y), vb = make_uint2(rg.v[it].z, rg.v[it].w);
-                if constexpr (WANT_ROW) {
-                    *reinterpret_cast<uint2*>(rowimg + (2 * rp) * TL::PR + dg * 4) = va;
-                    *reinterpret_cast<uint2*>(rowimg + (2 * rp + 1) * TL::PR + dg * 4) = vb;
-                }
-                if constexpr (WANT_TR) {
-                    uint32_t* p = reinterpret_cast<uint32_t*>(trimg);
-                    p[((dg * 4 + 0) * TL::PT) / 2 + rp] = (va.x & 0xffffu) | (vb.x << 16);
-                    p[((dg * 4 + 1) * TL::PT) / 2 + rp] = (va.x >> 16) | (vb.x & 0xffff0000u);
-                    p[((dg * 4 + 2) * TL::PT) / 2 + rp] = (va.y & 0xffffu) | (vb.y << 16);
-                    p[((dg * 4 + 3) * TL::PT) / 2 + rp] = (va.y >> 16) | (vb.y & 0xffff0000u);
-                }
-            } else {
+        for (int it = 0; it < N; ++it) {
+            const int item = tid + 256 * it;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
                 const int cv = item % (D / 4), r = item / (D / 4);
-                float* p = reinterpret_cast<float*>(rowimg) + r * TL::PR + cv * 4;
-                p[0] = __uint_as_float(rg.v[it].x); p[1] = __uint_as_float(rg.v[it].y);
-                p[2] = __uint_as_float(rg.v[it].z); p[3] = __uint_as_float(rg.v[it].w);
+                float* p = rowimg + r * PR + cv * 4;
+                p[0] = __uint_as_float(v[it].x); p[1] = __uint_as_float(v[it].y);
+                p[2] = __uint_as_float(v[it].z); p[3] = __uint_as_float(v[it].w);
             }
         }
     }
-}
+};
+
+// lane-constant LDS offsets of the bf16 fragment reads (empty for f32)
+template <typename T, int D> struct FragAddr { __device__ __forceinline__ void init(int, int, int) {} };
+template <int D> struct FragAddr<bf16_t, D> {
+    p3attn::ScoreAddr<D> s;
+    p3attn::TrAddr<D> t;
+    __device__ __forceinline__ void init(int lane, int l31, int hi) { s.init(l31, hi); t.init(lane); }
+};
 
 // score-like product: acc[rows32 x cols32] = X[rows from LDS row image] . Y[cols held in regs]^T   (contract over D)
 template <typename T, int D, int R>
 __device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], const float (&yf)[D / 2],
-                                            int l31, int hi) {
+                                            const FragAddr<T, D>& fa, int l31, int hi) {
     using TL = Tile<T, D, R>;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if constexpr (TL::BF) {
 #pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
-            s16x8 xf = *reinterpret_cast<const s16x8*>(rowimg + (sub * 32 + l31) * TL::PR + ks * 16 + 8 * hi);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), xf),
-                                                          __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), yb[ks]), acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < D / 16; ++ks) acc = p3attn::mfma_bf16(fa.s.frag(rowimg, sub, ks), yb[ks], acc);
     } else {
 #pragma unroll
         for (int ks = 0; ks < D / 2; ++ks) {
@@ -136,7 +108,7 @@ __device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x
 
 // accumulate product: out[dj][d32 x cols32] += X^T[d, rows(sub)] . W[rows(sub), cols]   with W lane-local (f32x16 of sub-tile `sub`)
 template <typename T, int D, int R>
-__device__ __forceinline__ void accum_mma(const T* rowimg, const T* trimg, int sub, const f32x16& w, f32x16 (&out)[D / 32], int l31, int hi) {
+__device__ __forceinline__ void accum_mma(const T* rowimg, int sub, const f32x16& w, f32x16 (&out)[D / 32], const FragAddr<T, D>& fa, int l31, int hi) {
     using TL = Tile<T, D, R>;
     if constexpr (TL::BF) {
 #pragma unroll
@@ -145,16 +117,9 @@ __device__ __forceinline__ void accum_mma(const T* rowimg, const T* trimg, int s
 #pragma unroll
             for (int i = 0; i < 4; ++i) pw[i] = pack_bf2(w[8 * c2 + 2 * i], w[8 * c2 + 2 * i + 1]);
             const s16x8 wb = __builtin_bit_cast(s16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-            const int rb = sub * 32 + 16 * c2 + 4 * hi;
 #pragma unroll
-            for (int j = 0; j < D / 32; ++j) {
-                const T* xr = trimg + (j * 32 + l31) * TL::PT + rb;
-                const uint2 v0 = *reinterpret_cast<const uint2*>(xr);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(xr + 8);
-                const s16x8 xf = __builtin_bit_cast(s16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
-                out[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), xf),
-                                                                 __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), wb), out[j], 0, 0, 0);
-            }
+            for (int j = 0; j < D / 32; ++j)      // X^T[d, rows 4hi + {0..3, 8..11}] of the 16-row group: the rows whose W this lane holds
+                out[j] = p3attn::mfma_bf16(fa.t.frag(rowimg, sub * 32 + 16 * c2, j), wb, out[j]);
         }
     } else {
 #pragma unroll
@@ -208,7 +173,6 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     using TK = Tile<T, D, KT>;
     __shared__ __attribute__((aligned(16))) T Krow[TK::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Vrow[TK::ROW_ELEMS];
-    __shared__ __attribute__((aligned(16))) T Ktr[BF ? TK::TR_ELEMS : 8];
     const p3_attn_desc& d = a.d;
     const int nqb = (d.Lq + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);      // blocks of one (batch, head) share an XCD's L2 (see attention.hip)
@@ -260,20 +224,21 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
     DropKey dkey; uint32_t drop_rk = 0;
     if constexpr (DROP) { dkey = drop_key(d.drop); drop_rk = drop_rowkey(dkey, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
-    StageRegs<T, D, KT> kreg, vreg;
-    if (ntiles > 0) { stage_load<T, D, KT>(Kp, 0, d.Lk, d.k_rs, kreg, tid); stage_load<T, D, KT>(Vp, 0, d.Lk, d.v_rs, vreg, tid); }
+    Stage<T, D, KT> kreg, vreg;
+    FragAddr<T, D> fa; fa.init(lane, l31, hi);
+    if (ntiles > 0) { kreg.load(Kp, 0, d.Lk, d.k_rs, tid); vreg.load(Vp, 0, d.Lk, d.v_rs, tid); }
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();
-        stage_store<T, D, KT, true, true>(kreg, Krow, Ktr, tid);
-        stage_store<T, D, KT, true, false>(vreg, Vrow, nullptr, tid);
+        kreg.store(Krow, tid);
+        vreg.store(Vrow, tid);
         __syncthreads();
-        if (t + 1 < ntiles) { stage_load<T, D, KT>(Kp, kv0 + KT, d.Lk, d.k_rs, kreg, tid); stage_load<T, D, KT>(Vp, kv0 + KT, d.Lk, d.v_rs, vreg, tid); }
+        if (t + 1 < ntiles) { kreg.load(Kp, kv0 + KT, d.Lk, d.k_rs, tid); vreg.load(Vp, kv0 + KT, d.Lk, d.v_rs, tid); }
         if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
-            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, l31, hi);       // S^T[kv, q]
-            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, l31, hi);      // dP^T[kv, q]
+            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, fa, l31, hi);   // S^T[kv, q]
+            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, fa, l31, hi);  // dP^T[kv, q]
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
             uint32_t dword = 0;
@@ -302,7 +267,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
                 }
                 s[r] = p * (dpv - dlt);                                       // dS^T
             }
-            accum_mma<T, D, KT>(Krow, Ktr, sub, s, dq, l31, hi);              // dQ^T[d, q] += K^T . dS^T
+            accum_mma<T, D, KT>(Krow, sub, s, dq, fa, l31, hi);               // dQ^T[d, q] += K^T . dS^T
         }
     }
     if (q < d.Lq) store_T_acc<T, D>(dQp + (int64_t)q * d.q_rs, dq, d.scale, hi);
@@ -316,8 +281,6 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
     using TQ = Tile<T, D, QT>;
     __shared__ __attribute__((aligned(16))) T Qrow[TQ::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Grow[TQ::ROW_ELEMS];
-    __shared__ __attribute__((aligned(16))) T Qtr[BF ? TQ::TR_ELEMS : 8];
-    __shared__ __attribute__((aligned(16))) T Gtr[BF ? TQ::TR_ELEMS : 8];
     __shared__ float Ls[QT], Ds[QT];
     const p3_attn_desc& d = a.d;
     const int nkb = (d.Lk + 127) / 128;
@@ -347,23 +310,24 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
     DropKey dkey; uint32_t drop_ck = 0; uint64_t drop_bh = 0;
     if constexpr (DROP != 0) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
-    StageRegs<T, D, QT> qreg, greg;
-    if (q_begin < d.Lq) { stage_load<T, D, QT>(Qp, q_begin, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q_begin, d.Lq, d.o_rs, greg, tid); }
+    Stage<T, D, QT> qreg, greg;
+    FragAddr<T, D> fa; fa.init(lane, l31, hi);
+    if (q_begin < d.Lq) { qreg.load(Qp, q_begin, d.Lq, d.q_rs, tid); greg.load(dOp, q_begin, d.Lq, d.o_rs, tid); }
     for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
         __syncthreads();
-        stage_store<T, D, QT, true, true>(qreg, Qrow, Qtr, tid);
-        stage_store<T, D, QT, true, true>(greg, Grow, Gtr, tid);
+        qreg.store(Qrow, tid);
+        greg.store(Grow, tid);
         if (tid < QT) {
             const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
             Ls[tid] = a.lse[stat_base + qq] * 1.4426950408889634f; Ds[tid] = a.delta[stat_base + qq];   // lse in log2 units
         }
         __syncthreads();
-        if (q0 + QT < d.Lq) { stage_load<T, D, QT>(Qp, q0 + QT, d.Lq, d.q_rs, qreg, tid); stage_load<T, D, QT>(dOp, q0 + QT, d.Lq, d.o_rs, greg, tid); }
+        if (q0 + QT < d.Lq) { qreg.load(Qp, q0 + QT, d.Lq, d.q_rs, tid); greg.load(dOp, q0 + QT, d.Lq, d.o_rs, tid); }
         if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
-            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, l31, hi);       // S[q, kv]
-            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, l31, hi);      // dP[q, kv]
+            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, fa, l31, hi);   // S[q, kv]
+            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, fa, l31, hi);  // dP[q, kv]
             f32x16 ds;
             // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
             const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
@@ -396,8 +360,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
                 s[r] = pd;
                 ds[r] = p * (dpv - Ds[ql]);
             }
-            accum_mma<T, D, QT>(Grow, Gtr, sub, s, dv, l31, hi);              // dV^T[d, kv] += dO^T . P
-            accum_mma<T, D, QT>(Qrow, Qtr, sub, ds, dk, l31, hi);             // dK^T[d, kv] += Q^T . dS
+            accum_mma<T, D, QT>(Grow, sub, s, dv, fa, l31, hi);               // dV^T[d, kv] += dO^T . P
+            accum_mma<T, D, QT>(Qrow, sub, ds, dk, fa, l31, hi);              // dK^T[d, kv] += Q^T . dS
         }
     }
     if (kv < d.Lk) {

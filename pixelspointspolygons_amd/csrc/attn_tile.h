@@ -1,0 +1,91 @@
+// LDS tiles of the bf16 attention kernels (attention.hip, attention_bwd.hip): ONE image per operand tile, rows as they lie in memory.
+//
+//   image  : R rows x D bf16, unpadded (128 B rows for D = 64, 64 B for D = 32); the 16-byte chunk c of row r sits at chunk
+//            c ^ sw(r).  Staged with 16-byte global loads and ds_write_b128 (no packing VALU, no 4-byte transposing stores).
+//   score  : MFMA A operand with k = head dim: lane (row l31, half hi) reads the 16 bytes of logical chunk 2*ks + hi (ds_read_b128).
+//   accum  : MFMA A operand with k = rows (V^T, K^T, Q^T, dO^T): gfx950's transposing read ds_read_b64_tr_b16 - per 16-lane group
+//            lanes 4j..4j+3 point at row j's 16 elements and lane i receives column i of those 4 rows (pinned by tools/probe/tr_probe.hip)
+//            - delivers rows rb + 4*hi + {0..3} and rb + 4*hi + {8..11}, the rows whose P / dS values the lane already holds in its
+//            score registers (crow32), so no transposed second image is built (r01 kept both: 2x the LDS bytes, 4 ds_write_b32 + 8
+//            VALU per 16 staged bytes).
+//   sw(r)  : D = 64: ((r>>1)&1)<<2 | (r>>2)&3 ; D = 32: (r>>2)&3.  Both read patterns are bank-conflict free: the 16 lanes of a
+//            ds_read_b128 group ({0-3,12-15,20-27}, ...) land on 16 distinct (row parity / row&3, chunk) bank sets, and the 4 rows x 64 B
+//            of a transposing read's 32-lane cycle land in 4 distinct 64-byte bank quarters.
+//   All per-read addresses are lane constants (computed once) plus compile-time immediates: sw() of the rows a lane touches depends only
+//   on the lane, because every tile / sub-tile base is a multiple of 16 rows.
+#pragma once
+#include "p3_common.h"
+
+namespace p3attn {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int D> __device__ __forceinline__ int sw(int row) {
+    return D == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+}
+// element offset of logical 16-byte chunk c of row `row`
+template <int D> __device__ __forceinline__ int img_off(int row, int c) { return row * D + ((c ^ sw<D>(row)) << 3); }
+
+// registers of one R x D bf16 tile in flight between global memory and LDS (256 threads)
+template <int D, int R> struct RowStage {
+    static constexpr int CPR = D / 8, ITEMS = R * CPR, N = (ITEMS + 255) / 256;
+    u32x4 v[N];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ src, int row0, int nvalid, int64_t row_stride, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int item = tid + 256 * i;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                int r = row0 + item / CPR; if (r >= nvalid) r = nvalid - 1;
+                v[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)r * row_stride + (item % CPR) * 8);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* img, int tid) const {
+        const int base = img_off<D>(tid / CPR, tid % CPR);       // row + 256/CPR * i keeps sw(): the step is a multiple of 32 rows
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int item = tid + 256 * i;
+            if (ITEMS % 256 == 0 || item < ITEMS) *reinterpret_cast<u32x4*>(img + base + i * (256 / CPR) * D) = v[i];
+        }
+    }
+};
+
+// lane-constant offsets of the score fragments: row sub*32 + l31, k-step ks  ->  img + sub*32*D + off[ks]
+template <int D> struct ScoreAddr {
+    int off[D / 16];
+    __device__ __forceinline__ void init(int l31, int hi) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) off[ks] = img_off<D>(l31, 2 * ks + hi);
+    }
+    __device__ __forceinline__ s16x8 frag(const bf16_t* img, int sub, int ks) const {
+        return *reinterpret_cast<const s16x8*>(img + sub * 32 * D + off[ks]);
+    }
+};
+
+// lane-constant offsets of the transposing reads: rows rb16 + 4*hi + {0..3} (sec 0) / + {8..11} (sec 1), column j*32 + l31
+template <int D> struct TrAddr {
+    int off[D / 32][2];
+    __device__ __forceinline__ void init(int lane) {
+        const int li = lane & 15, g4 = lane >> 4, hi = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < D / 32; ++j)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec)
+                off[j][sec] = img_off<D>(4 * hi + (li >> 2) + 8 * sec, j * 4 + (g4 & 1) * 2 + ((li & 3) >> 1)) + (li & 1) * 4;
+    }
+    // X^T fragment (8 k-slots) of column j*32 + l31 over the 16 rows starting at rb16 (multiple of 16)
+    __device__ __forceinline__ s16x8 frag(const bf16_t* img, int rb16, int j) const {
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb16 * D + off[j][0]));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb16 * D + off[j][1]));
+        return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(const s16x8& a, const s16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), a),
+                                                   __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), b), c, 0, 0, 0);
+}
+
+}  // namespace p3attn

@@ -6,6 +6,7 @@ are refreshed whenever the parameter changes.  Accumulation, LayerNorm/BatchNorm
 are always fp32.
 """
 import math
+import os
 
 import torch
 
@@ -33,6 +34,17 @@ SYNC_BN = [False]       # set by the model factories when cfg.host.multi_gpu (nn
 
 
 SYNC_CALLS = [0]        # collectives issued by sync_stats (tests / DESIGN: one per BatchNorm site and direction)
+# P3_FORCE_COLLECTIVES=1: a ONE-rank process group still issues every collective of the N > 1 path (SyncBatchNorm statistics, gradient
+# buckets).  It is how the RCCL path is exercised on a 1-GPU box (two ranks on one device are refused by RCCL); values are unchanged.
+SINGLE_RANK_COLLECTIVES = [os.environ.get("P3_FORCE_COLLECTIVES") == "1"]
+
+
+def collectives_active(group=None):
+    """True when this process takes part in data-path collectives: world > 1, or a 1-rank group under P3_FORCE_COLLECTIVES=1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or SINGLE_RANK_COLLECTIVES[0]
 
 
 def sync_stats(*tensors):
@@ -43,7 +55,7 @@ def sync_stats(*tensors):
     if not SYNC_BN[0]:
         return 1
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return 1
     ts = [t for t in tensors if t is not None]
     SYNC_CALLS[0] += 1
@@ -61,8 +73,7 @@ def sync_stats(*tensors):
 
 
 def sync_active():
-    import torch.distributed as dist
-    return SYNC_BN[0] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return SYNC_BN[0] and collectives_active()
 
 
 def bias_grad_before_bn(dH, training):

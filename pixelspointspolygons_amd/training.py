@@ -235,6 +235,7 @@ class GradBucketReducer:
         """overlap=False: no early launches; `finish()` reduces all buckets after backward."""
         self.opt, self.pg = opt, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = ops.collectives_active(process_group)     # world > 1 (or the 1-rank RCCL smoke mode): collectives are issued
         self.overlap = overlap
         nb = len(opt.buckets)
         self.bucket_of = []
@@ -246,7 +247,7 @@ class GradBucketReducer:
         self.seq, self.pos, self.following = [], 0, True
         self.early_launches = 0                   # buckets reduced before finish() over the life of the reducer (tests, DESIGN)
         self._hooks = []
-        if self.world > 1 and overlap:
+        if self.active and overlap:
             for i, p in enumerate(opt.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._report(i)))
             ops.GRAD_READY[0] = self._report_param      # one reducer per process: the operators report to the most recent one
@@ -279,7 +280,7 @@ class GradBucketReducer:
 
     def finish(self):
         """call after backward: reduce the buckets that are still open, wait, return the 1/world scale for AdamW."""
-        if self.world > 1:
+        if self.active:
             if self.overlap and self.ref is None:                    # first backward: turn the recording into triggers
                 last = {}
                 for pos, i in enumerate(self.seq):
@@ -308,7 +309,7 @@ class GradBucketReducer:
 
 def sync_bn_sums(sums):
     """SyncBatchNorm semantics for the HIP BatchNorm path: sum the per-rank (sum, sum-of-squares) vectors; returns world size."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if ops.collectives_active():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         return dist.get_world_size()
     return 1
