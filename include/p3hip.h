@@ -149,8 +149,9 @@ typedef struct {
     int dtype;             /* Q,K,V,O dtype */
     float* lse;            /* [B,H,Lq] or NULL */
     p3_dropout drop;       /* dropout of the attention probabilities; element = (row (b*H + h)*Lq + q, col k) */
-    unsigned int* drop_rows; /* optional keep-bit words [B*H*Lq, ceil(Lk/32)] (bit k%32 of word k/32 = element kept): WRITTEN by
-                              * p3_attention when given, READ by p3_attention_bwd instead of re-hashing (NULL: hash again) */
+    unsigned int* drop_rows; /* optional keep-bit words, B*H*ceil(Lk/32)*Lq of them laid out [B*H][ceil(Lk/32)][Lq] (bit k%32 of word k/32
+                              * of query q = element kept; q innermost so that a wave's 32 queries touch 128 contiguous bytes): WRITTEN
+                              * by p3_attention when given, READ by p3_attention_bwd instead of re-hashing (NULL: hash again) */
 } p3_attn_desc;
 int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream);
 

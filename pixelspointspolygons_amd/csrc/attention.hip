@@ -169,9 +169,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         if (!wave_live) continue;
 
         // ---- S^T = K . Q^T ----
+        // last tile: a 32-key half that lies entirely beyond the block's last visible key is skipped (785 = 12 x 64 + 17)
+        // (also per wave under the causal mask: keys beyond the wave's last query; a tile with no visible key is skipped entirely)
+        int vis_end = kv_end;
+        if (d.causal) { const int wl = qblk + wave * 32 + 32; if (wl < vis_end) vis_end = wl; }
+        const int nh2 = (vis_end - kv0 + 31) >> 5;          // visible 32-key halves of this tile (>= NH2: all)
+        if (nh2 <= 0) continue;
         f32x16 sacc[NH2];
 #pragma unroll
         for (int h2 = 0; h2 < NH2; ++h2) {
+            if (h2 >= nh2) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[h2][r] = 0.f;
             if constexpr (BF) {
@@ -194,13 +201,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         float mx = -INFINITY;
         if (full) {
 #pragma unroll
-            for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2)       // full tiles have nh2 >= NH2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[h2][r]);
             mx *= c;                                      // c > 0: max commutes with the scaling
         } else {
 #pragma unroll
-            for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2) {
+                if (h2 >= nh2) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + h2 * 32 + crow32(r, hi);
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                     sacc[h2][r] = s2;
                     mx = fmaxf(mx, s2);
                 }
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
@@ -226,13 +235,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 }
         } else {
 #pragma unroll
-            for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2) {
+                if (h2 >= nh2) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(sacc[h2][r] - m_use);
                     sacc[h2][r] = p;
                     psum += p;
                 }
+            }
         }
         // rescale the running state only when some row's maximum moved (wave-uniform test; alpha == 1 exactly otherwise)
         if (__any(m_new != m_run)) {
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         if constexpr (DROP) {   // attention-probability dropout: the row sum above stays undropped (softmax first, then dropout)
 #pragma unroll
             for (int h2 = 0; h2 < NH2; ++h2) {
+                if (h2 >= nh2) continue;            // invisible half: P == 0 there, the backward never uses its keep bits
                 uint32_t wrow = 0;                  // keep bits of this lane's 16 keys of the 32-key block (bit = key % 32)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {   // registers r, r+1 hold keys 2j, 2j+1: one hash per pair
@@ -260,8 +272,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 if (d.drop_rows) {                  // publish the mask for the backward kernels (they then skip the hashing)
                     wrow |= __shfl_xor(wrow, 32, 64);
                     const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + h2;
-                    if (hi == 0 && q < d.Lq && kw < nkw)      // kw == nkw: the 32-key half beyond Lk of the last tile (next row's word 0!)
-                        d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + q) * nkw + kw] = wrow;
+                    if (hi == 0 && q < d.Lq && kw < nkw)      // kw == nkw: the 32-key half beyond Lk of the last tile
+                        d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + q] = wrow;     // [b*H + h][key word][q]: 32 lanes = 128 contiguous bytes
                 }
             }
         }
@@ -269,7 +281,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         // ---- O^T += V^T . P^T ----
         if constexpr (BF) {
 #pragma unroll
-            for (int h2 = 0; h2 < NH2; ++h2)
+            for (int h2 = 0; h2 < NH2; ++h2) {
+                if (h2 >= nh2) continue;
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     uint32_t pw[4];
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                     for (int j = 0; j < NDJ; ++j)      // V^T[d, keys 4hi + {0..3, 8..11}] of the 16-key group: the keys this lane's P registers hold
                         oacc[j] = p3attn::mfma_bf16(tadr.frag(reinterpret_cast<const bf16_t*>(Vs), h2 * 32 + 16 * c2, j), pb, oacc[j]);
                 }
+            }
         } else {
 #pragma unroll
             for (int h2 = 0; h2 < NH2; ++h2)

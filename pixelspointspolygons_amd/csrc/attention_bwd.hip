@@ -235,8 +235,11 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
         __syncthreads();
         if (t + 1 < ntiles) { kreg.load(Kp, kv0 + KT, d.Lk, d.k_rs, tid); vreg.load(Vp, kv0 + KT, d.Lk, d.v_rs, tid); }
         if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
+        int vis_end = kv_end;                        // keys this wave's queries can see (causal: up to its last query)
+        if (d.causal) { const int wl = qblk + wave * 32 + 32; if (wl < vis_end) vis_end = wl; }
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
+            if (kv0 + sub * 32 >= vis_end) continue;                          // 32-key half with no visible key: dS == 0
             f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, fa, l31, hi);   // S^T[kv, q]
             f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, fa, l31, hi);  // dP^T[kv, q]
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
             uint32_t dword = 0;
             if constexpr (DROP == 2) {
                 const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + sub;     // kw == nkw: the all-masked half of the last tile
-                if (kw < nkw) dword = d.drop_rows[(((int64_t)b * d.H + h) * d.Lq + qc) * nkw + kw];
+                if (kw < nkw) dword = d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + qc];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -326,6 +329,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
         if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
+            // 32-query half beyond Lq, or (causal) entirely before this wave's first key: P == dS == 0
+            if (q0 + sub * 32 >= d.Lq || (d.causal && q0 + sub * 32 + 31 < kblk + wave * 32)) continue;
             f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, fa, l31, hi);   // S[q, kv]
             f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, fa, l31, hi);  // dP[q, kv]
             f32x16 ds;
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
             uint32_t myword = 0;
             if constexpr (DROP == 2) {
                 const int qr = q0 + sub * 32 + l31;
-                myword = d.drop_rows[((int64_t)drop_bh + (qr < d.Lq ? qr : d.Lq - 1)) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)];
+                myword = d.drop_rows[(((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq + (qr < d.Lq ? qr : d.Lq - 1)];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

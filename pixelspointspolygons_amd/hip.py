@@ -835,4 +835,4 @@ def transpose_many(src, dst, table, n_entries, total_tiles):
 
 def attention_mask_words(B, heads, Lq, Lk, device):
     """keep-bit words the attention forward publishes for its backward (p3_attn_desc.drop_rows)."""
-    return torch.empty((B * heads * Lq, (Lk + 31) // 32), dtype=torch.int32, device=device)
+    return torch.empty((B * heads, (Lk + 31) // 32, Lq), dtype=torch.int32, device=device)     # [b*H + h][key word][q]
