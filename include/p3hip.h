@@ -258,6 +258,32 @@ int p3_sinkhorn(const float* scores, const float* alpha, int B, int m, int n, in
 int p3_assignment(const float* scores, int B, int N, int maximize, int32_t* col4row, float* perm, int32_t* status, void* stream);
 /* greedy decode step (predictor_pix2poly.py:165,196-197): argmax over the last dim, first maximum wins */
 int p3_argmax(const float* x, int64_t* out, int rows, int cols, int ld, void* stream);
+
+/* One nn.TransformerDecoderLayer (post-norm, ReLU, eval mode) applied to ONE new position per sample with key/value caches: the body
+ * of Decoder.predict's loop (model_pix2poly.py:187-219, layer built at :138-141) as a single launch.  bf16 activations / weights, fp32
+ * biases and LayerNorm parameters; D = 256, 8 heads, FF = 2048.  Weights are row-major [out, in] like nn.Linear.weight. */
+typedef struct {
+    int B, t, steps, Lmem;       /* batch, index of the new position, cache length (positions), memory tokens */
+    int D, H, FF;
+    const void* x_in;  long long x_in_stride;    /* [B] rows of D bf16 */
+    void* x_out;       long long x_out_stride;   /* [B] rows of D bf16: norm3 output */
+    void* kv_self;               /* [B, steps, 3D] bf16: row t is WRITTEN (q|k|v of the new position), rows < t are read */
+    const void* kv_mem;          /* [B, Lmem, 2D] bf16: k|v of the memory tokens (multihead_attn.in_proj rows D..3D applied once) */
+    const float* key_bias; long long key_bias_stride;   /* [B] rows of >= t+1 floats added to the self-attention scores, or NULL */
+    const void* w_in;  const float* b_in;        /* self_attn.in_proj   [3D, D] */
+    const void* w_so;  const float* b_so;        /* self_attn.out_proj  [D, D] */
+    const void* w_q;   const float* b_q;         /* multihead_attn.in_proj rows 0..D (query)  [D, D] */
+    const void* w_co;  const float* b_co;        /* multihead_attn.out_proj [D, D] */
+    const void* w1;    const float* b1;          /* linear1 [FF, D] */
+    const void* w2;    const float* b2;          /* linear2 [D, FF] */
+    const float *g1, *be1, *g2, *be2, *g3, *be3; /* norm1..3 weight / bias */
+    float eps, scale;            /* LayerNorm eps; 1/sqrt(D/H) */
+    int cluster;                 /* workgroups per sample: 1, or 4 (heads / hidden units split over the cluster; needs the three below) */
+    float* exch;                 /* [B, 3, cluster, D] fp32 scratch: the partial projections the cluster members exchange */
+    unsigned int* sync;          /* [B, 2] {arrival count, generation}: zero before the FIRST launch, never touched by the host afterwards */
+    int* err;                    /* optional: set to 1 if a cluster barrier gave up (spin limit) - the outputs are then invalid */
+} p3_decode_layer_desc;
+int p3_decode_layer(const p3_decode_layer_desc* d, void* stream);
 int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* stream);
 /* out[b,t,:] = x[b,t,:] + pos[t,:]  (Decoder: encoder_out + encoder_pos_embed, model_pix2poly.py:171-173) */
 int p3_add_pos(const void* x, const float* pos, void* out, int B, int L, int D, int dtype, void* stream);

@@ -1,5 +1,6 @@
 """Thin tensor-level bindings of the C-ABI in include/p3hip.h (PyTorch = device memory + streams only)."""
 import ctypes
+import math
 from ctypes import POINTER, Structure, byref, c_float, c_int, c_int64, c_void_p
 
 import torch
@@ -428,6 +429,53 @@ def argmax(x):
     out = torch.empty(rows, dtype=torch.int64, device=x.device)
     check(lib().p3_argmax(ptr(x), ptr(out), c_int(rows), c_int(cols), c_int(x.stride(0)), stream()), "p3_argmax")
     return out
+
+
+class DecodeLayerDesc(Structure):
+    _fields_ = [("B", c_int), ("t", c_int), ("steps", c_int), ("Lmem", c_int), ("D", c_int), ("H", c_int), ("FF", c_int),
+                ("x_in", c_void_p), ("x_in_stride", c_int64), ("x_out", c_void_p), ("x_out_stride", c_int64),
+                ("kv_self", c_void_p), ("kv_mem", c_void_p), ("key_bias", c_void_p), ("key_bias_stride", c_int64),
+                ("w_in", c_void_p), ("b_in", c_void_p), ("w_so", c_void_p), ("b_so", c_void_p), ("w_q", c_void_p), ("b_q", c_void_p),
+                ("w_co", c_void_p), ("b_co", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+                ("g1", c_void_p), ("be1", c_void_p), ("g2", c_void_p), ("be2", c_void_p), ("g3", c_void_p), ("be3", c_void_p),
+                ("eps", c_float), ("scale", c_float), ("cluster", c_int), ("exch", c_void_p), ("sync", c_void_p), ("err", c_void_p)]
+
+
+def decode_layer_scratch(B, device):
+    """(exch fp32 [B, 3, 4, 256], sync int32 [B, 2] zeroed ONCE, err int32 [1]) for the 4-workgroup cluster form of p3_decode_layer."""
+    exch = torch.empty(B * 3 * 4 * 256 + 64, dtype=torch.float32, device=device)      # + 64: phase timestamps of the -DDL_TIMING build
+    return exch, torch.zeros((B, 2), dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def decode_layer(x_in, x_out, kv_self, kv_mem, key_bias, t, heads, w, eps, scratch=None):
+    """One decoder layer on the new position t of every sample (p3_decode_layer).  x_in / x_out: [B, D] bf16 rows (any row stride);
+    kv_self [B, steps, 3D] (row t written), kv_mem [B, Lmem, 2D], key_bias [B, >= t+1] fp32 or None; `w`: dict of the layer's tensors -
+    bf16 weights w_in, w_so, w_q, w_co, w1, w2 (row-major [out, in]) and fp32 b_in, b_so, b_q, b_co, b1, b2, g1, be1, g2, be2, g3, be3."""
+    _dev(x_in)
+    B, D = x_in.shape
+    for name in ("w_in", "w_so", "w_q", "w_co", "w1", "w2"):
+        if w[name].dtype != torch.bfloat16 or not w[name].is_contiguous():
+            raise P3Error(f"decode_layer: {name} must be a contiguous bf16 matrix")
+    if x_in.dtype != torch.bfloat16 or x_out.dtype != torch.bfloat16 or kv_self.dtype != torch.bfloat16 or kv_mem.dtype != torch.bfloat16:
+        raise P3Error("decode_layer: bf16 activations and caches only")
+    if not (kv_self.is_contiguous() and kv_mem.is_contiguous()) or x_in.stride(1) != 1 or x_out.stride(1) != 1:
+        raise P3Error("decode_layer: caches must be contiguous, activation rows dense")
+    d = DecodeLayerDesc()
+    d.B, d.t, d.steps, d.Lmem, d.D, d.H, d.FF = B, int(t), kv_self.shape[1], kv_mem.shape[1], D, heads, w["w1"].shape[0]
+    d.x_in, d.x_in_stride, d.x_out, d.x_out_stride = x_in.data_ptr(), x_in.stride(0), x_out.data_ptr(), x_out.stride(0)
+    d.kv_self, d.kv_mem = kv_self.data_ptr(), kv_mem.data_ptr()
+    if key_bias is not None:
+        d.key_bias, d.key_bias_stride = key_bias.data_ptr(), key_bias.stride(0)
+    for name in ("w_in", "b_in", "w_so", "b_so", "w_q", "b_q", "w_co", "b_co", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2", "g3", "be3"):
+        setattr(d, name, w[name].data_ptr())
+    d.eps, d.scale = float(eps), 1.0 / math.sqrt(D // heads)
+    # 4 workgroups per sample while the whole launch is co-resident (<= 512 workgroups incl. the padding to groups of 8 samples)
+    if scratch is not None and ((B + 7) // 8) * 8 * 4 <= 512:
+        d.cluster, d.exch, d.sync, d.err = 4, scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr()
+    else:
+        d.cluster = 1
+    check(lib().p3_decode_layer(byref(d), stream()), "p3_decode_layer")
+    return x_out
 
 
 def assignment(scores, maximize=True, want_perm=True):

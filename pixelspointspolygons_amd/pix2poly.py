@@ -6,6 +6,7 @@ only (nn.TransformerDecoder, nn.Conv2d, nn.BatchNorm2d: identical key names and 
 """
 import numpy as np
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -318,6 +319,27 @@ class Decoder(nn.Module):
             return st["preds"].clone(), st["feats"].clone()
         return st["preds"], st["feats"]
 
+    fused_decode = True      # bf16: one p3_decode_layer launch per layer and step (False: the 11-launch chain, as in fp32 mode)
+
+    def _fused_step_ok(self):
+        l0 = self.decoder.layers[0]
+        return (self.fused_decode and self.cd == torch.bfloat16 and self.dim == 256 and self.num_heads == 8 and l0.linear1.out_features == 2048
+                and os.environ.get("P3_DECODE_FUSED", "1") != "0")
+
+    def _fused_layer_tensors(self, lyr):
+        """bf16 weight copies (the optimizer's shadow arena or cached casts) + fp32 vectors of one layer, in p3_decode_layer's naming."""
+        cd, D = self.cd, self.dim
+        sa, ca = lyr.self_attn, lyr.multihead_attn
+        d = lambda p: p.detach()
+        return {"w_in": ops.shadow(sa.in_proj_weight, cd), "b_in": d(sa.in_proj_bias),
+                "w_so": ops.shadow(sa.out_proj.weight, cd), "b_so": d(sa.out_proj.bias),
+                "w_q": ops.shadow(ca.in_proj_weight, cd)[:D], "b_q": d(ca.in_proj_bias)[:D],
+                "w_co": ops.shadow(ca.out_proj.weight, cd), "b_co": d(ca.out_proj.bias),
+                "w1": ops.shadow(lyr.linear1.weight, cd), "b1": d(lyr.linear1.bias),
+                "w2": ops.shadow(lyr.linear2.weight, cd), "b2": d(lyr.linear2.bias),
+                "g1": d(lyr.norm1.weight), "be1": d(lyr.norm1.bias), "g2": d(lyr.norm2.weight), "be2": d(lyr.norm2.bias),
+                "g3": d(lyr.norm3.weight), "be3": d(lyr.norm3.bias)}
+
     def _decode_step(self, st, t):
         cd, D, H = self.cd, self.dim, self.num_heads
         scale = 1.0 / math.sqrt(D // H)
@@ -326,6 +348,20 @@ class Decoder(nn.Module):
         pos = self.decoder_pos_embed.detach().reshape(-1, D)
         x, kbt = hip.embed_tokens(preds[:, t:t + 1].contiguous(), emb, pos[t:t + 1], self.pad_idx, cd)      # [B,1,D], [B,1]
         kb[:, t:t + 1] = kbt
+        if self._fused_step_ok():
+            # one launch per layer (p3_decode_layer): bf16, the reference's decoder shape; the unfused chain below stays the fp32 path
+            if "xa" not in st:
+                st["xa"], st["xb"] = (torch.empty((x.shape[0], D), dtype=cd, device=x.device) for _ in range(2))
+                st["dl_scratch"] = hip.decode_layer_scratch(x.shape[0], x.device) if os.environ.get("P3_DECODE_CLUSTER", "4") == "4" else None
+            xa, xb = st["xa"], st["xb"]
+            cur = x.view(-1, D)
+            for li, lyr in enumerate(self.decoder.layers):
+                nxt = feats[:, t] if li == len(self.decoder.layers) - 1 else (xa if li % 2 == 0 else xb)
+                hip.decode_layer(cur, nxt, kv_self[li], kv_mem[li], kb, t, H, self._fused_layer_tensors(lyr), lyr.norm1.eps, scratch=st["dl_scratch"])
+                cur = nxt
+            logits = ops.linear(feats[:, t], self.output.weight, self.output.bias, out_dtype=torch.float32, cd=cd)
+            preds[:, t + 1] = hip.argmax(logits)
+            return
         kbc = kb[:, :t + 1].contiguous()
         for li, lyr in enumerate(self.decoder.layers):
             sa, ca = lyr.self_attn, lyr.multihead_attn

@@ -1,0 +1,84 @@
+"""p3_decode_layer (one launch per decoder layer and decode step) against the 11-launch chain it replaces (Decoder._decode_step, the body
+of the reference's Decoder.predict loop, model_pix2poly.py:187-219).  bf16 only: the fp32 parity mode keeps the unfused chain."""
+import pytest
+import torch
+
+from oracle import p3_oracle as O
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _decoder(seed, layers=2):
+    from pixelspointspolygons_amd.pix2poly import Decoder
+    sd = O.make_state_dict("image", dict(dim=64, depth=2, heads=2, mlp=128, patch=8, img=32, eps=1e-6), seed=seed, n_vertices=10,
+                           dec_dim=256, dec_layers=layers)
+    dec = Decoder(vocab_size=O.VOCAB, encoder_len=16, dim=256, num_heads=8, num_layers=layers, max_len=2 * 10 + 2, pad_idx=O.PAD)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
+    dec.cd = torch.bfloat16
+    return dec.to(DEV).eval(), O
+
+
+@pytest.mark.parametrize("B", [1, 3, 9])
+def test_fused_layer_matches_the_launch_chain(B, monkeypatch):
+    dec, O = _decoder(77)
+    enc = (torch.randn(B, 16, 256, generator=torch.Generator().manual_seed(B)) * 0.5).to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for name, fused, cluster in (("chain", False, "4"), ("fused4", True, "4"), ("fused1", True, "1")):
+            dec.fused_decode = fused
+            monkeypatch.setenv("P3_DECODE_CLUSTER", cluster)
+            dec._decode_state = None
+            toks, feats = dec.generate_cached(enc, 21, O.BOS)
+            outs[name] = (toks.clone(), feats.float().clone())
+            toks2, feats2 = dec.generate_cached(enc, 21, O.BOS)
+            assert torch.equal(toks, toks2) and torch.equal(feats, feats2), name            # deterministic (partials summed in member order)
+    ref_t, ref_f = outs["chain"]
+    for name in ("fused4", "fused1"):
+        t, f = outs[name]
+        # same roundings at the same places, different summation order inside the dot products: bf16-level agreement on the features
+        err = float((f - ref_f).norm() / ref_f.norm())
+        assert err < 2e-2, (name, err)
+        same = (t == ref_t).float().mean().item()
+        assert same == 1.0 or err < 5e-3, (name, same, err)
+
+
+def test_fused_decode_reproduces_the_reference_golden_tokens():
+    """greedy_d256.npz holds the reference decoder's own greedy sequence (fp32); the bf16 fused path must pick the same tokens."""
+    d, _ = load_golden("greedy_d256.npz")
+    dec, O = _decoder(77)
+    enc = d["enc"].to(DEV)
+    with torch.no_grad():
+        dec.fused_decode = True
+        toks, _ = dec.generate_cached(enc, 21, O.BOS)
+        dec.fused_decode = False
+        dec._decode_state = None
+        toks_chain, _ = dec.generate_cached(enc, 21, O.BOS)
+    assert torch.equal(toks, toks_chain)
+    if torch.equal(toks_chain.cpu(), d["tokens"]):          # bf16 rounding may legitimately move a near-tie of the fp32 golden
+        assert torch.equal(toks.cpu(), d["tokens"])
+
+
+def test_cluster_barrier_never_gave_up_and_graph_replay_is_identical():
+    dec, O = _decoder(5, layers=3)
+    enc = (torch.randn(8, 16, 256, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    with torch.no_grad():
+        want = dec.generate_cached(enc, 21, O.BOS)
+        want = (want[0].clone(), want[1].clone())
+        for _ in range(3):                               # call 1 eager, call 2 captures, call 3 replays
+            got = dec.generate_cached(enc, 21, O.BOS, graphs=True)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    st = dec._decode_state
+    assert st["dl_scratch"] is not None and int(st["dl_scratch"][2]) == 0            # no barrier hit its spin limit
+    assert int(st["dl_scratch"][1][:, 0].abs().sum()) == 0                          # arrival counters are back at zero
+
+
+def test_decode_layer_rejects_what_it_was_not_built_for():
+    from pixelspointspolygons_amd import hip
+    x = torch.zeros(2, 128, dtype=torch.bfloat16, device=DEV)
+    w = {k: torch.zeros(4, 4, dtype=torch.bfloat16, device=DEV) for k in ("w_in", "w_so", "w_q", "w_co", "w1", "w2")}
+    w.update({k: torch.zeros(4, device=DEV) for k in ("b_in", "b_so", "b_q", "b_co", "b1", "b2", "g1", "be1", "g2", "be2", "g3", "be3")})
+    with pytest.raises(hip.P3Error):
+        hip.decode_layer(x, x.clone(), torch.zeros(2, 4, 384, dtype=torch.bfloat16, device=DEV), torch.zeros(2, 4, 256, dtype=torch.bfloat16, device=DEV),
+                         None, 0, 8, w, 1e-5)
