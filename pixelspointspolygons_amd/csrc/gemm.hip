@@ -216,10 +216,15 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(lds, r0 + p * ROWS_PER_PASS, kq, ra[0][p]); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[0][p]); }
     __syncthreads();
 
-    auto step = [&](auto SET, int t) __attribute__((always_inline)) {
+    // FULL = steady state (slices t+1 and t+2 exist): no conditions around the loads / LDS stores.  With the conditions inside the loop the
+    // compiler's s_waitcnt pass sees a path on which a set's loads were never consumed and drains vmcnt BEFORE re-issuing loads into that
+    // set - i.e. the loads of slice t+2 waited for slice t+1 to land, one slice of prefetch instead of two (ISA of r02: vmcnt(3..0) at
+    // the loop head).  The last slices run the conditional form after the loop.
+    auto step = [&](auto SET, auto FULLT, int t) __attribute__((always_inline)) {
         constexpr int s0 = decltype(SET)::value;     // register set that held slice t (free now); slice t+1 is in set s0 ^ 1
+        constexpr bool FULL = decltype(FULLT)::value;
         const int cur = t & 1;
-        if (t + 2 < nk) {
+        if (FULL || t + 2 < nk) {
             const int k = (t + 2) * BK + kq;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) { ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = load_w<T>(W, wrow[p], k); }
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (t + 1 < nk) {
+        if (FULL || t + 1 < nk) {
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
@@ -266,9 +271,15 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         }
         __syncthreads();
     };
-    for (int t = 0; t < nk; t += 2) {
-        step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < nk) step(std::integral_constant<int, 1>{}, t + 1);
+    {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int t = 0;
+        for (; t + 3 < nk; t += 2) { step(S0{}, std::true_type{}, t); step(S1{}, std::true_type{}, t + 1); }
+        for (; t < nk; t += 2) {
+            step(S0{}, std::false_type{}, t);
+            if (t + 1 < nk) step(S1{}, std::false_type{}, t + 1);
+        }
     }
 
     // ---- epilogue: accumulators (+bias) -> LDS as fp32 [128][132] -> whole 8-element row chunks per thread ----------

@@ -36,7 +36,10 @@ template <typename T> struct TTr;
 template <> struct TTr<bf16_t> { static constexpr int BM = 64, PITCH = 160, ELEMS = 64 * 160; };
 template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS = 16 * 132; };  // [m][col]
 
-template <typename T>
+// GENB = false: B is a plain matrix (all weight gradients but two): no mode branches in the step, loads are UNCONDITIONAL on clamped
+// addresses and zeroed by selects (a conditional 16-byte load compiles to a branch per load; with the branches in the loop hipcc's
+// s_waitcnt pass drains vmcnt at every merge - ISA of r02: 8 branches and several vmcnt(0) per step).  GENB = true: generated B operand.
+template <typename T, bool GENB>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
@@ -87,9 +90,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
             if constexpr (BF) row = m0 + rt + 16 * i;         // thread = (row rt + 16 i, 8 columns at cv): 16-byte row-major stores
             else row = m0 + rt + 8 * i;
             const bool okr = row < m_end;
-            ra[i] = (okr && okn) ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * g.lda + coln) : u32x4{0, 0, 0, 0};
-            if (g.b_mode == 0) {
-                rb[i] = (okr && okk) ? *reinterpret_cast<const u32x4*>(B + (int64_t)row * g.ldb + colk) : u32x4{0, 0, 0, 0};
+            const int rowc = okr ? row : m_end - 1;            // m_end > m_beg whenever a step runs
+            const u32x4 va = *reinterpret_cast<const u32x4*>(A + (int64_t)rowc * g.lda + (okn ? coln : 0));
+            ra[i] = (okr && okn) ? va : u32x4{0, 0, 0, 0};
+            if constexpr (!GENB) {
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(B + (int64_t)rowc * g.ldb + (okk ? colk : 0));
+                rb[i] = (okr && okk) ? vb : u32x4{0, 0, 0, 0};
             } else {
                 u32x4 r = u32x4{0, 0, 0, 0};
                 if (okr && okk) {
@@ -174,11 +180,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     using S1 = std::integral_constant<int, 1>;
     if (nsteps > 0) { load_step(S0{}, m_beg); if (nsteps > 1) load_step(S1{}, m_beg + BM); store_step(S0{}, 0); }
     __syncthreads();
-    auto body = [&](auto SET, int t) __attribute__((always_inline)) {
+    // FULLT = steady state (steps t+1 and t+2 exist): the loads / LDS stores carry no condition.  With the conditions inside the loop hipcc's
+    // s_waitcnt pass drains vmcnt before re-issuing loads into a set (same finding as in gemm.hip); the last steps run the conditional form.
+    auto body = [&](auto SET, auto FULLT, int t) __attribute__((always_inline)) {
         // SET = register set that held step t (free now: step t is in LDS); step t+1 sits in the other set
         constexpr int s0 = decltype(SET)::value;
+        constexpr bool FULL = decltype(FULLT)::value;
         const int cur = t & 1;
-        if (t + 2 < nsteps) load_step(std::integral_constant<int, s0>{}, m_beg + (t + 2) * BM);
+        if (FULL || t + 2 < nsteps) load_step(std::integral_constant<int, s0>{}, m_beg + (t + 2) * BM);
         const T* as = lds + cur * ELEMS;
         const T* bs = lds + (2 + cur) * ELEMS;
         if constexpr (BF) {
@@ -241,12 +250,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (t + 1 < nsteps) store_step(std::integral_constant<int, s0 ^ 1>{}, cur ^ 1);
+        if (FULL || t + 1 < nsteps) store_step(std::integral_constant<int, s0 ^ 1>{}, cur ^ 1);
         __syncthreads();
     };
-    for (int t = 0; t < nsteps; t += 2) {
-        body(S0{}, t);
-        if (t + 1 < nsteps) body(S1{}, t + 1);
+    {
+        int t = 0;
+        for (; t + 3 < nsteps; t += 2) { body(S0{}, std::true_type{}, t); body(S1{}, std::true_type{}, t + 1); }
+        for (; t < nsteps; t += 2) {
+            body(S0{}, std::false_type{}, t);
+            if (t + 1 < nsteps) body(S1{}, std::false_type{}, t + 1);
+        }
     }
     if (do_cs) {   // fold the per-thread column partials (threads with equal cv) through the idle LDS, one atomic per column
         float* red = reinterpret_cast<float*>(lds);
@@ -378,8 +391,13 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.splits = splits;
     dim3 grid(tiles * splits), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, 0, s, g);
+    if (g.b_mode == 0) {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, block, 0, s, g);
+    } else {
+        if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, true>), grid, block, 0, s, g);
+    }
     if (g.slabs) {
         int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
