@@ -233,6 +233,17 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
         kreg.store(Krow, tid);
         vreg.store(Vrow, tid);
         __syncthreads();
+        // keep-bit words of this tile's 32-key halves: loaded BEFORE the next tile's prefetch is issued - vmcnt retires in order, so a
+        // small load issued after the prefetch would make its consumer wait for the whole prefetch (the ISA showed vmcnt(0) there)
+        uint32_t dwords[KT / 32];
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            dwords[sub] = 0;
+            if constexpr (DROP == 2) {
+                const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + sub;     // kw == nkw: the all-masked half of the last tile
+                if (kw < nkw) dwords[sub] = d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + qc];
+            }
+        }
         if (t + 1 < ntiles) { kreg.load(Kp, kv0 + KT, d.Lk, d.k_rs, tid); vreg.load(Vp, kv0 + KT, d.Lk, d.v_rs, tid); }
         if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
         int vis_end = kv_end;                        // keys this wave's queries can see (causal: up to its last query)
@@ -244,11 +255,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
             f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, fa, l31, hi);  // dP^T[kv, q]
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
-            uint32_t dword = 0;
-            if constexpr (DROP == 2) {
-                const int nkw = (d.Lk + 31) >> 5, kw = (kv0 >> 5) + sub;     // kw == nkw: the all-masked half of the last tile
-                if (kw < nkw) dword = d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + qc];
-            }
+            const uint32_t dword = dwords[sub];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + sub * 32 + crow32(r, hi);
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
     Stage<T, D, QT> qreg, greg;
     FragAddr<T, D> fa; fa.init(lane, l31, hi);
     if (q_begin < d.Lq) { qreg.load(Qp, q_begin, d.Lq, d.q_rs, tid); greg.load(dOp, q_begin, d.Lq, d.o_rs, tid); }
+    const int64_t word_row = (((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq;
     for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
         __syncthreads();
         qreg.store(Qrow, tid);
@@ -325,6 +333,17 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
             Ls[tid] = a.lse[stat_base + qq] * 1.4426950408889634f; Ds[tid] = a.delta[stat_base + qq];   // lse in log2 units
         }
         __syncthreads();
+        // DROP == 2: lane L loads the keep-bit word of query row q0 + sub*32 + (L & 31) for this wave's 32-key block, for both halves of
+        // the tile and BEFORE the next tile's prefetch (vmcnt retires in order: a load issued after the prefetch waits for all of it)
+        uint32_t mywords[QT / 32];
+#pragma unroll
+        for (int sub = 0; sub < QT / 32; ++sub) {
+            mywords[sub] = 0;
+            if constexpr (DROP == 2) {
+                const int qr = q0 + sub * 32 + l31;
+                if (kblk + wave * 32 < d.Lk) mywords[sub] = d.drop_rows[word_row + (qr < d.Lq ? qr : d.Lq - 1)];
+            }
+        }
         if (q0 + QT < d.Lq) { qreg.load(Qp, q0 + QT, d.Lq, d.q_rs, tid); greg.load(dOp, q0 + QT, d.Lq, d.o_rs, tid); }
         if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
@@ -336,13 +355,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
             f32x16 ds;
             // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
             const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
-            // DROP == 2: lane L loads the keep-bit word of query row q0 + sub*32 + (L & 31) for this wave's 32-key block; element r
-            // needs the word of row crow32(r, hi), fetched from that lane with two uniform-index readlanes + a select on hi
-            uint32_t myword = 0;
-            if constexpr (DROP == 2) {
-                const int qr = q0 + sub * 32 + l31;
-                myword = d.drop_rows[(((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq + (qr < d.Lq ? qr : d.Lq - 1)];
-            }
+            // element r needs the word of row crow32(r, hi), fetched from that lane with two uniform-index readlanes + a select on hi
+            const uint32_t myword = mywords[sub];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = sub * 32 + crow32(r, hi), qq = q0 + ql;
