@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     const int nqb = (d.Lq + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);      // blocks of one (batch, head) share an XCD's L2 (see attention.hip)
     const int qblk = (lid % nqb) * 128, h = (lid / nqb) % d.H, b = lid / (nqb * d.H);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
     const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(Bw
     const int nkb = (d.Lk + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int kblk = (lid % nkb) * 128, h = (lid / nkb) % d.H, b = lid / (nkb * d.H);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
     const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
