@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     __shared__ __attribute__((aligned(16))) T Ks[TR::K_ELEMS];
     __shared__ __attribute__((aligned(16))) T Vs[TR::V_ELEMS];
+    __shared__ float Kb[KT];
 
     const p3_attn_desc& d = a.d;
     // 1-D grid, XCD-aware: the q-blocks of one (batch, head) run back to back on ONE XCD, so K/V are fetched into one L2 once
@@ -162,6 +163,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();  // previous tile's LDS reads are done
         attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
+        // the tile's key bias goes through LDS (log2 units): read per element from global memory it was 32 dependent loads per tile, each
+        // followed by s_waitcnt vmcnt(0) - which also drained the next tile's prefetch (decoder self-attention: every tile has a bias)
+        if (kbias && tid < KT) { const int kvb = t * KT + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * 1.4426950408889634f; }
         __syncthreads();
         if (t + 1 < ntiles) attn_load_tile<T, D, KPT, VPT>(t + 1, tid, d, Kp, Vp, kreg, vreg);
         const int kv0 = t * KT;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + h2 * 32 + crow32(r, hi);
                     float s2 = sacc[h2][r] * c;
-                    if (kbias) s2 += kbias[kv < d.Lk ? kv : d.Lk - 1] * 1.4426950408889634f;
+                    if (kbias) s2 += Kb[h2 * 32 + crow32(r, hi)];
                     if (kv >= d.Lk || (d.causal && kv > q)) s2 = -INFINITY;
                     sacc[h2][r] = s2;
                     mx = fmaxf(mx, s2);

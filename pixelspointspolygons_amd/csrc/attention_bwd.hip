@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     using TK = Tile<T, D, KT>;
     __shared__ __attribute__((aligned(16))) T Krow[TK::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Vrow[TK::ROW_ELEMS];
+    __shared__ float Kb[KT];                                 // key bias of the staged tile, log2 units
     const p3_attn_desc& d = a.d;
     const int nqb = (d.Lq + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);      // blocks of one (batch, head) share an XCD's L2 (see attention.hip)
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
         __syncthreads();
         kreg.store(Krow, tid);
         vreg.store(Vrow, tid);
+        if (kbias && tid < KT) { const int kvb = kv0 + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * LOG2E; }   // see attention.hip
         __syncthreads();
         // keep-bit words of this tile's 32-key halves: loaded BEFORE the next tile's prefetch is issued - vmcnt retires in order, so a
         // small load issued after the prefetch would make its consumer wait for the whole prefetch (the ISA showed vmcnt(0) there)
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
                     p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse2));
                 } else {
                     float t2 = -lse2;
-                    if (kbias) t2 += kbias[kv < d.Lk ? kv : d.Lk - 1] * LOG2E;
+                    if (kbias) t2 += Kb[sub * 32 + crow32(r, hi)];
                     const bool masked = kv >= d.Lk || (d.causal && kv > q);
                     p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, t2));
                 }

@@ -29,10 +29,11 @@ for tag, B, Lq, Lk, H, D, causal, p in (("vit", 64, 785, 785, 6, 64, False, 0.0)
     drop = (seed, 7, p) if p > 0 else None
     bits = hip.attention_mask_words(B, H, Lq, Lk, "cuda") if p > 0 else None
     scale = D ** -0.5
-    o, lse = hip.attention(q, k, v, H, scale, causal=causal, need_lse=True, drop=drop, drop_rows=bits)
-    tf = timeit(lambda: hip.attention(q, k, v, H, scale, causal=causal, need_lse=True, drop=drop, drop_rows=bits))
-    tb = timeit(lambda: hip.attention_bwd(q, k, v, o, lse, do, H, scale, causal=causal, dq=dq, dk=dk, dv=dv, drop=drop, drop_rows=bits))
-    hip.attention_bwd(q, k, v, o, lse, do, H, scale, causal=causal, dq=dq, dk=dk, dv=dv, drop=drop, drop_rows=bits)
+    kb = (torch.rand(B, Lk, generator=g) < 0.1).float().cuda() if tag == "self" else None      # decoder self-attention: +1.0 on PAD keys
+    o, lse = hip.attention(q, k, v, H, scale, causal=causal, key_bias=kb, need_lse=True, drop=drop, drop_rows=bits)
+    tf = timeit(lambda: hip.attention(q, k, v, H, scale, causal=causal, key_bias=kb, need_lse=True, drop=drop, drop_rows=bits))
+    tb = timeit(lambda: hip.attention_bwd(q, k, v, o, lse, do, H, scale, causal=causal, key_bias=kb, dq=dq, dk=dk, dv=dv, drop=drop, drop_rows=bits))
+    hip.attention_bwd(q, k, v, o, lse, do, H, scale, causal=causal, key_bias=kb, dq=dq, dk=dk, dv=dv, drop=drop, drop_rows=bits)
     torch.cuda.synchronize()
     scores = B * H * Lq * Lk * (0.5 if causal else 1.0)
     r = {"shape": tag, "fwd_us": round(tf * 1e6, 1), "bwd_us": round(tb * 1e6, 1), "fwd_tflops": round(4 * scores * D / tf / 1e12, 1),
