@@ -38,11 +38,15 @@ template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS
 
 // GENB = false: B is a plain matrix (all weight gradients but two): no mode branches in the step, loads are UNCONDITIONAL on clamped
 // addresses and zeroed by selects (a conditional 16-byte load compiles to a branch per load; with the branches in the loop hipcc's
-// s_waitcnt pass drains vmcnt at every merge - ISA of r02: 8 branches and several vmcnt(0) per step).  GENB = true: generated B operand.
-template <typename T, bool GENB>
+// s_waitcnt pass drains vmcnt at every merge - ISA of r02: 8 branches and several vmcnt(0) per step).  BMODE = P3_A_AFFINE_RELU /
+// P3_A_PAIR_AFFINE_RELU: generated B operand - the raw rows (and, pair mode, the V rows) are LOADED in load_step like any operand and
+// turned into relu(scale * (x [+ y]) + shift) when they are stored to LDS (the transform at load time consumed every load at once:
+// vmcnt(0) inside the step, no prefetch at all; 519 us per ScoreNet weight gradient in r02).
+template <typename T, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
+    constexpr bool GENB = BMODE != 0, PAIR = BMODE == P3_A_PAIR_AFFINE_RELU;
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;          // byte offset of the tile buffers inside the LDS aperture (inline-asm reads)
@@ -77,8 +81,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     // two staging register sets: the loads of step t+2 are issued while step t is multiplied (a global load gets two MFMA phases to land;
     // r02 SQ counters: 46 % of the wave time parked on waits with the one-deep pipeline)
     u32x4 rsa[2][NLOAD], rsb[2][NLOAD];
+    u32x4 rsy[PAIR ? 2 : 1][PAIR ? NLOAD : 1];    // pair mode: the V rows
+    uint32_t rok[2];                              // generated B: bit i = row i of the set lies inside [m_beg, m_end)
     const int coln = tn * TN + cv, colk = tk * TK + cv;
     const bool okn = coln < g.N, okk = colk < g.K;  // N, K are multiples of VEC (checked on the host)
+    float bsc[GENB ? VEC : 1], bsh[GENB ? VEC : 1];
+    if constexpr (GENB) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { bsc[q] = okk ? g.b_scale[colk + q] : 0.f; bsh[q] = okk ? g.b_shift[colk + q] : 0.f; }
+    }
 
     auto load_step = [&](auto SET, int m0) __attribute__((always_inline)) {
         constexpr int ss = decltype(SET)::value;
@@ -97,44 +108,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                 const u32x4 vb = *reinterpret_cast<const u32x4*>(B + (int64_t)rowc * g.ldb + (okk ? colk : 0));
                 rb[i] = (okr && okk) ? vb : u32x4{0, 0, 0, 0};
             } else {
-                u32x4 r = u32x4{0, 0, 0, 0};
-                if (okr && okk) {
-                    int64_t r1 = row, r2 = 0;
-                    if (g.b_mode == P3_A_PAIR_AFFINE_RELU) {
-                        const int n = g.pair_n, nn = n * n;
-                        const int bb = row / nn, p = row - bb * nn, ii = p / n, jj = p - ii * n;
-                        r1 = (int64_t)bb * n + ii; r2 = (int64_t)bb * n + jj;
-                    }
-                    float v[VEC];
-                    const u32x4 x = *reinterpret_cast<const u32x4*>(B + r1 * g.ldb + colk);
-                    if constexpr (BF) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(x[q] << 16); v[2 * q + 1] = __uint_as_float(x[q] & 0xffff0000u); }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(x[q]);
-                    }
-                    if (g.b_mode == P3_A_PAIR_AFFINE_RELU) {
-                        const u32x4 y = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.pair_V) + r2 * g.ldb + colk);
-                        if constexpr (BF) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(y[q] << 16); v[2 * q + 1] += __uint_as_float(y[q] & 0xffff0000u); }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(y[q]);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[q] = fmaxf(v[q] * g.b_scale[colk + q] + g.b_shift[colk + q], 0.f);
-                    if constexpr (BF) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) r[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) r[q] = __float_as_uint(v[q]);
-                    }
+                int64_t r1 = rowc, r2 = 0;
+                if constexpr (PAIR) {
+                    const int n = g.pair_n, nn = n * n;
+                    const int bb = rowc / nn, p = rowc - bb * nn, ii = p / n, jj = p - ii * n;
+                    r1 = (int64_t)bb * n + ii; r2 = (int64_t)bb * n + jj;
                 }
-                rb[i] = r;
+                rb[i] = *reinterpret_cast<const u32x4*>(B + r1 * g.ldb + (okk ? colk : 0));
+                if constexpr (PAIR) rsy[ss][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.pair_V) + r2 * g.ldb + (okk ? colk : 0));
+                if (i == 0) rok[ss] = 0;
+                rok[ss] |= (uint32_t)(okr && okk) << i;
             }
         }
     };
@@ -156,6 +139,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) csum[q] += __uint_as_float(ra[i][q]);
                 }
+            }
+        }
+        if constexpr (GENB) {       // relu(scale * (x [+ y]) + shift), zero rows beyond the split
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                float v[VEC];
+                const u32x4 x = rb[i];
+                if constexpr (BF) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(x[q] << 16); v[2 * q + 1] = __uint_as_float(x[q] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(x[q]);
+                }
+                if constexpr (PAIR) {
+                    const u32x4 y = rsy[ss][i];
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(y[q] << 16); v[2 * q + 1] += __uint_as_float(y[q] & 0xffff0000u); }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += __uint_as_float(y[q]);
+                    }
+                }
+                const bool ok = (rok[ss] >> i) & 1u;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) v[q] = ok ? fmaxf(v[q] * bsc[q] + bsh[q], 0.f) : 0.f;
+                u32x4 r;
+                if constexpr (BF) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = pack_bf2(v[2 * q], v[2 * q + 1]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = __float_as_uint(v[q]);
+                }
+                rb[i] = r;
             }
         }
         T* as = lds + buf * ELEMS;
@@ -391,13 +410,15 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.splits = splits;
     dim3 grid(tiles * splits), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (g.b_mode == 0) {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, block, 0, s, g);
-    } else {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<float, true>), grid, block, 0, s, g);
-    }
+#define P3_TN_LAUNCH(MODE)                                                                            \
+    do {                                                                                              \
+        if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, MODE>), grid, block, 0, s, g); \
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, MODE>), grid, block, 0, s, g);                  \
+    } while (0)
+    if (g.b_mode == 0) P3_TN_LAUNCH(0);
+    else if (g.b_mode == P3_A_AFFINE_RELU) P3_TN_LAUNCH(P3_A_AFFINE_RELU);
+    else P3_TN_LAUNCH(P3_A_PAIR_AFFINE_RELU);
+#undef P3_TN_LAUNCH
     if (g.slabs) {
         int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
