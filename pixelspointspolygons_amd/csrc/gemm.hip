@@ -107,21 +107,26 @@ __device__ __forceinline__ uint4 load_a(const p3_gemm_desc& d, const T* A, const
         }
         return raw;
     }
-    raw = *reinterpret_cast<const uint4*>(A + r.off + k);
-    if (AMODE == P3_A_AFFINE_RELU || AMODE == P3_A_PAIR_AFFINE_RELU) {
-        float v[VEC];
-        unpack<T>(raw, v);
-        if (AMODE == P3_A_PAIR_AFFINE_RELU) {
-            float v2[VEC];
-            unpack<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(d.pair_V) + r.off2 + k), v2);
+    return *reinterpret_cast<const uint4*>(A + r.off + k);     // AFFINE_RELU / PAIR_AFFINE_RELU: raw row; xform_a() runs at LDS-store time
+}
+
+// generated A operand (ScoreNet conv2 / conv3: BN + ReLU of the producer [over the pair grid] folded into the operand): the raw U row
+// (and V row) are loaded like any operand; relu(scale * (u [+ v]) + shift) is applied when the slice is stored to LDS, with scale / shift
+// read from LDS.  (r02 applied it at load time: every load was consumed at once - s_waitcnt vmcnt(0) inside the step, no prefetch.)
+template <typename T, int AMODE>
+__device__ __forceinline__ uint4 xform_a(const uint4& raw, const uint4& raw2, const float* sc, const float* sh, int k) {
+    constexpr int VEC = VecOf<T>::VEC;
+    float v[VEC];
+    unpack<T>(raw, v);
+    if (AMODE == P3_A_PAIR_AFFINE_RELU) {
+        float v2[VEC];
+        unpack<T>(raw2, v2);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] += v2[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i] * d.a_scale[k + i] + d.a_shift[k + i], 0.f);
-        raw = repack<T>(v);
+        for (int i = 0; i < VEC; ++i) v[i] += v2[i];
     }
-    return raw;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i] * sc[k + i] + sh[k + i], 0.f);
+    return repack<T>(v);
 }
 
 // act'(.) for the fused activation backward: GELU' of the saved pre-activation, ReLU' from the saved output
@@ -204,16 +209,37 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     // sits in one set (loaded during the previous iteration, stored to the other LDS buffer after the MFMAs) and the loads of slice
     // t+2 are issued into the other set - two global-load latencies deep instead of one (SQ counters r01: GEMM waves parked 55 % of
     // their cycles on vmcnt / barriers with the one-deep pipeline).
+    constexpr bool XF = AMODE == P3_A_AFFINE_RELU || AMODE == P3_A_PAIR_AFFINE_RELU, PAIRA = AMODE == P3_A_PAIR_AFFINE_RELU;
+    constexpr int XF_MAXK = 512;                               // scale / shift of the generated operand live in LDS (host checks K)
+    __shared__ float xsc[XF ? XF_MAXK : 1], xsh[XF ? XF_MAXK : 1];
+    if constexpr (XF) {
+        for (int i = tid; i < d.K; i += 256) { xsc[i] = d.a_scale[i]; xsh[i] = d.a_shift[i]; }
+        __syncthreads();
+    }
     uint4 ra[2][NPASS], rb[2][NPASS];
+    uint4 rv[PAIRA ? 2 : 1][PAIRA ? NPASS : 1];                // pair mode: the V rows
+    auto load_v = [&](int p, int k) __attribute__((always_inline)) {
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(d.pair_V) + arow[p].off2 + k);
+    };
+    auto put_a = [&](T* buf, int set, int p, int k) __attribute__((always_inline)) {
+        if constexpr (XF) lds_put<T, PITCH>(buf, r0 + p * ROWS_PER_PASS, kq, xform_a<T, AMODE>(ra[set][p], rv[PAIRA ? set : 0][PAIRA ? p : 0], xsc, xsh, k));
+        else lds_put<T, PITCH>(buf, r0 + p * ROWS_PER_PASS, kq, ra[set][p]);
+    };
     const int nk = d.K / BK;
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { ra[0][p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[0][p] = load_w<T>(W, wrow[p], kq); }
+    for (int p = 0; p < NPASS; ++p) {
+        ra[0][p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[0][p] = load_w<T>(W, wrow[p], kq);
+        if constexpr (PAIRA) rv[0][p] = load_v(p, kq);
+    }
     if (nk > 1) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) { ra[1][p] = load_a<T, AMODE>(d, A, arow[p], BK + kq); rb[1][p] = load_w<T>(W, wrow[p], BK + kq); }
+        for (int p = 0; p < NPASS; ++p) {
+            ra[1][p] = load_a<T, AMODE>(d, A, arow[p], BK + kq); rb[1][p] = load_w<T>(W, wrow[p], BK + kq);
+            if constexpr (PAIRA) rv[1][p] = load_v(p, BK + kq);
+        }
     }
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(lds, r0 + p * ROWS_PER_PASS, kq, ra[0][p]); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[0][p]); }
+    for (int p = 0; p < NPASS; ++p) { put_a(lds, 0, p, kq); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[0][p]); }
     __syncthreads();
 
     // FULL = steady state (slices t+1 and t+2 exist): no conditions around the loads / LDS stores.  With the conditions inside the loop the
@@ -227,7 +253,10 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         if (FULL || t + 2 < nk) {
             const int k = (t + 2) * BK + kq;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = load_w<T>(W, wrow[p], k); }
+            for (int p = 0; p < NPASS; ++p) {
+                ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = load_w<T>(W, wrow[p], k);
+                if constexpr (PAIRA) rv[s0][p] = load_v(p, k);
+            }
         }
         const T* as = lds + cur * LDSE;
         const T* bs = lds + (2 + cur) * LDSE;
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { lds_put<T, PITCH>(an, r0 + p * ROWS_PER_PASS, kq, ra[s0 ^ 1][p]); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[s0 ^ 1][p]); }
+            for (int p = 0; p < NPASS; ++p) { put_a(an, s0 ^ 1, p, (t + 1) * BK + kq); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[s0 ^ 1][p]); }
         }
         __syncthreads();
     };
@@ -570,6 +599,8 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     }
     if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU || d->a_mode == P3_A_CONV3X3_AFFINE_RELU)
         P3_CHECK(d->a_scale && d->a_shift, P3_EINVAL, "p3_gemm: affine mode needs a_scale/a_shift");
+    if (d->a_mode == P3_A_AFFINE_RELU || d->a_mode == P3_A_PAIR_AFFINE_RELU)
+        P3_CHECK(d->K <= 512, P3_EUNSUP, "p3_gemm: generated A operand: K <= 512 (scale / shift tables in LDS)");
     if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
         P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
