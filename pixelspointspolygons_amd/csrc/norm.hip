@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256, (NV == 4 ? 2 : 4)) void ln_bwd_kernel(const TD
 // waiting, r01 SQ counters), so a wave carries two rows at once, gamma stays in registers for the whole block, and an optional bf16
 // copy of dx (`dx_lo`) is written from the same registers - the residual-gradient stream is fp32, but the GEMMs of the sublayer
 // below consume it in bf16: this saves their separate cast pass (a 77 MB read + a launch per sublayer).
-template <typename TDY, typename TX, typename TDX, int CPL>
+// HAS_RES: the incoming residual gradient is loaded WITH x / dy at the top of the row (r02 loaded each chunk right before its store,
+// behind `if (dres)`: three serialised load -> s_waitcnt vmcnt(0) -> store round trips per row).
+template <typename TDY, typename TX, typename TDX, int CPL, bool HAS_RES>
 __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const TDX* __restrict__ dres, TDX* __restrict__ dx, bf16_t* __restrict__ dx_lo,
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
         const bool ok = row < rend;
         const int64_t rr = ok ? row : rend - 1;
         const float mu = mean[rr], rs = rstd[rr];
-        float xh[CPL][4], d[CPL][4];
+        float xh[CPL][4], d[CPL][4], rres[HAS_RES ? CPL : 1][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
             float xv[4];
             load4<TX>(x + o, xv);
             load4<TDY>(dy + o, d[c]);
+            if constexpr (HAS_RES) load4<TDX>(dres + o, rres[c]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 xh[c][i] = (xv[i] - mu) * rs;
@@ -204,11 +207,9 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                 float ov[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ov[i] = rs * (g[c][i] * d[c][i] - s1 - xh[c][i] * s2);
-                if (dres) {
-                    float rv[4];
-                    load4<TDX>(dres + o, rv);
+                if constexpr (HAS_RES) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ov[i] += rv[i];
+                    for (int i = 0; i < 4; ++i) ov[i] += rres[c][i];
                 }
                 store4<TDX>(dx + o, ov);
                 if (dx_lo) store4<bf16_t>(dx_lo + o, ov);
@@ -282,8 +283,10 @@ extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* g
     static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)
     if (half_env < 0) { const char* e = getenv("P3_LN_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
     if ((half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768)) {
+#define LNH_R(TDY, TX, TDX, CPL, RES) \
+    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb)
 #define LNH_C(TDY, TX, TDX, CPL) \
-    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb)
+    do { if (dres) LNH_R(TDY, TX, TDX, CPL, true); else LNH_R(TDY, TX, TDX, CPL, false); } while (0)
 #define LNH(TDY, TX, TDX) \
     do { if (cols == 256) LNH_C(TDY, TX, TDX, 2); else if (cols == 384) LNH_C(TDY, TX, TDX, 3); else LNH_C(TDY, TX, TDX, 6); } while (0)
         if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNH(float, float, float);
@@ -293,6 +296,7 @@ extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* g
         else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
 #undef LNH
 #undef LNH_C
+#undef LNH_R
         P3_LAUNCH_CHECK();
         return P3_OK;
     }
