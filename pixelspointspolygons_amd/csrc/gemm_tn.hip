@@ -91,10 +91,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         for (int q = 0; q < VEC; ++q) { bsc[q] = okk ? g.b_scale[colk + q] : 0.f; bsh[q] = okk ? g.b_shift[colk + q] : 0.f; }
     }
 
-    auto load_step = [&](auto SET, int m0) __attribute__((always_inline)) {
+    // vector part of the operand addresses (thread row rt, column chunk); the step / pass part (m0 + 16 i) * ld is wave-uniform
+    const int64_t abase = (int64_t)rt * g.lda + (okn ? coln : 0), bbase = (int64_t)rt * g.ldb + (okk ? colk : 0);
+    auto load_step = [&](auto SET, auto INRANGE, int m0) __attribute__((always_inline)) {
         constexpr int ss = decltype(SET)::value;
         u32x4 (&ra)[NLOAD] = rsa[ss];
         u32x4 (&rb)[NLOAD] = rsb[ss];
+        if constexpr (decltype(INRANGE)::value && !GENB) {
+            // every row of the step lies inside the split (all steps but the last one): no clamp, no per-lane 64-bit multiply - the
+            // r02 form spent two v_mad_i64_i32 + a v_min per 16-byte load on the clamped row address
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                const int64_t ro = (int64_t)(m0 + (BF ? 16 : 8) * i);
+                const u32x4 va = *reinterpret_cast<const u32x4*>(A + abase + ro * g.lda);
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(B + bbase + ro * g.ldb);
+                ra[i] = okn ? va : u32x4{0, 0, 0, 0};
+                rb[i] = okk ? vb : u32x4{0, 0, 0, 0};
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             int row;
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     const int nsteps = (m_end - m_beg + BM - 1) / BM;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    if (nsteps > 0) { load_step(S0{}, m_beg); if (nsteps > 1) load_step(S1{}, m_beg + BM); store_step(S0{}, 0); }
+    if (nsteps > 0) { load_step(S0{}, std::false_type{}, m_beg); if (nsteps > 1) load_step(S1{}, std::false_type{}, m_beg + BM); store_step(S0{}, 0); }
     __syncthreads();
     // FULLT = steady state (steps t+1 and t+2 exist): the loads / LDS stores carry no condition.  With the conditions inside the loop hipcc's
     // s_waitcnt pass drains vmcnt before re-issuing loads into a set (same finding as in gemm.hip); the last steps run the conditional form.
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         constexpr int s0 = decltype(SET)::value;
         constexpr bool FULL = decltype(FULLT)::value;
         const int cur = t & 1;
-        if (FULL || t + 2 < nsteps) load_step(std::integral_constant<int, s0>{}, m_beg + (t + 2) * BM);
+        if (FULL || t + 2 < nsteps) load_step(std::integral_constant<int, s0>{}, FULLT, m_beg + (t + 2) * BM);
         const T* as = lds + cur * ELEMS;
         const T* bs = lds + (2 + cur) * ELEMS;
         if constexpr (BF) {
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     };
     {
         int t = 0;
-        for (; t + 3 < nsteps; t += 2) { body(S0{}, std::true_type{}, t); body(S1{}, std::true_type{}, t + 1); }
+        for (; t + 4 < nsteps; t += 2) { body(S0{}, std::true_type{}, t); body(S1{}, std::true_type{}, t + 1); }   // loads steps <= nsteps - 2: full rows
         for (; t < nsteps; t += 2) {
             body(S0{}, std::false_type{}, t);
             if (t + 1 < nsteps) body(S1{}, std::false_type{}, t + 1);
