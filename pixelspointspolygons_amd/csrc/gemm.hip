@@ -325,6 +325,44 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     const bool aux_grad = d.aux_mode == 1;
     const int act = d.act;
     const DropKey dk = drop_key(d.drop);
+    // Plain bf16 tile (bias only: no activation / aux copy / dropout / saved-activation factor / residual, N % 8 == 0): ONE pass through a
+    // bf16 image [128][136] - neighbouring lanes (= neighbouring columns of the MFMA fragment) exchange one value so that every lane packs
+    // a column PAIR of one row (32 ds_write_b32 instead of 64 per lane, all four waves at once), one barrier, 16-byte LDS reads, 16-byte
+    // stores.  No flag is tested inside the loops.  (The general form below: two passes of 64 rows through an fp32 image, four barriers.)
+    if constexpr (sizeof(TO) == 2 && sizeof(T) == 2 && !STATS) {
+        const bool simple = act == P3_ACT_NONE && !aux && !dk.on && !bwd_saved && !has_res && g.vec_epi && (d.N & 7) == 0;
+        if (__builtin_amdgcn_readfirstlane((int)simple)) {
+            constexpr int P16 = 68;                              // row pitch in dwords (136 bf16): 16-byte aligned rows
+            uint32_t* st16 = reinterpret_cast<uint32_t*>(lds);
+            const bool odd = l31 & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + l31;
+                const int col = tn * BN + cl;
+                const float bias = (d.bias && col < d.N) ? d.bias[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float v0 = acc[i][j][r] + bias, v1 = acc[i][j][r + 1] + bias;      // rows rw, rw + 1 of this lane's column
+                        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);                    // the partner's value of the row this lane packs
+                        const int rw = wm * 64 + i * 32 + crow32(r, hi) + (odd ? 1 : 0);
+                        st16[rw * P16 + (cl >> 1)] = odd ? pack_bf2(recv, v1) : pack_bf2(v0, recv);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int id = tid + 256 * c;
+                const int rl = id >> 4, cl = (id & 15) * 8;
+                const int row = tm * BM + rl, col = tn * BN + cl;
+                const uint4 o = *reinterpret_cast<const uint4*>(st16 + rl * P16 + (cl >> 1));
+                if (row < d.M && col < d.N) *reinterpret_cast<uint4*>(C + (int64_t)row * d.ldc + col) = o;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < EPI_PASSES; ++pass) {
         if (pass > 0) __syncthreads();               // the previous pass's readers are done with the staging buffer
