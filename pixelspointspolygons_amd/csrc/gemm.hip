@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const float v0 = acc[i][j][r] + bias, v1 = acc[i][j][r + 1] + bias;      // rows rw, rw + 1 of this lane's column
-                        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);                    // the partner's value of the row this lane packs
+                        // the partner's (lane ^ 1) value of the row this lane packs: DPP quad_perm [1,0,3,2] - one VALU move, no LDS crossbar
+                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v0 : v1), 0xB1, 0xf, 0xf, true));
                         const int rw = wm * 64 + i * 32 + crow32(r, hi) + (odd ? 1 : 0);
                         st16[rw * P16 + (cl >> 1)] = odd ? pack_bf2(recv, v1) : pack_bf2(v0, recv);
                     }
