@@ -44,6 +44,8 @@ __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc)
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float round_bf(float v) { return bf2f(f2bf(v)); }
+// value of lane ^ 1 (CTRL 0xB1 = quad_perm [1,0,3,2]) / lane ^ 2 (0x4E = [2,3,0,1]): a DPP move instead of an LDS-crossbar shuffle
+template <int CTRL> __device__ __forceinline__ float quad_xor(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
 
 // Sum R per-lane values over a group of LPR lanes (lane index l inside the group): every level that still has > 1 value per lane halves
 // the values (a lane keeps the half selected by its bit, the partner's half arrives by shuffle), the remaining levels are plain sums.
@@ -193,7 +195,7 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
                     d = fmaf(qv[0], bf_lo(r4.x), d); d = fmaf(qv[1], bf_hi(r4.x), d); d = fmaf(qv[2], bf_lo(r4.y), d); d = fmaf(qv[3], bf_hi(r4.y), d);
                     d = fmaf(qv[4], bf_lo(r4.z), d); d = fmaf(qv[5], bf_hi(r4.z), d); d = fmaf(qv[6], bf_lo(r4.w), d); d = fmaf(qv[7], bf_hi(r4.w), d);
                 }
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);             // 4 chunks = one head
+                d += quad_xor<0xB1>(d); d += quad_xor<0x4E>(d);             // 4 chunks = one head
                 if (j < Lk && (part & 3) == 0) s.sc[part >> 2][j] = d * scale + (kbias ? kbias[j] : 0.f);
             }
         }
@@ -292,7 +294,7 @@ __device__ __forceinline__ void attend_reg(Smem<4>& s, const bf16_t* __restrict_
             d = fmaf(qv[0], bf_lo(r4.x), d); d = fmaf(qv[1], bf_hi(r4.x), d); d = fmaf(qv[2], bf_lo(r4.y), d); d = fmaf(qv[3], bf_hi(r4.y), d);
             d = fmaf(qv[4], bf_lo(r4.z), d); d = fmaf(qv[5], bf_hi(r4.z), d); d = fmaf(qv[6], bf_lo(r4.w), d); d = fmaf(qv[7], bf_hi(r4.w), d);
         }
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);                     // 4 chunks = one head: all 4 lanes hold the score
+        d += quad_xor<0xB1>(d); d += quad_xor<0x4E>(d);                     // 4 chunks = one head: all 4 lanes hold the score
         sc[p] = j < Lk ? d * scale + kbv[p] : -INFINITY;
         mx = fmaxf(mx, sc[p]);
     }
