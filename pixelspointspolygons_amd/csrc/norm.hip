@@ -6,6 +6,17 @@
 
 namespace {
 
+// lane-group sums without the LDS crossbar where gfx9 DPP can do it: quad_perm [1,0,3,2] / [2,3,0,1] (lane ^ 1, lane ^ 2), row_half_mirror and
+// row_mirror (every lane of a 16-lane row ends up with the row sum); only the hops across rows (16, 32) use ds_bpermute.  A LayerNorm row
+// pays two such reductions; __shfl_xor compiles to ds_bpermute for every level (5-6 dependent LDS round trips).
+template <int CTRL> __device__ __forceinline__ float ln_dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float ln_row_sum(float v) {       // all 16 lanes of each DPP row <- sum over the row
+    v += ln_dpp<0xB1>(v); v += ln_dpp<0x4E>(v); v += ln_dpp<0x141>(v); v += ln_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float ln_half_sum(float v) { v = ln_row_sum(v); return v + __shfl_xor(v, 16, 64); }                 // 32-lane halves
+__device__ __forceinline__ float ln_wave_sum(float v) { v = ln_half_sum(v); return v + __shfl_xor(v, 32, 64); }                // whole wave
+
 constexpr int MAXV = 4;  // up to 4 float4-chunks per lane -> cols <= 1024
 
 template <typename T>
@@ -48,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, c
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
     }
-    const float mean = wave_sum(s) / (float)cols;
+    const float mean = ln_wave_sum(s) / (float)cols;
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, c
             for (int i = 0; i < 4; ++i) { const float dlt = v[c][i] - mean; q += dlt * dlt; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    const float rstd = rsqrtf(ln_wave_sum(q) / (float)cols + eps);
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
         const int ci = lane + 64 * c;
@@ -115,8 +126,8 @@ __global__ __launch_bounds__(256, (NV == 4 ? 2 : 4)) void ln_bwd_kernel(const TD
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)cols;
-        s2 = wave_sum(s2) / (float)cols;
+        s1 = ln_wave_sum(s1) / (float)cols;
+        s2 = ln_wave_sum(s2) / (float)cols;
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             const int ci = lane + 64 * c;
@@ -197,8 +208,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                 if (ok) { ag[c][i] += d[c][i] * xh[c][i]; ab[c][i] += d[c][i]; }
             }
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }   // within the 32-lane half
+        s1 = ln_half_sum(s1); s2 = ln_half_sum(s2);                                                      // within the 32-lane half
         s1 *= 1.f / (float)cols; s2 *= 1.f / (float)cols;
         if (ok) {
 #pragma unroll
