@@ -181,6 +181,14 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     const int ntiles = g.tiles_m * g.tiles_n;
     float cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};           // STATS: column sums of this workgroup's tiles (one tile column)
     int tn_stats = 0;
+    // -DP3_GEMM_TIMING (diagnostic build, tools/mb_gemm_stages.py): workgroup 0 stores 100 MHz timestamps of a plain tile's stages through
+    // the otherwise unused pair_V pointer
+#ifdef P3_GEMM_TIMING
+#define GT(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g.d.pair_V) reinterpret_cast<long long*>(const_cast<void*>(g.d.pair_V))[k] = wall_clock64(); } while (0)
+#else
+#define GT(k) do { } while (0)
+#endif
+    GT(0);
   int vb = blockIdx.x;
   do {
     // plain mode: one tile per workgroup, XCD-aware order (consecutive logical tiles = same A row-panel = one XCD's L2);
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         for (int i = tid; i < d.K; i += 256) { xsc[i] = d.a_scale[i]; xsh[i] = d.a_shift[i]; }
         __syncthreads();
     }
+    GT(1);
     uint4 ra[2][NPASS], rb[2][NPASS];
     uint4 rv[PAIRA ? 2 : 1][PAIRA ? NPASS : 1];                // pair mode: the V rows
     auto load_v = [&](int p, int k) __attribute__((always_inline)) {
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         }
         __syncthreads();
     };
+    GT(2);
     {
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
@@ -311,6 +321,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         }
     }
 
+    GT(3);
     // ---- epilogue: accumulators (+bias) -> LDS as fp32 [128][132] -> whole 8-element row chunks per thread ----------
     // A row-per-lane epilogue would issue 64 two-byte stores and 64 dependent residual loads per thread (measured: the
     // epilogue, not the MFMA loop, bounded the K <= 1536 GEMMs of this path); staging through the now idle operand LDS
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                 const uint4 o = *reinterpret_cast<const uint4*>(st16 + rl * P16 + (cl >> 1));
                 if (row < d.M && col < d.N) *reinterpret_cast<uint4*>(C + (int64_t)row * d.ldc + col) = o;
             }
+            GT(4);
             return;
         }
     }
