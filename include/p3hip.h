@@ -303,6 +303,9 @@ int p3_act_bwd(const void* dy, int dtype_dy, const void* saved, int dtype_saved,
                void* stream);
 /* dpos may be NULL (then take it as the column sums of dx viewed as [B, L*D]: no atomics) */
 int p3_embed_tokens_bwd(const void* dx, int dtype, const int64_t* tokens, float* demb, float* dpos, int B, int L, int D, void* stream);
+/* the embedding part alone for a vocabulary of V rows (nn.Embedding backward of model_pix2poly.py:135,164): tokens outside [0, V) are ignored;
+ * V * 256 bytes of LDS per workgroup (falls back to the atomics form above beyond 64 KiB) */
+int p3_embed_tokens_bwd_v(const void* dx, int dtype, const int64_t* tokens, float* demb, int B, int L, int D, int V, void* stream);
 /* dscale is the centred sum  sum dz*(src - mean)  when mean != NULL (feeds p3_bn_bwd_coeffs) */
 int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_ld, int dtype_src, const float* scale, const float* shift, const float* mean,
                            void* dsrc, float* dscale, float* dshift, int B, int np, int D, void* stream);

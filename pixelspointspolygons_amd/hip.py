@@ -653,8 +653,8 @@ def embed_tokens_bwd(dx, tokens, emb_shape, pos_shape):
     B, L, D = dx.shape
     demb = torch.zeros(emb_shape, dtype=torch.float32, device=dx.device)
     dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dx.device)
-    check(lib().p3_embed_tokens_bwd(ptr(dx), c_int(dt(dx)), ptr(tokens), ptr(demb), ptr(None), c_int(B), c_int(L), c_int(D), stream()),
-          "p3_embed_tokens_bwd")
+    check(lib().p3_embed_tokens_bwd_v(ptr(dx), c_int(dt(dx)), ptr(tokens), ptr(demb), c_int(B), c_int(L), c_int(D), c_int(emb_shape[0]), stream()),
+          "p3_embed_tokens_bwd_v")
     colsum(dx.reshape(B, L * D), out=dpos.reshape(-1)[:L * D])          # dpos[t] = sum over the batch: column sums, no atomics
     return demb, dpos
 

@@ -334,3 +334,18 @@ def test_decode_attention_one_query_vs_fp32_reference(B, H, D, Lk, bias):
     ref = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B, 1, E)
     assert out.shape == (B, 1, E) and out.dtype == torch.bfloat16
     assert rel_err(out.float().cpu(), ref.cpu()) < 8e-3          # bf16 output rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,dtype", [(227, torch.bfloat16), (227, torch.float32), (300, torch.bfloat16)])
+def test_embedding_backward_lds_table_vs_index_add(V, dtype):
+    """p3_embed_tokens_bwd_v: per-workgroup LDS table for small vocabularies (V = 300 takes the global-atomics fallback); PAD-heavy tokens."""
+    B, L, D = 5, 77, 256
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(0, V, (B, L), generator=g)
+    tok[:, 40:] = V - 1                                   # a long PAD tail: many rows on one table row
+    dx = (torch.randn(B, L, D, generator=g) * 0.5).to(dtype)
+    demb, dpos = _h().embed_tokens_bwd(dx.to(DEV), tok.to(DEV), (V, D), (1, L, D))
+    ref = torch.zeros(V, D, dtype=torch.float64).index_add_(0, tok.reshape(-1), dx.double().reshape(-1, D))
+    assert rel_err(demb.cpu().double(), ref) < 1e-5
+    assert rel_err(dpos.cpu().double().reshape(L, D), dx.double().sum(0)) < 1e-5
