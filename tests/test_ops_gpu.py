@@ -349,3 +349,19 @@ def test_embedding_backward_lds_table_vs_index_add(V, dtype):
     ref = torch.zeros(V, D, dtype=torch.float64).index_add_(0, tok.reshape(-1), dx.double().reshape(-1, D))
     assert rel_err(demb.cpu().double(), ref) < 1e-5
     assert rel_err(dpos.cpu().double().reshape(L, D), dx.double().sum(0)) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout,dtype", [(384, 256, torch.bfloat16), (384, 256, torch.float32), (96, 64, torch.float32), (100, 37, torch.float32)])
+def test_pool_backward_vs_adaptive_avg_pool_autograd(Din, Dout, dtype):
+    """p3_pool_pos_bwd (thread-per-channel form): gradient of drop-CLS + nn.AdaptiveAvgPool1d(Dout) over the channels (vit.py:41,49)."""
+    B, np_ = 3, 21
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(B, np_ + 1, Din, generator=g, dtype=torch.float64, requires_grad=True)
+    out = F.adaptive_avg_pool1d(y[:, 1:, :], Dout)
+    dout = torch.randn(B, np_, Dout, generator=g).to(dtype)
+    out.backward(dout.double())
+    dy = _h().pool_pos_bwd(dout.contiguous().to(DEV), (B, np_ + 1, Din), dtype)
+    tol = 1e-6 if dtype == torch.float32 else 5e-3
+    assert rel_err(dy.float().cpu().double(), y.grad) < tol
+    assert float(dy[:, 0].abs().max()) == 0.0                     # the CLS row gets no gradient from this path
