@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     for (int c = threadIdx.x; c < D; c += 256) {
         const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f, mu = mean ? mean[c] : 0.f;   // centred sum if mean given
         float a1 = 0.f, a2 = 0.f;
+        int64_t b = r0 / np;                                  // (b, p) tracked incrementally: no 64-bit division per row
+        int p = (int)(r0 - b * np);
         for (int64_t r = r0; r < r1; ++r) {
-            const int64_t b = r / np, p = r - b * np;
             float g = dx[(b * (np + 1) + 1 + p) * D + c];
+            if (++p == np) { p = 0; ++b; }
             if (scale) {
                 const float s = Cvt<TS>::to_f(src[r * src_ld + c]);
                 if (s * sc + sh <= 0.f) g = 0.f;
