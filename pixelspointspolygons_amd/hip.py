@@ -605,12 +605,16 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
     return dq, dk, dv
 
 
-TN_MAX_SLABS = 0     # > 0: store split-M partials in scratch slabs + reduce (measured slower than the fp32 atomics on MI355X; kept for A/B)
+import os as _os
+TN_MAX_SLABS = int(_os.environ.get("P3_TN_SLABS", "0"))     # > 0: store split-M partials in scratch slabs + reduce instead of fp32 atomics
+
+
+TN_SLAB_MAX_NK = int(_os.environ.get("P3_TN_SLAB_NK", "0"))    # slabs only for outputs of at most this many elements (0: every output)
 
 
 def _tn_slabs(N, K, device):
     """scratch for the split-M partial tiles of the weight-gradient GEMM (stored + reduced instead of fp32 atomics)."""
-    if TN_MAX_SLABS <= 0:
+    if TN_MAX_SLABS <= 0 or (TN_SLAB_MAX_NK > 0 and N * K > TN_SLAB_MAX_NK):
         return None
     return workspace(TN_MAX_SLABS * N * K * 4 + 16, device, "tn_slabs")
 
