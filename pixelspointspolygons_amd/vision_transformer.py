@@ -83,6 +83,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
 
+RESIDUAL_IN_CD = [__import__("os").environ.get("P3_RES_BF16") == "1"]    # bf16 residual stream in throughput mode (measured, not adopted: see DESIGN)
+
+
 class Block(nn.Module):
     """timm Block (pre-norm, no LayerScale, no drop-path): x += proj(SDPA(qkv(LN1 x))); x += fc2(GELU(fc1(LN2 x)))."""
 
@@ -94,14 +97,15 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, mlp_dim)
 
     def run(self, x, cd):
-        """x: fp32 residual stream [B, L, D]."""
+        """x: residual stream [B, L, D] - fp32 (default), or the compute dtype under RESIDUAL_IN_CD (experiment switch P3_RES_BF16=1)."""
+        rdt = cd if RESIDUAL_IN_CD[0] else torch.float32
         x, h = ops.layernorm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
         qkv = ops.linear(h, self.attn.qkv.weight, self.attn.qkv.bias, cd=cd)
         a = ops.self_attention(qkv, self.attn.num_heads)
-        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=torch.float32, cd=cd)
+        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=rdt, cd=cd)
         x, h = ops.layernorm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
         return ops.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, act=hip.ACT_GELU, residual=x,
-                       out_dtype=torch.float32, cd=cd)
+                       out_dtype=rdt, cd=cd)
 
 
 _TIMM_SHAPES = {  # model_name prefix -> (dim, depth, heads)
