@@ -22,6 +22,18 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
     }
 }
 
+// Row form (K = Cin*P*P <= 1024): one workgroup per patch, thread k = (c, py, px); the patch coordinates are worked out once per workgroup
+template <typename T>
+__global__ void patchify_rows_kernel(const float* __restrict__ img, T* __restrict__ out, int Cin, int H, int W, int P) {
+    const int gw = W / P, gh = H / P, K = Cin * P * P;
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    const int row = blockIdx.x;
+    const int gx = row % gw, gy = (row / gw) % gh, b = row / (gw * gh);
+    const int px = k % P, py = (k / P) % P, c = k / (P * P);
+    out[(int64_t)row * K + k] = Cvt<T>::from_f(img[(((int64_t)b * Cin + c) * H + gy * P + py) * W + gx * P + px]);
+}
+
 // ---- tokens_assemble: x[b,0,:] = cls + pos[0]; x[b,1+p,:] = f(src[b,p,:]) + pos[1+p]  (f = BN+ReLU affine or identity) ----
 template <typename TS>
 __global__ void tokens_assemble_kernel(const TS* __restrict__ src, int src_ld, const float* __restrict__ scale,
@@ -314,6 +326,13 @@ extern "C" int p3_patchify(const float* img, void* out, int B, int Cin, int H, i
     P3_CHECK(img && out && B > 0 && H % P == 0 && W % P == 0, P3_ESHAPE, "p3_patchify: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * Cin * H * W;
+    if (Cin * P * P <= 1024 && (int64_t)B * (H / P) * (W / P) < (1ll << 31)) {
+        const dim3 gr((unsigned)(B * (H / P) * (W / P))), bl((unsigned)((Cin * P * P + 63) / 64 * 64));
+        DISPATCH_T(dtype_out, hipLaunchKernelGGL((patchify_rows_kernel<bf16_t>), gr, bl, 0, s, img, (bf16_t*)out, Cin, H, W, P),
+                   hipLaunchKernelGGL((patchify_rows_kernel<float>), gr, bl, 0, s, img, (float*)out, Cin, H, W, P), "p3_patchify");
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     DISPATCH_T(dtype_out, hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, img, (bf16_t*)out, B, Cin, H, W, P),
                hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, img, (float*)out, B, Cin, H, W, P), "p3_patchify");
     P3_LAUNCH_CHECK();
