@@ -306,9 +306,22 @@ __global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restri
     const int b = blockIdx.x;
     const int per = (N + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = min(N, i0 + per);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float su = 0.f, sv = 0.f;
-        for (int i = 0; i < N; ++i) { su += Cvt<T>::to_f(U[((int64_t)b * N + i) * C + c]); sv += Cvt<T>::to_f(V[((int64_t)b * N + i) * C + c]); }
+        // eight rows in flight per step (four partial sums per operand): a one-row-at-a-time loop is a chain of N dependent load latencies
+        float pu[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* up = U + (int64_t)b * N * C + c;
+        const T* vp = V + (int64_t)b * N * C + c;
+        int i = 0;
+        for (; i + 8 <= N; i += 8) {
+            float tu[8], tv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { tu[q] = Cvt<T>::to_f(up[(int64_t)(i + q) * C]); tv[q] = Cvt<T>::to_f(vp[(int64_t)(i + q) * C]); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { pu[q & 3] += tu[q]; pv[q & 3] += tv[q]; }
+        }
+        for (; i < N; ++i) { pu[0] += Cvt<T>::to_f(up[(int64_t)i * C]); pv[0] += Cvt<T>::to_f(vp[(int64_t)i * C]); }
+        const float su = (pu[0] + pu[1]) + (pu[2] + pu[3]), sv = (pv[0] + pv[1]) + (pv[2] + pv[3]);
         const float ac = (float)N * a[c], bc = bco[c];
+#pragma unroll 4
         for (int i = i0; i < i1; ++i) {
             const int64_t o = ((int64_t)b * N + i) * C + c;
             dU[o] += ac + bc * ((float)N * Cvt<T>::to_f(U[o]) + sv);
