@@ -81,16 +81,26 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
         float a1 = 0.f, a2 = 0.f;
         int64_t b = r0 / np;                                  // (b, p) tracked incrementally: no 64-bit division per row
         int p = (int)(r0 - b * np);
-        for (int64_t r = r0; r < r1; ++r) {
-            float g = dx[(b * (np + 1) + 1 + p) * D + c];
-            if (++p == np) { p = 0; ++b; }
-            if (scale) {
-                const float s = Cvt<TS>::to_f(src[r * src_ld + c]);
-                if (s * sc + sh <= 0.f) g = 0.f;
-                a1 += g * (s - mu); a2 += g;
-                g *= sc;
+        for (int64_t rq = r0; rq < r1; rq += 4) {              // four rows in flight: loads first, then the arithmetic
+            float g[4], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = rq + q < r1;
+                g[q] = ok ? dx[(b * (np + 1) + 1 + p) * D + c] : 0.f;
+                sv[q] = (ok && scale) ? Cvt<TS>::to_f(src[(rq + q) * src_ld + c]) : 0.f;
+                if (ok && ++p == np) { p = 0; ++b; }
             }
-            dsrc[r * D + c] = Cvt<TS>::from_f(g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (rq + q >= r1) break;
+                float gg = g[q];
+                if (scale) {
+                    if (sv[q] * sc + sh <= 0.f) gg = 0.f;
+                    a1 += gg * (sv[q] - mu); a2 += gg;
+                    gg *= sc;
+                }
+                dsrc[(rq + q) * D + c] = Cvt<TS>::from_f(gg);
+            }
         }
         if (scale) { atomicAdd(dscale + c, a1); atomicAdd(dshift + c, a2); }
     }
@@ -227,7 +237,11 @@ extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_
     P3_CHECK(dx && src && dsrc && B > 0, P3_EINVAL, "p3_tokens_assemble_bwd: bad arguments");
     P3_CHECK(!scale || (shift && dscale && dshift), P3_EINVAL, "p3_tokens_assemble_bwd: scale needs shift/dscale/dshift");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = 64;
+    // rows per workgroup (P3_ASM_RPB): fewer rows = more same-address atomics on the per-channel sums, more rows = a longer serial walk per
+    // workgroup; measured 8: 200 us, 16: 125, 32: 94, 64: 99, 128: 142, 192: 205
+    static int rpb_env = -1;
+    if (rpb_env < 0) { const char* e = getenv("P3_ASM_RPB"); rpb_env = e ? atoi(e) : 0; }
+    const int rpb = rpb_env > 0 ? rpb_env : 48;
     dim3 g(p3_ceil_div((int64_t)B * np, rpb)), b(256);
     if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, mean, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb);
     else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, mean, (float*)dsrc, dscale, dshift, B, np, D, rpb);
