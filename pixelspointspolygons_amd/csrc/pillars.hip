@@ -622,6 +622,56 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max
     }
 }
 
+// bf16 canvas gradient, C % 8 == 0, C <= 512, 16-byte aligned rows: a lane owns 8 channels - the four per-channel BatchNorm vectors live in
+// registers for the whole walk (the column-group form re-read them for every pillar), one 16-byte / two 16-byte accesses per tensor
+__global__ __launch_bounds__(256) void pfn_bwd_l2_stats8_kernel(VoxTab t, int max_voxels, int nslots, int C, int ncell,
+                                                                const bf16_t* __restrict__ dcanvas, int dld, const float* __restrict__ sc2,
+                                                                const float* __restrict__ sh2, const float* __restrict__ mean2,
+                                                                const float* __restrict__ rstd2, float* __restrict__ hmax,
+                                                                float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = lane * 8;
+    const bool act = c0 < C;
+    float sc[8], sh[8], mu[8], rs[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = act ? sc2[c0 + k] : 0.f; sh[k] = act ? sh2[c0 + k] : 0.f; mu[k] = act ? mean2[c0 + k] : 0.f; rs[k] = act ? rstd2[c0 + k] : 0.f;
+        s1[k] = 0.f; s2[k] = 0.f;
+    }
+    for (int v = blockIdx.x * 4 + wv; v < nslots; v += gridDim.x * 4) {
+        const int b = v / max_voxels;
+        if ((v % max_voxels) >= t.nvox[b]) continue;
+        if (!act) continue;
+        const int xyf = t.xy[v];
+        const bool live = (xyf & (1 << 30)) == 0;
+        const uint4 raw = *reinterpret_cast<const uint4*>(dcanvas + ((int64_t)b * ncell + (xyf & 0xffffff)) * dld + c0);
+        float* hx = hmax + (int64_t)v * C + c0;
+        float* hn = hmin + (int64_t)v * C + c0;
+        const float4 x0 = *reinterpret_cast<const float4*>(hx), x1 = *reinterpret_cast<const float4*>(hx + 4);
+        const float4 n0 = *reinterpret_cast<const float4*>(hn), n1 = *reinterpret_cast<const float4*>(hn + 4);
+        const float hxv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, hnv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+        float gv[8], hs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hs[k] = sc[k] > 0.f ? hxv[k] : hnv[k];
+            const float y = sc[k] * hs[k] + sh[k];
+            const float g = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+            gv[k] = (live && y > 0.f) ? g : 0.f;
+            s1[k] += gv[k]; s2[k] += gv[k] * (hs[k] - mu[k]) * rs[k];
+        }
+        *reinterpret_cast<float4*>(hx) = make_float4(gv[0], gv[1], gv[2], gv[3]); *reinterpret_cast<float4*>(hx + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+        *reinterpret_cast<float4*>(hn) = make_float4(hs[0], hs[1], hs[2], hs[3]); *reinterpret_cast<float4*>(hn + 4) = make_float4(hs[4], hs[5], hs[6], hs[7]);
+    }
+    __shared__ float red[4][2 * 512];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[wv][c0 + k] = s1[k]; red[wv][512 + c0 + k] = s2[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dbeta + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        atomicAdd(dgamma + c, (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]));
+    }
+}
+
 // step 2: H2 rows -> dH2 rows in place:  gamma*rstd * (g [first arg-max row] - w_row * (dbeta + xhat * dgamma) / n)
 template <typename T>
 __global__ __launch_bounds__(256) void pfn_bwd_l2_rows_kernel(VoxTab t, int max_voxels, int max_points, int nslots, int C, T* __restrict__ H2,
@@ -649,6 +699,55 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows_kernel(VoxTab t, int max_
                 float dv = -wgt * (a + (val - mean) * rstd * bb);
                 if (!found && val == hs) { dv += gv; found = true; }
                 base[(int64_t)r * C + c] = Cvt<T>::from_f(gm * dv);
+            }
+        }
+    }
+}
+
+// bf16, C % 8 == 0, C <= 512: a lane owns 8 channels (16-byte row accesses, the per-channel constants in registers for the whole walk)
+__global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max_voxels, int max_points, int nslots, int C, bf16_t* __restrict__ H2,
+                                                               const float* __restrict__ g, const float* __restrict__ hsel,
+                                                               const float* __restrict__ gamma2, const float* __restrict__ mean2,
+                                                               const float* __restrict__ rstd2, const float* __restrict__ dbeta,
+                                                               const float* __restrict__ dgamma, const int* __restrict__ totals, int training) {
+    const int lane = threadIdx.x & 63, c0 = lane * 8;
+    if (c0 >= C) return;
+    const float inv_n = training ? 1.f / fmaxf((float)totals[0] * (float)max_points, 1.f) : 0.f;
+    float mean[8], rstd[8], gm[8], a[8], bb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mean[k] = mean2[c0 + k]; rstd[k] = rstd2[c0 + k]; gm[k] = gamma2[c0 + k] * rstd[k];
+        a[k] = dbeta[c0 + k] * inv_n; bb[k] = dgamma[c0 + k] * inv_n;
+    }
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        const int cnt = t.cnt[v];
+        const int nrow = cnt + (cnt < max_points ? 1 : 0);
+        bf16_t* base = H2 + (int64_t)t.row[v] * C + c0;
+        const float* gp = g + (int64_t)v * C + c0;
+        const float* hp = hsel + (int64_t)v * C + c0;
+        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(hp), h1 = *reinterpret_cast<const float4*>(hp + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, hs[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        uint32_t found = 0;                              // bit k: the arg-max row of channel k has been credited
+        for (int r0 = 0; r0 < nrow; r0 += 4) {
+            uint4 raw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[q] = r0 + q < nrow ? *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + q) * C) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (r0 + q >= nrow) break;
+                const float wgt = r0 + q < cnt ? 1.f : (float)(max_points - cnt);
+                const uint32_t wd[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float val = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    float dv = -wgt * (a[k] + (val - mean[k]) * rstd[k] * bb[k]);
+                    if (!((found >> k) & 1u) && val == hs[k]) { dv += gv[k]; found |= 1u << k; }
+                    o[k] = gm[k] * dv;
+                }
+                *reinterpret_cast<uint4*>(base + (int64_t)(r0 + q) * C) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
             }
         }
     }
@@ -921,13 +1020,18 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     const bool bf = d->dtype == P3_BF16;
     if (phases & 1) {
     if (bf)
+        if (C % 8 == 0 && C <= 512 && d->out_col_off % 8 == 0 && dcanvas_ld % 8 == 0 && ((uintptr_t)dcanvas % 16) == 0)
+            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel, dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+        else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     P3_LAUNCH_CHECK();
     }
     if (phases & 2) {
-    if (bf)
+    if (bf && C % 8 == 0 && C <= 512)
+        hipLaunchKernelGGL(pfn_bwd_l2_rows8_kernel, dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
+    else if (bf)
         hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
     else
         hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
