@@ -350,7 +350,8 @@ int p3_row_affine_bwd2(const void* dA, const float* dS, const void* H, const flo
                        const float* w4, void* dHd, float* acc, const float* fix_a, const float* fix_b, int64_t R, int C, int N,
                        int transpose, int dtype, void* stream);
 /* BatchNorm backward through scale/shift and (train mode) the batch statistics: d(pre) = direct + a[c] + b[c]*pre.
- * `dscale` is the CENTRED sum  sum dz*(pre - mean)  as accumulated by p3_row_affine_bwd / p3_pair_bwd (acc[0:C]) */
+ * `dscale` is the CENTRED sum  sum dz*(pre - mean)  as accumulated by p3_row_affine_bwd / p3_pair_bwd (acc[0:C]).
+ * training: bit 0 = batch statistics (a, b non-zero), bit 1 = dgamma / dbeta are accumulated (+=) instead of stored */
 int p3_bn_bwd_coeffs(const float* dscale, const float* dshift, const float* gamma, const float* mean, const float* rstd, float count,
                      int training, int C, float* dgamma, float* dbeta, float* a, float* b, void* stream);
 int p3_affine_fix(void* dH, const void* H, const float* a, const float* b, int64_t R, int C, int dtype, void* stream);

@@ -24,33 +24,36 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dS, w4 = dout.contiguous(), net.conv4.weight.detach().reshape(-1)
     dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dS, w4=w4, N=N, transpose=transpose_acc, store=not training)
     dw4, db4 = acc3[128:192].view(1, 64, 1, 1), acc3[192:193]
-    dg3, dbt3, a3, b3 = ops.bn_backward_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training)
+    dg3, dbt3, a3, b3 = ops.bn_backward_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training, params=(net.bn3.weight, net.bn3.bias))
     if training:
         dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, None, dS=dS, w4=w4, N=N, transpose=transpose_acc, fix=(a3, b3))
     # ---- conv3 (+ BN2/ReLU in front of it)
-    dW3 = hip.gemm_tn_ex(dH3, H2, torch.zeros(64, 128, **f32), hip.A_AFFINE_RELU, sc2, sh2)
+    # weight gradients: the split-M atomics of the TN GEMMs accumulate straight into the gradient arena in direct-gradient mode
+    gw = {n: ops.direct_grads(getattr(net, n).weight) for n in ("conv1", "conv2", "conv3")}
+    wout = lambda n, r, c: gw[n][0].view(r, c) if gw[n] is not None else torch.zeros(r, c, **f32)
+    dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
     db3 = ops.bias_grad_before_bn(dH3, training)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
     dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
-    dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training)
+    dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training, params=(net.bn2.weight, net.bn2.bias))
     if training:
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
-    dW2 = hip.gemm_tn_ex(dH2, U, torch.zeros(128, 256, **f32), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
+    dW2 = hip.gemm_tn_ex(dH2, U, wout("conv2", 128, 256), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
     db2 = ops.bias_grad_before_bn(dH2, training)
     w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
     dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
     acc1 = torch.zeros(2 * 256, **f32)
     dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
-    dg1, dbt1, a1, b1 = ops.bn_backward_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training)
+    dg1, dbt1, a1, b1 = ops.bn_backward_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training, params=(net.bn1.weight, net.bn1.bias))
     if training:
         hip.pair_stats_bwd(U, V, a1, b1, dU, dV, B, N)
     # ---- conv1 (separable): U = F W1a^T + b1, V = F W1b^T
     dUc, dVc = hip.cast(dU, cd), hip.cast(dV, cd)
     F2 = F_.view(B * N, D)
-    dW1 = torch.zeros(256, 2 * D, **f32)
+    dW1 = wout("conv1", 256, 2 * D)
     hip.gemm_tn(dUc, F2, out=dW1[:, :D])
     hip.gemm_tn(dVc, F2, out=dW1[:, D:])
     db1 = ops.bias_grad_before_bn(dU, training)
@@ -58,8 +61,11 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dF = hip.gemm(dUc, w1t[:D], out_dtype=torch.float32)
     dF = hip.gemm(dVc, w1t[D:], out_dtype=torch.float32, residual=dF)
     dfeats = hip.pair_mean_bwd(dF, B, L, N, D, feats.dtype)
-    grads = {"conv1.weight": dW1.view(256, 2 * D, 1, 1), "conv1.bias": db1, "bn1.weight": dg1, "bn1.bias": dbt1,
-             "conv2.weight": dW2.view(128, 256, 1, 1), "conv2.bias": db2, "bn2.weight": dg2, "bn2.bias": dbt2,
-             "conv3.weight": dW3.view(64, 128, 1, 1), "conv3.bias": db3, "bn3.weight": dg3, "bn3.bias": dbt3,
+    wret = lambda n, t, shape: None if gw[n] is not None else t.view(*shape)        # None: already in the arena
+    if any(v is not None for v in gw.values()):
+        ops._grad_ready(*(getattr(net, n).weight for n in gw if gw[n] is not None))
+    grads = {"conv1.weight": wret("conv1", dW1, (256, 2 * D, 1, 1)), "conv1.bias": db1, "bn1.weight": dg1, "bn1.bias": dbt1,
+             "conv2.weight": wret("conv2", dW2, (128, 256, 1, 1)), "conv2.bias": db2, "bn2.weight": dg2, "bn2.bias": dbt2,
+             "conv3.weight": wret("conv3", dW3, (64, 128, 1, 1)), "conv3.bias": db3, "bn3.weight": dg3, "bn3.bias": dbt3,
              "conv4.weight": dw4, "conv4.bias": db4}
     return dfeats, [grads[n] for n, _ in net.named_parameters()]

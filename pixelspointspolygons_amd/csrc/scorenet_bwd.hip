@@ -113,9 +113,9 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dscale, const flo
     if (c >= C) return;
     // dscale here is the CENTRED sum  sum dz*(pre - mean)  (= dscale_raw - dshift*mean, accumulated without cancellation)
     const float ds = dscale[c], dh = dshift[c], g = gamma[c], m = mean[c], rs = rstd[c];
-    dgamma[c] = ds * rs;
-    dbeta[c] = dh;
-    if (training) {
+    if (training & 2) { dgamma[c] += ds * rs; dbeta[c] += dh; }      // accumulate into the gradient arena (single writer per channel)
+    else { dgamma[c] = ds * rs; dbeta[c] = dh; }
+    if (training & 1) {
         const float dmean = -dh * g * rs;
         const float drstd = ds * g;
         const float dvar = -0.5f * drstd * rs * rs * rs;

@@ -79,7 +79,7 @@ class _FusionConvBN(torch.autograd.Function):
         scale, shift, mean, rstd = hip.bn_finalize(sums, float(B * g * g * world), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum, training, save=True)
         if training:
-            bn.num_batches_tracked += 1
+            ops.bump_batches_tracked(bn)
         ctx.save_for_backward(canvas, pre, w, gamma, mean, rstd)
         ctx.mod, ctx.B = mod, B
         ctx.mark_non_differentiable(mean)
@@ -92,18 +92,17 @@ class _FusionConvBN(torch.autograd.Function):
         canvas, pre, w, gamma, mean, rstd = ctx.saved_tensors
         mod, B = ctx.mod, ctx.B
         cd, g, D = mod.cd, mod.g, mod.D
+        bn = mod.fusion_layer[1]
         M = B * g * g
         dpre = dpre.contiguous()
-        dg, dbt, a, b = ops.bn_backward_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training)
+        dg, dbt, a, b = ops.bn_backward_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training, params=(bn.weight, bn.bias))
         if mod.training:
             hip.affine_fix(dpre, pre, a, b)
         db = ops.bias_grad_before_bn(dpre, mod.training)
         # weight gradient: dW[co, tap, ci] = sum_rows dpre[r, co] * canvas[r + shift(tap), ci] in the zero-bordered row space
         P = g + 2
-        dp = torch.zeros((B, P, P, D), dtype=cd, device=dpre.device)
-        dp[:, 1:g + 1, 1:g + 1] = dpre.view(B, g, g, D)
-        cp = torch.zeros((B, P, P, 2 * D), dtype=cd, device=dpre.device)
-        cp[:, 1:g + 1, 1:g + 1] = canvas.view(B, g, g, 2 * D)
+        dp = hip.pad_nhwc(dpre.view(M, D), D, None, None, 0, D, D, B, g, g)                      # border + interior in one pass each
+        cp = hip.pad_nhwc(canvas.reshape(M, 2 * D), 2 * D, None, None, 0, 2 * D, 2 * D, B, g, g)
         dp2, cp2 = dp.view(B * P * P, D), cp.view(B * P * P, 2 * D)
         R = B * P * P
         dW2 = torch.zeros((D, 9 * 2 * D), dtype=torch.float32, device=dpre.device)

@@ -762,12 +762,15 @@ def row_affine_bwd(H, scale, shift, mean, acc, *, dA=None, dS=None, w4=None, N=0
     return out
 
 
-def bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
+def bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training, acc=None):
+    """acc = (dgamma, dbeta) fp32 [C] accumulators (the parameters' .grad views): += instead of fresh tensors (returned as None)."""
     C = gamma.shape[0]
     o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
-    check(lib().p3_bn_bwd_coeffs(ptr(dscale), ptr(dshift), ptr(gamma), ptr(mean), ptr(rstd), c_float(count), c_int(int(training)), c_int(C),
-                                 ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), stream()), "p3_bn_bwd_coeffs")
-    return o[0], o[1], o[2], o[3]
+    dg, db = (acc[0], acc[1]) if acc is not None else (o[0], o[1])
+    check(lib().p3_bn_bwd_coeffs(ptr(dscale), ptr(dshift), ptr(gamma), ptr(mean), ptr(rstd), c_float(count),
+                                 c_int(int(bool(training)) | (2 if acc is not None else 0)), c_int(C),
+                                 ptr(dg), ptr(db), ptr(o[2]), ptr(o[3]), stream()), "p3_bn_bwd_coeffs")
+    return (None, None, o[2], o[3]) if acc is not None else (o[0], o[1], o[2], o[3])
 
 
 def affine_fix(dH, H, a, b, ldh=None):

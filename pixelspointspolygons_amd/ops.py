@@ -30,6 +30,31 @@ def _grad_ready(*params):
                 cb(p)
 
 
+_BUMPS = [None]         # list of num_batches_tracked buffers while a model forward defers their "+= 1" to one multi-tensor launch
+
+
+def bump_batches_tracked(bn):
+    """nn.BatchNorm's `num_batches_tracked += 1` of a training forward (one tiny launch per site, or deferred, see defer_bumps)."""
+    if _BUMPS[0] is None:
+        bn.num_batches_tracked += 1
+    else:
+        _BUMPS[0].append(bn.num_batches_tracked)
+
+
+class defer_bumps:
+    """Context of one model forward: the BatchNorm sites' counter increments are collected and issued as ONE multi-tensor add."""
+
+    def __enter__(self):
+        self.outer, _BUMPS[0] = _BUMPS[0], []
+        return self
+
+    def __exit__(self, *exc):
+        mine, _BUMPS[0] = _BUMPS[0], self.outer
+        if mine and exc[0] is None:
+            torch._foreach_add_(mine, 1)
+        return False
+
+
 SYNC_BN = [False]       # set by the model factories when cfg.host.multi_gpu (nn.SyncBatchNorm.convert_sync_batchnorm, model_pix2poly.py:326)
 
 
@@ -82,14 +107,25 @@ def bias_grad_before_bn(dH, training):
     (0.3-0.6 GB per ScoreNet layer) is not computed; the reference's autograd produces rounding noise (~1e-9) there.  Eval mode
     (running statistics) has a real gradient."""
     if training:
-        return torch.zeros(dH.shape[1], dtype=torch.float32, device=dH.device)
+        return None if DIRECT_GRAD[0] else torch.zeros(dH.shape[1], dtype=torch.float32, device=dH.device)
     return hip.colsum(dH)
 
 
-def bn_backward_coeffs(dscale, dshift, gamma, mean, rstd, count, training):
+def direct_grads(*params):
+    """The parameters' gradient-arena views when kernels may accumulate straight into them (FlatAdamW direct_grad), else None."""
+    if DIRECT_GRAD[0] and all(p is not None and p.grad is not None and p.grad.is_contiguous() for p in params):
+        return tuple(p.grad for p in params)
+    return None
+
+
+def bn_backward_coeffs(dscale, dshift, gamma, mean, rstd, count, training, params=None):
     """(dgamma, dbeta, a, b) of a BatchNorm backward: parameter gradients from THIS rank's sums (DDP averages them), input-gradient
-    coefficients from the all-reduced sums and the global count when SyncBatchNorm is on (torch's SyncBatchNorm backward)."""
-    dg, dbt, a, b = hip.bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training)
+    coefficients from the all-reduced sums and the global count when SyncBatchNorm is on (torch's SyncBatchNorm backward).
+    params = (weight, bias) Parameters: in direct-gradient mode dgamma / dbeta are accumulated into their .grad (returned as None)."""
+    acc = direct_grads(*params) if params is not None else None
+    dg, dbt, a, b = hip.bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training, acc=acc)
+    if acc is not None:
+        _grad_ready(*params)
     if training and sync_active():
         gs, gh = dscale.clone(), dshift.clone()
         w = sync_stats(gs, gh)
@@ -249,13 +285,37 @@ def _to_cd(t2, cd):
 
 
 # ---------------------------------------------------------------------------------------------- Linear
+class GradSlot:
+    """Hand-over of a gradient between two backward nodes that autograd would otherwise join with a cast + add pass.
+
+    A tensor x that feeds both a GEMM (`linear(x, ..., gin=slot)` / `mlp`) and a later residual add (`linear(a, ..., residual=x,
+    gout_res=slot)`) gets  dL/dx = dX_gemm + dY_residual.  The residual consumer runs first in backward: it leaves its fp32 dY in
+    the slot (and returns no gradient for `residual`), the GEMM consumer adds it in the epilogue of its dX GEMM (p3_gemm residual,
+    fp32 in, compute dtype out).  `gout_x` chains the same way through several GEMM consumers of one tensor (the six memory
+    projections of the decoder).  The slot is armed by the forward of the node that will consume it, so nothing is dropped when
+    that node needs no input gradient."""
+    __slots__ = ("g", "armed")
+
+    def __init__(self):
+        self.g, self.armed = None, False
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x [.., K] compute dtype; W [N, K] fp32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows, drop):
+    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows, drop, gin, gout_res, gout_x):
         w = shadow(weight, cd)
         ctx.bias_param = bias
+        ctx.gout_x = gout_x if (gout_x is not None and gout_x.armed) else None        # read before this node arms the same slot
+        ctx.gin = gin if ctx.needs_input_grad[0] else None
+        if ctx.gin is not None:
+            gin.armed = True
+        ctx.gout_res = gout_res if (gout_res is not None and gout_res.armed and residual is not None) else None
         if rows is not None:
             w = w[rows[0]:rows[1]]
             bias = bias[rows[0]:rows[1]] if bias is not None else None
@@ -282,6 +342,8 @@ class _Linear(torch.autograd.Function):
         cd = ctx.cd
         dy2 = dy.reshape(-1, dy.shape[-1])
         dres = dy if ctx.has_res else None
+        if ctx.gout_res is not None:
+            ctx.gout_res.g, dres = dy, None
         # dpre = dy * act'(pre), in compute dtype
         drop = ctx.drop
         if ctx.act == hip.ACT_NONE:
@@ -304,7 +366,10 @@ class _Linear(torch.autograd.Function):
             nfull = (weight.shape[0] + 63) // 64 * 64
             wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
             wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
-            dx = hip.gemm(dpre, wt, out_dtype=cd).view(ctx.xshape)
+            gother = ctx.gin.take() if ctx.gin is not None else None
+            dx = hip.gemm(dpre, wt, out_dtype=cd, residual=gother.reshape(-1, gother.shape[-1]) if gother is not None else None).view(ctx.xshape)
+            if ctx.gout_x is not None:
+                ctx.gout_x.g, dx = dx, None
         direct = DIRECT_GRAD[0] and weight.grad is not None and dpre.shape[1] == n_true
         bias_p = ctx.bias_param
         if direct:
@@ -318,7 +383,7 @@ class _Linear(torch.autograd.Function):
                 else:
                     db = hip.colsum(dpre)
             _grad_ready(weight, bias_p if ctx.has_bias else None)
-            return dx, None, db, dres, None, None, None, None, None
+            return dx, None, db, dres, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
             if rows is not None:
@@ -331,13 +396,15 @@ class _Linear(torch.autograd.Function):
                 full = torch.zeros(weight.shape[0], dtype=torch.float32, device=db.device)
                 full[rows[0]:rows[1]] = db
                 db = full
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=None, cd=torch.float32, rows=None, drop=None):
+def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=None, cd=torch.float32, rows=None, drop=None, gin=None,
+           gout_res=None, gout_x=None):
     """rows=(a, b): use only weight[a:b] / bias[a:b] (packed in_proj of nn.MultiheadAttention).
-    drop=(seed, site, p): dropout of the activated output before the residual add (fused into the GEMM epilogue)."""
-    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop)
+    drop=(seed, site, p): dropout of the activated output before the residual add (fused into the GEMM epilogue).
+    gin / gout_res / gout_x: GradSlot hand-overs of the backward (see GradSlot)."""
+    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop, gin, gout_res, gout_x)
 
 
 def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
@@ -368,6 +435,7 @@ class _Mlp(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, act, out_dtype, cd, drop1, drop2):
+        ctx.res_is_x = bool(ctx.needs_input_grad[0]) and residual is not None and (residual is x or (residual.data_ptr() == x.data_ptr() and residual.shape == x.shape and residual.stride() == x.stride()))          # x + f(x): dY joins dX in the epilogue of the dX GEMM
         if w1.shape[0] % 64 or w2.shape[0] % 64:
             raise hip.P3Error("mlp: hidden / output widths must be multiples of 64")
         w1c, w2c = shadow(w1, cd), shadow(w2, cd)
@@ -406,7 +474,9 @@ class _Mlp(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())                   # [in, hidden]
-            dx = hip.gemm(dpre1, w1t, out_dtype=cd).view(xshape)
+            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=dy2 if ctx.res_is_x else None).view(xshape)
+            if ctx.res_is_x:
+                dres = None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
 
 

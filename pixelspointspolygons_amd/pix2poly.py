@@ -128,7 +128,7 @@ def _bn_scale_shift(sums, count, bn, training, save=False):
     r = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                         training, save=save)
     if training:
-        bn.num_batches_tracked += 1
+        ops.bump_batches_tracked(bn)
     return r
 
 
@@ -227,19 +227,23 @@ class Decoder(nn.Module):
         x = ops.dropout(x, dr(self.SITE_DEC_POS, self.decoder_pos_drop.p))
         enc = encoder_out if encoder_out.dtype == cd else ops.cast(encoder_out, cd)
         mem = ops.dropout(ops.add_pos(enc, self.encoder_pos_embed), dr(self.SITE_ENC_POS, self.encoder_pos_drop.p))
+        # backward joins (x feeds a projection AND the residual add; `mem` feeds six projections) go through GradSlots: the second
+        # gradient is added in the epilogue of the projection's dX GEMM instead of by a cast + add pass of autograd
+        gmem = ops.GradSlot()
         for li, lyr in enumerate(self.decoder.layers):
             sa, ca = lyr.self_attn, lyr.multihead_attn
             s0 = 8 * li
-            qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd)
+            g1, g2 = ops.GradSlot(), ops.GradSlot()
+            qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, cd=cd, gin=g1)
             a = ops.self_attention(qkv, H, causal=True, key_bias=kb, drop=dr(s0 + self.SITE_SA_ATTN, sa.dropout))
             y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
-                           drop=dr(s0 + self.SITE_SA_OUT, lyr.dropout1.p))
+                           drop=dr(s0 + self.SITE_SA_OUT, lyr.dropout1.p), gout_res=g1)
             x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
-            q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D))
-            kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D))
+            q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D), gin=g2)
+            kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D), gin=gmem, gout_x=gmem)
             a = ops.cross_attention(q, kv, H, drop=dr(s0 + self.SITE_CA_ATTN, ca.dropout))
             y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
-                           drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p))
+                           drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p), gout_res=g2)
             x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
             y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
                         out_dtype=torch.float32, cd=cd, drop_act=dr(s0 + self.SITE_FFN_ACT, lyr.dropout.p),
@@ -408,6 +412,10 @@ class EncoderDecoder(nn.Module):
         return self.scorenet2.scores_into(features, out, True)
 
     def forward(self, x_images, x_lidar, y):
+        with ops.defer_bumps():
+            return self._forward(x_images, x_lidar, y)
+
+    def _forward(self, x_images, x_lidar, y):
         enc = self.cfg.experiment.encoder
         if enc.use_images and not enc.use_lidar:
             features = self.encoder(x_images)

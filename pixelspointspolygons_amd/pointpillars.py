@@ -92,8 +92,8 @@ class _PillarStem(torch.autograd.Function):
                             max_voxels=mod.max_voxels[0] if training else mod.max_voxels[1], training=training, col_off=col_off,
                             keep_workspace=need, sync=ops.sync_stats if ops.sync_active() else None)
         if training:
-            l0.norm.num_batches_tracked += 1
-            l1.norm.num_batches_tracked += 1
+            ops.bump_batches_tracked(l0.norm)
+            ops.bump_batches_tracked(l1.norm)
         ctx.mark_dirty(canvas)
         if need:
             _, ctx.ws, ctx.desc = r

@@ -10,7 +10,7 @@ for i in range(3):
     st.step(pool[i % len(pool)])
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     st.step(pool[0])
     torch.cuda.synchronize()
 cnt = collections.Counter(); tim = collections.Counter()
@@ -21,7 +21,7 @@ for ev in prof.events():
     if t <= 0:
         continue
     frames = [f for f in (ev.stack or []) if "/repo/" in f and "bench.py" not in f]
-    frame = frames[0].split("/repo/")[-1][:100] if frames else ((ev.stack or ["?"])[0][-100:])
+    frame = frames[0].split("/repo/")[-1][:100] if frames else str(getattr(ev, "input_shapes", "?"))[:110]
     cnt[(ev.name, frame)] += 1; tim[(ev.name, frame)] += t
-for key, n in cnt.most_common(50):
+for key, n in cnt.most_common(70):
     print(f"{n:4d} {tim[key]:8.0f}us  {key[0]:24s} {key[1]}")
