@@ -200,6 +200,43 @@ def test_residual_gradient_twin_replaces_the_cast_pass():
     assert torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
 
 
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_gradslot_joins_equal_autograd_joins(cd):
+    """Post-norm decoder pattern (nn.TransformerDecoderLayer as model_pix2poly.py:136-143 runs it): x feeds a projection AND the residual
+    add behind it, and one memory tensor feeds several projections.  With GradSlots the second gradient is added inside the dX GEMM
+    epilogue (and autograd sees no gradient for the residual input); the sums must equal autograd's own cast + add joins."""
+    from pixelspointspolygons_amd import ops
+    torch.manual_seed(1)
+    D = 256
+    l1, l2, m1, m2 = (torch.nn.Linear(D, D).to(DEV) for _ in range(4))
+    x0 = torch.randn(3, 40, D, device=DEV)
+    mem0 = torch.randn(3, 24, D, device=DEV)
+
+    def run(slots):
+        for mod in (l1, l2, m1, m2):
+            for p_ in mod.parameters():
+                p_.grad = None
+        xf = x0.clone().requires_grad_(True)
+        memf = mem0.clone().requires_grad_(True)
+        x, mem = (xf, memf) if cd == torch.float32 else (ops.cast(xf, cd), ops.cast(memf, cd))
+        g1 = ops.GradSlot() if slots else None
+        gm = ops.GradSlot() if slots else None
+        a = ops.linear(x, l1.weight, l1.bias, cd=cd, gin=g1)
+        y = ops.linear(a, l2.weight, l2.bias, residual=x, out_dtype=torch.float32, cd=cd, gout_res=g1)
+        k1 = ops.linear(mem, m1.weight, m1.bias, cd=cd, gin=gm, gout_x=gm)          # first consumer: arms the slot, hands nothing on
+        k2 = ops.linear(mem, m2.weight, m2.bias, cd=cd, gin=gm, gout_x=gm)          # later consumer: its dX travels through the slot
+        z = (y ** 2).sum() + (k1.float() * 0.3).sum() + (k2.float() ** 2).sum()
+        z.backward()
+        if slots:
+            assert g1.g is None and gm.g is None                                    # both hand-overs consumed
+        return xf.grad.clone(), memf.grad.clone(), l1.weight.grad.clone(), m2.weight.grad.clone()
+    got, ref = run(True), run(False)
+    tol = 1e-5 if cd == torch.float32 else 2e-2         # bf16: the slot path adds in fp32 before ONE rounding, autograd rounds twice
+    for g_, r_ in zip(got, ref):
+        assert rel_err(g_, r_) < tol
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])             # weight gradients do not depend on the join
+
+
 # ------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, heads, scale, causal, kb):
     B, Lq, Dm = q.shape
