@@ -170,6 +170,34 @@ def test_bucketed_allreduce_and_syncbn_sums_world2(tmp_path):
     assert torch.allclose(r["grads"], flat, atol=1e-6)
 
 
+def test_deferred_batchnorm_counters_and_gradslot_host_logic():
+    """Host side of two backward / forward plumbing helpers (no kernel involved): `defer_bumps` turns the BatchNorm sites'
+    `num_batches_tracked += 1` (nn.BatchNorm training forward) into one multi-tensor add with the same result, nests, and drops the
+    increments of a forward that raised; a GradSlot hands its tensor over exactly once."""
+    from pixelspointspolygons_amd import ops
+    bns = [torch.nn.BatchNorm1d(4) for _ in range(3)]
+    ops.bump_batches_tracked(bns[0])                                   # outside any context: immediate
+    assert int(bns[0].num_batches_tracked) == 1
+    with ops.defer_bumps():
+        for bn in bns:
+            ops.bump_batches_tracked(bn)
+        with ops.defer_bumps():                                        # an inner forward (e.g. an encoder called on its own) flushes its own
+            ops.bump_batches_tracked(bns[2])
+        assert int(bns[2].num_batches_tracked) == 1 and int(bns[1].num_batches_tracked) == 0      # inner flushed, outer still pending
+    assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 2]
+    with pytest.raises(RuntimeError):
+        with ops.defer_bumps():
+            ops.bump_batches_tracked(bns[1])
+            raise RuntimeError("forward failed")
+    assert int(bns[1].num_batches_tracked) == 1                        # nothing counted for the failed forward
+    ops.bump_batches_tracked(bns[1])                                   # and the context is closed again
+    assert int(bns[1].num_batches_tracked) == 2
+    slot = ops.GradSlot()
+    assert slot.take() is None and not slot.armed
+    slot.g = torch.ones(2)
+    assert torch.equal(slot.take(), torch.ones(2)) and slot.take() is None
+
+
 def test_synthetic_inputs_follow_the_survey_contract():
     inp = O.make_inputs(4, seed=1234)
     assert inp["image"].shape == (4, 3, 224, 224) and 0 <= float(inp["image"].min()) and float(inp["image"].max()) < 1
