@@ -32,7 +32,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     gw = {n: ops.direct_grads(getattr(net, n).weight) for n in ("conv1", "conv2", "conv3")}
     wout = lambda n, r, c: gw[n][0].view(r, c) if gw[n] is not None else torch.zeros(r, c, **f32)
     dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
-    db3 = ops.bias_grad_before_bn(dH3, training)
+    db3 = ops.bias_grad_before_bn(dH3, training, net.conv3.bias)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
@@ -42,7 +42,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
     dW2 = hip.gemm_tn_ex(dH2, U, wout("conv2", 128, 256), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
-    db2 = ops.bias_grad_before_bn(dH2, training)
+    db2 = ops.bias_grad_before_bn(dH2, training, net.conv2.bias)
     w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
     dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
     acc1 = torch.zeros(2 * 256, **f32)
@@ -56,7 +56,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dW1 = wout("conv1", 256, 2 * D)
     hip.gemm_tn(dUc, F2, out=dW1[:, :D])
     hip.gemm_tn(dVc, F2, out=dW1[:, D:])
-    db1 = ops.bias_grad_before_bn(dU, training)
+    db1 = ops.bias_grad_before_bn(dU, training, net.conv1.bias)
     w1t = ops.shadow(net.conv1.weight, cd, key="2dT2", fn=lambda t: torch.cat([t.reshape(256, -1)[:, :D].t(), t.reshape(256, -1)[:, D:].t()], 0))  # [2D, 256]
     dF = hip.gemm(dUc, w1t[:D], out_dtype=torch.float32)
     dF = hip.gemm(dVc, w1t[D:], out_dtype=torch.float32, residual=dF)

@@ -98,7 +98,7 @@ class _FusionConvBN(torch.autograd.Function):
         dg, dbt, a, b = ops.bn_backward_coeffs(dscC, dshift, gamma.detach(), mean, rstd, float(M), mod.training, params=(bn.weight, bn.bias))
         if mod.training:
             hip.affine_fix(dpre, pre, a, b)
-        db = ops.bias_grad_before_bn(dpre, mod.training)
+        db = ops.bias_grad_before_bn(dpre, mod.training, mod.fusion_layer[0].bias)
         # weight gradient: dW[co, tap, ci] = sum_rows dpre[r, co] * canvas[r + shift(tap), ci] in the zero-bordered row space
         P = g + 2
         dp = hip.pad_nhwc(dpre.view(M, D), D, None, None, 0, D, D, B, g, g)                      # border + interior in one pass each

@@ -101,13 +101,13 @@ def sync_active():
     return SYNC_BN[0] and collectives_active()
 
 
-def bias_grad_before_bn(dH, training):
+def bias_grad_before_bn(dH, training, param=None):
     """Gradient of a conv / linear bias that feeds a BatchNorm directly.  In training mode it is identically zero (the batch mean
     absorbs any constant: sum over rows of the BatchNorm input gradient vanishes), so the column sum over the [rows, C] gradient
     (0.3-0.6 GB per ScoreNet layer) is not computed; the reference's autograd produces rounding noise (~1e-9) there.  Eval mode
     (running statistics) has a real gradient."""
-    if training:
-        return None if DIRECT_GRAD[0] else torch.zeros(dH.shape[1], dtype=torch.float32, device=dH.device)
+    if training:       # param = the bias Parameter: with an arena-backed .grad (already zeroed for the step) nothing needs to be returned at all
+        return None if direct_grads(param) is not None else torch.zeros(dH.shape[1], dtype=torch.float32, device=dH.device)
     return hip.colsum(dH)
 
 
