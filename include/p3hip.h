@@ -124,6 +124,13 @@ int p3_layernorm_bwd_res(const void* dy, const void* x, const float* gamma, cons
 int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                         void* dx, void* dx_lo, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                         void* stream);
+/* lo_drop (optional; needs dx_lo, no dres, bf16 dy, fp32 x / dx, cols 256 / 384 / 768): dx_lo = mask(dx) / (1-p) with the mask of
+ * dropout site lo_drop at element (row, col) - the gradient the nn.Dropout in front of this LayerNorm's residual add
+ * (nn.TransformerDecoderLayer.dropout1..3, model_pix2poly.py:136) passes down, so that sublayer's backward needs no p3_dropout_apply pass.
+ * dx (the residual path) is not masked. */
+int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                             void* dx, void* dx_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
+                             int dtype_dy, int dtype_x, int dtype_dx, void* stream);
 int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                      void* stream);

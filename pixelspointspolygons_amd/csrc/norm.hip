@@ -168,12 +168,18 @@ __global__ __launch_bounds__(256, (NV == 4 ? 2 : 4)) void ln_bwd_kernel(const TD
 // below consume it in bf16: this saves their separate cast pass (a 77 MB read + a launch per sublayer).
 // HAS_RES: the incoming residual gradient is loaded WITH x / dy at the top of the row (r02 loaded each chunk right before its store,
 // behind `if (dres)`: three serialised load -> s_waitcnt vmcnt(0) -> store round trips per row).
-template <typename TDY, typename TX, typename TDX, int CPL, bool HAS_RES>
+// LODROP: the bf16 copy additionally carries the dropout mask of the sublayer below (the Linear that produced this LayerNorm's input
+// applied dropout to its output: its backward wants mask(dx)/(1-p) in bf16 - same (seed, site, row, col) hash as the forward epilogue),
+// which replaces that sublayer's dropout_apply pass over the fp32 stream.  dx itself (the residual path) stays unmasked.
+template <typename TDY, typename TX, typename TDX, int CPL, bool HAS_RES, bool LODROP = false>
 __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const TDX* __restrict__ dres, TDX* __restrict__ dx, bf16_t* __restrict__ dx_lo,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block,
+                                                             p3_dropout lo_drop = p3_dropout{nullptr, 0u, 0.f}) {
     constexpr int cols = CPL * 128;
+    DropKey dk;
+    if constexpr (LODROP) dk = drop_key(lo_drop);
     __shared__ float sg[8][cols], sb[8][cols];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     float g[CPL][4], ag[CPL][4], ab[CPL][4];
@@ -222,7 +228,16 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                     for (int i = 0; i < 4; ++i) ov[i] += rres[c][i];
                 }
                 store4<TDX>(dx + o, ov);
-                if (dx_lo) store4<bf16_t>(dx_lo + o, ov);
+                if constexpr (LODROP) {
+                    const uint32_t rk = drop_rowkey(dk, (uint64_t)row), cb = (uint32_t)(l31 + 32 * c) * 4u;
+                    const uint32_t b0 = drop_bits(rk, drop_colkey(dk, cb)), b1 = drop_bits(rk, drop_colkey(dk, cb + 2u));
+                    float lv[4];
+                    lv[0] = drop_keep_lo(dk, b0) ? ov[0] * dk.inv_keep : 0.f; lv[1] = drop_keep_hi(dk, b0) ? ov[1] * dk.inv_keep : 0.f;
+                    lv[2] = drop_keep_lo(dk, b1) ? ov[2] * dk.inv_keep : 0.f; lv[3] = drop_keep_hi(dk, b1) ? ov[3] * dk.inv_keep : 0.f;
+                    store4<bf16_t>(dx_lo + o, lv);
+                } else {
+                    if (dx_lo) store4<bf16_t>(dx_lo + o, ov);
+                }
             }
         }
     }
@@ -278,7 +293,16 @@ extern "C" int p3_layernorm_bwd_res(const void* dy, const void* x, const float* 
 extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                                    void* dx, void* dx_lo, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x,
                                    int dtype_dx, void* stream) {
+    return p3_layernorm_bwd_lo_drop(dy, x, gamma, mean, rstd, dres, dx, dx_lo, nullptr, dgamma, dbeta, rows, cols, dtype_dy, dtype_x, dtype_dx, stream);
+}
+
+extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                        void* dx, void* dx_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
+                                        int dtype_dy, int dtype_x, int dtype_dx, void* stream) {
     P3_CHECK(dy && x && gamma && mean && rstd && dx, P3_EINVAL, "p3_layernorm_bwd: null pointer");
+    const bool lod = lo_drop && lo_drop->seed && lo_drop->p > 0.f;
+    P3_CHECK(!lod || (dx_lo && !dres && dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32 && (cols == 256 || cols == 384 || cols == 768)),
+             P3_EUNSUP, "p3_layernorm_bwd: a masked bf16 copy needs dx_lo, no dres, bf16 dy, fp32 x / dx and 256 / 384 / 768 columns");
     P3_CHECK(!dx_lo || (cols % 128 == 0 && dtype_dx == P3_F32), P3_EUNSUP, "p3_layernorm_bwd: the bf16 copy needs cols % 128 == 0 and an fp32 dx");
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
@@ -292,6 +316,13 @@ extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* g
     hipStream_t s = (hipStream_t)stream;
     static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)
     if (half_env < 0) { const char* e = getenv("P3_LN_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
+    if (lod) {
+#define LNH_D(CPL) hipLaunchKernelGGL((ln_bwd_half_kernel<bf16_t, float, float, CPL, false, true>), grid, block, 0, s, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const float*)nullptr, (float*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, *lo_drop)
+        if (cols == 256) LNH_D(2); else if (cols == 384) LNH_D(3); else LNH_D(6);
+#undef LNH_D
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     if ((half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768)) {
 #define LNH_R(TDY, TX, TDX, CPL, RES) \
     hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb)

@@ -189,9 +189,10 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
     return (out, mean, rstd) if save_stats else out
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None):
     """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass.
-    want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo)."""
+    want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo).
+    lo_drop = (seed, site, p): the bf16 copy carries that dropout site's mask and 1/(1-p) (see p3_layernorm_bwd_lo_drop)."""
     cols = x.shape[-1]
     dy2, x2 = dy.reshape(-1, cols).contiguous(), x.reshape(-1, cols).contiguous()
     rows = x2.shape[0]
@@ -203,8 +204,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=No
     lo = None
     if want_lo and dx.dtype == torch.float32 and cols % 128 == 0:
         lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(lib().p3_layernorm_bwd_lo(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo), ptr(dgamma), ptr(dbeta),
-                                    c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
+    if lo_drop is not None and lo is None:
+        raise P3Error("layernorm_bwd: lo_drop needs the bf16 copy (want_lo, fp32 dx, cols % 128 == 0)")
+    dspec = _drop(lo_drop)
+    check(lib().p3_layernorm_bwd_lo_drop(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo),
+                                         byref(dspec) if lo_drop is not None else None, ptr(dgamma), ptr(dbeta),
+                                         c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
           "p3_layernorm_bwd")
     return (dx, lo) if want_lo else dx
 

@@ -262,11 +262,12 @@ def _needs_grad(*ts):
 _twins = {}
 
 
-def _register_twin(t, lo):
+def _register_twin(t, lo, drop=None):
+    """drop: the dropout site whose mask (and 1/(1-p)) the bf16 copy already carries (ln_bwd lo_drop); None = a plain cast copy"""
     if lo is not None:
         if len(_twins) > 48:
             _twins.clear()
-        _twins[t.data_ptr()] = (t, lo)
+        _twins[t.data_ptr()] = (t, lo, drop)
 
 
 def clear_twins():
@@ -279,9 +280,23 @@ def _to_cd(t2, cd):
         return t2
     if cd == torch.bfloat16 and t2.dtype == torch.float32:
         ent = _twins.pop(t2.data_ptr(), None)
-        if ent is not None and ent[1].numel() == t2.numel() and t2.is_contiguous():
+        if ent is not None and ent[2] is None and ent[1].numel() == t2.numel() and t2.is_contiguous():
             return ent[1].view(t2.shape)
     return hip.cast(t2, cd)
+
+
+def _same_drop(a, b):
+    return a is not None and b is not None and a[0].data_ptr() == b[0].data_ptr() and int(a[1]) == int(b[1]) and float(a[2]) == float(b[2])
+
+
+def _to_cd_dropped(t2, cd, drop):
+    """dropout backward of gradient `t2` [rows, N] in the compute dtype: the producer's masked bf16 twin when ln_bwd wrote one for exactly
+    this site, the p3_dropout_apply pass (mask regenerated while casting) otherwise"""
+    if cd == torch.bfloat16 and t2.dtype == torch.float32:
+        ent = _twins.pop(t2.data_ptr(), None)
+        if ent is not None and _same_drop(ent[2], drop) and ent[1].numel() == t2.numel() and t2.is_contiguous():
+            return ent[1].view(t2.shape)
+    return hip.dropout_apply(t2, cd, drop)
 
 
 # ---------------------------------------------------------------------------------------------- Linear
@@ -347,8 +362,8 @@ class _Linear(torch.autograd.Function):
         # dpre = dy * act'(pre), in compute dtype
         drop = ctx.drop
         if ctx.act == hip.ACT_NONE:
-            if drop is not None:        # same (seed, site, row*N + col) mask as the forward epilogue, regenerated while casting
-                dpre = hip.dropout_apply(dy2, cd, drop)
+            if drop is not None:        # same (seed, site, row*N + col) mask as the forward epilogue: ln_bwd's masked twin, or regenerated while casting
+                dpre = _to_cd_dropped(dy2, cd, drop)
             else:
                 dpre = _to_cd(dy2, cd)
         else:                           # ReLU then dropout: the saved output is already masked, only the 1/(1-p) factor remains
@@ -462,7 +477,7 @@ class _Mlp(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dres = dy if has_res else None
         if drop2 is not None:
-            dpre2 = hip.dropout_apply(dy2, cd, drop2)
+            dpre2 = _to_cd_dropped(dy2, cd, drop2)
         else:
             dpre2 = _to_cd(dy2, cd)
         dw2, db2 = _weight_grads(dpre2, h, w2, ctx.b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
@@ -487,9 +502,10 @@ def mlp(x, w1, b1, w2, b2, *, act, residual=None, out_dtype=None, cd=torch.float
 # ---------------------------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, out_dtype, twin_drop):
         need = any(ctx.needs_input_grad)
         ctx.beta_param = beta
+        ctx.twin_drop = twin_drop if (twin_drop is not None and twin_drop[2] > 0.0) else None
         if need:
             y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
             ctx.save_for_backward(x, gamma, mean, rstd)
@@ -502,24 +518,27 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
         lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] % 128 == 0   # fp32 stream under bf16 GEMMs
+        td = ctx.twin_drop if (lo and x.shape[-1] in (256, 384, 768)) else None                   # masked twin for the sublayer below
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo)
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo, lo_drop=td)
             _grad_ready(gamma, beta)
             if lo:
-                _register_twin(*dx)
+                _register_twin(*dx, drop=td)
                 dx = dx[0]
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
-        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, want_lo=lo)
+        dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, want_lo=lo, lo_drop=td)
         if lo:
-            _register_twin(*dx)
+            _register_twin(*dx, drop=td)
             dx = dx[0]
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
-def layernorm(x, gamma, beta, eps, out_dtype=None):
-    return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype)
+def layernorm(x, gamma, beta, eps, out_dtype=None, twin_drop=None):
+    """twin_drop = (seed, site, p): the dropout the producer of `x` applied to its output before the residual add (post-norm decoder);
+    in bf16 mode the backward then hands that sublayer its masked, scaled bf16 gradient directly (no dropout_apply pass)."""
+    return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype, twin_drop)
 
 
 class _LayerNormFork(torch.autograd.Function):

@@ -238,17 +238,17 @@ class Decoder(nn.Module):
             a = ops.self_attention(qkv, H, causal=True, key_bias=kb, drop=dr(s0 + self.SITE_SA_ATTN, sa.dropout))
             y = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
                            drop=dr(s0 + self.SITE_SA_OUT, lyr.dropout1.p), gout_res=g1)
-            x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd)
+            x = ops.layernorm(y, lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, out_dtype=cd, twin_drop=dr(s0 + self.SITE_SA_OUT, lyr.dropout1.p))
             q = ops.linear(x, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(0, D), gin=g2)
             kv = ops.linear(mem, ca.in_proj_weight, ca.in_proj_bias, cd=cd, rows=(D, 3 * D), gin=gmem, gout_x=gmem)
             a = ops.cross_attention(q, kv, H, drop=dr(s0 + self.SITE_CA_ATTN, ca.dropout))
             y = ops.linear(a, ca.out_proj.weight, ca.out_proj.bias, residual=x, out_dtype=torch.float32, cd=cd,
                            drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p), gout_res=g2)
-            x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd)
+            x = ops.layernorm(y, lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, out_dtype=cd, twin_drop=dr(s0 + self.SITE_CA_OUT, lyr.dropout2.p))
             y = ops.mlp(x, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight, lyr.linear2.bias, act=hip.ACT_RELU, residual=x,
                         out_dtype=torch.float32, cd=cd, drop_act=dr(s0 + self.SITE_FFN_ACT, lyr.dropout.p),
                         drop_out=dr(s0 + self.SITE_FFN_OUT, lyr.dropout3.p))
-            x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd)
+            x = ops.layernorm(y, lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, out_dtype=cd, twin_drop=dr(s0 + self.SITE_FFN_OUT, lyr.dropout3.p))
         return x
 
     def forward(self, encoder_out, tgt):

@@ -187,7 +187,7 @@ def test_residual_gradient_twin_replaces_the_cast_pass():
         r, hn = ops.layernorm_fork(y, norm.weight, norm.bias, norm.eps, out_dtype=torch.bfloat16)
         z = (r * 0.5).sum() + (hn.float() ** 2).sum()
         if not use_twin:
-            reg, ops._register_twin = ops._register_twin, (lambda t, lo: None)
+            reg, ops._register_twin = ops._register_twin, (lambda t, lo, drop=None: None)
         try:
             z.backward()
         finally:
@@ -198,6 +198,28 @@ def test_residual_gradient_twin_replaces_the_cast_pass():
     gx0, gw0, _ = run(False)
     assert left1 == 0                                   # the twin was consumed by the Linear's backward
     assert torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
+
+
+@pytest.mark.parametrize("cols", [256, 384, 768])
+def test_layernorm_backward_masked_twin_equals_the_dropout_pass(cols):
+    """p3_layernorm_bwd_lo_drop: the bf16 copy of dx that carries a dropout site's mask is bit-identical to p3_dropout_apply over the
+    fp32 dx (what the sublayer's backward ran before), and dx itself is untouched by the mask."""
+    from pixelspointspolygons_amd import ops
+    h = _h()
+    torch.manual_seed(3)
+    rows = 333
+    x = torch.randn(rows, cols, device=DEV)
+    gamma, beta = torch.randn(cols, device=DEV), torch.randn(cols, device=DEV)
+    dy = torch.randn(rows, cols, device=DEV).bfloat16()
+    _, mean, rstd = h.layernorm(x, gamma, beta, 1e-5, out_dtype=torch.bfloat16, save_stats=True)
+    drop = (ops.rng_seed(DEV), 13, 0.1)
+    dx0, lo0 = h.layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=torch.float32, want_lo=True)
+    dx1, lo1 = h.layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=torch.float32, want_lo=True, lo_drop=drop)
+    assert torch.equal(dx0, dx1) and torch.equal(lo0, dx0.bfloat16())
+    ref = h.dropout_apply(dx0, torch.bfloat16, drop)
+    assert torch.equal(lo1, ref.view_as(lo1))
+    dropped = float((lo1 == 0).float().mean())
+    assert 0.07 < dropped < 0.13
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
