@@ -67,3 +67,97 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), (f, pat.search(src).group(0))
+
+
+def test_descriptor_structs_have_the_layout_the_header_declares(tmp_path):
+    """The ctypes mirrors in hip.py (GemmDesc, AttnDesc, ...) must match include/p3hip.h field for field: a probe compiled with gcc from
+    the header itself prints sizeof / offsetof of every member, compared with the ctypes classes (names, order, offsets, total size)."""
+    import shutil
+    import subprocess
+    import pixelspointspolygons_amd.hip as h
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    mirrors = {"p3_dropout": h.Dropout, "p3_gemm_desc": h.GemmDesc, "p3_attn_desc": h.AttnDesc, "p3_pillar_desc": h.PillarDesc,
+               "p3_decode_layer_desc": h.DecodeLayerDesc}
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(p3_\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):               # "int M, N, K" / "const float *g1, *be1"
+                name = re.findall(r"(\w+)\s*(?:\[[^\]]*\])?\s*$", part.strip())
+                assert name, decl
+                fields.append(name[0])
+        structs[m.group(2)] = fields
+    assert set(mirrors) == set(structs), (sorted(structs), sorted(mirrors))
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    for sname, fields in structs.items():
+        src.append(f'  printf("{sname} size %zu\\n", sizeof({sname}));')
+        for f in fields:
+            src.append(f'  printf("{sname} {f} %zu\\n", offsetof({sname}, {f}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {}
+    for line in out.splitlines():
+        sname, f, v = line.split()
+        got.setdefault(sname, []).append((f, int(v)))
+    for sname, cls in mirrors.items():
+        rows = got[sname]
+        assert rows[0] == ("size", ctypes.sizeof(cls)), (sname, rows[0], ctypes.sizeof(cls))
+        want = [(n, getattr(cls, n).offset) for n, *_ in cls._fields_]
+        assert rows[1:] == want, (sname, [a for a, b in zip(rows[1:], want) if a != b][:4])
+
+
+def _split_top_level(argtext):
+    """split on commas that are not nested in (), [] or {}"""
+    out, depth, cur = [], 0, []
+    for ch in argtext:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append("".join(cur)); cur = []
+        else:
+            cur.append(ch)
+    if "".join(cur).strip():
+        out.append("".join(cur))
+    return out
+
+
+def test_every_binding_call_passes_as_many_arguments_as_the_header_declares():
+    """ctypes does not check arity: a call that drifted from its prototype would read garbage registers on the device side.  Static check of
+    every `lib().p3_*(...)` call in the package against the parameter count of the declaration in include/p3hip.h."""
+    text = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(p3_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_top_level(args))
+    checked = 0
+    pkg = os.path.join(ROOT, "pixelspointspolygons_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        src = open(os.path.join(pkg, fn)).read()
+        for m in re.finditer(r"(?:lib\(\)|\bL)\.(p3_\w+)\(", src):
+            name, i, depth = m.group(1), m.end(), 1
+            j = i
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[j], 0)
+                j += 1
+            parts = _split_top_level(src[i:j - 1])
+            assert name in protos, (fn, name)
+            if any(a.strip().startswith("*") for a in parts):       # star-expanded argument tuples (the pillar stem variants) cannot be counted statically
+                continue
+            nargs = len(parts)
+            assert nargs == protos[name], (fn, name, nargs, protos[name])
+            checked += 1
+    assert checked >= 55
