@@ -1,0 +1,78 @@
+"""bench.py's output contract and its CPU-side helpers (no GPU): the committed bench line under profiles/ carries every key the driver and
+the tier brief ask for (metric / value / unit / ..., `roofline`, `cpu_baseline`), its numbers are mutually consistent, and the helpers
+that fold the committed PMC table into the line read it the way DESIGN.md says."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+        return bench, bench.parse()
+    finally:
+        sys.argv = argv
+
+
+def _line(name="r02_bench.json"):
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
+        return json.loads(fh.read().strip().splitlines()[-1])
+
+
+def test_defaults_are_one_gpu_and_a_run_of_minutes():
+    bench, a = _bench()
+    assert a.gpus == 1 and a.steps == 20 and a.warmup == 5 and a.batch == 64 and a.points == 3000
+    assert a.workload == "fusion_s8" and a.precision == "bf16" and a.graph == 1 and a.sync_bn == 1
+    assert not (a.no_cpu_baseline or a.no_fp32_leg or a.no_predict or a.no_host_feed)      # the default run reports every leg
+
+
+def test_committed_bench_line_has_the_contract_keys_and_is_self_consistent():
+    d = _line()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "tiles/s"      # BASELINE names the N = 1/2/4/8 sweep and fwd ms/tile after it
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    tiles = d["config"]["tiles_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - tiles / d["ms_per_step"] * 1e3) < 0.01 * d["value"]            # value = whole-job tiles / step time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # achieved = algorithmic bytes per launch / measured launch time: re-derive it from the line's own fields
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]   # counter traffic cannot be below the algorithmic bytes
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+    f = d["fp32_parity_mode"]
+    assert f["dtype"] == "f32" and f["value"] > 0 and abs(f["value"] - tiles / f["ms_per_step"] * 1e3) < 0.01 * f["value"]
+    p = d["pcie_inclusive"]
+    assert p["value"] <= d["value"] * 1.02 and len(p["ms_per_step_all"]) == p["repeats"] >= 3
+
+
+def test_pmc_table_feeds_the_roofline_traffic_fields():
+    bench, _ = _bench()
+    table, src = bench.pmc_step_traffic()
+    assert table is not None and src == "profiles/r02_pmc_traffic.json"
+    per_launch = bench.kernel_traffic(table, "gemm_kernel<bf16,plain>")
+    # hand computation of the same average: every plain-A bf16 GEMM instantiation, launches-weighted
+    tot = n = 0.0
+    for k, v in table.items():
+        if isinstance(v, dict) and k.startswith("gemm_kernel<unsigned short,") and k.split(",")[2].strip() == "0":
+            tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
+            n += v["launches"]
+    assert n > 0 and per_launch == round(tot / n)
+    assert 0.5e11 < table["_step_total_bytes"] < 2e11 and table["_steps"] >= 1
+    assert bench.kernel_traffic(None, "gemm_kernel<bf16,plain>") is None
+    for v in table.values():
+        if isinstance(v, dict) and "fetch_bytes_raw" in v:                                   # gfx950 correction of the guide: FETCH_SIZE doubled
+            assert abs(v["fetch_bytes_corrected"] - 2.0 * v["fetch_bytes_raw"]) <= 1e-6 * max(1.0, v["fetch_bytes_corrected"])
