@@ -715,6 +715,54 @@ def ffl_heads(features, sd, training=False):
 
 
 # ----------------------------------------------------------------------------------------------
+# HiSup head set.  Restates /root/reference/pixelspointspolygons/models/hisup/model_hisup.py:122-226
+# (`EncoderDecoder.__init__`, `_make_conv`, `_make_predictor`, `forward_common`), `ECA` (:39-64) and
+# models/multitask_head.py:5-23.  Pinned by tests/golden/hisup_heads.npz (emitted by the reference's own module,
+# tests/golden/make_hisup_heads_golden.py).  There is no HIP path for these heads yet: oracle only.
+# ----------------------------------------------------------------------------------------------
+def _conv_tower(x, sd, pre, training):
+    """`_make_conv` (model_hisup.py:149-161): three Conv3x3 + BatchNorm2d + ReLU (Sequential indices 0/1, 3/4, 6/7)."""
+    for c, b in ((0, 1), (3, 4), (6, 7)):
+        x = conv_bn_relu(x, sd, f"{pre}.{c}", f"{pre}.{b}", training)
+    return x
+
+
+def _predictor(x, sd, pre):
+    """`_make_predictor` (model_hisup.py:163-170) and one MultitaskHead branch (multitask_head.py:13-17): Conv3x3 -> ReLU -> Conv1x1."""
+    h = F.relu(F.conv2d(x, sd[pre + ".0.weight"], sd[pre + ".0.bias"], padding=1))
+    return F.conv2d(h, sd[pre + ".2.weight"], sd[pre + ".2.bias"])
+
+
+def eca(x1, x2, sd, pre, training):
+    """`ECA.forward` (model_hisup.py:57-64): channel gate = sigmoid(conv1d_k(global_avg_pool(x1 + x2))) over the channel axis (k odd,
+    from log2(C), zero padding k // 2, no bias), applied to x2, then Conv1x1 (no bias) + BatchNorm2d + ReLU."""
+    y = (x1 + x2).mean((2, 3))                                        # [B, C]
+    w = sd[pre + ".conv.weight"]                                      # [1, 1, k]
+    y = torch.sigmoid(F.conv1d(y[:, None, :], w, padding=w.shape[-1] // 2))[:, 0, :]
+    z = F.conv2d(x2 * y[:, :, None, None], sd[pre + ".out_conv.0.weight"])
+    return F.relu(_bn(z, sd, pre + ".out_conv.1", training, 1e-5, 0.1, dims=(0, 2, 3)))
+
+
+def hisup_heads(features, sd, prefix="", training=False):
+    """`EncoderDecoder.forward_common` after the encoder (model_hisup.py:205-226): features [B, C, H, W] ->
+    {joff [B,2,H,W], jloc [B,3,H,W], mask [B,2,H,W], afm [B,2,H,W], remask [B,2,H,W]} (raw logits, as the reference returns them).
+    BatchNorm running statistics in `sd` are updated in training mode, in the reference's module order of execution."""
+    p = prefix
+    joff = torch.cat([_predictor(features, sd, p + "joff_head.heads.0")], 1)          # head_size [[2]]: a single two-channel branch
+    mask_f = _conv_tower(features, sd, p + "mask_head", training)
+    jloc_f = _conv_tower(features, sd, p + "jloc_head", training)
+    afm_f = _conv_tower(features, sd, p + "afm_head", training)
+    mask_att = eca(afm_f, mask_f, sd, p + "a2m_att", training)
+    jloc_att = eca(afm_f, jloc_f, sd, p + "a2j_att", training)
+    mask = _predictor(mask_f + mask_att, sd, p + "mask_predictor")
+    jloc = _predictor(jloc_f + jloc_att, sd, p + "jloc_predictor")
+    afm_pred = _predictor(afm_f, sd, p + "afm_predictor")
+    afm_conv = _conv_tower(afm_pred, sd, p + "refuse_conv", training)
+    remask = _conv_tower(torch.cat((features, afm_conv), 1), sd, p + "final_conv", training)
+    return {"joff": joff, "jloc": jloc, "mask": mask, "afm": afm_pred, "remask": remask}
+
+
+# ----------------------------------------------------------------------------------------------
 # seeded weights + synthetic inputs (SURVEY §8d); shared by tests, bench and the product's init
 # ----------------------------------------------------------------------------------------------
 def make_state_dict(kind="fusion", cfg=VIT_S8, seed=42, n_vertices=MAX_VERTS, dec_dim=256, dec_layers=6,

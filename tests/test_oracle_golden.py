@@ -148,3 +148,29 @@ def test_demo_tile_fixture_is_consistent_with_the_oracle():
     assert torch.equal(logits[0, :eos].argmax(-1), toks[0, 1:eos + 1])        # causal decoder: teacher forcing == the greedy loop's choices
     assert torch.equal(O.scores_to_permutations(torch.from_numpy(fx["scores"])), torch.from_numpy(fx["perm"]).float())
     assert fx["image_u8"].shape == (224, 224, 3) and fx["poly_len"].sum() == len(fx["poly_flat"])
+
+
+def test_hisup_head_set_matches_the_reference_module():
+    """`EncoderDecoder.forward_common` of the HiSup model (model_hisup.py:205-226) on a fixed feature map - eval mode
+    (running statistics) and one training-mode forward (batch statistics + the running-statistics update), golden from the reference's
+    own module (tests/golden/make_hisup_heads_golden.py)."""
+    d, w = load_golden("hisup_heads.npz")
+    out = O.hisup_heads(d["features"], w, training=False)
+    assert set(out) == {"joff", "jloc", "mask", "afm", "remask"}
+    for k, v in out.items():
+        assert v.shape == d["eval." + k].shape and rel_err(v, d["eval." + k]) < 1e-5, k
+    w2 = {k: v.clone() for k, v in w.items()}
+    out = O.hisup_heads(d["features"], w2, training=True)
+    for k, v in out.items():
+        assert rel_err(v, d["train." + k]) < 1e-4, k
+    n = 0
+    for k, v in d.items():
+        if k.startswith("after."):
+            name = k[len("after."):]
+            if "num_batches" in name:
+                assert int(w2[name]) == int(v)
+            else:
+                assert rel_err(w2[name], v) < 1e-5, name
+            n += 1
+    assert n == 3 * 17                     # 17 BatchNorm2d sites: 9 in the three towers, 2 ECA, 3 + 3 in refuse / final conv
+
