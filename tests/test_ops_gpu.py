@@ -256,7 +256,7 @@ def test_gradslot_joins_equal_autograd_joins(cd):
     tol = 1e-5 if cd == torch.float32 else 2e-2         # bf16: the slot path adds in fp32 before ONE rounding, autograd rounds twice
     for g_, r_ in zip(got, ref):
         assert rel_err(g_, r_) < tol
-    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])             # weight gradients do not depend on the join
+    assert rel_err(got[2], ref[2]) < 1e-6 and rel_err(got[3], ref[3]) < 1e-6       # weight gradients do not depend on the join (split-M atomics: order may differ)
 
 
 # ------------------------------------------------------------------ attention
