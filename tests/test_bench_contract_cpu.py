@@ -76,3 +76,15 @@ def test_pmc_table_feeds_the_roofline_traffic_fields():
     for v in table.values():
         if isinstance(v, dict) and "fetch_bytes_raw" in v:                                   # gfx950 correction of the guide: FETCH_SIZE doubled
             assert abs(v["fetch_bytes_corrected"] - 2.0 * v["fetch_bytes_raw"]) <= 1e-6 * max(1.0, v["fetch_bytes_corrected"])
+
+
+def test_rocprof_summary_agrees_with_the_live_kernel_timing():
+    """The roofline object's launch time comes from HIP events inside bench.py; the committed rocprofv3 --kernel-trace --stats summary of the
+    same workload must show the same average for that kernel (tier brief, measurement section)."""
+    import re
+    r = _line()["roofline"]
+    txt = open(os.path.join(ROOT, "profiles", "r02_train_step_graph_summary.txt")).read()
+    m = re.search(r"avg=\s*([0-9.]+) us\s+gemm_kernel<bf16, bf16, 0, 32, false", txt)
+    assert m, "plain bf16 GEMM line missing from the rocprof summary"
+    assert abs(float(m.group(1)) - r["avg_launch_us"]) < 0.10 * r["avg_launch_us"]
+
