@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark of the Pix2Poly / FFL hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>` itself as a CHILD process - before anything here has touched the
+GPU - relays its output and exits with its code (the reference's launch is `torchrun --nproc_per_node=N scripts/train.py`, README.md:540,
+and `setup_ddp`, misc/shared_utils.py:205-230).  Under a launcher (the driver's torch.distributed.run) the ranks check WORLD_SIZE == N.
 
 A "step" = one reference train step (train/trainer_pix2poly.py:305-329) on one synthetic batch that is already resident
 in HBM: forward (encoder + fusion + decoder + 2x ScoreNet + Sinkhorn) -> 1.0*CE + 10.0*BCE -> backward -> AdamW.
@@ -423,9 +428,57 @@ def build(args, dev, local, precision, S, rank, world, sync_bn):
     return cfg, model, opt, reducer, pool, st
 
 
+def self_launch(args):
+    """`--gpus N` with N > 1 and no launcher around us: become the launcher.  Nothing in this process has initialised the GPU yet (importing
+    torch does not), the ranks are CHILD processes (never an exec of a process that may hold the device), their stdout is relayed line by
+    line - rank 0's JSON line stays the last one - and their exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=os.getcwd())
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args, world, rank, backend):
+    """P3_BENCH_DRYRUN=1 (test hook, no GPU needed): the launch / rendezvous / bracket / one-JSON-line control flow with the step replaced
+    by a sleep - what the CPU test of `bench.py --gpus 2` runs.  The line says so (`dry_run`: true, value 0)."""
+    if world > 1:
+        dist.init_process_group("gloo", init_method="env://")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        got = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        got = 1
+    if rank == 0:
+        print(json.dumps({"metric": "training tiles/sec (224px img + 3k-pt lidar)", "value": 0.0, "unit": "tiles/s", "n_gpus": got, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "config": {"workload": f"pix2poly_{args.workload}_bs{args.batch}x{got}",
+                                                                            "collectives": {"world": got}, "parallelism": f"dp{got}"}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and os.environ.get("P3_FORCE_COLLECTIVES") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (they must agree)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks for the 1-GPU development boxes (the N > 1 control flow is exercised with two ranks sharing device 0 over gloo):
@@ -433,6 +486,8 @@ def main():
     if os.environ.get("P3_BENCH_ONE_DEVICE") == "1":
         local = 0
     backend = os.environ.get("P3_BENCH_BACKEND", "nccl")
+    if os.environ.get("P3_BENCH_DRYRUN") == "1":
+        return dry_run(args, world, rank, backend)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     forced = world == 1 and os.environ.get("P3_FORCE_COLLECTIVES") == "1"   # 1-rank RCCL smoke run (ops.SINGLE_RANK_COLLECTIVES)
@@ -444,6 +499,7 @@ def main():
             dist.init_process_group("nccl", init_method="env://", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend, init_method="env://")
+        assert dist.get_world_size() == (args.gpus if not forced else 1), (dist.get_world_size(), args.gpus)
         warm = torch.zeros(1, device=dev)
         dist.all_reduce(warm)                             # communicator set-up (and RCCL's banner) happen here, before anything is timed
         torch.cuda.synchronize()

@@ -88,3 +88,25 @@ def test_rocprof_summary_agrees_with_the_live_kernel_timing():
     assert m, "plain bf16 GEMM line missing from the rocprof summary"
     assert abs(float(m.group(1)) - r["avg_launch_us"]) < 0.10 * r["avg_launch_us"]
 
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts torch.distributed.run as a child (two ranks over gloo here; the step is
+    replaced by the dry-run hook because this container has no GPU), relays rank 0's JSON line as the last line of stdout and reports
+    n_gpus = 2.  The reference's launch: `torchrun --nproc_per_node=N` (README.md:540) + setup_ddp (misc/shared_utils.py:205-230)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(P3_BENCH_BACKEND="gloo", P3_BENCH_ONE_DEVICE="1", P3_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--lean"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["collectives"]["world"] == 2 and d["config"]["parallelism"] == "dp2" and d["steps"] == 3
+    assert d["config"]["workload"].endswith("x2")
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", P3_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--lean"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
