@@ -48,6 +48,15 @@ extern "C" {
 int p3_version(void);
 const char* p3_last_error_string(void);
 
+/* Deterministic reductions.  The reference seeds everything and sets cudnn.deterministic (misc/shared_utils.py:120-126, trainer.py:214);
+ * here the kernels that would finish in fp32 atomicAdd's over workgroup partials (BatchNorm sums of the ScoreNet, split-M weight
+ * gradients, bias-gradient column sums) store the partials into `scratch` instead and add them in workgroup order in float64: the same
+ * bits every run.  scratch: device memory owned by the caller (16-byte aligned, >= 8 MB for the shapes of this path; a launch whose
+ * partials do not fit falls back to atomics), used launch by launch in stream order on ONE stream; NULL / 0 switches the mode off.
+ * all_dtypes = 0: only fp32 (parity-mode) launches take the path; 1: bf16 launches too.  p3_get_deterministic: 0 off, 1 fp32, 2 all. */
+int p3_set_deterministic(void* scratch, int64_t bytes, int all_dtypes);
+int p3_get_deterministic(void);
+
 /* ------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[M,N] = act(A'[M,K] * W[N,K]^T + bias) + residual
  * Replaces every nn.Linear / 1x1 / kxk(stride k) conv on the path:
@@ -370,6 +379,7 @@ int p3_pair_bwd(const void* dA, const void* U, const void* V, const float* scale
 /* same with a scratch of p3_pair_bwd_workspace_bytes(B, N, C) bytes: the per-block dV partial rows are stored there and summed by a second
  * kernel instead of being added with global fp32 atomics (bf16 path; other dtypes ignore the workspace) */
 int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C);
+int64_t p3_pair_bwd_workspace_bytes_dt(int B, int N, int C, int dtype);   /* per dtype: the fp32 form takes smaller row chunks (more slabs) */
 int p3_pair_bwd_ws(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV,
                    float* acc, int B, int N, int C, int dtype, void* workspace, void* stream);
 int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,

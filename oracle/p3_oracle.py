@@ -320,6 +320,71 @@ def scorenet(feats, sd, prefix, n_vertices=MAX_VERTS, training=False):
     return x[:, 0]
 
 
+def scorenet_staged(feats, grad_out, sd, prefix, n_vertices=MAX_VERTS, training=False, transpose=False, decisions=None):
+    """ScoreNet.forward + its analytic backward (model_pix2poly.py:86-112) in float64, in the separable staging (U_i + V_j, conv1 split
+    over the pair; same function as `scorenet`, pinned against its autograd by tests/test_oracle_golden.py).
+
+    Exists for ONE reason: a ReLU behind a train-mode BatchNorm has a kink, and over the 3.3e7 pre-activations of an N = 192 pair grid
+    a handful lie within 1e-6 of it; fp32 arithmetic (the reference's own included) lands on the other side of the kink for some of
+    those, and ONE such element moves the L2 error of a weight gradient against float64 by ~3e-4.  Both choices are valid subgradients.
+    `decisions` = (k1, k2, k3) boolean [B*N*N, C] tensors replaces this function's own z > 0 by the decisions the checked
+    implementation took, so the comparison measures arithmetic, not which side of a kink 5 of 33 million elements fell on.
+    Returns (scores, grads, dfeats, (z1, z2, z3)) with grads keyed like the state_dict (without prefix)."""
+    dt = torch.float64
+    W = {k[len(prefix):]: v.to(dt) for k, v in sd.items() if k.startswith(prefix) and v.is_floating_point()}
+    B, L, D = feats.shape
+    N, eps = n_vertices, 1e-5
+    F_ = feats[:, 1:].reshape(B, N, 2, D).to(dt).mean(2).reshape(B * N, D)
+    W1 = W["conv1.weight"].reshape(256, 2 * D)
+    U = F_ @ W1[:, :D].t() + W["conv1.bias"]
+    V = F_ @ W1[:, D:].t()
+    P = (U.view(B, N, 1, 256) + V.view(B, 1, N, 256)).reshape(-1, 256)
+    R = P.shape[0]
+
+    def bn(H, pre):
+        if training:
+            m, var = H.mean(0), H.var(0, unbiased=False)
+        else:
+            m, var = W[pre + ".running_mean"], W[pre + ".running_var"]
+        rs = 1 / torch.sqrt(var + eps)
+        return (H - m) * rs * W[pre + ".weight"] + W[pre + ".bias"], m, rs
+    z1, m1, r1 = bn(P, "bn1")
+    k1 = (z1 > 0) if decisions is None else decisions[0]
+    A1 = z1 * k1
+    H2 = A1 @ W["conv2.weight"].reshape(128, 256).t() + W["conv2.bias"]
+    z2, m2, r2 = bn(H2, "bn2")
+    k2 = (z2 > 0) if decisions is None else decisions[1]
+    A2 = z2 * k2
+    H3 = A2 @ W["conv3.weight"].reshape(64, 128).t() + W["conv3.bias"]
+    z3, m3, r3 = bn(H3, "bn3")
+    k3 = (z3 > 0) if decisions is None else decisions[2]
+    A3 = z3 * k3
+    w4 = W["conv4.weight"].reshape(64)
+    scores = (A3 @ w4 + W["conv4.bias"]).view(B, N, N)
+    dS = (grad_out.transpose(1, 2) if transpose else grad_out).reshape(-1).to(dt)
+
+    def bn_bwd(G, H, k, m, rs, gamma):
+        dz = G * k
+        xh = (H - m) * rs
+        dbeta, dgamma = dz.sum(0), (dz * xh).sum(0)
+        dH = gamma * rs * (dz - dbeta / R - xh * dgamma / R) if training else gamma * rs * dz
+        return dH, dgamma, dbeta
+    dH3, dg3, dbt3 = bn_bwd(dS[:, None] * w4[None, :], H3, k3, m3, r3, W["bn3.weight"])
+    dA3 = dH3 @ W["conv3.weight"].reshape(64, 128)
+    dH2, dg2, dbt2 = bn_bwd(dA3, H2, k2, m2, r2, W["bn2.weight"])
+    dA2 = dH2 @ W["conv2.weight"].reshape(128, 256)
+    dH1, dg1, dbt1 = bn_bwd(dA2, P, k1, m1, r1, W["bn1.weight"])
+    dU = dH1.view(B, N, N, 256).sum(2).reshape(B * N, 256)
+    dV = dH1.view(B, N, N, 256).sum(1).reshape(B * N, 256)
+    grads = {"conv1.weight": torch.cat([dU.t() @ F_, dV.t() @ F_], 1).view(256, 2 * D, 1, 1), "conv1.bias": dH1.sum(0),
+             "bn1.weight": dg1, "bn1.bias": dbt1, "conv2.weight": (dH2.t() @ A1).view(128, 256, 1, 1), "conv2.bias": dH2.sum(0),
+             "bn2.weight": dg2, "bn2.bias": dbt2, "conv3.weight": (dH3.t() @ A2).view(64, 128, 1, 1), "conv3.bias": dH3.sum(0),
+             "bn3.weight": dg3, "bn3.bias": dbt3, "conv4.weight": (dS[:, None] * A3).sum(0).view(1, 64, 1, 1), "conv4.bias": dS.sum().view(1)}
+    dF = (dU @ W1[:, :D] + dV @ W1[:, D:]).view(B, N, 1, D).expand(B, N, 2, D).reshape(B, 2 * N, D) / 2
+    dfeats = torch.cat([torch.zeros(B, 1, D, dtype=dt), dF], 1)
+    return (scores.transpose(1, 2) if transpose else scores), grads, dfeats, (z1, z2, z3)
+
+
 def log_optimal_transport(scores, alpha, iters):
     """model_pix2poly.py:35-66 (SuperGlue log-Sinkhorn with dustbin row/col = alpha)."""
     b, m, n = scores.shape

@@ -168,7 +168,7 @@ __global__ void pair_mean_kernel(const T* __restrict__ feats, T* __restrict__ ou
 
 // ---- ScoreNet BN1 batch statistics in closed form: h[b,i,j,c] = U[b,i,c] + V[b,j,c] ----
 template <typename T>
-__global__ void pair_stats_kernel(const T* __restrict__ U, const T* __restrict__ V, int N, int C, float* __restrict__ sums) {
+__global__ void pair_stats_kernel(const T* __restrict__ U, const T* __restrict__ V, int N, int C, float* __restrict__ sums, float* __restrict__ slab) {
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         // eight rows in flight per step, four partial sums per moment (a one-row loop is N dependent load latencies on 64 workgroups)
@@ -189,8 +189,9 @@ __global__ void pair_stats_kernel(const T* __restrict__ U, const T* __restrict__
         }
         const float su = (pu[0] + pu[1]) + (pu[2] + pu[3]), sv = (pv[0] + pv[1]) + (pv[2] + pv[3]);
         const float su2 = (pu2[0] + pu2[1]) + (pu2[2] + pu2[3]), sv2 = (pv2[0] + pv2[1]) + (pv2[2] + pv2[3]);
-        atomicAdd(sums + c, (float)N * (su + sv));
-        atomicAdd(sums + C + c, (float)N * (su2 + sv2) + 2.f * su * sv);
+        const float t1 = (float)N * (su + sv), t2 = (float)N * (su2 + sv2) + 2.f * su * sv;
+        if (slab) { slab[(int64_t)b * 2 * C + c] = t1; slab[(int64_t)b * 2 * C + C + c] = t2; }     // deterministic mode: per-sample parts
+        else { atomicAdd(sums + c, t1); atomicAdd(sums + C + c, t2); }
     }
 }
 
@@ -296,15 +297,20 @@ __global__ void bn_finalize2_kernel(const float* __restrict__ sums, int C, float
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean, var;
+    double rstd_d = 0.0;
     if (training) {
-        mean = sums[c] / count;
-        var = fmaxf(sums[C + c] / count - mean * mean, 0.f);
+        // E[x^2] - mean^2 in float64: in fp32 the subtraction loses log2(1 + mean^2 / var) bits (the sums are fp32 values; with the
+        // deterministic reduction they are float64 sums of workgroup partials rounded once)
+        const double md = (double)sums[c] / (double)count;
+        const double vd = fmax((double)sums[C + c] / (double)count - md * md, 0.0);
+        mean = (float)md; var = (float)vd;
+        rstd_d = 1.0 / sqrt(vd + (double)eps);
         if (rmean) {
             rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
             rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
         }
     } else { mean = rmean[c]; var = rvar[c]; }
-    const float rstd = rsqrtf(var + eps), s = gamma[c] * rstd;
+    const float rstd = training ? (float)rstd_d : (float)(1.0 / sqrt((double)var + (double)eps)), s = gamma[c] * rstd;
     scale[c] = s; shift[c] = beta[c] - mean * s;
     if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
 }
@@ -472,9 +478,11 @@ extern "C" int p3_pair_mean(const void* feats, void* out, int B, int L, int N, i
 extern "C" int p3_pair_stats(const void* U, const void* V, int B, int N, int C, int dtype, float* sums, void* stream) {
     P3_CHECK(U && V && sums && B > 0, P3_EINVAL, "p3_pair_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((pair_stats_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, N, C, sums),
-               hipLaunchKernelGGL((pair_stats_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)U, (const float*)V, N, C, sums), "p3_pair_stats");
+    float* slab = p3_det_scratch((int64_t)B * 2 * C, dtype);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pair_stats_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)U, (const bf16_t*)V, N, C, sums, slab),
+               hipLaunchKernelGGL((pair_stats_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)U, (const float*)V, N, C, sums, slab), "p3_pair_stats");
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, B, 2 * (int64_t)C, sums, 2 * C, 1, s);
     return P3_OK;
 }
 

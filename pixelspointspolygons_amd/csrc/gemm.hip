@@ -20,6 +20,7 @@ struct GemmArgs {
     p3_gemm_desc d;
     int tiles_m, tiles_n;
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
+    float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2][N] workgroup partials of (colsum, colsumsq) instead of atomics
 };
 
 constexpr int BM = 128, BN = 128;
@@ -502,7 +503,12 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
         for (int j = 0; j < 2; ++j) {
             const int col = tn_stats * BN + wn * 64 + j * 32 + l31;
             const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64), s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-            if (hi == 0 && col < d.N && blockIdx.x < (unsigned)ntiles) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+            if (hi == 0 && col < d.N && blockIdx.x < (unsigned)ntiles) {
+                if (g.stat_slab) {                    // workgroups of one tile column are the parts p = blockIdx.x / tiles_n (det_reduce.hip)
+                    float* part = g.stat_slab + (int64_t)(blockIdx.x / g.tiles_n) * 2 * d.N;
+                    part[col] = s1; part[d.N + col] = s2;
+                } else { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+            }
         }
     }
 }
@@ -599,6 +605,11 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
         if (cap >= g.tiles_n && nwg > cap) nwg = cap;
     }
     dim3 grid(nwg), block(256);
+    GemmArgs gs = g;
+    const int nparts = nwg / g.tiles_n;
+    if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
+    {
+    const GemmArgs& g = gs;
     switch (g.d.a_mode) {
         case P3_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_PLAIN, BKSEL, STATS>), grid, block, 0, s, g); break;
         case P3_A_CONV3X3: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3, BKSEL, STATS>), grid, block, 0, s, g); break;
@@ -607,7 +618,13 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
         case P3_A_CONV3X3_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, TO, P3_A_CONV3X3_AFFINE_RELU, BKSEL, STATS>), grid, block, 0, s, g); break;
         default: p3_set_error("p3_gemm: bad a_mode"); return P3_EINVAL;
     }
+    }
     P3_LAUNCH_CHECK();
+    if (STATS && gs.stat_slab) {
+        int rc = p3_det_reduce(gs.stat_slab, nparts, 2 * (int64_t)g.d.N, g.d.colsum, g.d.N, 1, s);
+        if (rc != P3_OK) return rc;
+        return p3_det_reduce(gs.stat_slab + g.d.N, nparts, 2 * (int64_t)g.d.N, g.d.colsumsq, g.d.N, 1, s);
+    }
     return P3_OK;
 }
 
@@ -657,7 +674,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
     P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
     GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.d = *d;
+    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
     {

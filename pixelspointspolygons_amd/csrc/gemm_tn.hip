@@ -25,6 +25,7 @@ struct TnArgs {
     float* slabs;               // optional [splits][N][K] fp32: partial tiles are STORED here (coalesced) and summed by tn_reduce_kernel
                                 // instead of splits x N x K fp32 atomics on C (measured: the atomics, not the MFMAs, bounded this kernel)
     float* colsum;              // optional [N]: += column sums of A (bias gradient), accumulated by the tk == 0 tiles from the staged registers
+    float* cs_slab;             // deterministic mode: [splits][N] partial column sums (det_reduce.hip) instead of atomics on colsum
 };
 
 template <typename T> struct TTr;
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         if (tid < TN && tn * TN + tid < g.N) {
             float a = 0.f;
             for (int r = 0; r < NRT; ++r) a += red[r * TN + tid];
-            atomicAdd(g.colsum + tn * TN + tid, a);
+            if (g.cs_slab) g.cs_slab[(int64_t)split * g.N + tn * TN + tid] = a;
+            else atomicAdd(g.colsum + tn * TN + tid, a);
         }
     }
 #pragma unroll
@@ -328,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 __global__ void tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int N, int K, int ldc, int splits) {
     const int64_t total = (int64_t)N * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += slabs[(int64_t)s * total + i];
+        double a = 0.0;                        // split order, float64: bit-reproducible and nothing lost between the partial tiles
+        for (int s = 0; s < splits; ++s) a += (double)slabs[(int64_t)s * total + i];
         const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
-        C[(int64_t)n * ldc + k] += a;
+        C[(int64_t)n * ldc + k] = (float)((double)C[(int64_t)n * ldc + k] + a);
     }
 }
 
@@ -423,6 +425,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     splits = p3_ceil_div(M, g.rows_per_split);
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
     g.splits = splits;
+    g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, dtype) : nullptr;
     dim3 grid(tiles * splits), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define P3_TN_LAUNCH(MODE)                                                                            \
@@ -439,6 +442,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
     }
     P3_LAUNCH_CHECK();
+    if (g.cs_slab) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
     return P3_OK;
 }
 

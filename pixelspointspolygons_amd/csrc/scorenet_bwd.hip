@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict
                                                              const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
                                                              const float* __restrict__ w4, T* __restrict__ dHd, float* __restrict__ acc,
                                                              int64_t R, int N, int transpose, const float* __restrict__ fix_a,
-                                                             const float* __restrict__ fix_b) {
+                                                             const float* __restrict__ fix_b, float* __restrict__ slab) {
     // Two-pass use (train-mode BatchNorm): pass 1 with dHd == NULL only accumulates the sums (no store), pass 2 with fix_a / fix_b
     // writes the FINAL gradient dz*sc + a + b*H in one go (acc == NULL: no sums) - one read of H less and no separate affine_fix pass.
     constexpr int LPR = C / 4, RPW = 64 / LPR;
@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict
     }
     __syncthreads();
     const int nvals = TAIL ? 3 * C + 1 : 2 * C;
-    for (int i = threadIdx.x; i < nvals; i += 256) atomicAdd(acc + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+    // slab != NULL (deterministic mode): the block's partials are stored and det_reduce_kernel adds them in block order in float64
+    for (int i = threadIdx.x; i < nvals; i += 256) {
+        const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        if (slab) slab[(int64_t)blockIdx.x * nvals + i] = v;
+        else atomicAdd(acc + i, v);
+    }
 }
 
 // scale = gamma*rstd, shift = beta - mean*scale, mean = S1/n, var = S2/n - mean^2  ->  dgamma, dbeta and (a, b) such that
@@ -143,7 +148,10 @@ __global__ void affine_fix_kernel(T* __restrict__ dH, const T* __restrict__ H, c
 template <typename T, int IC>
 __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA, const T* __restrict__ U, const T* __restrict__ V,
                                                        const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
-                                                       float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C) {
+                                                       float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C,
+                                                       float* __restrict__ slab, float* __restrict__ acc_slab) {
+    // slab / acc_slab != NULL (deterministic mode): dV partial rows -> slab[b][blockIdx.x][N][C] (summed by pair_dv_reduce_kernel in block
+    // order), (dscale, dshift) partials -> acc_slab[b * gridDim.x + blockIdx.x][2C] (det_reduce_kernel): no atomics at all
     __shared__ float red[4][IC + 2][256];     // C == 256
     const int b = blockIdx.y, i0 = blockIdx.x * IC;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c0 = lane * 4;
@@ -176,8 +184,12 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
                 }
             }
         }
+        if (slab) {
+            *reinterpret_cast<float4*>(slab + (((int64_t)b * gridDim.x + blockIdx.x) * N + j) * C + c0) = make_float4(av[0], av[1], av[2], av[3]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k, av[k]);
+            for (int k = 0; k < 4; ++k) atomicAdd(dV + ((int64_t)b * N + j) * C + c0 + k, av[k]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < IC; ++i)
@@ -189,8 +201,12 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
     const int c = threadIdx.x;
     for (int i = 0; i < IC; ++i)
         if (i0 + i < N) dU[((int64_t)b * N + i0 + i) * C + c] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
-    atomicAdd(acc + c, (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]));
-    atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
+    const float t_sc = (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]);
+    const float t_sh = (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]);
+    if (acc_slab) {
+        float* part = acc_slab + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;
+        part[c] = t_sc; part[C + c] = t_sh;
+    } else { atomicAdd(acc + c, t_sc); atomicAdd(acc + C + c, t_sh); }
 }
 
 // bf16 form with 16-byte accesses (r02: the 8-byte form above ran at 1.4 TB/s on the 1.2 GB of dA; 8-byte accesses reach 0.54-0.70x the
@@ -200,7 +216,7 @@ template <int IC>
 __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ U, const bf16_t* __restrict__ V,
                                                          const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
                                                          float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C,
-                                                         float* __restrict__ slab) {
+                                                         float* __restrict__ slab, float* __restrict__ acc_slab) {
     // slab != NULL: the block's dV partial rows go to slab[b][blockIdx.x][N][C] with plain 16-byte stores and pair_dv_reduce_kernel sums
     // the N / IC slabs afterwards - no global atomics at all (r02: ~50 M fp32 atomics per launch bound this kernel at ~87 G atomics/s).
     constexpr int IH = IC / 2;
@@ -278,8 +294,12 @@ __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __rest
     const int c = threadIdx.x;
     for (int i = 0; i < IC; ++i)
         if (i0 + i < N) dU[((int64_t)b * N + i0 + i) * C + c] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
-    atomicAdd(acc + c, (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]));
-    atomicAdd(acc + C + c, (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]));
+    const float t_sc = (red[0][IC][c] + red[1][IC][c]) + (red[2][IC][c] + red[3][IC][c]);
+    const float t_sh = (red[0][IC + 1][c] + red[1][IC + 1][c]) + (red[2][IC + 1][c] + red[3][IC + 1][c]);
+    if (acc_slab) {
+        float* part = acc_slab + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;
+        part[c] = t_sc; part[C + c] = t_sh;
+    } else { atomicAdd(acc + c, t_sc); atomicAdd(acc + C + c, t_sh); }
 }
 
 // dV[b, j, :] += sum over the nblk slabs of a tile (16-byte accesses, one thread per 4 channels)
@@ -351,14 +371,17 @@ extern "C" int p3_row_affine_bwd2(const void* dA, const float* dS, const void* H
     P3_CHECK(dS ? (C == 64 && w4) : (C == 128), P3_EUNSUP, "p3_row_affine_bwd: tail needs C = 64, matrix mode C = 128");
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_rows(R, 64)), b(256);
+    const int nvals = dS ? 3 * 64 + 1 : 2 * 128;
+    float* slab = acc ? p3_det_scratch((int64_t)g.x * nvals, dtype) : nullptr;
     if (dS) {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 64, true>), g, b, 0, s, nullptr, dS, (const bf16_t*)H, scale, shift, mean, w4, (bf16_t*)dHd, acc, R, N, transpose, fix_a, fix_b);
-        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 64, true>), g, b, 0, s, nullptr, dS, (const float*)H, scale, shift, mean, w4, (float*)dHd, acc, R, N, transpose, fix_a, fix_b);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 64, true>), g, b, 0, s, nullptr, dS, (const bf16_t*)H, scale, shift, mean, w4, (bf16_t*)dHd, acc, R, N, transpose, fix_a, fix_b, slab);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 64, true>), g, b, 0, s, nullptr, dS, (const float*)H, scale, shift, mean, w4, (float*)dHd, acc, R, N, transpose, fix_a, fix_b, slab);
     } else {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 128, false>), g, b, 0, s, (const bf16_t*)dA, nullptr, (const bf16_t*)H, scale, shift, mean, nullptr, (bf16_t*)dHd, acc, R, N, 0, fix_a, fix_b);
-        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 128, false>), g, b, 0, s, (const float*)dA, nullptr, (const float*)H, scale, shift, mean, nullptr, (float*)dHd, acc, R, N, 0, fix_a, fix_b);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((row_affine_bwd_kernel<bf16_t, 128, false>), g, b, 0, s, (const bf16_t*)dA, nullptr, (const bf16_t*)H, scale, shift, mean, nullptr, (bf16_t*)dHd, acc, R, N, 0, fix_a, fix_b, slab);
+        else hipLaunchKernelGGL((row_affine_bwd_kernel<float, 128, false>), g, b, 0, s, (const float*)dA, nullptr, (const float*)H, scale, shift, mean, nullptr, (float*)dHd, acc, R, N, 0, fix_a, fix_b, slab);
     }
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, (int)g.x, nvals, acc, nvals, 1, s);
     return P3_OK;
 }
 
@@ -387,6 +410,10 @@ extern "C" int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a
 }
 
 extern "C" int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C) { return (int64_t)B * ((N + 11) / 12) * N * C * 4; }
+// per dtype: the fp32 kernel takes 8 rows i per block (more, smaller slabs), the bf16 one 12
+extern "C" int64_t p3_pair_bwd_workspace_bytes_dt(int B, int N, int C, int dtype) {
+    return dtype == P3_F32 ? (int64_t)B * ((N + 7) / 8) * N * C * 4 : p3_pair_bwd_workspace_bytes(B, N, C);
+}
 
 static int pair_bwd_impl(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
                          int B, int N, int C, int dtype, float* slab, void* stream);
@@ -409,26 +436,38 @@ static int pair_bwd_impl(const void* dA, const void* U, const void* V, const flo
     static int ic_env = -1;
     if (ic_env < 0) { const char* e = getenv("P3_PAIR_IC"); ic_env = e ? atoi(e) : 0; }
     const int ic = ic_env > 0 ? ic_env : 16;     // rows i per block: dV gets N/IC atomic adds per element (same-box sweep r01: 4 -> 60.2 ms, 8 -> 58.0, 12 -> 57.7, 16 -> 57.6)
-#define PB(T, IC) hipLaunchKernelGGL((pair_bwd_kernel<T, IC>), dim3((N + IC - 1) / IC, B), dim3(256), 0, s, (const T*)dA, (const T*)U, (const T*)V, scale, shift, mean, dU, dV, acc, N, C)
+#define PB(T, IC) do { nblk = (N + IC - 1) / IC; acc_slab = p3_det_scratch((int64_t)B * nblk * 2 * C, dtype); if (!acc_slab) dslab = nullptr; \
+                       hipLaunchKernelGGL((pair_bwd_kernel<T, IC>), dim3(nblk, B), dim3(256), 0, s, (const T*)dA, (const T*)U, (const T*)V, scale, shift, mean, dU, dV, acc, N, C, dslab, acc_slab); } while (0)
+    int nblk = 0;
+    float* acc_slab = nullptr;
+    float* dslab = slab;          // the plain forms use the dV slab only together with the deterministic (dscale, dshift) partials
     static int wide = -1;                             // P3_PAIR_WIDE=0: the 8-byte form (A/B switch)
     if (wide < 0) { const char* e = getenv("P3_PAIR_WIDE"); wide = e ? atoi(e) : 1; }   // 0: 8-byte form
     if (dtype == P3_BF16 && wide && ic_env <= 0) {
         // IC = 12 rows i per block (6 per half-wave): the register budget of two waves per SIMD without spills (IC = 16 spills 270 B / lane)
-        const int nblk = (N + 11) / 12;
+        nblk = (N + 11) / 12;
+        acc_slab = p3_det_scratch((int64_t)B * nblk * 2 * C, dtype);
         hipLaunchKernelGGL((pair_bwd_kernel16<12>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
-                           mean, dU, dV, acc, N, C, slab);
+                           mean, dU, dV, acc, N, C, slab, acc_slab);
         P3_LAUNCH_CHECK();
         if (slab) {
             const int64_t per = (int64_t)N * C / 4, total = (int64_t)B * per;
             hipLaunchKernelGGL(pair_dv_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, slab, dV, nblk, per, total);
             P3_LAUNCH_CHECK();
         }
+        if (acc_slab) return p3_det_reduce(acc_slab, B * nblk, 2 * (int64_t)C, acc, 2 * C, 1, s);
         return P3_OK;
     }
-    if (dtype == P3_BF16) { if (ic == 16) PB(bf16_t, 16); else if (ic == 12) PB(bf16_t, 12); else if (ic == 4) PB(bf16_t, 4); else PB(bf16_t, 8); }
+    if (dtype == P3_BF16) { dslab = nullptr; if (ic == 16) PB(bf16_t, 16); else if (ic == 12) PB(bf16_t, 12); else if (ic == 4) PB(bf16_t, 4); else PB(bf16_t, 8); }
     else PB(float, 8);
 #undef PB
     P3_LAUNCH_CHECK();
+    if (dslab) {
+        const int64_t per = (int64_t)N * C / 4, total = (int64_t)B * per;
+        hipLaunchKernelGGL(pair_dv_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, dslab, dV, nblk, per, total);
+        P3_LAUNCH_CHECK();
+    }
+    if (acc_slab) return p3_det_reduce(acc_slab, B * nblk, 2 * (int64_t)C, acc, 2 * C, 1, s);
     return P3_OK;
 }
 

@@ -70,7 +70,38 @@ def ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+# Deterministic reductions (csrc/det_reduce.hip): P3_DETERMINISTIC = 0 off | 1 (default) every fp32 (parity-mode) launch | 2 bf16 too.
+# A 16 MB scratch for workgroup partials is registered with the library at the first launch of the process (one device per process).
+import os as _os0
+DETERMINISTIC = int(_os0.environ.get("P3_DETERMINISTIC", "1"))
+_det_state = {"buf": None}
+
+
+def set_deterministic(level):
+    """0: atomics everywhere; 1: fp32 launches reduce workgroup partials in a fixed order (float64); 2: bf16 launches too."""
+    global DETERMINISTIC
+    DETERMINISTIC = int(level)
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise P3Error("set_deterministic during a hipGraph capture")
+    if DETERMINISTIC <= 0:
+        check(lib().p3_set_deterministic(c_void_p(0), c_int64(0), c_int(0)), "p3_set_deterministic")
+        _det_state["buf"] = False
+        return
+    buf = _det_state["buf"]
+    if buf is None or buf is False:
+        buf = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+    _det_state["buf"] = buf
+    check(lib().p3_set_deterministic(c_void_p(buf.data_ptr()), c_int64(buf.numel()), c_int(1 if DETERMINISTIC >= 2 else 0)), "p3_set_deterministic")
+
+
+def det_on(t):
+    """True when launches on tensors of t's dtype take the deterministic path (Python-side workspaces follow the library's rule)."""
+    return DETERMINISTIC >= 2 or (DETERMINISTIC == 1 and t.dtype == torch.float32)
+
+
 def stream():
+    if _det_state["buf"] is None:
+        set_deterministic(DETERMINISTIC)
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -617,11 +648,15 @@ TN_MAX_SLABS = int(_os.environ.get("P3_TN_SLABS", "0"))     # > 0: store split-M
 TN_SLAB_MAX_NK = int(_os.environ.get("P3_TN_SLAB_NK", "0"))    # slabs only for outputs of at most this many elements (0: every output)
 
 
-def _tn_slabs(N, K, device):
-    """scratch for the split-M partial tiles of the weight-gradient GEMM (stored + reduced instead of fp32 atomics)."""
+def _tn_slabs(N, K, a):
+    """(scratch, max slabs) for the split-M partial tiles of the weight-gradient GEMM: stored + summed in split order by tn_reduce_kernel
+    instead of fp32 atomics.  Always in deterministic launches (hip.det_on); P3_TN_SLABS forces it elsewhere (A/B switch)."""
+    if det_on(a):
+        ns = max(8, min(512, (64 << 20) // (N * K * 4)))         # <= 64 MB of slabs, at least 8
+        return workspace(ns * N * K * 4 + 16, a.device, "tn_slabs"), ns
     if TN_MAX_SLABS <= 0 or (TN_SLAB_MAX_NK > 0 and N * K > TN_SLAB_MAX_NK):
-        return None
-    return workspace(TN_MAX_SLABS * N * K * 4 + 16, device, "tn_slabs")
+        return None, 0
+    return workspace(TN_MAX_SLABS * N * K * 4 + 16, a.device, "tn_slabs"), TN_MAX_SLABS
 
 
 def gemm_tn(a, b, out=None, colsum_out=None):
@@ -630,9 +665,10 @@ def gemm_tn(a, b, out=None, colsum_out=None):
     K = b.shape[1]
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
+    slabs, ns = _tn_slabs(N, K, a)
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
-                              ptr(_tn_slabs(N, K, a.device)), c_int(TN_MAX_SLABS), stream()), "p3_gemm_tn")
+                              ptr(slabs), c_int(ns), stream()), "p3_gemm_tn")
     return out
 
 
@@ -748,9 +784,10 @@ def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, sha
 def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=None):
     M_ = a.shape[0] if M is None else M
     N, K = a.shape[1], b.shape[1]
+    slabs, ns = _tn_slabs(N, K, a)
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
-                              ptr(None), ptr(_tn_slabs(N, K, a.device)), c_int(TN_MAX_SLABS), stream()), "p3_gemm_tn_ex")
+                              ptr(None), ptr(slabs), c_int(ns), stream()), "p3_gemm_tn_ex")
     return out
 
 
@@ -792,9 +829,10 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
     dV = torch.zeros((B * N, C), dtype=torch.float32, device=U.device)
     L = lib()
     import os
-    if dt(U) == BF16 and os.environ.get("P3_PAIR_SLAB", "1") != "0":       # dV partials through a scratch slab instead of global atomics
-        L.p3_pair_bwd_workspace_bytes.restype = c_int64
-        ws = workspace(L.p3_pair_bwd_workspace_bytes(c_int(B), c_int(N), c_int(C)), U.device, "pair_bwd")
+    # dV partials through a scratch slab instead of global atomics: the bf16 form always, the fp32 one in deterministic launches
+    if (dt(U) == BF16 and os.environ.get("P3_PAIR_SLAB", "1") != "0") or (dt(U) == F32 and det_on(U)):
+        L.p3_pair_bwd_workspace_bytes_dt.restype = c_int64
+        ws = workspace(L.p3_pair_bwd_workspace_bytes_dt(c_int(B), c_int(N), c_int(C), c_int(dt(U))), U.device, "pair_bwd")
         check(L.p3_pair_bwd_ws(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),
                                c_int(dt(U)), ptr(ws), stream()), "p3_pair_bwd_ws")
     else:

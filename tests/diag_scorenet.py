@@ -2,7 +2,7 @@
 
 Runs the HIP forward + backward several times (run-to-run spread = reduction order), counts the ReLU decisions that differ from the
 float64 restatement and re-evaluates the float64 gradient with the product's own decisions replayed ("arithmetic-only" error).
-Test infrastructure: imports the oracle.  Usage: python tools/diag_scorenet.py [runs] [B] [N]
+Test infrastructure: imports the oracle.  Usage: python tests/diag_scorenet.py [runs] [B] [N]
 """
 import json
 import os
@@ -19,59 +19,8 @@ def _rand(*shape, seed=0):
 
 
 def staged64(sd, feats, g, B, N, masks=None, transpose=False):
-    """float64 restatement in the product's staging (U, V, H2, H3); masks = optional (m1, m2, m3) overrides of the ReLU decisions."""
-    dt = torch.float64
-    W = {k[len("scorenet1."):]: v.to(dt) for k, v in sd.items() if k.startswith("scorenet1.")}
-    D, eps = 256, 1e-5
-    F = feats[:, 1:].reshape(B, N, 2, D).to(dt).mean(2).reshape(B * N, D)
-    W1 = W["conv1.weight"].reshape(256, 512)
-    U = F @ W1[:, :D].t() + W["conv1.bias"]
-    V = F @ W1[:, D:].t()
-    P = (U.view(B, N, 1, 256) + V.view(B, 1, N, 256)).reshape(-1, 256)
-    R = P.shape[0]
-
-    def bn(H, pre):
-        m = H.mean(0)
-        var = H.var(0, unbiased=False)
-        rs = 1 / torch.sqrt(var + eps)
-        z = (H - m) * rs * W[pre + ".weight"] + W[pre + ".bias"]
-        return z, m, rs
-    z1, m1, r1 = bn(P, "bn1")
-    k1 = (z1 > 0) if masks is None else masks[0]
-    A1 = z1 * k1
-    H2 = A1 @ W["conv2.weight"].reshape(128, 256).t() + W["conv2.bias"]
-    z2, m2, r2 = bn(H2, "bn2")
-    k2 = (z2 > 0) if masks is None else masks[1]
-    A2 = z2 * k2
-    H3 = A2 @ W["conv3.weight"].reshape(64, 128).t() + W["conv3.bias"]
-    z3, m3, r3 = bn(H3, "bn3")
-    k3 = (z3 > 0) if masks is None else masks[2]
-    A3 = z3 * k3
-    w4 = W["conv4.weight"].reshape(64)
-    dS = (g.transpose(1, 2) if transpose else g).reshape(-1).to(dt)
-
-    def bn_bwd(G, H, k, m, rs, gamma):
-        dz = G * k
-        xh = (H - m) * rs
-        dbeta, dgamma = dz.sum(0), (dz * xh).sum(0)
-        dH = gamma * rs * (dz - dbeta / R - xh * dgamma / R)
-        return dH, dgamma, dbeta
-    G3 = dS[:, None] * w4[None, :]
-    dw4, db4 = (dS[:, None] * A3).sum(0), dS.sum()
-    dH3, dg3, dbt3 = bn_bwd(G3, H3, k3, m3, r3, W["bn3.weight"])
-    dW3 = dH3.t() @ A2
-    dA3 = dH3 @ W["conv3.weight"].reshape(64, 128)
-    dH2, dg2, dbt2 = bn_bwd(dA3, H2, k2, m2, r2, W["bn2.weight"])
-    dW2 = dH2.t() @ A1
-    dA2 = dH2 @ W["conv2.weight"].reshape(128, 256)
-    dH1, dg1, dbt1 = bn_bwd(dA2, P, k1, m1, r1, W["bn1.weight"])
-    dU = dH1.view(B, N, N, 256).sum(2).reshape(B * N, 256)
-    dV = dH1.view(B, N, N, 256).sum(1).reshape(B * N, 256)
-    dW1 = torch.cat([dU.t() @ F, dV.t() @ F], 1)
-    grads = {"conv1.weight": dW1.view(256, 512, 1, 1), "bn1.weight": dg1, "bn1.bias": dbt1, "conv2.weight": dW2.view(128, 256, 1, 1),
-             "bn2.weight": dg2, "bn2.bias": dbt2, "conv3.weight": dW3.view(64, 128, 1, 1), "bn3.weight": dg3, "bn3.bias": dbt3,
-             "conv4.weight": dw4.view(1, 64, 1, 1), "conv4.bias": db4.view(1)}
-    return grads, (z1, z2, z3)
+    _, grads, _, zs = O.scorenet_staged(feats, g, sd, "scorenet1.", n_vertices=N, training=True, transpose=transpose, decisions=masks)
+    return grads, zs
 
 
 def main():

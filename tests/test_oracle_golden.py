@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/p3_oracle.py) against fixtures emitted by the REFERENCE's own modules
 (tests/golden/make_golden.py, run in the build container).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import p3_oracle as O
@@ -174,3 +175,26 @@ def test_hisup_head_set_matches_the_reference_module():
             n += 1
     assert n == 3 * 17                     # 17 BatchNorm2d sites: 9 in the three towers, 2 ECA, 3 + 3 in refuse / final conv
 
+
+
+@pytest.mark.parametrize("train,transpose", [(True, False), (True, True), (False, False)])
+def test_scorenet_staged_backward_equals_autograd_of_the_dense_oracle(train, transpose):
+    """`scorenet_staged` (float64, analytic backward in the separable U_i + V_j staging, used by the GPU backward test to replay ReLU
+    decisions at the kink) is the same function and the same gradient as float64 autograd of the dense restatement `scorenet`, which is
+    pinned against the reference's own ScoreNet (scorenet_*.npz)."""
+    N, B = 24, 3
+    sd = O.make_state_dict("image", dict(dim=64, depth=1, heads=2, mlp=128, patch=8, img=32, eps=1e-6), seed=9, n_vertices=N)
+    gen = torch.Generator().manual_seed(4)
+    feats, g = torch.randn(B, 2 * N + 1, 256, generator=gen), torch.randn(B, N, N, generator=gen)
+    p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+         for k, v in sd.items() if k.startswith("scorenet1.")}
+    f = feats.double().requires_grad_(True)
+    s = O.scorenet(f, p, "scorenet1.", n_vertices=N, training=train)
+    (s.transpose(1, 2) if transpose else s).backward(g.double())
+    out, grads, dfeats, zs = O.scorenet_staged(feats, g, sd, "scorenet1.", n_vertices=N, training=train, transpose=transpose)
+    assert float((out - (s.transpose(1, 2) if transpose else s)).abs().max()) < 1e-12
+    gn = max(float(v.grad.norm()) for v in p.values() if v.is_floating_point() and v.requires_grad)
+    for k, v in grads.items():
+        assert float((v - p["scorenet1." + k].grad).norm()) < 1e-11 * gn, k
+    assert float((dfeats - f.grad).norm()) < 1e-11 * float(f.grad.norm())
+    assert all(z.shape[0] == B * N * N for z in zs)
