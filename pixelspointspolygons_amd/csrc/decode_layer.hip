@@ -482,8 +482,14 @@ extern "C" int p3_decode_layer(const p3_decode_layer_desc* d, void* stream) {
     for (const void* p : {d->x_in, (const void*)d->x_out, (const void*)d->kv_self, d->kv_mem, d->w_in, d->w_so, d->w_q, d->w_co, d->w1, d->w2})
         P3_CHECK(((uintptr_t)p % 16) == 0, P3_EALIGN, "p3_decode_layer: 16-byte alignment");
     const int groups = p3_ceil_div(d->B, 8);
-    // every workgroup of a cluster must be resident while its partners spin: 2 workgroups fit a CU (60 KB LDS, 512 threads)
-    P3_CHECK(d->cluster == 1 || groups * 8 * d->cluster <= 512, P3_ESHAPE, "p3_decode_layer: cluster launch exceeds the co-resident workgroups (use cluster = 1)");
+    // every workgroup of a cluster must be resident while its partners spin: 2 workgroups fit a CU (60 KB LDS, 512 threads); the CU count
+    // is the device's (a partition or another part has fewer than the 256 of a full MI355X)
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 1;
+    }
+    P3_CHECK(d->cluster == 1 || groups * 8 * d->cluster <= 2 * cus, P3_ESHAPE, "p3_decode_layer: cluster launch exceeds the co-resident workgroups (use cluster = 1)");
     if (d->cluster == 4) hipLaunchKernelGGL(decode_layer_kernel<4>, dim3(groups * 8 * 4), dim3(DL_NT), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(decode_layer_kernel<1>, dim3(groups * 8), dim3(DL_NT), 0, (hipStream_t)stream, *d);
     P3_LAUNCH_CHECK();

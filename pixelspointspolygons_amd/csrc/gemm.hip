@@ -20,7 +20,7 @@ struct GemmArgs {
     p3_gemm_desc d;
     int tiles_m, tiles_n;
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
-    float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2][N] workgroup partials of (colsum, colsumsq) instead of atomics
+    float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2 row halves][2][N] partials of (colsum, colsumsq) instead of atomics
 };
 
 constexpr int BM = 128, BN = 128;
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
             const int col = tn_stats * BN + wn * 64 + j * 32 + l31;
             const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64), s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
             if (hi == 0 && col < d.N && blockIdx.x < (unsigned)ntiles) {
-                if (g.stat_slab) {                    // workgroups of one tile column are the parts p = blockIdx.x / tiles_n (det_reduce.hip)
-                    float* part = g.stat_slab + (int64_t)(blockIdx.x / g.tiles_n) * 2 * d.N;
+                if (g.stat_slab) {                    // parts of a column: (workgroup of its tile column, row half wm) (det_reduce.hip)
+                    float* part = g.stat_slab + ((int64_t)(blockIdx.x / g.tiles_n) * 2 + wm) * 2 * d.N;
                     part[col] = s1; part[d.N + col] = s2;
                 } else { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
             }
@@ -606,7 +606,7 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
     }
     dim3 grid(nwg), block(256);
     GemmArgs gs = g;
-    const int nparts = nwg / g.tiles_n;
+    const int nparts = 2 * (nwg / g.tiles_n);       // two row halves (wave rows) per workgroup
     if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
     {
     const GemmArgs& g = gs;

@@ -344,7 +344,7 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, float* __restr
 // atomics on 128 addresses made this kernel run at 1.5 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block,
-                                                     int ncq) {
+                                                     int ncq, float* __restrict__ slab) {
     __shared__ float red[1024];
     const int q = threadIdx.x % ncq, ry = threadIdx.x / ncq, nrl = 256 / ncq;
     const int c0 = (blockIdx.y * 64 + q) * 4;
@@ -376,19 +376,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
         float s = 0.f;
         for (int y = 0; y < nrl; ++y) s += red[y * (ncq * 4) + threadIdx.x];
         const int c = blockIdx.y * 256 + threadIdx.x;
-        if (c < N) atomicAdd(out + c, s);
+        if (c < N) {
+            if (slab) slab[(int64_t)blockIdx.x * N + c] = s;      // deterministic mode: row-block partials, summed in block order
+            else atomicAdd(out + c, s);
+        }
     }
 }
 
 // scalar fallback for N / ld not a multiple of 4
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int ld, int rows_per_block,
+                                                            float* __restrict__ slab) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     for (int c = threadIdx.x + blockIdx.y * 256; c < N; c += 256 * gridDim.y) {
         float s = 0.f;
         for (int64_t r = r0; r < r1; ++r) s += Cvt<T>::to_f(x[r * ld + c]);
-        atomicAdd(out + c, s);
+        if (slab) slab[(int64_t)blockIdx.x * N + c] = s;
+        else atomicAdd(out + c, s);
     }
 }
 
@@ -466,16 +471,20 @@ extern "C" int p3_colsum(const void* x, float* out, int64_t M, int N, int ld, in
         const int64_t r = (M + want - 1) / want;
         if (r > rpb) rpb = (int)r;
         dim3 grid(p3_ceil_div(M, rpb), cols_blocks), block(256);
-        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb, ncq);
-        else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb, ncq);
+        float* slab = p3_det_scratch((int64_t)grid.x * N, dtype);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb, ncq, slab);
+        else hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb, ncq, slab);
         P3_LAUNCH_CHECK();
+        if (slab) return p3_det_reduce(slab, (int)grid.x, N, out, N, 1, s);
         return P3_OK;
     }
     dim3 grid(p3_ceil_div(M, rpb), p3_ceil_div(N, 256)), block(256);
+    float* slab = p3_det_scratch((int64_t)grid.x * N, dtype);
     {
-        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb);
-        else hipLaunchKernelGGL((colsum_scalar_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb);
+        if (dtype == P3_BF16) hipLaunchKernelGGL((colsum_scalar_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, out, M, N, ld, rpb, slab);
+        else hipLaunchKernelGGL((colsum_scalar_kernel<float>), grid, block, 0, s, (const float*)x, out, M, N, ld, rpb, slab);
     }
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, (int)grid.x, N, out, N, 1, s);
     return P3_OK;
 }

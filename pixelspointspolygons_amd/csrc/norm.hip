@@ -303,7 +303,8 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     const bool lod = lo_drop && lo_drop->seed && lo_drop->p > 0.f;
     P3_CHECK(!lod || (dx_lo && !dres && dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32 && (cols == 256 || cols == 384 || cols == 768)),
              P3_EUNSUP, "p3_layernorm_bwd: a masked bf16 copy needs dx_lo, no dres, bf16 dy, fp32 x / dx and 256 / 384 / 768 columns");
-    P3_CHECK(!dx_lo || (cols % 128 == 0 && dtype_dx == P3_F32), P3_EUNSUP, "p3_layernorm_bwd: the bf16 copy needs cols % 128 == 0 and an fp32 dx");
+    P3_CHECK(!dx_lo || ((cols == 256 || cols == 384 || cols == 768) && dtype_dx == P3_F32), P3_EUNSUP,
+             "p3_layernorm_bwd: the bf16 copy is written by the half-wave kernel only: 256 / 384 / 768 columns and an fp32 dx");
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
     if (rows <= 0) return P3_OK;

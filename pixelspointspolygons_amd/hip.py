@@ -220,6 +220,11 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
     return (out, mean, rstd) if save_stats else out
 
 
+# widths served by the half-wave LayerNorm backward kernel, the only one that writes the bf16 twin of dx (norm.hip); any other width gets
+# no twin (lo = None) and the consumer casts dx itself - an uninitialised twin must never be registered
+LN_TWIN_COLS = (256, 384, 768)
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None):
     """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass.
     want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo).
@@ -233,10 +238,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=No
         if dres.dtype != dx.dtype:
             raise P3Error("layernorm_bwd: dres dtype must equal the dx dtype")
     lo = None
-    if want_lo and dx.dtype == torch.float32 and cols % 128 == 0:
+    if want_lo and dx.dtype == torch.float32 and cols in LN_TWIN_COLS:
         lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     if lo_drop is not None and lo is None:
-        raise P3Error("layernorm_bwd: lo_drop needs the bf16 copy (want_lo, fp32 dx, cols % 128 == 0)")
+        raise P3Error("layernorm_bwd: lo_drop needs the bf16 copy (want_lo, fp32 dx, 256 / 384 / 768 columns)")
     dspec = _drop(lo_drop)
     check(lib().p3_layernorm_bwd_lo_drop(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo),
                                          byref(dspec) if lo_drop is not None else None, ptr(dgamma), ptr(dbeta),
@@ -477,6 +482,17 @@ class DecodeLayerDesc(Structure):
                 ("eps", c_float), ("scale", c_float), ("cluster", c_int), ("exch", c_void_p), ("sync", c_void_p), ("err", c_void_p)]
 
 
+_cu_count = {}
+
+
+def coresident_workgroups(device, per_cu):
+    """workgroups of a launch that can be resident at once: per_cu x the device's CU count (queried, not assumed)."""
+    key = str(device)
+    if key not in _cu_count:
+        _cu_count[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return per_cu * _cu_count[key]
+
+
 def decode_layer_scratch(B, device):
     """(exch fp32 [B, 3, 4, 256], sync int32 [B, 2] zeroed ONCE, err int32 [1]) for the 4-workgroup cluster form of p3_decode_layer."""
     exch = torch.empty(B * 3 * 4 * 256 + 64, dtype=torch.float32, device=device)      # + 64: phase timestamps of the -DDL_TIMING build
@@ -505,8 +521,9 @@ def decode_layer(x_in, x_out, kv_self, kv_mem, key_bias, t, heads, w, eps, scrat
     for name in ("w_in", "b_in", "w_so", "b_so", "w_q", "b_q", "w_co", "b_co", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2", "g3", "be3"):
         setattr(d, name, w[name].data_ptr())
     d.eps, d.scale = float(eps), 1.0 / math.sqrt(D // heads)
-    # 4 workgroups per sample while the whole launch is co-resident (<= 512 workgroups incl. the padding to groups of 8 samples)
-    if scratch is not None and ((B + 7) // 8) * 8 * 4 <= 512:
+    # 4 workgroups per sample while the whole launch is co-resident: 2 workgroups fit a CU (60 KB LDS, 512 threads), the CU count comes
+    # from the device (256 on a full MI355X, fewer on a partition); incl. the padding to groups of 8 samples
+    if scratch is not None and ((B + 7) // 8) * 8 * 4 <= coresident_workgroups(x_in.device, 2):
         d.cluster, d.exch, d.sync, d.err = 4, scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr()
     else:
         d.cluster = 1

@@ -517,8 +517,8 @@ class _LayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
-        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] % 128 == 0   # fp32 stream under bf16 GEMMs
-        td = ctx.twin_drop if (lo and x.shape[-1] in (256, 384, 768)) else None                   # masked twin for the sublayer below
+        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS   # fp32 stream under bf16 GEMMs
+        td = ctx.twin_drop if lo else None                                                        # masked twin for the sublayer below
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo, lo_drop=td)
             _grad_ready(gamma, beta)
@@ -561,7 +561,7 @@ class _LayerNormFork(torch.autograd.Function):
         beta = ctx.beta_param
         if dres is not None and dres.dtype != x.dtype:
             dres = dres.to(x.dtype)
-        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] % 128 == 0
+        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres, want_lo=lo)
             _grad_ready(gamma, beta)

@@ -300,25 +300,38 @@ class Decoder(nn.Module):
         mem = hip.add_pos(enc.contiguous(), self.encoder_pos_embed.detach().reshape(-1, D))
         for li, l in enumerate(layers):
             st["kv_mem"][li].copy_(ops.linear(mem, l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias, cd=cd, rows=(D, 3 * D)))
-        st["preds"].fill_(self.pad_idx)
-        st["preds"][:, 0] = bos
-        st["kb"].zero_()
-        if not graphs or not st["warm"]:
-            for t in range(steps):
-                self._decode_step(st, t)
-            st["warm"] = True
-        else:
-            if st["graphs"] is None:
-                torch.cuda.synchronize()
-                pool, gs = torch.cuda.graph_pool_handle(), []
+        def run_steps():
+            st["preds"].fill_(self.pad_idx)
+            st["preds"][:, 0] = bos
+            st["kb"].zero_()
+            if not graphs or not st["warm"]:
                 for t in range(steps):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
-                        self._decode_step(st, t)
-                    gs.append(g)
-                st["graphs"] = gs
-            for g in st["graphs"]:
-                g.replay()
+                    self._decode_step(st, t)
+                st["warm"] = True
+            else:
+                if st["graphs"] is None:
+                    torch.cuda.synchronize()
+                    pool, gs = torch.cuda.graph_pool_handle(), []
+                    for t in range(steps):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool):
+                            self._decode_step(st, t)
+                        gs.append(g)
+                    st["graphs"] = gs
+                for g in st["graphs"]:
+                    g.replay()
+        run_steps()
+        # The 4-workgroup cluster of p3_decode_layer meets at a spin barrier that needs all its workgroups resident; a member that gives
+        # up waiting raises the error flag and the launch's results are invalid (other streams holding CUs, a smaller partition).  One
+        # check per generate call: on error the barrier words are reset (a timed-out barrier leaves its arrival counter behind) and the
+        # decode is redone with one workgroup per sample, which needs no co-residency.
+        sc = st.get("dl_scratch")
+        if sc is not None and int(sc[2].item()) != 0:
+            sc[1].zero_()
+            sc[2].zero_()
+            st["dl_scratch"], st["graphs"], st["warm"] = None, None, False
+            st["dl_cluster_failed"] = True
+            run_steps()
         if graphs:
             return st["preds"].clone(), st["feats"].clone()
         return st["preds"], st["feats"]
@@ -356,7 +369,8 @@ class Decoder(nn.Module):
             # one launch per layer (p3_decode_layer): bf16, the reference's decoder shape; the unfused chain below stays the fp32 path
             if "xa" not in st:
                 st["xa"], st["xb"] = (torch.empty((x.shape[0], D), dtype=cd, device=x.device) for _ in range(2))
-                st["dl_scratch"] = hip.decode_layer_scratch(x.shape[0], x.device) if os.environ.get("P3_DECODE_CLUSTER", "4") == "4" else None
+                st["dl_scratch"] = (hip.decode_layer_scratch(x.shape[0], x.device)
+                                    if os.environ.get("P3_DECODE_CLUSTER", "4") == "4" and not st.get("dl_cluster_failed") else None)
             xa, xb = st["xa"], st["xb"]
             cur = x.view(-1, D)
             for li, lyr in enumerate(self.decoder.layers):

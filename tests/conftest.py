@@ -12,7 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+# Order of the GPU suite (the driver runs it with -x): the BASELINE-config parity and bit-exact evidence first - whole-model forward parity
+# (configs #2 S/8 and B/16, #3 incl. the bs-64 batch, pillar membership, greedy tokens), configs[0] on the demo tile, FFL (config #5),
+# decode / assignment / post-processing (integer outputs) - then training-step and multi-rank tests, micro-op and backward-kernel tests last.
+_ORDER = ["test_model_gpu", "test_predict_demo_gpu", "test_ffl_gpu", "test_decode_layer_gpu", "test_assignment_gpu", "test_postprocess_gpu",
+          "test_input_pipeline_gpu", "test_ffl_loss_gpu", "test_afm_gpu", "test_train_gpu", "test_syncbn_gpu", "test_rccl_single_rank_gpu",
+          "test_ops_gpu", "test_backward_gpu"]
+
+
+def _rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    return _ORDER.index(name) if name in _ORDER else len(_ORDER)
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_rank)          # stable: the order inside a file stays
     try:
         import torch
         has_gpu = torch.cuda.is_available()

@@ -222,6 +222,53 @@ def test_layernorm_backward_masked_twin_equals_the_dropout_pass(cols):
     assert 0.07 < dropped < 0.13
 
 
+@pytest.mark.parametrize("cols", [128, 512, 640, 1024])
+def test_layernorm_backward_twin_only_at_the_widths_its_kernel_serves(cols):
+    """the bf16 twin of dx is written by the half-wave kernel only (256 / 384 / 768 columns).  At any other width
+    (vit_large: 1024) the binding must hand back NO twin - an uninitialised buffer used to be registered and consumed as the gradient -,
+    the C entry must refuse a dx_lo pointer, and the ViT-style chain in bf16 mode must produce the gradients of the cast path."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd._lib import P3Error
+    h = _h()
+    torch.manual_seed(5)
+    x = torch.randn(77, cols, device=DEV)
+    gamma, beta = torch.randn(cols, device=DEV), torch.randn(cols, device=DEV)
+    dy = torch.randn(77, cols, device=DEV).bfloat16()
+    _, mean, rstd = h.layernorm(x, gamma, beta, 1e-6, out_dtype=torch.bfloat16, save_stats=True)
+    dx, lo = h.layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=torch.float32, want_lo=True)
+    assert lo is None and torch.isfinite(dx).all()
+    import ctypes
+    from ctypes import c_int, c_int64
+    bogus = torch.empty(77, cols, dtype=torch.bfloat16, device=DEV)
+    rc = h.lib().p3_layernorm_bwd_lo_drop(h.ptr(dy), h.ptr(x), h.ptr(gamma), h.ptr(mean), h.ptr(rstd), h.ptr(None), h.ptr(dx), h.ptr(bogus), None,
+                                          h.ptr(None), h.ptr(None), c_int64(77), c_int(cols), c_int(h.BF16), c_int(h.F32), c_int(h.F32), h.stream())
+    assert rc != 0
+    # the chain of test_residual_gradient_twin_replaces_the_cast_pass at this width: no twin is left behind, gradients == cast path
+    lin = torch.nn.Linear(cols, cols).to(DEV)
+    norm = torch.nn.LayerNorm(cols, eps=1e-6).to(DEV)
+    x0 = torch.randn(3, 20, cols, device=DEV)
+
+    def run(use_twin):
+        ops.clear_twins()
+        for p_ in list(lin.parameters()) + list(norm.parameters()):
+            p_.grad = None
+        xx = x0.clone().requires_grad_(True)
+        y = ops.linear(xx.bfloat16(), lin.weight, lin.bias, residual=xx, out_dtype=torch.float32, cd=torch.bfloat16)
+        r, hn = ops.layernorm_fork(y, norm.weight, norm.bias, norm.eps, out_dtype=torch.bfloat16)
+        z = (r * 0.5).sum() + (hn.float() ** 2).sum()
+        if not use_twin:
+            reg, ops._register_twin = ops._register_twin, (lambda t, lo, drop=None: None)
+        try:
+            z.backward()
+        finally:
+            if not use_twin:
+                ops._register_twin = reg
+        return xx.grad.clone(), lin.weight.grad.clone(), len(ops._twins)
+    gx1, gw1, left = run(True)
+    gx0, gw0, _ = run(False)
+    assert left == 0 and torch.equal(gx1, gx0) and torch.equal(gw1, gw0) and torch.isfinite(gw1).all()
+
+
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_gradslot_joins_equal_autograd_joins(cd):
     """Post-norm decoder pattern (nn.TransformerDecoderLayer as model_pix2poly.py:136-143 runs it): x feeds a projection AND the residual
