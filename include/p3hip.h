@@ -115,6 +115,10 @@ typedef struct {
                            * without bounds checks; conv_H / conv_W stay the OUTPUT size */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
+/* The 256 x 256-tile kernel behind p3_gemm for wide plain bf16 products (csrc/gemm8.hip: 8 waves, LDS-DMA staging, phased K loop), callable
+ * directly for A/B measurements: same descriptor, P3_EUNSUP when the problem is not eligible (plain bf16 A, K % 64 == 0, N % 8 == 0,
+ * 16-byte aligned rows, no column sums).  stagger = 1: the two wave groups run one barrier apart (LDS reads of one overlap the MFMAs of the other). */
+int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim:  y = (x - mean) / sqrt(var + eps) * gamma + beta

@@ -650,6 +650,21 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
+// gemm8.hip: 256 x 256 tile, LDS-DMA, phased K loop
+int p3_gemm8_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
+int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, hipStream_t s);
+
+// P3_GEMM8: 0 never, 1 (default) by the shape rule below, 2 whenever eligible (A/B sweeps); P3_GEMM8_STAGGER=0|1
+static int gemm8_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8"); m = e ? atoi(e) : 0; } return m; }   // r03: off until it beats the 128^2 kernel on the path's K = 384 shapes (tools/mb_gemm8.py)
+static int gemm8_stagger() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8_STAGGER"); m = e ? atoi(e) : 1; } return m; }
+
+extern "C" int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, void* stream) {
+    P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm8: null pointer");
+    P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm8: empty problem");
+    P3_CHECK(p3_gemm8_eligible(d, A, W, C), P3_EUNSUP, "p3_gemm8: plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums");
+    return p3_gemm8_launch(A, W, C, d, stagger, (hipStream_t)stream);
+}
+
 extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm: empty problem");
@@ -685,6 +700,12 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (gemm8_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
+        // wide outputs: whole 256-column tiles or at most ~12 % of padding columns (1152 = 4.5 tiles); K deep enough for the phased pipeline
+        const int tn = (d->N + 255) / 256;
+        const bool wide = d->N >= 768 && tn * 256 * 8 <= d->N * 9;
+        if (gemm8_mode() >= 2 || (wide && d->K >= 256)) return p3_gemm8_launch(A, W, C, d, gemm8_stagger(), s);
+    }
     static int no_skinny = -1;                        // P3_NO_SKINNY=1: A/B switch
     if (no_skinny < 0) { const char* e = getenv("P3_NO_SKINNY"); no_skinny = (e && e[0] == '1') ? 1 : 0; }
     if (!no_skinny && d->dtype_in == P3_BF16 && d->M <= 128 && d->a_mode == P3_A_PLAIN && !d->colsum && !d->aux && !d->bwd_saved &&

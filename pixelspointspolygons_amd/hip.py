@@ -134,8 +134,9 @@ class GemmDesc(Structure):
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False):
-    """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p)."""
+         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, force8=None):
+    """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p).
+    force8 = 0 | 1: call the 256 x 256-tile kernel (p3_gemm8, stagger off / on) directly instead of p3_gemm's own choice (A/B tools, tests)."""
     _dev(a)
     N, K = w.shape
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
@@ -180,7 +181,10 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
             raise P3Error("gemm: bwd_saved must match the output's dtype and row stride")
         d.bwd_saved, d.bwd_act, d.bwd_scale = sv.data_ptr(), bact, bscale
     ev = KTIMER.begin()
-    check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
+    if force8 is not None:
+        check(lib().p3_gemm8(ptr(a), ptr(w), ptr(out), byref(d), c_int(int(force8)), stream()), "p3_gemm8")
+    else:
+        check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
     if ev is not None:
         # algorithmic HBM bytes of this launch: A read once (generated A: its sources), W once, C written once, residual / aux /
         # saved-activation streams once each

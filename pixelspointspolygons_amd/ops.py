@@ -177,6 +177,21 @@ def unregister(params):
         del _shadow_cache[k]
 
 
+def reset_process_state():
+    """Forget every process-wide registration: optimizer arena views and the copies derived from them, the direct-gradient switch, the
+    reducer's report channel, pending gradient twins, SyncBatchNorm.  For a process that builds one model after another (tests, sweeps):
+    an optimizer that was never close()d otherwise keeps its arenas alive and leaves DIRECT_GRAD / GRAD_READY set for the next model."""
+    _registered.clear()
+    _registered_T.clear()
+    _shadow_cache.clear()
+    _twins.clear()
+    DIRECT_GRAD[0] = False
+    GRAD_READY[0] = None
+    SYNC_BN[0] = False
+    _BUMPS[0] = None
+    _epoch[0] += 1
+
+
 def invalidate_derived():
     _epoch[0] += 1
 

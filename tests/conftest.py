@@ -38,3 +38,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_process_state(request):
+    """Every GPU test starts from a clean product state: an optimizer a previous test never closed must not leak its arena views, the
+    direct-gradient switch or the reducer hook into the next test (the suite's order is not the files' alphabetical order any more)."""
+    yield
+    if "gpu" in request.keywords:
+        try:
+            from pixelspointspolygons_amd import ops
+            ops.reset_process_state()
+        except Exception:
+            pass
