@@ -117,8 +117,9 @@ typedef struct {
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 /* The 256 x 256-tile kernel behind p3_gemm for wide plain bf16 products (csrc/gemm8.hip: 8 waves, LDS-DMA staging, phased K loop), callable
  * directly for A/B measurements: same descriptor, P3_EUNSUP when the problem is not eligible (plain bf16 A, K % 64 == 0, N % 8 == 0,
- * 16-byte aligned rows, no column sums).  stagger = 1: the two wave groups run one barrier apart (LDS reads of one overlap the MFMAs of the other). */
-int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, void* stream);
+ * 16-byte aligned rows, no column sums).  structure: 0 four two-barrier phases per K-tile, 1 the same with the two wave groups one barrier apart,
+ * 2 one barrier per K-tile, < 0 chosen by K. */
+int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim:  y = (x - mean) / sqrt(var + eps) * gamma + beta

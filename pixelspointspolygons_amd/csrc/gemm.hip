@@ -652,17 +652,20 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 
 // gemm8.hip: 256 x 256 tile, LDS-DMA, phased K loop
 int p3_gemm8_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
-int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, hipStream_t s);
+int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, hipStream_t s);
 
-// P3_GEMM8: 0 never, 1 (default) by the shape rule below, 2 whenever eligible (A/B sweeps); P3_GEMM8_STAGGER=0|1
-static int gemm8_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8"); m = e ? atoi(e) : 0; } return m; }   // r03: off until it beats the 128^2 kernel on the path's K = 384 shapes (tools/mb_gemm8.py)
-static int gemm8_stagger() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8_STAGGER"); m = e ? atoi(e) : 1; } return m; }
+// P3_GEMM8: 0 (default) never, 1 by the shape rule below, 2 whenever eligible (A/B sweeps); P3_GEMM8_STRUCT=0|1|2 forces a loop structure.
+// Default OFF: same-box A/B of the whole train step (r03): 42.55 ms without, 43.35 ms with it - on the path's shapes (K = 384 .. 1536, output
+// 116 - 154 MB per launch) a tile's life is bounded by its epilogue and HBM, not by the K loop the 256^2 structure speeds up (8192^3: 1097 vs
+// 880 TF); profiles/r03_g8_probe.txt has the ablation (epilogue + prologue alone = 26 of 67 us on the qkv shape).
+static int gemm8_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8"); m = e ? atoi(e) : 0; } return m; }
+static int gemm8_struct() { static int m = -2; if (m < -1) { const char* e = getenv("P3_GEMM8_STRUCT"); m = e ? atoi(e) : -1; } return m; }
 
-extern "C" int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, void* stream) {
+extern "C" int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, void* stream) {
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm8: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm8: empty problem");
     P3_CHECK(p3_gemm8_eligible(d, A, W, C), P3_EUNSUP, "p3_gemm8: plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums");
-    return p3_gemm8_launch(A, W, C, d, stagger, (hipStream_t)stream);
+    return p3_gemm8_launch(A, W, C, d, structure, (hipStream_t)stream);
 }
 
 extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
@@ -701,10 +704,13 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     }
     hipStream_t s = (hipStream_t)stream;
     if (gemm8_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
-        // wide outputs: whole 256-column tiles or at most ~12 % of padding columns (1152 = 4.5 tiles); K deep enough for the phased pipeline
+        // where it measured faster than the 128^2 kernel (tools/mb_gemm8.py, profiles/r03_mb_gemm8.txt): the ViT's wide products (N >= 1152:
+        // qkv, fc1, dX of fc2; <= 12 % padding columns) and from K = 1024 on also its 384-column ones (fc2, dX of fc1 / qkv); the decoder's
+        // shapes (M = 24640 / 50176, K = 256 or N = 256) stay on the 128^2 kernel, which is up to 1.5x faster there
         const int tn = (d->N + 255) / 256;
-        const bool wide = d->N >= 768 && tn * 256 * 8 <= d->N * 9;
-        if (gemm8_mode() >= 2 || (wide && d->K >= 256)) return p3_gemm8_launch(A, W, C, d, gemm8_stagger(), s);
+        const bool fits = tn * 256 * 8 <= d->N * 9 || d->N == 384;
+        const bool win = d->M >= 32768 && fits && ((d->N >= 1152 && d->K >= 384) || (d->N >= 384 && d->K >= 1024));
+        if (gemm8_mode() >= 2 || win) return p3_gemm8_launch(A, W, C, d, gemm8_struct(), s);
     }
     static int no_skinny = -1;                        // P3_NO_SKINNY=1: A/B switch
     if (no_skinny < 0) { const char* e = getenv("P3_NO_SKINNY"); no_skinny = (e && e[0] == '1') ? 1 : 0; }

@@ -41,9 +41,14 @@ __device__ __forceinline__ float g8_act_grad(float x, int act) {
     return x > 0.f ? 1.f : 0.f;
 }
 
-// STAGGER: the waves of the second row half (wr = 1) run one barrier behind the first, so that one group's LDS reads / DMA issue overlap
-// the other group's MFMAs (the guide's `if (wr == 1) s_barrier`).
-template <typename TO, bool STAGGER>
+// Loop structures (tools/probe/g8_probe.hip measured them side by side, profiles/r03_g8_probe.txt):
+//   STRUCT 0  four phases per K-tile, two barriers each, one half-tile of DMA per phase (the description above);
+//   STRUCT 1  the same with the waves of the second row half (wr = 1) one barrier behind the first, so that one group's LDS reads / DMA
+//             issue overlap the other group's MFMAs (the guide's `if (wr == 1) s_barrier`): best from ~16 K-tiles on (K = 1536: 84 vs 104 us);
+//   STRUCT 2  ONE barrier per K-tile: wait for this wave's pieces of K-tile kt, barrier (K-tile kt readable by all, buffer of kt - 1 free),
+//             issue all of K-tile kt + 1, then the four quadrants without any barrier between them: best on the 6-K-tile ViT shapes
+//             (qkv 65 vs 73 us, fc1 84 vs 94).
+template <typename TO, int STRUCT>
 __global__ __launch_bounds__(512, 1) void gemm8_kernel(G8Args g) {
     __shared__ __attribute__((aligned(1024))) uint4 lds[8 * SLOT_U4];       // [buffer 0/1][A_lo, A_hi, B_lo, B_hi][128][8]
     const p3_gemm_desc& d = g.d;
@@ -92,6 +97,53 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(G8Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int sw = (l31 >> 1) & 7;
+    uint4 af[2][4], bfr[2][4];
+    const int arow = l31 * 8, brow = ((wc & 1) * 64 + l31) * 8;      // uint4 index of the fragment row inside its half-tile (+ 32-row blocks)
+    constexpr bool STAGGER = STRUCT == 1;
+    if constexpr (STRUCT == 2) {
+        // RAW: vmcnt(0) retires this wave's pieces of K-tile kt (the only DMA in flight), the barrier extends that to every wave's pieces.
+        // WAR: a wave reaches the barrier of iteration kt after the MFMAs that consumed its reads of K-tile kt - 1, so after the barrier the
+        // buffer of kt - 1 belongs to the DMA of kt + 1.
+        stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(kt + 1, 0); stage(kt + 1, 1); stage(kt + 1, 2); stage(kt + 1, 3);
+            const uint4* abuf = lds + ((kt & 1) * 4 + wr) * SLOT_U4;
+            const uint4* bbuf = lds + ((kt & 1) * 4 + 2 + (wc >> 1)) * SLOT_U4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[j][kk] = bbuf[brow + j * 256 + ((2 * kk + hi) ^ sw)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i][kk] = abuf[arow + i * 256 + ((2 * kk + hi) ^ sw)];
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) af[i][kk] = abuf[arow + (2 + i) * 256 + ((2 * kk + hi) ^ sw)];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = half == 0 ? jj : 1 - jj;
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[2 * half + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][kk]), __builtin_bit_cast(bf16x8_t, bfr[j][kk]),
+                                                                                          acc[2 * half + i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // every wave is done with the operands: the epilogue may overwrite them
+    } else {
     // ---- prologue: K-tile 0 whole, then the three half-tiles of K-tile 1 the steady state would have issued in phases 2..4 of "K-tile -1"
     stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
     stage(1, 2); stage(1, 3); stage(1, 0);
@@ -99,10 +151,6 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(G8Args g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (STAGGER) { if (wr == 1) __builtin_amdgcn_s_barrier(); }
-
-    const int sw = (l31 >> 1) & 7;
-    uint4 af[2][4], bfr[2][4];
-    const int arow = l31 * 8, brow = ((wc & 1) * 64 + l31) * 8;      // uint4 index of the fragment row inside its half-tile (+ 32-row blocks)
     for (int kt = 0; kt < nk; ++kt) {
         const uint4* abuf = lds + ((kt & 1) * 4 + wr) * SLOT_U4;
         const uint4* bbuf = lds + ((kt & 1) * 4 + 2 + (wc >> 1)) * SLOT_U4;
@@ -170,6 +218,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(G8Args g) {
         __builtin_amdgcn_s_barrier();
     }
     if constexpr (STAGGER) { if (wr == 0) __builtin_amdgcn_s_barrier(); }      // the lagging group catches up: every wave is done with the operands
+    }
 
     // ---- epilogue: per wave, four 32 x 64 blocks through a private fp32 image [32][72] (9 KB of the wave's 16 KB slice of the operand LDS)
     constexpr int EP = 72;
@@ -276,18 +325,22 @@ int p3_gemm8_eligible(const p3_gemm_desc* d, const void* A, const void* W, const
     return 1;
 }
 
-int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int stagger, hipStream_t s) {
+// structure: 0 / 1 / 2 as above, < 0 = by K (one barrier per K-tile for short K, staggered phases from 16 K-tiles on)
+int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, hipStream_t s) {
     G8Args g;
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, G8_BM);
     g.tiles_n = p3_ceil_div(d->N, G8_BN);
     dim3 grid(g.tiles_m * g.tiles_n), block(512);
+    if (structure < 0) structure = d->K >= 1024 ? 1 : 2;
     if (d->dtype_out == P3_BF16) {
-        if (stagger) hipLaunchKernelGGL((gemm8_kernel<bf16_t, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm8_kernel<bf16_t, false>), grid, block, 0, s, g);
+        if (structure == 1) hipLaunchKernelGGL((gemm8_kernel<bf16_t, 1>), grid, block, 0, s, g);
+        else if (structure == 2) hipLaunchKernelGGL((gemm8_kernel<bf16_t, 2>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm8_kernel<bf16_t, 0>), grid, block, 0, s, g);
     } else {
-        if (stagger) hipLaunchKernelGGL((gemm8_kernel<float, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm8_kernel<float, false>), grid, block, 0, s, g);
+        if (structure == 1) hipLaunchKernelGGL((gemm8_kernel<float, 1>), grid, block, 0, s, g);
+        else if (structure == 2) hipLaunchKernelGGL((gemm8_kernel<float, 2>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm8_kernel<float, 0>), grid, block, 0, s, g);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

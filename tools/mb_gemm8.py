@@ -43,7 +43,7 @@ def check_variant(tag, M, N, K, **kw):
     if kw.get("drop"):
         args["drop"] = (torch.full((1,), 77, dtype=torch.int64, device="cuda"), 5, 0.1)
     outs = []
-    for f8 in (None, 0, 1):
+    for f8 in (None, 0, 1, 2):
         aux = torch.zeros(M, N, device="cuda", dtype=odt) if kw.get("aux") is not None else None
         o = h.gemm(a, w, out_dtype=odt, aux=aux, aux_grad=bool(kw.get("aux")), force8=f8, **args)
         outs.append((o.clone(), None if aux is None else aux.clone()))
@@ -80,7 +80,7 @@ def main():
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ref = h.gemm(a, w, bias=b).clone()
         line = f"  {tag:14s} M={M:6d} N={N:5d} K={K:5d}: "
-        for name, f8 in (("128^2", None), ("256^2", 0), ("256^2 stagger", 1)):
+        for name, f8 in (("128^2", None), ("256^2 S0", 0), ("S1 stagger", 1), ("S2 1-barrier", 2)):
             bad = 0
             for _ in range(6):
                 o = h.gemm(a, w, bias=b, out=out, force8=f8)
