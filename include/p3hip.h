@@ -419,6 +419,23 @@ int p3_affine_relu_bwd256(const void* dA, const void* H, int ldh, int dtype, con
                           void* dHd, float* acc, int64_t R, void* stream);
 int p3_pad_nhwc(const void* src, int ld_src, int dtype, const float* scale, const float* shift, int c_aff, int C, int Cp, void* dst, int B, int H,
                 int W, void* stream);
+
+/* ---- HiSup head set (models/hisup/model_hisup.py:38-64 `ECA`, :122-226 `EncoderDecoder.forward_common` after the encoder).
+ * The 3x3 / 1x1 convolutions, BatchNorm statistics and zero-bordered images are p3_gemm (P3_A_CONV3X3 + conv_pad, column sums), p3_bn_finalize
+ * and p3_pad_nhwc; these three entries are the rest.  Maps are token-major [B*H*W, ld] in `dtype`, a producer's BatchNorm + ReLU travels as
+ * per-channel (scale, shift) and is applied where the map is read.
+ * p3_nchw_to_nhwc:    the encoder's NCHW fp32 feature map (what the reference hands to the heads, model_hisup.py:205) -> token-major.
+ * p3_eca_gate:        pooled[b,c] = mean_hw(relu(bn(a1)) + relu(bn(a2)))  (ECA.avg_pool(x1 + x2)), gate = sigmoid(conv1d_k(pooled) over c)
+ *                     (Conv1d(1, 1, k, padding k/2, no bias), model_hisup.py:47,59-61); k odd.
+ * p3_affine_relu_mix: out = f(a) * gate[b, c] + g(b)  with f / g = relu(x*scale + shift) when scale is given, identity otherwise; gate and the
+ *                     second source are optional: x2 * y (ECA.forward, :63), feature + attention feature (:217-218), the channel halves of
+ *                     torch.cat((features, afm_conv)) (:222). */
+int p3_nchw_to_nhwc(const float* X, void* out, int ld, int dtype, int B, int C, int64_t HW, void* stream);
+int p3_eca_gate(const void* a1, int ld1, const float* scale1, const float* shift1, const void* a2, int ld2, const float* scale2,
+                const float* shift2, const float* conv_w, int k, float* pooled, float* gate, int B, int64_t HW, int C, int dtype, void* stream);
+int p3_affine_relu_mix(void* out, int ld_out, const void* a, int ld_a, const float* scale_a, const float* shift_a, const float* gate,
+                       const void* b, int ld_b, const float* scale_b, const float* shift_b, int64_t R, int C, int64_t HW, int dtype,
+                       void* stream);
 int p3_upsample_bilinear_bwd(const void* dUp, int dtype, float* tmp, void* dtok, int B, int h, int w, int C, int H, int W, int tok_off,
                              int tok_per_img, void* stream);
 

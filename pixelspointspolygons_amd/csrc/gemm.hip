@@ -21,6 +21,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
     float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2 row halves][2][N] partials of (colsum, colsumsq) instead of atomics
+    int col_major;      // STATS walk: tiles in column-major order (every workgroup of the chip on ONE column panel of W at a time)
 };
 
 constexpr int BM = 128, BN = 128;
@@ -195,7 +196,24 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     // plain mode: one tile per workgroup, XCD-aware order (consecutive logical tiles = same A row-panel = one XCD's L2);
     // STATS mode: gridDim.x is a multiple of tiles_n, so tn stays fixed along a workgroup's walk
     const int bid = STATS ? vb : xcd_remap(vb, ntiles);
-    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    if constexpr (STATS) {
+        // col_major (a weight matrix larger than one XCD's L2: the fusion conv's 5.3 MB): all resident workgroups sit on the same 128-column
+        // panel of W, which then stays in every L2 (r02 PMC: 2.14 GB fetched per launch in row-major order, the panels evicting each other);
+        // the A rows are read once per panel instead.  A workgroup's walk then crosses panels: its column sums are flushed at the crossing.
+        if (g.col_major) {
+            tn = bid / g.tiles_m; tm = bid - tn * g.tiles_m;
+            if (tn != tn_stats && vb != (int)blockIdx.x) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = tn_stats * BN + wn * 64 + j * 32 + l31;
+                    const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64), s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+                    if (hi == 0 && col < d.N) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
+                    cs1[j] = 0.f; cs2[j] = 0.f;
+                }
+            }
+        }
+    }
     tn_stats = tn;
     RowSrc arow[NPASS];
     int64_t wrow[NPASS];
@@ -608,6 +626,10 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
     GemmArgs gs = g;
     const int nparts = 2 * (nwg / g.tiles_n);       // two row halves (wave rows) per workgroup
     if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
+    // column-major walk when W (N x K) cannot stay in a 4 MB L2 next to the A stream; the deterministic (slab) form keeps the row-major walk
+    static int cm_env = -1;                               // P3_GEMM_COLMAJOR=0: A/B switch
+    if (cm_env < 0) { const char* e = getenv("P3_GEMM_COLMAJOR"); cm_env = (e && e[0] == '0') ? 0 : 1; }
+    gs.col_major = (STATS && cm_env && !gs.stat_slab && g.tiles_n > 1 && (int64_t)g.d.N * g.d.K * (int)sizeof(T) > (3ll << 20)) ? 1 : 0;
     {
     const GemmArgs& g = gs;
     switch (g.d.a_mode) {
@@ -692,7 +714,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
     P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
     GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr;
+    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.col_major = 0;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
     {

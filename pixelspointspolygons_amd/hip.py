@@ -938,6 +938,39 @@ def pad_nhwc(src, ld_src, scale, shift, c_aff, C, Cp, B, H, W, out=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------ HiSup head set
+def nchw_to_nhwc(x, dtype, ld=None):
+    """fp32 [B, C, H, W] -> token-major [B*H*W, ld] in `dtype` (columns >= C zero)."""
+    _dev(x)
+    B, C, H, W = x.shape
+    ld = ld or C
+    out = torch.zeros((B * H * W, ld), dtype=dtype, device=x.device) if ld != C else torch.empty((B * H * W, ld), dtype=dtype, device=x.device)
+    check(lib().p3_nchw_to_nhwc(ptr(x.contiguous().float()), ptr(out), c_int(ld), c_int(dt(out)), c_int(B), c_int(C), c_int64(H * W), stream()),
+          "p3_nchw_to_nhwc")
+    return out
+
+
+def eca_gate(a1, aff1, a2, aff2, conv_w, B, HW, C):
+    """sigmoid(conv1d_k(mean_hw(relu(bn(a1)) + relu(bn(a2))))) -> fp32 [B, C]; aff = (scale, shift) of the producing BatchNorm."""
+    pooled = torch.empty((B, C), dtype=torch.float32, device=a1.device)
+    gate = torch.empty_like(pooled)
+    w = conv_w.detach().reshape(-1).float().contiguous()
+    check(lib().p3_eca_gate(ptr(a1), c_int(a1.stride(0)), ptr(aff1[0]), ptr(aff1[1]), ptr(a2), c_int(a2.stride(0)), ptr(aff2[0]), ptr(aff2[1]), ptr(w),
+                            c_int(w.numel()), ptr(pooled), ptr(gate), c_int(B), c_int64(HW), c_int(C), c_int(dt(a1)), stream()), "p3_eca_gate")
+    return gate
+
+
+def affine_relu_mix(out, a, aff_a, HW, C, gate=None, b=None, aff_b=None):
+    """out[:, :C] = f(a) * gate[b(r)] + g(b): f / g = relu(x*scale + shift) when aff is given, identity otherwise (see p3_affine_relu_mix)."""
+    R = a.shape[0]
+    sa, ha = aff_a if aff_a is not None else (None, None)
+    sb, hb = aff_b if aff_b is not None else (None, None)
+    check(lib().p3_affine_relu_mix(ptr(out), c_int(out.stride(0)), ptr(a), c_int(a.stride(0)), ptr(sa), ptr(ha), ptr(gate), ptr(b),
+                                   c_int(b.stride(0) if b is not None else 0), ptr(sb), ptr(hb), c_int64(R), c_int(C), c_int64(HW), c_int(dt(a)),
+                                   stream()), "p3_affine_relu_mix")
+    return out
+
+
 def upsample_bilinear_bwd(dUp, B, h, w, H, W, tok_off=1):
     """dUp [B, H, W, C] -> dtokens [B, tok_off + h*w, C] (rows before tok_off are zero)."""
     C = dUp.shape[-1]
