@@ -334,6 +334,7 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
         if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNH(float, float, float);
         else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNH(bf16_t, float, float);
         else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNH(bf16_t, bf16_t, bf16_t);
+        else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_BF16) LNH(bf16_t, float, bf16_t);      // fp32 stream, bf16 gradient stream
         else if (dtype_dy == P3_F32 && dtype_x == P3_BF16 && dtype_dx == P3_F32) LNH(float, bf16_t, float);
         else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
 #undef LNH
@@ -349,6 +350,7 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     if (dtype_dy == P3_F32 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(float, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32) LNB(bf16_t, float, float);
     else if (dtype_dy == P3_BF16 && dtype_x == P3_BF16 && dtype_dx == P3_BF16) LNB(bf16_t, bf16_t, bf16_t);
+    else if (dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_BF16) LNB(bf16_t, float, bf16_t);
     else if (dtype_dy == P3_F32 && dtype_x == P3_BF16 && dtype_dx == P3_F32) LNB(float, bf16_t, float);
     else { p3_set_error("p3_layernorm_bwd: dtype combination"); return P3_EUNSUP; }
 #undef LNB

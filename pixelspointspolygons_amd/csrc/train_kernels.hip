@@ -138,7 +138,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                                  int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
                                                                  const float* __restrict__ dperm, float* __restrict__ dscores,
-                                                                 float* __restrict__ dalpha, int* __restrict__ tile_flags, float* __restrict__ vecs) {
+                                                                 float* __restrict__ dalpha, int* __restrict__ tile_flags, float* __restrict__ vecs,
+                                                                 int forced) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1, VS = 2 * (M1 + N1);
     float* E = sm;                   // [M1][N1]
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int idx = tid & 255, part = tid >> 8;
     const int chj = (N1 + 3) / 4, chi = (M1 + 3) / 4;
-    const int forced = tile_flags[b] != 0;                   // host request (P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel
+    // forced (kernel argument; P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel.  tile_flags is WRITE-only here: r03's
+    // rocprofv3 runs of the captured step showed the flags non-zero on entry (a memset node ahead of this kernel had cleared them before:
+    // every tile then took the 1.2 ms log-domain path under the profiler only) - nothing is read that this launch did not write
     const float alpha = alpha_p[0];
     for (int i = tid; i < M1 * N1; i += 1024) {
         const int r = i / N1, c = i - r * N1;
@@ -434,11 +437,9 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
     hipStream_t s = (hipStream_t)stream;
     int* tile_flags = reinterpret_cast<int*>(workspace);
     float* vecs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * 4 + 255) / 256 * 256);
-    hipError_t me = hipMemsetAsync(tile_flags, force_log ? 1 : 0, sizeof(int32_t) * (size_t)B, s);
-    if (me != hipSuccess) { p3_set_error(hipGetErrorString(me)); return (int)me; }
     // two launches: the linear-domain kernel takes every tile whose row spread allows it and flags the others for the log-domain
     // kernel, which returns at once for the tiles already done (one kernel holding both loops spilled 40 more registers)
-    hipLaunchKernelGGL(sinkhorn_bwd_fast_kernel, dim3(B), dim3(1024), lds_fast, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags, vecs);
+    hipLaunchKernelGGL(sinkhorn_bwd_fast_kernel, dim3(B), dim3(1024), lds_fast, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags, vecs, force_log);
     hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
     P3_LAUNCH_CHECK();
     return P3_OK;

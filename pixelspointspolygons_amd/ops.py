@@ -287,12 +287,46 @@ def _register_twin(t, lo, drop=None):
 
 def clear_twins():
     _twins.clear()
+    _stream.clear()
+
+
+# ---- bf16 residual-GRADIENT stream of the ViT (P3_GRAD_BF16=1) -------------------------------------------------------------------------
+# The forward residual stream stays fp32 (its bf16 form costs accuracy: encoder feature error 1.0 % -> 3.3 %, r02); its GRADIENT need not:
+# every consumer (the dX / dW GEMMs of proj, fc2, the next LayerNorm backward) reads it in bf16 anyway.  autograd insists that the gradient
+# of an fp32 tensor is fp32, so what travels along the stream through autograd is a CARRIER - an fp32 tensor of the right shape with stride 0
+# over one element (no memory, no kernel) - and the real bf16 gradient rides in this table under the carrier's address.  Producers:
+# _LayerNormFork / the ViT's final _LayerNorm (ln_bwd writes bf16 dx and takes a bf16 dres: one 38 MB write instead of 77 MB + the 38 MB
+# twin, one 38 MB read instead of 77 MB per LayerNorm backward).  Consumers resolve a carrier with _stream_real(): _to_cd (the GEMMs),
+# _LayerNormFork.backward (dres), _Assemble.backward (end of the chain: one cast back to fp32).  A residual pass-through (`dres = dy` in
+# _Linear / _Mlp backward) hands the carrier on untouched.
+GRAD_STREAM_BF16 = [os.environ.get("P3_GRAD_BF16", "1") == "1"]    # r03: -0.35 ms per step (ln_bwd 68.6 -> 55.8 us x 24), encoder gradient cosine at the run-to-run noise floor (tools/diag_gradstream.py)
+_stream = {}
+
+
+def _stream_carrier(real, shape):
+    if len(_stream) > 8:
+        _stream.clear()
+    base = torch.empty(1, dtype=torch.float32, device=real.device)
+    _stream[base.data_ptr()] = (base, real)
+    return base.expand(shape)
+
+
+def _stream_real(t, last=False):
+    """the bf16 gradient a carrier stands for, or None when `t` is an ordinary tensor; last=True: this is the carrier's final consumer
+    (the LayerNorm backward that takes it as dres, or the end of the chain) - the entry and its 38 MB are released"""
+    if t is None or not _stream or t.dtype != torch.float32 or any(t.stride()):
+        return None
+    ent = _stream.pop(t.data_ptr(), None) if last else _stream.get(t.data_ptr())
+    return ent[1] if ent is not None else None
 
 
 def _to_cd(t2, cd):
     """gradient `t2` in the compute dtype: the producer's bf16 twin when there is one, a cast pass otherwise"""
     if t2.dtype == cd:
         return t2
+    real = _stream_real(t2)
+    if real is not None:
+        return real.view(t2.shape) if real.dtype == cd else hip.cast(real.view(t2.shape), cd)
     if cd == torch.bfloat16 and t2.dtype == torch.float32:
         ent = _twins.pop(t2.data_ptr(), None)
         if ent is not None and ent[2] is None and ent[1].numel() == t2.numel() and t2.is_contiguous():
@@ -520,7 +554,7 @@ class _LayerNorm(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps, out_dtype, twin_drop):
         need = any(ctx.needs_input_grad)
         ctx.beta_param = beta
-        ctx.twin_drop = twin_drop if (twin_drop is not None and twin_drop[2] > 0.0) else None
+        ctx.twin_drop = twin_drop if (twin_drop is not None and (twin_drop == ("stream",) or twin_drop[2] > 0.0)) else None
         if need:
             y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
             ctx.save_for_backward(x, gamma, mean, rstd)
@@ -533,7 +567,12 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
         lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS   # fp32 stream under bf16 GEMMs
-        td = ctx.twin_drop if lo else None                                                        # masked twin for the sublayer below
+        stream = ctx.twin_drop == ("stream",)
+        if stream and lo and GRAD_STREAM_BF16[0]:
+            if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
+                return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, None), None, None, None, None, None
+            return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, None, loose=True) + (None, None, None)
+        td = ctx.twin_drop if (lo and not stream) else None                                       # masked twin for the sublayer below
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo, lo_drop=td)
             _grad_ready(gamma, beta)
@@ -550,10 +589,30 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
-def layernorm(x, gamma, beta, eps, out_dtype=None, twin_drop=None):
+def _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres, loose=False):
+    """LayerNorm backward on the bf16 gradient stream: dres (a carrier, a real tensor or None) in bf16, dx written in bf16, a carrier returned.
+    loose: parameter gradients as fresh tensors -> (carrier, dgamma, dbeta); else they are accumulated into the arena (.grad)."""
+    real = _stream_real(dres, last=True)
+    if real is not None:
+        dres_bf = real.view(dres.shape) if real.dtype == torch.bfloat16 else hip.cast(real.view(dres.shape), torch.bfloat16)
+    else:
+        dres_bf = None if dres is None else (dres if dres.dtype == torch.bfloat16 else hip.cast(dres.contiguous(), torch.bfloat16))
+    if loose:
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    else:
+        dg, db = gamma.grad, beta.grad
+    dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=torch.bfloat16, dgamma=dg, dbeta=db, dres=dres_bf)
+    if not loose:
+        _grad_ready(gamma, beta)
+    car = _stream_carrier(dx, x.shape)
+    return (car, dg, db) if loose else car
+
+
+def layernorm(x, gamma, beta, eps, out_dtype=None, twin_drop=None, stream_grad=False):
     """twin_drop = (seed, site, p): the dropout the producer of `x` applied to its output before the residual add (post-norm decoder);
-    in bf16 mode the backward then hands that sublayer its masked, scaled bf16 gradient directly (no dropout_apply pass)."""
-    return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype, twin_drop)
+    in bf16 mode the backward then hands that sublayer its masked, scaled bf16 gradient directly (no dropout_apply pass).
+    stream_grad: x is the ViT's fp32 residual stream - under GRAD_STREAM_BF16 its gradient leaves as a bf16 carrier (see _stream_carrier)."""
+    return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype, ("stream",) if (stream_grad and twin_drop is None) else twin_drop)
 
 
 class _LayerNormFork(torch.autograd.Function):
@@ -574,9 +633,16 @@ class _LayerNormFork(torch.autograd.Function):
     def backward(ctx, dres, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
+        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS
+        if lo and GRAD_STREAM_BF16[0]:
+            if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
+                return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres), None, None, None, None
+            return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres, loose=True) + (None, None)
+        real = _stream_real(dres, last=True)
+        if real is not None:                      # a carrier reached a fork that does not produce one (width without the half-wave kernel)
+            dres = hip.cast(real.view(dres.shape), x.dtype)
         if dres is not None and dres.dtype != x.dtype:
             dres = dres.to(x.dtype)
-        lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
             dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres, want_lo=lo)
             _grad_ready(gamma, beta)

@@ -151,7 +151,7 @@ class VisionTransformer(nn.Module):
         x = _Assemble.apply(tok, self.cls_token, self.pos_embed, scale, shift, B, np_, self.embed_dim, src_ld, mean)
         for blk in self.blocks:
             x = blk.run(x, self.cd)
-        return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=self.cd)
+        return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=self.cd, stream_grad=True)
 
     def forward(self, x):
         pe = self.patch_embed
@@ -181,7 +181,8 @@ class _Assemble(torch.autograd.Function):
     def backward(ctx, dx):
         tok, scale, shift = ctx.saved_tensors
         B, np_, D, src_ld, tdt = ctx.meta
-        dxc = dx.contiguous()
+        real = ops._stream_real(dx, last=True)  # end of the bf16 gradient stream (ops.GRAD_STREAM_BF16): back to fp32 once
+        dxc = hip.cast(real.view(dx.shape), torch.float32) if real is not None else dx.contiguous()
         dpos = hip.batch_sum(dxc).view(1, np_ + 1, D)
         dcls = hip.colsum(dxc.view(B, (np_ + 1) * D)[:, :D]).view(1, 1, D)
         # dscale comes back CENTRED (sum dz*(pre - mean)) when the BatchNorm mean is known: see p3_bn_bwd_coeffs

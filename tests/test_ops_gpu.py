@@ -269,6 +269,44 @@ def test_layernorm_backward_twin_only_at_the_widths_its_kernel_serves(cols):
     assert left == 0 and torch.equal(gx1, gx0) and torch.equal(gw1, gw0) and torch.isfinite(gw1).all()
 
 
+def test_bf16_residual_gradient_stream_equals_the_fp32_stream_to_bf16_rounding():
+    """ops.GRAD_STREAM_BF16: along the ViT's fp32 residual stream the GRADIENT travels in bf16 (autograd sees zero-stride fp32 carriers, the
+    real tensor rides in ops._stream).  Two ViT blocks + final norm in bf16 mode: every parameter gradient and the token gradient agree with
+    the fp32-stream run to bf16 rounding of the stream (cosine > 0.9995, norms within 1 %), the chain ends in a real fp32 tensor, no carrier
+    is left behind; a width without the half-wave LayerNorm kernel (512) runs the fp32 stream."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.vision_transformer import VisionTransformer
+    for dim, heads in ((384, 6), (512, 8)):
+        torch.manual_seed(11)
+        vit = VisionTransformer(img_size=32, patch_size=8, embed_dim=dim, depth=2, num_heads=heads, cd=torch.bfloat16).to(DEV)
+        tok0 = torch.randn(3 * 16, dim, device=DEV).bfloat16()
+
+        def run(flag):
+            old, ops.GRAD_STREAM_BF16[0] = ops.GRAD_STREAM_BF16[0], flag
+            try:
+                ops.clear_twins()
+                for p_ in vit.parameters():
+                    p_.grad = None
+                tok = tok0.clone().requires_grad_(True)
+                y = vit.forward_tokens(tok, 3)
+                (y.float() ** 2).sum().backward()
+                left = len(ops._stream)
+                return {n: p_.grad.float().clone() for n, p_ in vit.named_parameters() if p_.grad is not None}, tok.grad.float().clone(), left
+            finally:
+                ops.GRAD_STREAM_BF16[0] = old
+        g0, t0, _ = run(False)
+        g1, t1, left = run(True)
+        assert left == 0 and t1.dtype == torch.float32 and torch.isfinite(t1).all()       # every carrier was released by its last consumer
+        for n in g0:
+            a, b = g0[n].flatten(), g1[n].flatten()
+            if float(a.norm()) == 0:
+                continue
+            cos = float((a * b).sum() / (a.norm() * b.norm()))
+            assert cos > 0.9995 and abs(float(b.norm() / a.norm()) - 1) < 1e-2, (dim, n, cos)
+        cos = float((t0.flatten() * t1.flatten()).sum() / (t0.norm() * t1.norm()))
+        assert cos > 0.9995, (dim, cos)
+
+
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_gradslot_joins_equal_autograd_joins(cd):
     """Post-norm decoder pattern (nn.TransformerDecoderLayer as model_pix2poly.py:136-143 runs it): x feeds a projection AND the residual

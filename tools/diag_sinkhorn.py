@@ -14,7 +14,7 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     sys.argv = [sys.argv[0]]
     args = bench.parse()
-    args.graph = 0
+    args.graph = int(__import__("os").environ.get("DIAG_GRAPH", "0"))
     dev = "cuda:0"
     torch.cuda.set_device(0)
     cfg, model, opt, reducer, pool, st = bench.build(args, dev, 0, "bf16", S, 0, 1, False)
@@ -22,6 +22,9 @@ def main():
     orig = ops.sinkhorn_softmax
 
     def spy(scores, alpha, iters):
+        if torch.cuda.is_current_stream_capturing():
+            seen["spread"] = "graph"
+            return orig(scores, alpha, iters)
         s = scores.detach()
         full = torch.cat([torch.cat([s, alpha.detach().float().expand(s.shape[0], s.shape[1], 1)], 2),
                           alpha.detach().float().expand(s.shape[0], 1, s.shape[2] + 1)], 1)
