@@ -626,9 +626,11 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
     GemmArgs gs = g;
     const int nparts = 2 * (nwg / g.tiles_n);       // two row halves (wave rows) per workgroup
     if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
-    // column-major walk when W (N x K) cannot stay in a 4 MB L2 next to the A stream; the deterministic (slab) form keeps the row-major walk
-    static int cm_env = -1;                               // P3_GEMM_COLMAJOR=0: A/B switch
-    if (cm_env < 0) { const char* e = getenv("P3_GEMM_COLMAJOR"); cm_env = (e && e[0] == '0') ? 0 : 1; }
+    // column-major walk when W (N x K) cannot stay in a 4 MB L2 next to the A stream; the deterministic (slab) form keeps the row-major walk.
+    // P3_GEMM_COLMAJOR=1 switches it on: measured on the fusion conv (r03, rocprofv3 same box) 408 us row-major vs 423 us column-major - the
+    // weight re-fetch the PMC pass shows (2.1 GB per launch) is served by the MALL and is not what bounds the launch; default off.
+    static int cm_env = -1;
+    if (cm_env < 0) { const char* e = getenv("P3_GEMM_COLMAJOR"); cm_env = (e && e[0] == '1') ? 1 : 0; }
     gs.col_major = (STATS && cm_env && !gs.stat_slab && g.tiles_n > 1 && (int64_t)g.d.N * g.d.K * (int)sizeof(T) > (3ll << 20)) ? 1 : 0;
     {
     const GemmArgs& g = gs;
