@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const T* __restrict__ dA,
 // bf16 form with 16-byte accesses (r02: the 8-byte form above ran at 1.4 TB/s on the 1.2 GB of dA; 8-byte accesses reach 0.54-0.70x the
 // rate of 16-byte ones on this chip): a lane owns EIGHT channels, the two half-waves take the two halves of the block's IC rows i, the
 // dV partial sums of the halves are paired with v_permlane32_swap so that the atomic count per dV element stays N / IC.
-template <int IC>
+template <int IC, bool PRE>
 __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ U, const bf16_t* __restrict__ V,
                                                          const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
                                                          float* __restrict__ dU, float* __restrict__ dV, float* __restrict__ acc, int N, int C,
@@ -243,13 +243,30 @@ __global__ __launch_bounds__(256, 2) void pair_bwd_kernel16(const bf16_t* __rest
     float a_sc[8], a_sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { a_sc[k] = 0.f; a_sh[k] = 0.f; }
-    for (int j = grp; j < N; j += 4) {
-        float v[8], av[8];
-        unpack8(*reinterpret_cast<const uint4*>(V + ((int64_t)b * N + j) * C + c0), v);
-        uint4 graw[IH];
+    // r03: the rows of step j + 4 are loaded BEFORE step j is worked on (two register sets, SQ counters r03: 78 % of the wave cycles were
+    // spent waiting with one set of IH loads in flight per wave - 601 us for a 1.2 GB stream)
+    uint4 gnext[IH], vnext;
+    auto load_j = [&](int j, uint4 (&g)[IH], uint4& vv) __attribute__((always_inline)) {
+        const int jc = j < N ? j : N - 1;                  // clamped: the surplus loads of the last step are never used
+        vv = *reinterpret_cast<const uint4*>(V + ((int64_t)b * N + jc) * C + c0);
 #pragma unroll
         for (int i = 0; i < IH; ++i)
-            graw[i] = (ib + i < N) ? *reinterpret_cast<const uint4*>(dA + (((int64_t)b * N + ib + i) * N + j) * C + c0) : make_uint4(0, 0, 0, 0);
+            g[i] = (ib + i < N) ? *reinterpret_cast<const uint4*>(dA + (((int64_t)b * N + ib + i) * N + jc) * C + c0) : make_uint4(0, 0, 0, 0);
+    };
+    if constexpr (PRE) load_j(grp, gnext, vnext);
+    for (int j = grp; j < N; j += 4) {
+        float v[8], av[8];
+        uint4 graw[IH];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < IH; ++i) graw[i] = gnext[i];
+            unpack8(vnext, v);
+            load_j(j + 4, gnext, vnext);
+        } else {
+            uint4 vv;
+            load_j(j, graw, vv);
+            unpack8(vv, v);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) av[k] = 0.f;
 #pragma unroll
@@ -412,7 +429,8 @@ extern "C" int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a
 extern "C" int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C) { return (int64_t)B * ((N + 11) / 12) * N * C * 4; }
 // per dtype: the fp32 kernel takes 8 rows i per block (more, smaller slabs), the bf16 one 12
 extern "C" int64_t p3_pair_bwd_workspace_bytes_dt(int B, int N, int C, int dtype) {
-    return dtype == P3_F32 ? (int64_t)B * ((N + 7) / 8) * N * C * 4 : p3_pair_bwd_workspace_bytes(B, N, C);
+    (void)dtype;                                       // both forms may run with 8 rows i per block (bf16: P3_PAIR_IC16=8)
+    return (int64_t)B * ((N + 7) / 8) * N * C * 4;
 }
 
 static int pair_bwd_impl(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV, float* acc,
@@ -445,9 +463,17 @@ static int pair_bwd_impl(const void* dA, const void* U, const void* V, const flo
     if (wide < 0) { const char* e = getenv("P3_PAIR_WIDE"); wide = e ? atoi(e) : 1; }   // 0: 8-byte form
     if (dtype == P3_BF16 && wide && ic_env <= 0) {
         // IC = 12 rows i per block (6 per half-wave): the register budget of two waves per SIMD without spills (IC = 16 spills 270 B / lane)
-        nblk = (N + 11) / 12;
+        // 8 rows i per block (4 per half-wave) with the next step's rows prefetched: 238 VGPRs, no spills (the 12-row form needs 256 + 35
+        // spilled and cannot hold a second register set).  rocprofv3 A/B (r03): 592 -> 348 us per launch, the dV slab sum 44 -> 68 us.
+        // P3_PAIR_IC16=12 selects the old form.
+        static int ic16 = -1;
+        if (ic16 < 0) { const char* e = getenv("P3_PAIR_IC16"); ic16 = e ? atoi(e) : 8; }
+        const int icb = (ic16 == 8 && slab) ? 8 : 12;
+        nblk = (N + icb - 1) / icb;
         acc_slab = p3_det_scratch((int64_t)B * nblk * 2 * C, dtype);
-        hipLaunchKernelGGL((pair_bwd_kernel16<12>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
+        if (icb == 8) hipLaunchKernelGGL((pair_bwd_kernel16<8, true>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
+                                         mean, dU, dV, acc, N, C, slab, acc_slab);
+        else hipLaunchKernelGGL((pair_bwd_kernel16<12, false>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,
                            mean, dU, dV, acc, N, C, slab, acc_slab);
         P3_LAUNCH_CHECK();
         if (slab) {
