@@ -351,6 +351,9 @@ int p3_bce_loss_bwd(const float* p, const float* y, int64_t n, const float* gsca
  * Launch it right before p3_adamw on the same stream (inside the captured step graph). */
 int p3_adamw_schedule(long long* step, float* hyper, float base_lr, int kind, int warmup_steps, int total_steps, float beta1, float beta2,
                       void* stream);
+/* the same with sched = device float[4] {base_lr, kind, warm-up steps, total steps} (all < 2^24: exact in fp32) read by the kernel: a captured
+ * step follows a learning rate / schedule the host rewrites after the capture */
+int p3_adamw_schedule_dev(long long* step, float* hyper, const float* sched, float beta1, float beta2, void* stream);
 /* torch.optim.AdamW step over a flat parameter arena; hyper = {lr, 1-beta1^t, 1-beta2^t} on the device; optional bf16 shadow */
 int p3_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1,
              float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow, void* stream);

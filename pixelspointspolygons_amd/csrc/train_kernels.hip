@@ -407,12 +407,37 @@ __global__ void adamw_schedule_kernel(long long* __restrict__ step, float* __res
     step[0] = s + 1;
 }
 
+// same, with (base_lr, kind, warm-up steps, total steps) read from a 4-float device buffer: a captured step graph then follows a schedule or
+// learning rate the host changes AFTER the capture (the scalar-argument form bakes them into the graph)
+__global__ void adamw_schedule_dev_kernel(long long* __restrict__ step, float* __restrict__ hyper, const float* __restrict__ sched, float beta1, float beta2) {
+    const long long s = step[0];
+    const float base_lr = sched[0];
+    const int kind = (int)sched[1], warmup = (int)sched[2], total = (int)sched[3];
+    double lam = 1.0;
+    if (kind == 1) {
+        if (s < warmup) lam = (double)s / (double)(warmup > 1 ? warmup : 1);
+        else { const int den = total - warmup; lam = (double)(total - s) / (double)(den > 1 ? den : 1); if (lam < 0.0) lam = 0.0; }
+    }
+    const double t = (double)(s + 1);
+    hyper[0] = (float)((double)base_lr * lam);
+    hyper[1] = (float)(1.0 - pow((double)beta1, t));
+    hyper[2] = (float)(1.0 - pow((double)beta2, t));
+    step[0] = s + 1;
+}
+
 inline int grid_for(int64_t work) {
     int64_t g = (work + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
 }  // namespace
+
+extern "C" int p3_adamw_schedule_dev(long long* step, float* hyper, const float* sched, float beta1, float beta2, void* stream) {
+    P3_CHECK(step && hyper && sched, P3_EINVAL, "p3_adamw_schedule_dev: bad arguments");
+    hipLaunchKernelGGL(adamw_schedule_dev_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, hyper, sched, beta1, beta2);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
 
 extern "C" int64_t p3_sinkhorn_bwd_workspace_bytes(int B, int m, int n, int iters) {
     return 256 + ((int64_t)B * 4 + 255) / 256 * 256 + (int64_t)B * iters * 2 * (m + n + 2) * 4;

@@ -796,6 +796,10 @@ def adamw_schedule(step, hyper, base_lr, kind, warmup, total, beta1, beta2):
                                   c_float(beta2), stream()), "p3_adamw_schedule")
 
 
+def adamw_schedule_dev(step, hyper, sched, beta1, beta2):
+    check(lib().p3_adamw_schedule_dev(ptr(step), ptr(hyper), ptr(sched), c_float(beta1), c_float(beta2), stream()), "p3_adamw_schedule_dev")
+
+
 def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, shadow=None):
     check(lib().p3_adamw(ptr(params), ptr(grads), ptr(m), ptr(v), c_int64(params.numel()), ptr(hyper), c_float(beta1), c_float(beta2),
                          c_float(eps), c_float(wd), c_float(grad_scale), ptr(shadow), stream()), "p3_adamw")

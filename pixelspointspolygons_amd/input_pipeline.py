@@ -204,8 +204,24 @@ class DevicePrefetcher:
             self.ready.put((None, None, None, e))
 
     def close(self):
+        """stop the feeder thread (it may be parked on free.get()) and drop the pinned / device staging; idempotent"""
+        if self._stop:
+            return
         self._stop = True
         self.free.put({"pin": {}, "dev": {}, "copied": None, "consumed": None})
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):                       # an abandoned iterator must not leave the thread blocked holding pinned + device buffers
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
         return self
@@ -222,6 +238,7 @@ class DevicePrefetcher:
         if err is not None:
             self.ready.put((None, None, None, err))            # stay exhausted / keep raising
             if isinstance(err, StopIteration):
+                self.close()
                 raise StopIteration
             raise err
         cur.wait_event(ready)

@@ -197,11 +197,20 @@ def invalidate_derived():
 
 
 class _Derived:
-    """one cached compute-dtype / re-laid-out copy of a parameter"""
-    __slots__ = ("p", "out", "fn", "dtype", "ver", "arena")
+    """one cached compute-dtype / re-laid-out copy of a parameter.  `in_graph`: a refresh_derived() pass that ran while a hipGraph was being
+    captured has covered this entry, so every replay rewrites it in place; an arena-derived entry WITHOUT that mark (first created after the
+    capture, e.g. an eval-only layout) is refreshed by no replay and is therefore versioned by the optimizer's step generation instead
+    (such entries went stale silently)."""
+    __slots__ = ("p", "out", "fn", "dtype", "ver", "arena", "in_graph")
 
     def __init__(self, p, out, fn, dtype, ver, arena):
-        self.p, self.out, self.fn, self.dtype, self.ver, self.arena = p, out, fn, dtype, ver, arena
+        self.p, self.out, self.fn, self.dtype, self.ver, self.arena, self.in_graph = p, out, fn, dtype, ver, arena, False
+
+
+# Step generation: FlatAdamW.prepare_step() bumps it on the host once per step, replayed or not.  An arena-derived copy carries the generation
+# of the forward it is valid for: created / re-derived in shadow() -> the current one; rewritten by refresh_derived() after an update -> the
+# next one.  shadow() trusts a copy when a captured refresh covers it (in_graph) or its generation is not behind.
+ARENA_GEN = [0]
 
 
 def refresh_derived(params=None):
@@ -211,9 +220,12 @@ def refresh_derived(params=None):
     invalidated by a Python-side counter instead, which a graph replay never advances: an eager evaluation after replayed training
     steps read copies that were one update old.)"""
     ids = None if params is None else {id(p) for p in params}
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     for k, ent in _shadow_cache.items():
         if not ent.arena or (ids is not None and k[0] not in ids):
             continue
+        if capturing:
+            ent.in_graph = True
         reg = _registered.get(k[0])
         if reg is None or reg[0] is not ent.p:
             continue
@@ -221,6 +233,7 @@ def refresh_derived(params=None):
             continue                             # a view of the arena itself (e.g. a reshape): fresh by construction
         src = ent.fn(reg[1]) if ent.fn is not None else reg[1]
         ent.out.copy_(src)                       # strided gather + (no-op) cast in one pass, into the buffer everyone already holds
+        ent.ver = ARENA_GEN[0] + 1               # valid for the forward of the NEXT step generation (the weights just changed)
 
 
 def shadow(p, dtype, key=None, fn=None):
@@ -239,15 +252,26 @@ def shadow(p, dtype, key=None, fn=None):
         return reg[1]
     k = (id(p), dtype, key)
     ent = _shadow_cache.get(k)
-    # arena copies are kept fresh in place by refresh_derived(); everything else is versioned by autograd's counter + the epoch
+    # non-arena copies are versioned by autograd's counter + the epoch.  Arena copies are rewritten in place by refresh_derived() after every
+    # optimizer step - by the replayed graph too when that pass was captured (in_graph); one that no captured pass covers and that predates
+    # the current step generation is derived again here, in place (its buffer may already be held by callers)
     ver = None if arena else (p._version, _epoch[0])
-    if ent is not None and ent.p is p and ent.ver == ver and ent.arena == arena:
-        return ent.out
+    if ent is not None and ent.p is p and ent.arena == arena:
+        if not arena:
+            if ent.ver == ver:
+                return ent.out
+        elif ent.in_graph or ent.ver >= ARENA_GEN[0]:
+            return ent.out
+        else:
+            src = ent.fn(reg[1]) if ent.fn is not None else reg[1]
+            ent.out.copy_(src)
+            ent.ver = ARENA_GEN[0]
+            return ent.out
     src = reg[1] if arena else p.detach()        # derive from the bf16 arena when there is one (no fp32 -> bf16 cast pass)
     if fn is not None:
         src = fn(src)
     out = hip.cast(src, dtype) if src.dtype != dtype else src.contiguous()
-    _shadow_cache[k] = _Derived(p, out, fn, dtype, ver, arena)
+    _shadow_cache[k] = _Derived(p, out, fn, dtype, ARENA_GEN[0] if arena else ver, arena)
     return out
 
 

@@ -89,6 +89,10 @@ class FlatAdamW:
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self.step_count = 0                      # host mirror of step_dev (logging / lr queries); prepare_step() advances it
         self._sched = (0, 0, 0)                  # (kind, warm-up steps, total steps): constant learning rate
+        # what the schedule kernel reads: {base lr, kind, warm-up, total} in a device buffer that prepare_step() rewrites whenever the host
+        # values changed - also after the step was captured in a graph (kernel ARGUMENTS would be baked into it)
+        self.sched_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._sched_sent = None
         self._lr_lambda = lambda step: 1.0
         self._host_fed = False
         self._slots = None
@@ -156,6 +160,8 @@ class FlatAdamW:
             if step < nw:
                 return float(step) / float(max(1, nw))
             return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - nw)))
+        if self._host_fed:                       # coming back from a host-fed schedule: the device counter did not advance meanwhile
+            self.step_dev.fill_(self.step_count)
         self._lr_lambda, self._sched, self._host_fed = lam, (1, nw, int(num_training_steps)), False
 
     @property
@@ -176,6 +182,11 @@ class FlatAdamW:
         {lr, 1 - beta1^t, 1 - beta2^t} into the next pinned slot (waiting for the copy that last used the slot) and queues its copy."""
         lr = self.lr * self._lr_lambda(self.step_count)
         self.step_count += 1
+        ops.ARENA_GEN[0] += 1                    # arena-derived weight copies no captured refresh covers are re-derived on their next use
+        want = (float(self.lr), float(self._sched[0]), float(self._sched[1]), float(self._sched[2]))
+        if want != self._sched_sent and not self._host_fed:
+            self.sched_dev.copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            self._sched_sent = want
         if self._host_fed:
             t = self.step_count
             if self._slots is None:
@@ -195,8 +206,10 @@ class FlatAdamW:
         """device side (capturable): schedule kernel + one fused update kernel over the arena (which also refreshes the bf16 shadow),
         then the transposed / re-laid-out weight copies are rewritten in place."""
         if not self._host_fed:
-            kind, nw, nt = self._sched
-            hip.adamw_schedule(self.step_dev, self.hyper, self.lr, kind, nw, nt, self.betas[0], self.betas[1])
+            if self._sched_sent is None:         # apply() without prepare_step() (tests): upload once, outside any capture
+                self._sched_sent = (float(self.lr), float(self._sched[0]), float(self._sched[1]), float(self._sched[2]))
+                self.sched_dev.copy_(torch.tensor(self._sched_sent, dtype=torch.float32))
+            hip.adamw_schedule_dev(self.step_dev, self.hyper, self.sched_dev, self.betas[0], self.betas[1])
         hip.adamw(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
                   grad_scale=grad_scale, shadow=self.shadow)
         if self.shadow_T is not None:

@@ -298,6 +298,84 @@ def test_derived_weight_layouts_stay_fresh_across_graph_replays_and_external_wri
     assert not any(v[2] is opt for v in ops._registered.values()) and not ops.DIRECT_GRAD[0]
 
 
+def test_learning_rate_change_after_capture_reaches_the_replayed_step():
+    """(lr, schedule) used to be kernel arguments of p3_adamw_schedule, i.e. baked into a captured step; they now sit in a
+    device buffer that prepare_step() rewrites when the host values change.  Replay with lr = 0 must leave the weights alone, replay after
+    set_linear_schedule must follow the warm-up factor; the device step counter keeps counting through both."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.training import FlatAdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    opt = FlatAdamW(lin, lr=1e-2, weight_decay=0.0, compute_dtype=torch.bfloat16)
+    x = torch.randn(16, 64, device=DEV)
+
+    def fwd_bwd():
+        y = ops.linear(x.bfloat16(), lin.weight, lin.bias, cd=torch.bfloat16)
+        opt.zero_grad()
+        (y.float() ** 2).sum().backward()
+    for _ in range(2):
+        fwd_bwd()
+        opt.step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd_bwd()
+        opt.apply(1.0)
+    opt.prepare_step(); g.replay()
+    w0 = lin.weight.detach().clone()
+    opt.lr = 0.0
+    opt.prepare_step(); g.replay()
+    assert torch.equal(lin.weight.detach(), w0)                       # lr = 0 reached the replayed update
+    opt.lr = 1e-2
+    opt.prepare_step(); g.replay()
+    assert not torch.equal(lin.weight.detach(), w0)
+    opt.set_linear_schedule(1000, warmup_frac=0.5)                    # warm-up of 500 steps: factor ~ step / 500 at step 5
+    opt.prepare_step(); g.replay()
+    torch.cuda.synchronize()
+    assert int(opt.step_dev) == opt.step_count == 6
+    assert abs(float(opt.hyper[0]) - 1e-2 * 5 / 500) < 1e-9
+    opt.close()
+
+
+def test_a_derived_layout_first_created_after_capture_does_not_go_stale():
+    """an arena-derived copy created AFTER the step graph was captured (an eval-only layout) is rewritten by no replay.
+    ops.shadow() now versions such copies by the optimizer's step generation: after more replayed steps the next use re-derives it in
+    place; copies the captured refresh covers keep being trusted without a re-derivation."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.training import FlatAdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    opt = FlatAdamW(lin, lr=1e-1, compute_dtype=torch.bfloat16)
+    x = torch.randn(32, 64, device=DEV)
+
+    def fwd_bwd():
+        y = ops.linear(x.bfloat16(), lin.weight, lin.bias, cd=torch.bfloat16)
+        opt.zero_grad()
+        (y.float() ** 2).sum().backward()
+    for _ in range(2):
+        fwd_bwd()
+        opt.step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd_bwd()
+        opt.apply(1.0)
+    opt.prepare_step()
+    g.replay()
+    flip = lambda t: t.flip(0).contiguous()
+    late = ops.shadow(lin.weight, torch.bfloat16, key="late_layout", fn=flip)       # first created after the capture
+    assert torch.equal(late, flip(ops.shadow(lin.weight, torch.bfloat16)))
+    before = late.clone()
+    for _ in range(3):
+        opt.prepare_step()
+        g.replay()
+    again = ops.shadow(lin.weight, torch.bfloat16, key="late_layout", fn=flip)
+    assert again.data_ptr() == late.data_ptr()                                       # re-derived IN PLACE
+    assert torch.equal(again, flip(ops.shadow(lin.weight, torch.bfloat16))) and not torch.equal(again, before)
+    assert torch.equal(again.float(), flip(lin.weight.detach().bfloat16()).float())  # and the arena is what the fp32 master rounds to
+    opt.close()
+
+
 def _oracle_grads(sd, inp, kind="fusion"):
     """float64 autograd of the oracle = ground truth (fp32 CPU sums over 10^5 rows are themselves ~1e-3 noisy)."""
     p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
