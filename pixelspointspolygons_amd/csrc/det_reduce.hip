@@ -30,35 +30,88 @@ float* p3_det_scratch(int64_t floats, int dtype) {
     return g_det;
 }
 
+// any launch (bf16 included) may borrow the registered scratch for per-tile partials that replace a slower scheme (the GEMM's BatchNorm column
+// sums: gemm.hip); NULL when none is registered or it is too small - the caller then takes its other path
+float* p3_reduce_scratch(int64_t floats) { return (g_det && floats <= g_det_floats) ? g_det : nullptr; }
+
 namespace {
-// out[i] (+)= sum_p parts[p*stride + i], p ascending, float64 accumulation.  Block = 64 values x 4 part lanes (each lane takes a
-// contiguous quarter of the parts), the four partial sums are combined in lane order.
-__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ parts, int nparts, int64_t stride, float* __restrict__ out,
-                                                         int nvals, int accumulate) {
+// level 1 of a long reduction: tmp[chunk][i] = sum of the parts [chunk*CH, (chunk+1)*CH) (float64, part order)
+__global__ __launch_bounds__(256) void det_reduce_chunk_kernel(const float* __restrict__ parts, int nparts, int64_t stride, float* __restrict__ tmp, int nvals, int ch) {
     __shared__ double red[4][64];
     const int v = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int per = (nparts + 3) / 4, p0 = q * per, p1 = min(nparts, p0 + per);
+    const int c0 = blockIdx.y * ch, c1 = min(nparts, c0 + ch);
+    const int per = (c1 - c0 + 3) / 4, p0 = c0 + q * per, p1 = min(c1, p0 + per);
     double a = 0.0;
     if (v < nvals) {
         int p = p0;
-        for (; p + 4 <= p1; p += 4) {           // four loads in flight, added in part order
-            const float x0 = parts[(int64_t)p * stride + v], x1 = parts[(int64_t)(p + 1) * stride + v];
-            const float x2 = parts[(int64_t)(p + 2) * stride + v], x3 = parts[(int64_t)(p + 3) * stride + v];
-            a += (double)x0; a += (double)x1; a += (double)x2; a += (double)x3;
+        for (; p + 8 <= p1; p += 8) {            // eight loads in flight, added in part order
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = parts[(int64_t)(p + u) * stride + v];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)x[u];
+        }
+        for (; p < p1; ++p) a += (double)parts[(int64_t)p * stride + v];
+    }
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && v < nvals) tmp[(int64_t)blockIdx.y * nvals + v] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// out[i] (+)= sum_p parts[p*stride + i], p ascending, float64 accumulation.  Block = 64 values x 4 part lanes (each lane takes a
+// contiguous quarter of the parts), the four partial sums are combined in lane order.
+template <int NQ>
+__global__ __launch_bounds__(64 * NQ) void det_reduce_kernel(const float* __restrict__ parts, int nparts, int64_t stride, float* __restrict__ out,
+                                                            int nvals, int accumulate, float* __restrict__ out2 = nullptr, int split = 0) {
+    __shared__ double red[NQ][64];
+    const int v = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (nparts + NQ - 1) / NQ, p0 = q * per, p1 = min(nparts, p0 + per);
+    double a = 0.0;
+    if (v < nvals) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {           // eight loads in flight, added in part order
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = parts[(int64_t)(p + u) * stride + v];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)x[u];
         }
         for (; p < p1; ++p) a += (double)parts[(int64_t)p * stride + v];
     }
     red[q][threadIdx.x & 63] = a;
     __syncthreads();
     if (q == 0 && v < nvals) {
-        const double s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        out[v] = accumulate ? (float)((double)out[v] + s) : (float)s;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) s += red[k][threadIdx.x];                 // lane order: fixed
+        float* o = (out2 && v >= split) ? out2 + (v - split) : out + v;       // values >= split go to the second output (sum | sum of squares)
+        *o = accumulate ? (float)((double)*o + s) : (float)s;
     }
 }
 }  // namespace
 
 int p3_det_reduce(const float* parts, int nparts, int64_t stride, float* out, int nvals, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(det_reduce_kernel, dim3((nvals + 63) / 64), dim3(256), 0, s, parts, nparts, stride, out, nvals, accumulate);
+    hipLaunchKernelGGL(det_reduce_kernel<4>, dim3((nvals + 63) / 64), dim3(256), 0, s, parts, nparts, stride, out, nvals, accumulate, (float*)nullptr, 0);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+// many parts (tens of thousands of tiles): chunks of 256 parts are summed by their own workgroups into `tmp` ([ceil(nparts / 256)][nvals]
+// floats, caller-provided), then those chunk sums in chunk order - same bits every run, the whole chip at work
+// values [0, split) are added to out, [split, nvals) to out2 (one pass for a (sum | sum of squares) pair); tmp: [ceil(nparts / 128)][nvals]
+int p3_det_reduce2(const float* parts, int nparts, int64_t stride, float* tmp, float* out, float* out2, int split, int nvals, int accumulate, hipStream_t s) {
+    constexpr int CH = 128;
+    const float* src = parts;
+    int n = nparts;
+    int64_t st = stride;
+    if (nparts > 4 * CH) {
+        const int nch = (nparts + CH - 1) / CH;
+        hipLaunchKernelGGL(det_reduce_chunk_kernel, dim3((nvals + 63) / 64, nch), dim3(256), 0, s, parts, nparts, stride, tmp, nvals, CH);
+        P3_LAUNCH_CHECK();
+        src = tmp; n = nch; st = nvals;
+    }
+    if (n > 64) hipLaunchKernelGGL(det_reduce_kernel<16>, dim3((nvals + 63) / 64), dim3(1024), 0, s, src, n, st, out, nvals, accumulate, out2, split);
+    else hipLaunchKernelGGL(det_reduce_kernel<4>, dim3((nvals + 63) / 64), dim3(256), 0, s, src, n, st, out, nvals, accumulate, out2, split);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

@@ -22,6 +22,7 @@ struct GemmArgs {
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
     float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2 row halves][2][N] partials of (colsum, colsumsq) instead of atomics
     int col_major;      // STATS walk: tiles in column-major order (every workgroup of the chip on ONE column panel of W at a time)
+    float* tile_stats;  // non-STATS launch that still owes BatchNorm column sums: [tiles_m][2 row halves][2][N] per-tile partials (see launch_bk)
 };
 
 constexpr int BM = 128, BN = 128;
@@ -365,11 +366,30 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
             constexpr int P16 = 68;                              // row pitch in dwords (136 bf16): 16-byte aligned rows
             uint32_t* st16 = reinterpret_cast<uint32_t*>(lds);
             const bool odd = l31 & 1;
+            const bool ts = g.tile_stats != nullptr;
+            const bool full_rows = (tm + 1) * BM <= d.M;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cl = wn * 64 + j * 32 + l31;
                 const int col = tn * BN + cl;
                 const float bias = (d.bias && col < d.N) ? d.bias[col] : 0.f;
+                float t1 = 0.f, t2 = 0.f;                 // this lane's column over the wave's 64 rows (tile_stats)
+                if (__builtin_amdgcn_readfirstlane((int)ts)) {           // a loop of its own: the packing loop below stays free of selects
+                    if (__builtin_amdgcn_readfirstlane((int)full_rows)) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r] + bias; t1 += v; t2 = fmaf(v, v, t2); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = (tm * BM + wm * 64 + i * 32 + crow32(r, hi) < d.M) ? acc[i][j][r] + bias : 0.f;
+                                t1 += v; t2 = fmaf(v, v, t2);
+                            }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -379,6 +399,13 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                         const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v0 : v1), 0xB1, 0xf, 0xf, true));
                         const int rw = wm * 64 + i * 32 + crow32(r, hi) + (odd ? 1 : 0);
                         st16[rw * P16 + (cl >> 1)] = odd ? pack_bf2(recv, v1) : pack_bf2(v0, recv);
+                    }
+                }
+                if (ts) {      // BatchNorm column sums as per-tile partials (pre-rounding fp32 values, bias included): no persistence, no atomics
+                    t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+                    if (hi == 0 && col < d.N) {
+                        float* part = g.tile_stats + ((int64_t)(tm * 2 + wm) * 2) * d.N;
+                        part[col] = t1; part[d.N + col] = t2;
                     }
                 }
             }
@@ -417,6 +444,13 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                     }
                 }
                 if constexpr (STATS) { cs1[j] += s1; cs2[j] += s2; }
+                else if (g.tile_stats) {
+                    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                    if (hi == 0 && cok) {
+                        float* part = g.tile_stats + ((int64_t)(tm * 2 + wm) * 2) * d.N;
+                        part[col] = s1; part[d.N + col] = s2;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -654,7 +688,23 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
 
 template <typename T, typename TO, int BKSEL>
 int launch_bk(const GemmArgs& g, hipStream_t s) {
-    return g.d.colsum ? launch_bk2<T, TO, BKSEL, true>(g, s) : launch_bk2<T, TO, BKSEL, false>(g, s);
+    if (!g.d.colsum) return launch_bk2<T, TO, BKSEL, false>(g, s);
+    // BatchNorm column sums.  Preferred form (r03): the ordinary one-tile-per-workgroup kernel (3 workgroups / CU, single-pass bf16 epilogue)
+    // writes per-tile, per-row-half partial sums into the registered scratch and a two-level fixed-order float64 reduction adds them -
+    // tools/mb_sn_fwd.py: the persistent register-resident form below costs 573 vs 431 us (ScoreNet conv2) and 391 vs 215 us (conv3) over the
+    // same product without sums.  Also bit-reproducible in bf16.  P3_GEMM_TILESTATS=0, or no / too small a scratch: the persistent form.
+    static int ts_env = -1;
+    if (ts_env < 0) { const char* e = getenv("P3_GEMM_TILESTATS"); ts_env = (e && e[0] == '0') ? 0 : 1; }
+    const int nparts = g.tiles_m * 2, nch = (nparts + 127) / 128;
+    const int64_t slab_f = (int64_t)nparts * 2 * g.d.N;
+    float* scratch = ts_env ? p3_reduce_scratch(slab_f + (int64_t)nch * 2 * g.d.N) : nullptr;
+    if (!scratch) return launch_bk2<T, TO, BKSEL, true>(g, s);
+    GemmArgs gt = g;
+    gt.tile_stats = scratch;
+    gt.d.colsum = nullptr; gt.d.colsumsq = nullptr;
+    int rc = launch_bk2<T, TO, BKSEL, false>(gt, s);
+    if (rc != P3_OK) return rc;
+    return p3_det_reduce2(scratch, nparts, 2 * (int64_t)g.d.N, scratch + slab_f, g.d.colsum, g.d.colsumsq, g.d.N, 2 * g.d.N, 1, s);   // (sum | sum of squares) in one go
 }
 
 template <typename T, typename TO>
@@ -716,7 +766,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
     P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
     GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.col_major = 0;
+    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.col_major = 0; g.tile_stats = nullptr;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
     {

@@ -111,6 +111,8 @@ void p3_set_error(const char* msg);
 // deterministic reductions (det_reduce.hip): scratch for workgroup partials (NULL: atomics path) and the fixed-order float64 reduce
 float* p3_det_scratch(int64_t floats, int dtype);
 int p3_det_reduce(const float* parts, int nparts, int64_t stride, float* out, int nvals, int accumulate, hipStream_t s);
+float* p3_reduce_scratch(int64_t floats);     // the registered scratch for any dtype (per-tile partials), NULL if none / too small
+int p3_det_reduce2(const float* parts, int nparts, int64_t stride, float* tmp, float* out, float* out2, int split, int nvals, int accumulate, hipStream_t s);
 #define P3_CHECK(cond, code, msg) \
     do {                          \
         if (!(cond)) {            \

@@ -71,10 +71,12 @@ def ptr(t):
 
 
 # Deterministic reductions (csrc/det_reduce.hip): P3_DETERMINISTIC = 0 off | 1 (default) every fp32 (parity-mode) launch | 2 bf16 too.
-# A 16 MB scratch for workgroup partials is registered with the library at the first launch of the process (one device per process).
+# A 128 MB scratch (P3_SCRATCH_MB) for workgroup / tile partials is registered with the library at the first launch of the process (one
+# device per process); the GEMM's BatchNorm column sums use it in every dtype (per-tile partials + fixed-order reduce, gemm.hip launch_bk).
 import os as _os0
 DETERMINISTIC = int(_os0.environ.get("P3_DETERMINISTIC", "1"))
 _det_state = {"buf": None}
+_DET_SCRATCH_BYTES = int(_os0.environ.get("P3_SCRATCH_MB", "128")) << 20     # per-tile BatchNorm partials of the tall ScoreNet / FFL GEMMs: <= 103 MB
 
 
 def set_deterministic(level):
@@ -89,7 +91,7 @@ def set_deterministic(level):
         return
     buf = _det_state["buf"]
     if buf is None or buf is False:
-        buf = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+        buf = torch.empty(_DET_SCRATCH_BYTES, dtype=torch.uint8, device="cuda")
     _det_state["buf"] = buf
     check(lib().p3_set_deterministic(c_void_p(buf.data_ptr()), c_int64(buf.numel()), c_int(1 if DETERMINISTIC >= 2 else 0)), "p3_set_deterministic")
 
