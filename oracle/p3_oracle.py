@@ -306,8 +306,11 @@ def decoder_predict(enc, tgt, sd, prefix="decoder.", max_len=MAX_LEN, pad_idx=PA
 # ----------------------------------------------------------------------------------------------
 # ScoreNet + Sinkhorn (model_pix2poly.py:35-112)
 # ----------------------------------------------------------------------------------------------
-def scorenet(feats, sd, prefix, n_vertices=MAX_VERTS, training=False):
-    """ScoreNet.forward (model_pix2poly.py:86-112), dense formulation (materialises [B,512,N,N]: small B only)."""
+def scorenet(feats, sd, prefix, n_vertices=MAX_VERTS, training=False, decisions=None, zs_out=None):
+    """ScoreNet.forward (model_pix2poly.py:86-112), dense formulation (materialises [B,512,N,N]: small B only).
+    decisions = three boolean [B, C_l, N, N] tensors: the ReLU decisions of the implementation under test replace this function's own
+    z > 0 (see `scorenet_staged`: a handful of the 3.3e7 pre-activations sit within 1e-6 of the kink, where both sides are valid
+    subgradients and fp32 arithmetic - the reference's included - may land on either); zs_out: list that receives the detached z."""
     f = feats[:, 1:]
     B = f.shape[0]
     f = f.reshape(B, f.shape[1] // 2, 2, f.shape[2]).mean(2)                    # [B,N,256]
@@ -316,7 +319,10 @@ def scorenet(feats, sd, prefix, n_vertices=MAX_VERTS, training=False):
     for li, last in ((1, False), (2, False), (3, False), (4, True)):
         x = F.conv2d(x, sd[f"{prefix}conv{li}.weight"], sd[f"{prefix}conv{li}.bias"])
         if not last:
-            x = F.relu(_bn(x, sd, f"{prefix}bn{li}", training, 1e-5, 0.1, dims=(0, 2, 3)))
+            z = _bn(x, sd, f"{prefix}bn{li}", training, 1e-5, 0.1, dims=(0, 2, 3))
+            if zs_out is not None:
+                zs_out.append(z.detach())
+            x = F.relu(z) if decisions is None else z * decisions[li - 1].to(z.dtype)
     return x[:, 0]
 
 
@@ -401,14 +407,17 @@ def log_optimal_transport(scores, alpha, iters):
     return Z + u.unsqueeze(2) + v.unsqueeze(1) - norm
 
 
-def perm_head(feats, sd, iters=100, training=False):
-    """EncoderDecoder.forward tail (model_pix2poly.py:256-264)."""
-    s = scorenet(feats, sd, "scorenet1.", training=training) + scorenet(feats, sd, "scorenet2.", training=training).transpose(1, 2)
+def perm_head(feats, sd, iters=100, training=False, sn_decisions=None, sn_zs=None):
+    """EncoderDecoder.forward tail (model_pix2poly.py:256-264).  sn_decisions / sn_zs: {"scorenet1.": ..., "scorenet2.": ...} (see `scorenet`)."""
+    dec = sn_decisions or {}
+    zs = sn_zs if sn_zs is not None else {}
+    s = scorenet(feats, sd, "scorenet1.", training=training, decisions=dec.get("scorenet1."), zs_out=zs.setdefault("scorenet1.", []) if sn_zs is not None else None) + \
+        scorenet(feats, sd, "scorenet2.", training=training, decisions=dec.get("scorenet2."), zs_out=zs.setdefault("scorenet2.", []) if sn_zs is not None else None).transpose(1, 2)
     z = log_optimal_transport(s, sd["bin_score"], iters)[:, :s.shape[1], :s.shape[2]]
     return torch.softmax(z, -1), s
 
 
-def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, training=False, dec_masks=None):
+def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, training=False, dec_masks=None, sn_decisions=None, sn_zs=None):
     """EncoderDecoder.forward (model_pix2poly.py:245-266).  lidar = (values, offsets)."""
     if img is not None and lidar is not None:
         enc = encoder_fusion(img, lidar[0], lidar[1], sd, cfg, training=training)
@@ -417,7 +426,7 @@ def pix2poly_forward(sd, y, img=None, lidar=None, cfg=VIT_S8, iters=100, trainin
     else:
         enc = encoder_lidar(lidar[0], lidar[1], sd, cfg, training=training)
     logits, feats = decoder_forward(enc, y, sd, masks=dec_masks)
-    perm, _ = perm_head(feats, sd, iters, training)
+    perm, _ = perm_head(feats, sd, iters, training, sn_decisions=sn_decisions, sn_zs=sn_zs)
     return logits, perm
 
 

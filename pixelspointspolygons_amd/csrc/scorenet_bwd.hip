@@ -60,27 +60,42 @@ __global__ __launch_bounds__(256) void row_affine_bwd_kernel(const T* __restrict
         for (int k = 0; k < 4; ++k) { fa[k] = fix_a[c0 + k]; fb[k] = fix_b[c0 + k]; }
     }
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t r0 = wave_id * RPW; r0 < R; r0 += nwaves * RPW) {
-        const int64_t r = r0 + rsel;
-        if (r < R) {
-            float hv[4], g[4];
-            ld4<T>(H + r * C + c0, hv);
-            if constexpr (TAIL) {
-                int64_t rs = r;
-                if (transpose) { const int64_t nn = (int64_t)N * N, b = r / nn, p = r - b * nn; const int i = (int)(p / N), j = (int)(p - (int64_t)i * N); rs = b * nn + (int64_t)j * N + i; }
-                const float gr = dS[rs];
-                if (sub == 0) a_b += gr;
+    // r03: UNR row groups per step with all their loads issued first (the one-group-per-step loop was a chain of two dependent loads per
+    // iteration: the C = 64 tail form streamed its 302 MB at 2.2 TB/s)
+    constexpr int UNR = TAIL ? 4 : 1;          // rocprofv3 A/B: tail form 135 -> 113 us; the C = 128 matrix form got slower unrolled (298 -> 317 us)
+    for (int64_t r0 = wave_id * RPW; r0 < R; r0 += nwaves * RPW * UNR) {
+        float hv[UNR][4], g[UNR][4], gr[UNR];
+        bool ok[UNR];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { g[k] = gr * wv[k]; a_w[k] += gr * fmaxf(hv[k] * s[k] + h[k], 0.f); }
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t r = r0 + (int64_t)u * nwaves * RPW + rsel;
+            ok[u] = r < R;
+            const int64_t rc = ok[u] ? r : R - 1;
+            ld4<T>(H + rc * C + c0, hv[u]);
+            gr[u] = 0.f;
+            if constexpr (TAIL) {
+                int64_t rs = rc;
+                if (transpose) { const int64_t nn = (int64_t)N * N, b = rc / nn, p = rc - b * nn; const int i = (int)(p / N), j = (int)(p - (int64_t)i * N); rs = b * nn + (int64_t)j * N + i; }
+                gr[u] = dS[rs];
             } else {
-                ld4<T>(dA + r * C + c0, g);
+                ld4<T>(dA + rc * C + c0, g[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (!ok[u]) continue;
+            const int64_t r = r0 + (int64_t)u * nwaves * RPW + rsel;
+            if constexpr (TAIL) {
+                if (sub == 0) a_b += gr[u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { g[u][k] = gr[u] * wv[k]; a_w[k] += gr[u] * fmaxf(hv[u][k] * s[k] + h[k], 0.f); }
             }
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float dz = (hv[k] * s[k] + h[k] > 0.f) ? g[k] : 0.f;
-                a_sc[k] += dz * (hv[k] - mu[k]); a_sh[k] += dz;   // centred: sum dz*(H - mean) is what BN backward needs (no cancellation)
-                o[k] = dz * s[k] + fa[k] + fb[k] * hv[k];
+                const float dz = (hv[u][k] * s[k] + h[k] > 0.f) ? g[u][k] : 0.f;
+                a_sc[k] += dz * (hv[u][k] - mu[k]); a_sh[k] += dz;   // centred: sum dz*(H - mean) is what BN backward needs (no cancellation)
+                o[k] = dz * s[k] + fa[k] + fb[k] * hv[u][k];
             }
             if (dHd) st4<T>(dHd + r * C + c0, o);
         }

@@ -168,6 +168,8 @@ class _ScoreNetFn(torch.autograd.Function):
     def forward(ctx, feats, net, out, transpose_acc, *params):
         keep = {} if any(ctx.needs_input_grad) else None
         scorenet_forward(net, feats, out, transpose_acc, keep)
+        if keep is not None and getattr(net, "debug_keep", False):
+            net._last_keep = dict(keep)      # tests: the saved state gives the ReLU decisions this forward took (tests/test_backward_gpu.py)
         ctx.net, ctx.keep, ctx.transpose_acc = net, keep, transpose_acc
         ctx.save_for_backward(feats)
         ctx.mark_dirty(out)
