@@ -18,7 +18,7 @@ def _bench():
         sys.argv = argv
 
 
-def _line(name="r02_bench.json"):
+def _line(name="r03_bench.json"):
     with open(os.path.join(ROOT, "profiles", name)) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
@@ -62,7 +62,7 @@ def test_committed_bench_line_has_the_contract_keys_and_is_self_consistent():
 def test_pmc_table_feeds_the_roofline_traffic_fields():
     bench, _ = _bench()
     table, src = bench.pmc_step_traffic()
-    assert table is not None and src == "profiles/r02_pmc_traffic.json"
+    assert table is not None and src == "profiles/r03_pmc_traffic.json"
     per_launch = bench.kernel_traffic(table, "gemm_kernel<bf16,plain>")
     # hand computation of the same average: every plain-A bf16 GEMM instantiation, launches-weighted
     tot = n = 0.0
@@ -83,7 +83,7 @@ def test_rocprof_summary_agrees_with_the_live_kernel_timing():
     same workload must show the same average for that kernel (tier brief, measurement section)."""
     import re
     r = _line()["roofline"]
-    txt = open(os.path.join(ROOT, "profiles", "r02_train_step_graph_summary.txt")).read()
+    txt = open(os.path.join(ROOT, "profiles", "r03_train_step_graph_summary.txt")).read()
     m = re.search(r"avg=\s*([0-9.]+) us\s+gemm_kernel<bf16, bf16, 0, 32, false", txt)
     assert m, "plain bf16 GEMM line missing from the rocprof summary"
     assert abs(float(m.group(1)) - r["avg_launch_us"]) < 0.10 * r["avg_launch_us"]
