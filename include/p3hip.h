@@ -303,6 +303,9 @@ typedef struct {
     float* exch;                 /* [B, 3, cluster, D] fp32 scratch: the partial projections the cluster members exchange */
     unsigned int* sync;          /* [B, 2] {arrival count, generation}: zero before the FIRST launch, never touched by the host afterwards */
     int* err;                    /* optional: set to 1 if a cluster barrier gave up (spin limit) - the outputs are then invalid */
+    int fp32;                    /* 0 (a zeroed descriptor, the r02 layout's meaning): x_in / x_out / kv_self / kv_mem and the six weight matrices are
+                                  * bf16 as the comments above say; 1 (r03): all of them fp32 - the parity mode's decode step as one launch per
+                                  * layer too, nothing rounded between the stages */
 } p3_decode_layer_desc;
 int p3_decode_layer(const p3_decode_layer_desc* d, void* stream);
 int p3_cast(const void* a, int dtype_a, void* b, int dtype_b, int64_t n, void* stream);

@@ -123,11 +123,87 @@ __device__ __forceinline__ void gemv_kslice64(const bf16_t* __restrict__ W, int 
     if (wr) out[nb + grp * 4 + row] = tot;
 }
 
-template <int C> struct Smem {
+// ---- element type of weights / activations / caches: bf16 (throughput mode) or fp32 (parity mode, r03) -----------------------------------
+// fp32 keeps every value unrounded between the stages (where the bf16 form rounds to bf16 exactly like the unfused bf16 path stores) and
+// multiplies with fmaf chains; the summation ORDER differs from the MFMA GEMMs of the unfused fp32 path (lane-split dot products folded by
+// shuffles), so features agree to fp32 rounding (1e-6), not bit for bit - tokens are compared against the goldens (tests/test_decode_layer_gpu.py).
+template <typename T> struct DT;
+template <> struct DT<bf16_t> {
+    static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+        const u32x4 r4 = *reinterpret_cast<const u32x4*>(p);
+        v[0] = bf_lo(r4.x); v[1] = bf_hi(r4.x); v[2] = bf_lo(r4.y); v[3] = bf_hi(r4.y); v[4] = bf_lo(r4.z); v[5] = bf_hi(r4.z); v[6] = bf_lo(r4.w); v[7] = bf_hi(r4.w);
+    }
+    static __device__ __forceinline__ float rnd(float v) { return round_bf(v); }
+    static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+    static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+};
+template <> struct DT<float> {
+    static __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+};
+
+// fp32 form of gemv_rows: half-wave per row, a lane owns 8 of the 256 k-values of a block (two 16-byte loads), 8 rows per half-wave in flight
+template <int KB>
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ W, int pitch, int row0, int seg, int seg_stride, int nrows, const float* xs,
+                                          float* out, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, hl = lane & 31, half = lane >> 5;
+    for (int nb = wave * 16; nb < nrows; nb += DL_NW * 16) {
+        const int i0 = nb + half * 8;
+        const float* wrow = W + (int64_t)(row0 + (i0 / seg) * seg_stride + i0 % seg) * pitch + 8 * hl;
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < KB; ++kb) {
+            float4 wa[8], wb[8];
+            const float* wp = wrow + kb * 256;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { wa[r] = *reinterpret_cast<const float4*>(wp); wb[r] = *reinterpret_cast<const float4*>(wp + 4); wp += pitch; }
+            const float4 xa = *reinterpret_cast<const float4*>(xs + kb * 256 + 8 * hl), xb = *reinterpret_cast<const float4*>(xs + kb * 256 + 8 * hl + 4);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float a = acc[r];
+                a = fmaf(wa[r].x, xa.x, a); a = fmaf(wa[r].y, xa.y, a); a = fmaf(wa[r].z, xa.z, a); a = fmaf(wa[r].w, xa.w, a);
+                a = fmaf(wb[r].x, xb.x, a); a = fmaf(wb[r].y, xb.y, a); a = fmaf(wb[r].z, xb.z, a); a = fmaf(wb[r].w, xb.w, a);
+                acc[r] = a;
+            }
+        }
+        int row; bool wr;
+        const float tot = fold_rows<8, 32>(acc, hl, row, wr);
+        if (wr) out[i0 + row] = tot;
+    }
+}
+
+// fp32 form of gemv_kslice64: 8 lanes per row (8 x 8 = the 64-wide K slice), 4 rows per lane group
+__device__ __forceinline__ void gemv_kslice64(const float* __restrict__ W, int col0, const float* xs, float* out, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, l8 = lane & 7, grp = lane >> 3;
+    const int nb = wave * 32;
+    const float* wrow = W + (int64_t)(nb + grp * 4) * DL_D + col0 + 8 * l8;
+    const float4 xa = *reinterpret_cast<const float4*>(xs + 8 * l8), xb = *reinterpret_cast<const float4*>(xs + 8 * l8 + 4);
+    float acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 wa = *reinterpret_cast<const float4*>(wrow + r * DL_D), wb = *reinterpret_cast<const float4*>(wrow + r * DL_D + 4);
+        float a = 0.f;
+        a = fmaf(wa.x, xa.x, a); a = fmaf(wa.y, xa.y, a); a = fmaf(wa.z, xa.z, a); a = fmaf(wa.w, xa.w, a);
+        a = fmaf(wb.x, xb.x, a); a = fmaf(wb.y, xb.y, a); a = fmaf(wb.z, xb.z, a); a = fmaf(wb.w, xb.w, a);
+        acc[r] = a;
+    }
+    int row; bool wr;
+    const float tot = fold_rows<4, 8>(acc, l8, row, wr);
+    if (wr) out[nb + grp * 4 + row] = tot;
+}
+
+template <int C, typename T = bf16_t> struct Smem {
     static constexpr int CW = DL_D / C, HPB = DL_H / C, FW = DL_FF / C;
-    __attribute__((aligned(16))) bf16_t xs[DL_D];        // current activation row (bf16) = the operand of the full-K GEMVs
-    __attribute__((aligned(16))) bf16_t as[CW];          // this member's slice of the attention output (bf16)
-    __attribute__((aligned(16))) bf16_t hb[FW];          // this member's slice of the hidden layer (bf16)
+    __attribute__((aligned(16))) T xs[DL_D];             // current activation row (element type) = the operand of the full-K GEMVs
+    __attribute__((aligned(16))) T as[CW];               // this member's slice of the attention output
+    __attribute__((aligned(16))) T hb[FW];               // this member's slice of the hidden layer
     float xres[DL_D];                                    // the activation row as fp32 (residual)
     float g[FW > 3 * CW ? FW : 3 * CW];                  // raw GEMV sums
     float part[DL_D];                                    // partial projection over this member's K slice
@@ -164,24 +240,28 @@ __device__ __forceinline__ void cluster_barrier(unsigned* sync, int C, int* err,
 
 // softmax(q.K^T * scale + bias) . V for this member's heads; K/V rows in global memory (bf16, row stride rs elements, already offset to
 // the member's channels), optionally the key / value row `cur` taken from LDS.  Result (bf16) -> s.as.
-template <int C>
-__device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, int rs, int Lk, int cur,
+template <int C, typename T>
+__device__ __forceinline__ void attend(Smem<C, T>& s, const T* __restrict__ Kp, const T* __restrict__ Vp, int rs, int Lk, int cur,
                                        const float* __restrict__ kbias, float scale, int tid) {
-    constexpr int CW = Smem<C>::CW, HPB = Smem<C>::HPB, TPK = CW / 8, KPP = DL_NT / TPK;   // threads per key, keys per pass
+    constexpr int CW = Smem<C, T>::CW, HPB = Smem<C, T>::HPB, TPK = CW / 8, KPP = DL_NT / TPK;   // threads per key, keys per pass
+    constexpr int NB = sizeof(T) == 2 ? 13 : 6;          // passes per batch of loads (fp32 chunks are two 16-byte loads: half the passes in flight)
     const int wave = tid >> 6, lane = tid & 63;
     {   // scores: TPK threads per key, each one 16-byte chunk (4 chunks = one head); the chunk's 8 query values live in registers
         const int part = tid % TPK, js = tid / TPK;
         float qv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = s.q[part * 8 + i];
-        // NB passes of KPP keys per batch: all NB loads are issued before the first dot product (13 x 64 keys = the 784 memory tokens)
-        constexpr int NB = 13;
+        // NB passes of KPP keys per batch: all NB loads are issued before the first dot product (bf16: 13 x 64 keys = the 784 memory tokens)
         for (int j0 = 0; j0 < Lk; j0 += KPP * NB) {
-            u32x4 raw[NB];
+            float raw[NB][8];
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
                 const int j = j0 + p * KPP + js;
-                raw[p] = (j < Lk && j != cur) ? *reinterpret_cast<const u32x4*>(Kp + (int64_t)j * rs + part * 8) : u32x4{0u, 0u, 0u, 0u};
+                if (j < Lk && j != cur) DT<T>::load8(Kp + (int64_t)j * rs + part * 8, raw[p]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) raw[p][i] = 0.f;
+                }
             }
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -191,9 +271,8 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
 #pragma unroll
                     for (int i = 0; i < 8; ++i) d = fmaf(qv[i], s.kcur[part * 8 + i], d);
                 } else {
-                    const u32x4 r4 = raw[p];
-                    d = fmaf(qv[0], bf_lo(r4.x), d); d = fmaf(qv[1], bf_hi(r4.x), d); d = fmaf(qv[2], bf_lo(r4.y), d); d = fmaf(qv[3], bf_hi(r4.y), d);
-                    d = fmaf(qv[4], bf_lo(r4.z), d); d = fmaf(qv[5], bf_hi(r4.z), d); d = fmaf(qv[6], bf_lo(r4.w), d); d = fmaf(qv[7], bf_hi(r4.w), d);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d = fmaf(qv[i], raw[p][i], d);
                 }
                 d += quad_xor<0xB1>(d); d += quad_xor<0x4E>(d);             // 4 chunks = one head
                 if (j < Lk && (part & 3) == 0) s.sc[part >> 2][j] = d * scale + (kbias ? kbias[j] : 0.f);
@@ -217,13 +296,16 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
-        constexpr int NB = 13;
         for (int j0 = slot; j0 < Lk; j0 += SLOTS * NB) {
-            u32x4 raw[NB];
+            float raw[NB][8];
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
                 const int j = j0 + p * SLOTS;
-                raw[p] = (j < Lk && j != cur) ? *reinterpret_cast<const u32x4*>(Vp + (int64_t)j * rs + c * 8) : u32x4{0u, 0u, 0u, 0u};
+                if (j < Lk && j != cur) DT<T>::load8(Vp + (int64_t)j * rs + c * 8, raw[p]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) raw[p][i] = 0.f;
+                }
             }
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -234,9 +316,8 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = fmaf(pr, s.vcur[c * 8 + i], o[i]);
                 } else {
-                    const u32x4 r4 = raw[p];
-                    o[0] = fmaf(pr, bf_lo(r4.x), o[0]); o[1] = fmaf(pr, bf_hi(r4.x), o[1]); o[2] = fmaf(pr, bf_lo(r4.y), o[2]); o[3] = fmaf(pr, bf_hi(r4.y), o[3]);
-                    o[4] = fmaf(pr, bf_lo(r4.z), o[4]); o[5] = fmaf(pr, bf_hi(r4.z), o[5]); o[6] = fmaf(pr, bf_lo(r4.w), o[6]); o[7] = fmaf(pr, bf_hi(r4.w), o[7]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = fmaf(pr, raw[p][i], o[i]);
                 }
             }
         }
@@ -255,7 +336,7 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < DL_NW; ++w) a += s.red[w][tid];
-        s.as[tid] = f2bf(a * s.inv[tid >> 5]);
+        s.as[tid] = DT<T>::from_f(a * s.inv[tid >> 5]);
     }
     __syncthreads();
 }
@@ -263,7 +344,7 @@ __device__ __forceinline__ void attend(Smem<C>& s, const bf16_t* __restrict__ Kp
 // Register form of attend() for the 4-member cluster (8 threads per key: 2 heads x 4 chunks; 64 keys per pass, at most 13 passes): the
 // thread that owns chunk c of key j in the score pass is the thread that needs p(j, head(c)) in the P.V pass, so scores, probabilities
 // and the K AND V chunks of all passes stay in registers - one round of loads, no LDS score table, the softmax spread over all 8 waves.
-__device__ __forceinline__ void attend_reg(Smem<4>& s, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, int rs, int Lk, int cur,
+__device__ __forceinline__ void attend_reg(Smem<4, bf16_t>& s, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, int rs, int Lk, int cur,
                                            const float* __restrict__ kbias, float scale, int tid) {
     constexpr int CW = 64, TPK = 8, KPP = DL_NT / TPK, NB = DL_MAXK / KPP;          // 64 keys per pass, 13 passes
     const int wave = tid >> 6, lane = tid & 63, part = tid % TPK, js = tid / TPK, h = part >> 2;
@@ -350,9 +431,9 @@ __device__ __forceinline__ void attend_reg(Smem<4>& s, const bf16_t* __restrict_
 
 // publish this member's partial [256], wait for the cluster, y = sum of the partials (member order) + bias + residual -> LayerNorm ->
 // s.xs (bf16) / s.xres (the rounded value as fp32); member 0 optionally stores the row to global memory
-template <int C>
-__device__ __forceinline__ void combine_norm(Smem<C>& s, float* __restrict__ exch, unsigned* sync, int* err, int c, const float* __restrict__ bias,
-                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, bf16_t* __restrict__ gout, int tid) {
+template <int C, typename T>
+__device__ __forceinline__ void combine_norm(Smem<C, T>& s, float* __restrict__ exch, unsigned* sync, int* err, int c, const float* __restrict__ bias,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ gout, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     float y = 0.f;
     if constexpr (C > 1) {
@@ -376,9 +457,9 @@ __device__ __forceinline__ void combine_norm(Smem<C>& s, float* __restrict__ exc
     __syncthreads();
     const float rstd = rsqrtf((s.stat[8] + s.stat[9] + s.stat[10] + s.stat[11]) * (1.f / DL_D) + eps);
     if (tid < DL_D) {
-        const bf16_t o = f2bf(dv * rstd * gamma[tid] + beta[tid]);
+        const T o = DT<T>::from_f(dv * rstd * gamma[tid] + beta[tid]);
         s.xs[tid] = o;
-        s.xres[tid] = bf2f(o);
+        s.xres[tid] = DT<T>::to_f(o);
         if (gout && c == 0) gout[tid] = o;
     }
     __syncthreads();
@@ -391,10 +472,11 @@ __device__ __forceinline__ void combine_norm(Smem<C>& s, float* __restrict__ exc
 #define DL_T(k) do { } while (0)
 #endif
 
-template <int C>
+template <int C, typename T>
 __global__ __launch_bounds__(DL_NT) void decode_layer_kernel(p3_decode_layer_desc d) {
-    constexpr int CW = Smem<C>::CW, FW = Smem<C>::FW;
-    __shared__ Smem<C> s;
+    constexpr int CW = Smem<C, T>::CW, FW = Smem<C, T>::FW;
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ Smem<C, T> s;
     const int tid = threadIdx.x;
     // cluster members on one XCD: workgroup id = (k * C + c) * 8 + xcd, sample = k * 8 + xcd
     const int xcd = blockIdx.x & 7, kc = blockIdx.x >> 3, c = kc % C, b = (kc / C) * 8 + xcd;
@@ -402,69 +484,69 @@ __global__ __launch_bounds__(DL_NT) void decode_layer_kernel(p3_decode_layer_des
     const int ch0 = c * CW;
     unsigned* sync = d.sync ? d.sync + 2 * b : nullptr;
     float* exch = d.exch ? d.exch + (int64_t)b * 3 * C * DL_D : nullptr;
-    const bf16_t* xin = reinterpret_cast<const bf16_t*>(d.x_in) + (int64_t)b * d.x_in_stride;
+    const T* xin = reinterpret_cast<const T*>(d.x_in) + (int64_t)b * d.x_in_stride;
     DL_T(0);
-    if (tid < DL_D) { const bf16_t v = xin[tid]; s.xs[tid] = v; s.xres[tid] = bf2f(v); }
+    if (tid < DL_D) { const T v = xin[tid]; s.xs[tid] = v; s.xres[tid] = DT<T>::to_f(v); }
     __syncthreads();
     DL_T(1);
     // ---- self-attention: q|k|v rows of this member's heads -> cache, attention over positions 0..t, partial out_proj, norm1
     {
-        const bf16_t* w = reinterpret_cast<const bf16_t*>(d.w_in);
+        const T* w = reinterpret_cast<const T*>(d.w_in);
         gemv_rows<1>(w, DL_D, ch0, CW, DL_D, 3 * CW, s.xs, s.g, tid);         // q, k, v rows of this member's heads: one pass over all waves
         __syncthreads();
         DL_T(2);
-        bf16_t* crow = reinterpret_cast<bf16_t*>(d.kv_self) + ((int64_t)b * d.steps + d.t) * 3 * DL_D;
+        T* crow = reinterpret_cast<T*>(d.kv_self) + ((int64_t)b * d.steps + d.t) * 3 * DL_D;
         for (int n = tid; n < 3 * CW; n += DL_NT) {
             const int seg = n / CW, i = n - seg * CW, col = seg * DL_D + ch0 + i;
-            const bf16_t o = f2bf(s.g[n] + d.b_in[col]);
+            const T o = DT<T>::from_f(s.g[n] + d.b_in[col]);
             crow[col] = o;
-            const float f = bf2f(o);
+            const float f = DT<T>::to_f(o);
             if (seg == 0) s.q[i] = f; else if (seg == 1) s.kcur[i] = f; else s.vcur[i] = f;
         }
         __syncthreads();
         DL_T(3);
-        const bf16_t* cache = reinterpret_cast<const bf16_t*>(d.kv_self) + (int64_t)b * d.steps * 3 * DL_D;
+        const T* cache = reinterpret_cast<const T*>(d.kv_self) + (int64_t)b * d.steps * 3 * DL_D;
         const float* kb = d.key_bias ? d.key_bias + (int64_t)b * d.key_bias_stride : nullptr;
-        if constexpr (C == 4) attend_reg(s, cache + DL_D + ch0, cache + 2 * DL_D + ch0, 3 * DL_D, d.t + 1, d.t, kb, d.scale, tid);
-        else attend<C>(s, cache + DL_D + ch0, cache + 2 * DL_D + ch0, 3 * DL_D, d.t + 1, d.t, kb, d.scale, tid);
+        if constexpr (C == 4 && BF) attend_reg(s, cache + DL_D + ch0, cache + 2 * DL_D + ch0, 3 * DL_D, d.t + 1, d.t, kb, d.scale, tid);
+        else attend<C, T>(s, cache + DL_D + ch0, cache + 2 * DL_D + ch0, 3 * DL_D, d.t + 1, d.t, kb, d.scale, tid);
         DL_T(4);
-        if constexpr (C == 4) gemv_kslice64(reinterpret_cast<const bf16_t*>(d.w_so), ch0, s.as, s.part, tid);
-        else gemv_rows<1>(reinterpret_cast<const bf16_t*>(d.w_so), DL_D, 0, DL_D, 0, DL_D, s.as, s.part, tid);
+        if constexpr (C == 4) gemv_kslice64(reinterpret_cast<const T*>(d.w_so), ch0, s.as, s.part, tid);
+        else gemv_rows<1>(reinterpret_cast<const T*>(d.w_so), DL_D, 0, DL_D, 0, DL_D, s.as, s.part, tid);
         __syncthreads();
         DL_T(5);
-        combine_norm<C>(s, exch, sync, d.err, c, d.b_so, d.g1, d.be1, d.eps, nullptr, tid);
+        combine_norm<C, T>(s, exch, sync, d.err, c, d.b_so, d.g1, d.be1, d.eps, nullptr, tid);
         DL_T(6);
     }
     // ---- cross-attention over the memory tokens
     {
-        gemv_rows<1>(reinterpret_cast<const bf16_t*>(d.w_q), DL_D, ch0, CW, 0, CW, s.xs, s.g, tid);
+        gemv_rows<1>(reinterpret_cast<const T*>(d.w_q), DL_D, ch0, CW, 0, CW, s.xs, s.g, tid);
         __syncthreads();
-        if (tid < CW) s.q[tid] = round_bf(s.g[tid] + d.b_q[ch0 + tid]);
+        if (tid < CW) s.q[tid] = DT<T>::rnd(s.g[tid] + d.b_q[ch0 + tid]);
         __syncthreads();
         DL_T(7);
-        const bf16_t* mem = reinterpret_cast<const bf16_t*>(d.kv_mem) + (int64_t)b * d.Lmem * 2 * DL_D;
-        if constexpr (C == 4) attend_reg(s, mem + ch0, mem + DL_D + ch0, 2 * DL_D, d.Lmem, -1, nullptr, d.scale, tid);
-        else attend<C>(s, mem + ch0, mem + DL_D + ch0, 2 * DL_D, d.Lmem, -1, nullptr, d.scale, tid);
+        const T* mem = reinterpret_cast<const T*>(d.kv_mem) + (int64_t)b * d.Lmem * 2 * DL_D;
+        if constexpr (C == 4 && BF) attend_reg(s, mem + ch0, mem + DL_D + ch0, 2 * DL_D, d.Lmem, -1, nullptr, d.scale, tid);
+        else attend<C, T>(s, mem + ch0, mem + DL_D + ch0, 2 * DL_D, d.Lmem, -1, nullptr, d.scale, tid);
         DL_T(8);
-        if constexpr (C == 4) gemv_kslice64(reinterpret_cast<const bf16_t*>(d.w_co), ch0, s.as, s.part, tid);
-        else gemv_rows<1>(reinterpret_cast<const bf16_t*>(d.w_co), DL_D, 0, DL_D, 0, DL_D, s.as, s.part, tid);
+        if constexpr (C == 4) gemv_kslice64(reinterpret_cast<const T*>(d.w_co), ch0, s.as, s.part, tid);
+        else gemv_rows<1>(reinterpret_cast<const T*>(d.w_co), DL_D, 0, DL_D, 0, DL_D, s.as, s.part, tid);
         __syncthreads();
         DL_T(9);
-        combine_norm<C>(s, exch ? exch + C * DL_D : nullptr, sync, d.err, c, d.b_co, d.g2, d.be2, d.eps, nullptr, tid);
+        combine_norm<C, T>(s, exch ? exch + C * DL_D : nullptr, sync, d.err, c, d.b_co, d.g2, d.be2, d.eps, nullptr, tid);
         DL_T(10);
     }
     // ---- feed-forward: own linear1 rows -> own hidden slice -> partial linear2 over that slice
     {
-        gemv_rows<1>(reinterpret_cast<const bf16_t*>(d.w1), DL_D, c * FW, FW, 0, FW, s.xs, s.g, tid);
+        gemv_rows<1>(reinterpret_cast<const T*>(d.w1), DL_D, c * FW, FW, 0, FW, s.xs, s.g, tid);
         __syncthreads();
         DL_T(11);
-        for (int n = tid; n < FW; n += DL_NT) s.hb[n] = f2bf(fmaxf(s.g[n] + d.b1[c * FW + n], 0.f));
+        for (int n = tid; n < FW; n += DL_NT) s.hb[n] = DT<T>::from_f(fmaxf(s.g[n] + d.b1[c * FW + n], 0.f));
         __syncthreads();
-        gemv_rows<FW / 256>(reinterpret_cast<const bf16_t*>(d.w2) + c * FW, DL_FF, 0, DL_D, 0, DL_D, s.hb, s.part, tid);
+        gemv_rows<FW / 256>(reinterpret_cast<const T*>(d.w2) + c * FW, DL_FF, 0, DL_D, 0, DL_D, s.hb, s.part, tid);
         __syncthreads();
         DL_T(12);
-        combine_norm<C>(s, exch ? exch + 2 * C * DL_D : nullptr, sync, d.err, c, d.b2, d.g3, d.be3, d.eps,
-                        reinterpret_cast<bf16_t*>(d.x_out) + (int64_t)b * d.x_out_stride, tid);
+        combine_norm<C, T>(s, exch ? exch + 2 * C * DL_D : nullptr, sync, d.err, c, d.b2, d.g3, d.be3, d.eps,
+                           reinterpret_cast<T*>(d.x_out) + (int64_t)b * d.x_out_stride, tid);
         DL_T(13);
     }
 }
@@ -490,8 +572,14 @@ extern "C" int p3_decode_layer(const p3_decode_layer_desc* d, void* stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 1;
     }
     P3_CHECK(d->cluster == 1 || groups * 8 * d->cluster <= 2 * cus, P3_ESHAPE, "p3_decode_layer: cluster launch exceeds the co-resident workgroups (use cluster = 1)");
-    if (d->cluster == 4) hipLaunchKernelGGL(decode_layer_kernel<4>, dim3(groups * 8 * 4), dim3(DL_NT), 0, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(decode_layer_kernel<1>, dim3(groups * 8), dim3(DL_NT), 0, (hipStream_t)stream, *d);
+    P3_CHECK(d->fp32 == 0 || d->fp32 == 1, P3_EINVAL, "p3_decode_layer: fp32 must be 0 or 1");
+    if (d->fp32) {
+        if (d->cluster == 4) hipLaunchKernelGGL((decode_layer_kernel<4, float>), dim3(groups * 8 * 4), dim3(DL_NT), 0, (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL((decode_layer_kernel<1, float>), dim3(groups * 8), dim3(DL_NT), 0, (hipStream_t)stream, *d);
+    } else {
+        if (d->cluster == 4) hipLaunchKernelGGL((decode_layer_kernel<4, bf16_t>), dim3(groups * 8 * 4), dim3(DL_NT), 0, (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL((decode_layer_kernel<1, bf16_t>), dim3(groups * 8), dim3(DL_NT), 0, (hipStream_t)stream, *d);
+    }
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

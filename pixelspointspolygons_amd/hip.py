@@ -485,7 +485,7 @@ class DecodeLayerDesc(Structure):
                 ("w_in", c_void_p), ("b_in", c_void_p), ("w_so", c_void_p), ("b_so", c_void_p), ("w_q", c_void_p), ("b_q", c_void_p),
                 ("w_co", c_void_p), ("b_co", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
                 ("g1", c_void_p), ("be1", c_void_p), ("g2", c_void_p), ("be2", c_void_p), ("g3", c_void_p), ("be3", c_void_p),
-                ("eps", c_float), ("scale", c_float), ("cluster", c_int), ("exch", c_void_p), ("sync", c_void_p), ("err", c_void_p)]
+                ("eps", c_float), ("scale", c_float), ("cluster", c_int), ("exch", c_void_p), ("sync", c_void_p), ("err", c_void_p), ("fp32", c_int)]
 
 
 _cu_count = {}
@@ -506,16 +506,20 @@ def decode_layer_scratch(B, device):
 
 
 def decode_layer(x_in, x_out, kv_self, kv_mem, key_bias, t, heads, w, eps, scratch=None):
-    """One decoder layer on the new position t of every sample (p3_decode_layer).  x_in / x_out: [B, D] bf16 rows (any row stride);
-    kv_self [B, steps, 3D] (row t written), kv_mem [B, Lmem, 2D], key_bias [B, >= t+1] fp32 or None; `w`: dict of the layer's tensors -
-    bf16 weights w_in, w_so, w_q, w_co, w1, w2 (row-major [out, in]) and fp32 b_in, b_so, b_q, b_co, b1, b2, g1, be1, g2, be2, g3, be3."""
+    """One decoder layer on the new position t of every sample (p3_decode_layer).  x_in / x_out: [B, D] rows (any row stride), bf16 or
+    fp32 - activations, caches and weight matrices share that one dtype; kv_self [B, steps, 3D] (row t written), kv_mem [B, Lmem, 2D],
+    key_bias [B, >= t+1] fp32 or None; `w`: dict of the layer's tensors - weights w_in, w_so, w_q, w_co, w1, w2 (row-major [out, in]) and
+    fp32 b_in, b_so, b_q, b_co, b1, b2, g1, be1, g2, be2, g3, be3."""
     _dev(x_in)
     B, D = x_in.shape
+    edt = x_in.dtype
+    if edt not in (torch.bfloat16, torch.float32):
+        raise P3Error("decode_layer: bf16 or fp32 activations")
     for name in ("w_in", "w_so", "w_q", "w_co", "w1", "w2"):
-        if w[name].dtype != torch.bfloat16 or not w[name].is_contiguous():
-            raise P3Error(f"decode_layer: {name} must be a contiguous bf16 matrix")
-    if x_in.dtype != torch.bfloat16 or x_out.dtype != torch.bfloat16 or kv_self.dtype != torch.bfloat16 or kv_mem.dtype != torch.bfloat16:
-        raise P3Error("decode_layer: bf16 activations and caches only")
+        if w[name].dtype != edt or not w[name].is_contiguous():
+            raise P3Error(f"decode_layer: {name} must be a contiguous matrix of the activations' dtype ({edt})")
+    if x_out.dtype != edt or kv_self.dtype != edt or kv_mem.dtype != edt:
+        raise P3Error("decode_layer: activations and caches must share one dtype")
     if not (kv_self.is_contiguous() and kv_mem.is_contiguous()) or x_in.stride(1) != 1 or x_out.stride(1) != 1:
         raise P3Error("decode_layer: caches must be contiguous, activation rows dense")
     d = DecodeLayerDesc()
@@ -526,7 +530,7 @@ def decode_layer(x_in, x_out, kv_self, kv_mem, key_bias, t, heads, w, eps, scrat
         d.key_bias, d.key_bias_stride = key_bias.data_ptr(), key_bias.stride(0)
     for name in ("w_in", "b_in", "w_so", "b_so", "w_q", "b_q", "w_co", "b_co", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2", "g3", "be3"):
         setattr(d, name, w[name].data_ptr())
-    d.eps, d.scale = float(eps), 1.0 / math.sqrt(D // heads)
+    d.eps, d.scale, d.fp32 = float(eps), 1.0 / math.sqrt(D // heads), int(edt == torch.float32)
     # 4 workgroups per sample while the whole launch is co-resident: 2 workgroups fit a CU (60 KB LDS, 512 threads), the CU count comes
     # from the device (256 on a full MI355X, fewer on a partition); incl. the padding to groups of 8 samples
     if scratch is not None and ((B + 7) // 8) * 8 * 4 <= coresident_workgroups(x_in.device, 2):

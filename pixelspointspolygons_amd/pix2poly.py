@@ -288,7 +288,7 @@ class Decoder(nn.Module):
             raise hip.P3Error(f"generate: {steps} steps exceed the positional table ({self.max_len - 1})")
         layers = self.decoder.layers
         sig = (B, steps, str(dev), cd, tuple(encoder_out.shape[1:]), ops._epoch[0], tuple(p._version for p in self.parameters()),
-               tuple(p.data_ptr() for p in self.parameters()))
+               tuple(p.data_ptr() for p in self.parameters()), self._fused_step_ok(), os.environ.get("P3_DECODE_CLUSTER", "4"))
         st = getattr(self, "_decode_state", None)
         if st is None or st["sig"] != sig:
             st = dict(sig=sig, warm=False, graphs=None, steps=steps, bos=bos,
@@ -338,15 +338,18 @@ class Decoder(nn.Module):
             return st["preds"].clone(), st["feats"].clone()
         return st["preds"], st["feats"]
 
-    fused_decode = True      # bf16: one p3_decode_layer launch per layer and step (False: the 11-launch chain, as in fp32 mode)
+    fused_decode = True      # one p3_decode_layer launch per layer and step, bf16 and (r03) fp32 (False: the 11-launch chain)
 
     def _fused_step_ok(self):
         l0 = self.decoder.layers[0]
-        return (self.fused_decode and self.cd == torch.bfloat16 and self.dim == 256 and self.num_heads == 8 and l0.linear1.out_features == 2048
+        # bf16 and (r03) fp32: the parity mode's decode step is one launch per layer as well (P3_DECODE_FUSED_F32=0: the 11-launch chain)
+        ok_dt = self.cd == torch.bfloat16 or (self.cd == torch.float32 and os.environ.get("P3_DECODE_FUSED_F32", "1") != "0")
+        return (self.fused_decode and ok_dt and self.dim == 256 and self.num_heads == 8 and l0.linear1.out_features == 2048
                 and os.environ.get("P3_DECODE_FUSED", "1") != "0")
 
     def _fused_layer_tensors(self, lyr):
-        """bf16 weight copies (the optimizer's shadow arena or cached casts) + fp32 vectors of one layer, in p3_decode_layer's naming."""
+        """Weight matrices in the compute dtype (bf16: the optimizer's shadow arena or cached casts; fp32: the parameters) + fp32 vectors
+        of one layer, in p3_decode_layer's naming."""
         cd, D = self.cd, self.dim
         sa, ca = lyr.self_attn, lyr.multihead_attn
         d = lambda p: p.detach()
@@ -368,7 +371,8 @@ class Decoder(nn.Module):
         x, kbt = hip.embed_tokens(preds[:, t:t + 1].contiguous(), emb, pos[t:t + 1], self.pad_idx, cd)      # [B,1,D], [B,1]
         kb[:, t:t + 1] = kbt
         if self._fused_step_ok():
-            # one launch per layer (p3_decode_layer): bf16, the reference's decoder shape; the unfused chain below stays the fp32 path
+            # one launch per layer (p3_decode_layer), the reference's decoder shape; the unfused chain below serves other shapes and is the
+            # form whose fp32 features are bit-identical to predict's full re-runs (fused_decode = False)
             if "xa" not in st:
                 st["xa"], st["xb"] = (torch.empty((x.shape[0], D), dtype=cd, device=x.device) for _ in range(2))
                 st["dl_scratch"] = (hip.decode_layer_scratch(x.shape[0], x.device)

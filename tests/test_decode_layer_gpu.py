@@ -1,5 +1,5 @@
 """p3_decode_layer (one launch per decoder layer and decode step) against the 11-launch chain it replaces (Decoder._decode_step, the body
-of the reference's Decoder.predict loop, model_pix2poly.py:187-219).  bf16 only: the fp32 parity mode keeps the unfused chain."""
+of the reference's Decoder.predict loop, model_pix2poly.py:187-219), in bf16 and (r03) in the fp32 parity mode."""
 import pytest
 import torch
 
@@ -10,13 +10,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _decoder(seed, layers=2):
+def _decoder(seed, layers=2, cd=torch.bfloat16):
     from pixelspointspolygons_amd.pix2poly import Decoder
     sd = O.make_state_dict("image", dict(dim=64, depth=2, heads=2, mlp=128, patch=8, img=32, eps=1e-6), seed=seed, n_vertices=10,
                            dec_dim=256, dec_layers=layers)
     dec = Decoder(vocab_size=O.VOCAB, encoder_len=16, dim=256, num_heads=8, num_layers=layers, max_len=2 * 10 + 2, pad_idx=O.PAD)
     dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
-    dec.cd = torch.bfloat16
+    dec.cd = cd
     return dec.to(DEV).eval(), O
 
 
@@ -42,6 +42,37 @@ def test_fused_layer_matches_the_launch_chain(B, monkeypatch):
         assert err < 2e-2, (name, err)
         same = (t == ref_t).float().mean().item()
         assert same == 1.0 or err < 5e-3, (name, same, err)
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_fused_fp32_layer_matches_the_fp32_launch_chain(B, monkeypatch):
+    """fp32 (parity mode): nothing is rounded between the stages; the fused layer's dot products are summed in another order than the MFMA
+    GEMMs of the chain, so features agree to fp32 rounding (2e-5 after 21 steps x 2 layers), tokens are identical, both cluster forms."""
+    dec, O = _decoder(77, cd=torch.float32)
+    enc = (torch.randn(B, 16, 256, generator=torch.Generator().manual_seed(B)) * 0.5).to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for name, fused, cluster in (("chain", False, "4"), ("fused4", True, "4"), ("fused1", True, "1")):
+            dec.fused_decode = fused
+            monkeypatch.setenv("P3_DECODE_CLUSTER", cluster)
+            dec._decode_state = None
+            toks, feats = dec.generate_cached(enc, 21, O.BOS)
+            outs[name] = (toks.clone(), feats.float().clone())
+            toks2, feats2 = dec.generate_cached(enc, 21, O.BOS)
+            assert torch.equal(toks, toks2) and torch.equal(feats, feats2), name
+    ref_t, ref_f = outs["chain"]
+    for name in ("fused4", "fused1"):
+        t, f = outs[name]
+        assert torch.equal(t, ref_t), name
+        assert float((f - ref_f).norm() / ref_f.norm()) < 2e-5, (name, float((f - ref_f).norm() / ref_f.norm()))
+
+
+def test_fused_fp32_decode_reproduces_the_reference_golden_tokens():
+    d, _ = load_golden("greedy_d256.npz")
+    dec, O = _decoder(77, cd=torch.float32)
+    with torch.no_grad():
+        toks, _ = dec.generate_cached(d["enc"].to(DEV), 21, O.BOS)
+    assert dec._fused_step_ok() and torch.equal(toks.cpu(), d["tokens"])
 
 
 def test_fused_decode_reproduces_the_reference_golden_tokens():

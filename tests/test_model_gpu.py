@@ -226,10 +226,15 @@ def test_kv_cached_decode_is_bit_identical_to_the_full_rerun_and_to_the_referenc
         for _ in range(21):
             lg, feats = dec.predict(enc, preds)
             preds = torch.cat([preds, hip.argmax(lg).view(-1, 1)], 1)
+        dec.fused_decode = False                                     # the launch chain: same arithmetic per (position, channel) as predict
         toks, cfeats = dec.generate_cached(enc, 21, O.BOS)
+        dec.fused_decode, dec._decode_state = True, None             # r03: one p3_decode_layer launch per layer in fp32 too
+        ftoks, ffeats = dec.generate_cached(enc, 21, O.BOS)
     assert torch.equal(toks.cpu(), d["tokens"])                      # the reference's own greedy sequence
     assert torch.equal(toks, preds)
-    assert torch.equal(cfeats, feats[:, :21])                        # bit-identical features (fp32 mode)
+    assert torch.equal(cfeats, feats[:, :21])                        # bit-identical features (fp32 mode, launch chain)
+    assert torch.equal(ftoks.cpu(), d["tokens"])                     # fused fp32 layer: the same tokens as the reference ...
+    assert rel_err(ffeats.cpu(), cfeats.cpu()) < 2e-5                # ... features to fp32 rounding (another summation order inside the dot products)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -243,10 +248,19 @@ def test_kv_cached_generate_full_model(precision):
     with torch.no_grad():
         lj = torch.nested.nested_tensor_from_jagged(d["lidar_values"], d["lidar_offsets"])
         enc = m.encoder(d["image"], lj)
+        if precision == "fp32":                                      # bit-identity with the literal loop is a property of the launch chain
+            m.decoder.fused_decode = False
         torch.cuda.synchronize(); t0 = time.time()
         toks, feats = m.generate(enc)
         torch.cuda.synchronize(); t_cached = time.time() - t0
         assert toks.shape == (2, 386) and feats.shape == (2, 385, 256)
+        if precision == "fp32":                                      # the fused fp32 layer (r03, the default): same tokens, features to fp32 rounding
+            m.decoder.fused_decode, m.decoder._decode_state = True, None
+            torch.cuda.synchronize(); t0 = time.time()
+            ftoks, ffeats = m.generate(enc)
+            torch.cuda.synchronize(); t_fused = time.time() - t0
+            print(f"\n[fp32] fused decode layer: {t_fused:.2f} s against the launch chain's {t_cached:.2f} s")
+            assert torch.equal(ftoks[:, :60], toks[:, :60]) and rel_err(ffeats[:, :59].cpu(), feats[:, :59].cpu()) < 1e-4
         torch.cuda.synchronize(); t0 = time.time()
         ref_toks, ref_feats = m.generate(enc, steps=24, use_cache=False)
         torch.cuda.synchronize(); t_full24 = time.time() - t0
