@@ -727,6 +727,9 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 // gemm8.hip: 256 x 256 tile, LDS-DMA, phased K loop
 int p3_gemm8_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, hipStream_t s);
+// gemm_dma.hip: 128 x 128 tile, LDS-DMA, 2 - 3 workgroups / CU (variants 3 / 4 / 5)
+int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
+static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = e ? atoi(e) : 1; } return m; }
 
 // P3_GEMM8: 0 (default) never, 1 by the shape rule below, 2 whenever eligible (A/B sweeps); P3_GEMM8_STRUCT=0|1|2 forces a loop structure.
 // Default OFF: same-box A/B of the whole train step (r03): 42.55 ms without, 43.35 ms with it - on the path's shapes (K = 384 .. 1536, output
@@ -739,6 +742,7 @@ extern "C" int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_des
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm8: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm8: empty problem");
     P3_CHECK(p3_gemm8_eligible(d, A, W, C), P3_EUNSUP, "p3_gemm8: plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums");
+    if (structure >= 3) return p3_gemm_dma_launch(A, W, C, d, structure, (hipStream_t)stream);
     return p3_gemm8_launch(A, W, C, d, structure, (hipStream_t)stream);
 }
 
@@ -777,6 +781,17 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
+        // P3_GEMM_DMA: 0 never, 1 (default; same-box A/B of the train step r03: 40.60 -> 40.15 ms) by shape (tools/mb_gemm8.py: the 64-deep two-slice form from K = 1024 on - fc2, dX of fc1 / qkv, decoder
+        // linear2: 74 vs 87, 59 vs 67, 33 vs 42 us; the 32-deep two-slice form, 4 workgroups / CU, on wide outputs with K <= 512 - qkv, fc1,
+        // dX of fc2, linear1: 66 vs 69, 86 vs 92, 44 vs 45 us; everything else stays on the register-staged kernel), >= 3 that variant always
+        const int m = gemm_dma_mode();
+        int v = m >= 3 ? m : (d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0));
+        if (m == 7) v = d->K >= 1024 ? 4 : 0;                                   // A/B: only the deep-K rule
+        if (m == 8) v = (d->K <= 512 && d->N >= 1024) ? 6 : 0;                  //      only the wide-output rule
+        if (m == 9) v = d->K >= 1024 ? (d->dtype_out == P3_BF16 ? 4 : 0) : (d->K <= 512 && d->N >= 1024 ? 6 : 0);   // deep K only with bf16 output
+        if (v) return p3_gemm_dma_launch(A, W, C, d, v, s);
+    }
     if (gemm8_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
         // where it measured faster than the 128^2 kernel (tools/mb_gemm8.py, profiles/r03_mb_gemm8.txt): the ViT's wide products (N >= 1152:
         // qkv, fc1, dX of fc2; <= 12 % padding columns) and from K = 1024 on also its 384-column ones (fc2, dX of fc1 / qkv); the decoder's

@@ -138,7 +138,8 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
          lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, force8=None):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p).
-    force8 = 0 | 1 | 2: call the 256 x 256-tile kernel (p3_gemm8, loop structure 0 / 1 / 2) directly instead of p3_gemm's own choice (A/B tools, tests)."""
+    force8 = 0 | 1 | 2: call the 256 x 256-tile kernel (p3_gemm8, loop structure 0 / 1 / 2), 3 .. 6: the 128 x 128-tile LDS-DMA kernel (gemm_dma.hip),
+    directly instead of p3_gemm's own choice (A/B tools, tests)."""
     _dev(a)
     N, K = w.shape
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):

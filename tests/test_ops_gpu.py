@@ -100,6 +100,47 @@ def test_gemm_bf16_tall_tiles(M, N, K, epi):
         assert torch.equal(keep | (pre == 0), ref_mask | (pre == 0))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+def test_gemm_lds_dma_kernels_equal_the_register_staged_kernel(variant):
+    """csrc/gemm8.hip (256 x 256 tile, structures 0-2) and csrc/gemm_dma.hip (128 x 128 tile, LDS-DMA, variants 3-6; what p3_gemm picks
+    from M = 2048 on for K >= 1024 and for wide outputs with K <= 512): every kernel adds the same 16-deep MFMA blocks in ascending k order, so
+    outputs and aux tensors are bit-identical to the register-staged kernel (M < 2048 keeps p3_gemm on it), with every epilogue of the path
+    and ragged M / N; six repeats as a race screen of the counted-vmcnt / barrier protocol."""
+    h = _h()
+    cases = [(1000, 1152, 384, dict(bias=True)),
+             (777, 1536, 384, dict(bias=True, act=h.ACT_GELU, aux=1)),
+             (1500, 2048, 256, dict(bias=True, act=h.ACT_RELU, drop=True)),
+             (1901, 384, 1536, dict(bias=True, odt=torch.float32, res=torch.float32)),
+             (2047, 256, 2048, dict(res=torch.float32)),
+             (1500, 1536, 384, dict(bwd=h.ACT_GELU)),
+             (300, 264, 64, dict(bias=True)),
+             (513, 768, 192, dict(bias=True))]
+    for M, N, K, kw in cases:
+        a, w = _rand(M, K, seed=1).bfloat16().to(DEV), _rand(N, K, seed=2, scale=0.05).bfloat16().to(DEV)
+        odt = kw.get("odt", torch.bfloat16)
+        args = {}
+        if kw.get("bias"):
+            args["bias"] = _rand(N, seed=3).to(DEV)
+        if kw.get("act"):
+            args["act"] = kw["act"]
+        if kw.get("res"):
+            args["residual"] = _rand(M, N, seed=4).to(kw["res"]).to(DEV)
+        if kw.get("bwd"):
+            args["bwd"] = (_rand(M, N, seed=5).to(odt).to(DEV), kw["bwd"], 1.0)
+        if kw.get("drop"):
+            args["drop"] = (torch.full((1,), 77, dtype=torch.int64, device=DEV), 5, 0.1)
+
+        def run(f8):
+            aux = torch.zeros(M, N, device=DEV, dtype=odt) if kw.get("aux") is not None else None
+            o = h.gemm(a, w, out_dtype=odt, aux=aux, aux_grad=bool(kw.get("aux")), force8=f8, **args)
+            return o.clone(), (None if aux is None else aux.clone())
+        ref, ref_aux = run(None)
+        for _ in range(6):
+            o, ax = run(variant)
+            assert torch.equal(o, ref), (M, N, K, variant)
+            assert ax is None or torch.equal(ax, ref_aux), (M, N, K, variant)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_conv3x3_implicit(dtype):
     h = _h()
