@@ -14,6 +14,8 @@
 //     whole slice readable and proves that slice kt - 1 has been consumed by every wave, then slice kt + NBUF - 1 is issued into that buffer;
 //   * epilogue = gemm8.hip's: wave-private fp32 staging of 32 x 64 blocks, whole 8-column chunks, 16-byte accesses.
 // BK = 32, NBUF = 3: 48 KB -> 3 workgroups / CU;  BK = 64, NBUF = 2: 64 KB -> 2 workgroups / CU.
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -22,6 +24,8 @@ struct GDArgs {
     const bf16_t* A; const bf16_t* W; void* C;
     p3_gemm_desc d;
     int tiles_m, tiles_n;
+    long long* timeline;        // diagnostic (P3_GD_TIMELINE=<device address>, tools/mb_gemm_dma_timeline.py): per workgroup {start, first slice readable, loop end, end} at 100 MHz + HW_ID + XCC_ID
+    int ablate;                 // diagnostic (P3_GD_ABLATE, tools/mb_gemm8.py): 1 no C / aux stores, 2 no MFMAs, 4 only the first slices are loaded
 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -59,6 +63,9 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
     const int bid = xcd_remap(blockIdx.x, ntiles);     // consecutive tiles = one A row panel = one XCD's L2
     const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
     const int nk = d.K / BK;
+#define GD_T(k) do { if (g.timeline && tid == 0) g.timeline[(int64_t)blockIdx.x * 6 + (k)] = wall_clock64(); } while (0)
+    GD_T(0);
+    if (g.timeline && tid == 0) { g.timeline[(int64_t)blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); g.timeline[(int64_t)blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); }
 
     // LDS-DMA source offsets (bytes, 32 bit): piece q of wave w = rows (w * PW + q) * RPP .. of the slice, lane -> (row = lane / CPR,
     // slot = lane % CPR), source chunk = slot ^ swz(row).  Rows beyond M / N are clamped (their products are never stored).
@@ -110,13 +117,14 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
         // RAW: slices kt + 1 .. kt + LA - 1 may stay in flight (they were issued after slice kt: loads retire in order, no store is
         // outstanding in this loop); the barrier extends this wave's wait to every wave's pieces.
         // WAR: a wave reaches this barrier after the MFMAs that consumed its reads of slice kt - 1, whose buffer slice kt + LA takes.
-        const int ahead = min(LA - 1, nk - 1 - kt);
+        const int ahead = (g.ablate & 4) ? 0 : min(LA - 1, nk - 1 - kt);
         if (ahead <= 0) wait_vm<0>();
         else if (LA >= 2 && ahead == 1) wait_vm<PER_SLICE>();
         else if (LA >= 3 && ahead == 2) wait_vm<2 * PER_SLICE>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + LA < nk) stage(kt + LA);
+        if (kt == 0) GD_T(1);
+        if (kt + LA < nk && !(g.ablate & 4)) stage(kt + LA);
         const uint4* abuf = lds + ((kt % NBUF) * 2 + 0) * TILE_U4;
         const uint4* bbuf = lds + ((kt % NBUF) * 2 + 1) * TILE_U4;
         uint4 af[2][KK], bfr[2][KK];
@@ -128,6 +136,7 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
                 bfr[i][kk] = bbuf[brow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
             }
         }
+        if (g.ablate & 2) { acc[0][0][0] += __uint_as_float(af[0][0].x ^ bfr[0][0].y ^ af[1][KK - 1].z ^ bfr[1][KK - 1].w); continue; }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // every wave is done with the operands: the epilogue may overwrite them
+    GD_T(2);
 
     // ---- epilogue: per wave, two 32 x 64 blocks through a private fp32 image [32][72] (9 KB)
     constexpr int EP = 72;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
             const int row = tm * 128 + wr * 64 + ib * 32 + rl;
             const float4 v0 = *reinterpret_cast<const float4*>(st + rl * EP + c8);
             const float4 v1 = *reinterpret_cast<const float4*>(st + rl * EP + c8 + 4);
-            if (row >= d.M || col >= d.N) continue;
+            if (row >= d.M || col >= d.N || ((g.ablate & 1) && v0.x != 12345.678f)) continue;
             float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
             const int64_t co = (int64_t)row * d.ldc + col;
             if (act == P3_ACT_GELU) {
@@ -229,6 +239,8 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
             else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GD_T(3);
 }
 
 }  // namespace
@@ -241,6 +253,8 @@ int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, 128);
     g.tiles_n = p3_ceil_div(d->N, 128);
+    { const char* e = getenv("P3_GD_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("P3_GD_TIMELINE"); g.timeline = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
     const bool bf = d->dtype_out == P3_BF16;
     if (variant == 4) {
