@@ -6,6 +6,8 @@
 // N = 192 passed or failed on that order).  With a scratch region registered by the host (p3_set_deterministic) those kernels store their
 // workgroup partials with plain stores instead and det_reduce_kernel adds them in workgroup order in float64: same bits every run, and the
 // 10^3..10^5-term BatchNorm sums lose nothing to cancellation.  The region is used launch by launch in stream order (one compute stream).
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 static float* g_det = nullptr;
@@ -104,7 +106,9 @@ int p3_det_reduce2(const float* parts, int nparts, int64_t stride, float* tmp, f
     const float* src = parts;
     int n = nparts;
     int64_t st = stride;
-    if (nparts > 4 * CH) {
+    static int one_level = -1;                      // parts up to which one 16-lane pass does it (P3_DET_1LVL; r03 A/B on the LayerNorm partials)
+    if (one_level < 0) { const char* e = getenv("P3_DET_1LVL"); one_level = e ? atoi(e) : 16 * CH; }
+    if (nparts > one_level) {
         const int nch = (nparts + CH - 1) / CH;
         hipLaunchKernelGGL(det_reduce_chunk_kernel, dim3((nvals + 63) / 64, nch), dim3(256), 0, s, parts, nparts, stride, tmp, nvals, CH);
         P3_LAUNCH_CHECK();

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const TDX* __restrict__ dres, TDX* __restrict__ dx, bf16_t* __restrict__ dx_lo,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block,
-                                                             p3_dropout lo_drop = p3_dropout{nullptr, 0u, 0.f}) {
+                                                             float* __restrict__ slab, p3_dropout lo_drop = p3_dropout{nullptr, 0u, 0.f}) {
     constexpr int cols = CPL * 128;
     DropKey dk;
     if constexpr (LODROP) dk = drop_key(lo_drop);
@@ -251,8 +251,10 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) { a += sg[q][cidx]; b += sb[q][cidx]; }
-            atomicAdd(dgamma + cidx, a);
-            atomicAdd(dbeta + cidx, b);
+            // slab: this workgroup's partial row [dgamma | dbeta], summed in workgroup order by p3_det_reduce2 - ~1000 workgroups x 2 cols
+            // same-address atomics per launch otherwise (r03: the chains, not the 200 MB of rows, bounded this kernel)
+            if (slab) { slab[(int64_t)blockIdx.x * (2 * cols) + cidx] = a; slab[(int64_t)blockIdx.x * (2 * cols) + cols + cidx] = b; }
+            else { atomicAdd(dgamma + cidx, a); atomicAdd(dbeta + cidx, b); }
         }
     }
 }
@@ -317,16 +319,24 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     hipStream_t s = (hipStream_t)stream;
     static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)
     if (half_env < 0) { const char* e = getenv("P3_LN_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
+    // dgamma / dbeta partials of the half-wave kernel through the registered scratch (P3_LN_SLAB=0: atomics)
+    static int slab_env = -1;
+    if (slab_env < 0) { const char* e = getenv("P3_LN_SLAB"); slab_env = (e && e[0] == '0') ? 0 : 1; }
+    const bool halfk = (lod || half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768);
+    const int nblk = (int)grid.x;
+    const int64_t slab_floats = (int64_t)nblk * 2 * cols, tmp_floats = (int64_t)p3_ceil_div(nblk, 128) * 2 * cols;
+    float* slab = (halfk && dgamma && slab_env && nblk > 8) ? p3_reduce_scratch(slab_floats + tmp_floats) : nullptr;
+    auto finish = [&]() { return slab ? p3_det_reduce2(slab, nblk, 2 * cols, slab + slab_floats, dgamma, dbeta, cols, 2 * cols, 1, s) : P3_OK; };
     if (lod) {
-#define LNH_D(CPL) hipLaunchKernelGGL((ln_bwd_half_kernel<bf16_t, float, float, CPL, false, true>), grid, block, 0, s, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const float*)nullptr, (float*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, *lo_drop)
+#define LNH_D(CPL) hipLaunchKernelGGL((ln_bwd_half_kernel<bf16_t, float, float, CPL, false, true>), grid, block, 0, s, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const float*)nullptr, (float*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab, *lo_drop)
         if (cols == 256) LNH_D(2); else if (cols == 384) LNH_D(3); else LNH_D(6);
 #undef LNH_D
         P3_LAUNCH_CHECK();
-        return P3_OK;
+        return finish();
     }
     if ((half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768)) {
 #define LNH_R(TDY, TX, TDX, CPL, RES) \
-    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb)
+    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab)
 #define LNH_C(TDY, TX, TDX, CPL) \
     do { if (dres) LNH_R(TDY, TX, TDX, CPL, true); else LNH_R(TDY, TX, TDX, CPL, false); } while (0)
 #define LNH(TDY, TX, TDX) \
@@ -341,7 +351,7 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
 #undef LNH_C
 #undef LNH_R
         P3_LAUNCH_CHECK();
-        return P3_OK;
+        return finish();
     }
 #define LNB_NV(TDY, TX, TDX, NV) \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NV>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, dgamma, dbeta, rows, cols, rpb)
