@@ -420,7 +420,10 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // 512 blocks is better still when the tile count divides it (decoder linear1: 64 vs 82 us).  P3_TN_BLOCKS overrides for sweeps.
     static int target_blocks = 0;
     if (target_blocks == 0) { const char* e = getenv("P3_TN_BLOCKS"); target_blocks = e ? atoi(e) : -1; if (target_blocks == 0) target_blocks = -1; }
-    const int tgt = target_blocks > 0 ? target_blocks : 896;   // same-box sweep r01: 600 -> 60.1 ms, 700 -> 59.6, 768 -> 59.6, 850 -> 59.3, 950 -> 59.3
+    // same-box sweep r01: 600 -> 60.1 ms, 700 -> 59.6, 768 -> 59.6, 850 -> 59.3, 950 -> 59.3; r03 (two-deep prefetch since r02, every split costs
+    // N x K fp32 atomics whose lines migrate between the XCDs' L2s - 15 us of the 70 us mean launch, P3_DETERMINISTIC=2 A/B): 512 -> 39.59 ms,
+    // 576 -> 39.47, 640 -> 39.05, 704 -> 39.00, 768 -> 39.39, 896 -> 39.34, 1024 -> 39.91
+    const int tgt = target_blocks > 0 ? target_blocks : 704;
     int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
