@@ -36,12 +36,77 @@ __device__ __forceinline__ float gd_act_grad(float x, int act) {
     return x > 0.f ? 1.f : 0.f;
 }
 
+// one row chunk of 8 columns: v = product + bias -> activation (+ aux) -> dropout -> saved-activation factor -> residual -> C (16-byte accesses)
+template <typename TO>
+__device__ __forceinline__ void gd_epi8(const p3_gemm_desc& d, const DropKey& dk, TO* C, TO* aux, const TO* bwd_saved, bool has_res, bool res_bf, bool aux_grad,
+                                        int act, int row, int col, float (&v)[8]) {
+    const int64_t co = (int64_t)row * d.ldc + col;
+    if (act == P3_ACT_GELU) {
+        float gd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float x = v[k]; gelu_and_grad(x, v[k], gd[k]); if (!aux_grad) gd[k] = x; }
+        if (aux) {
+            if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(gd[0], gd[1]), pack_bf2(gd[2], gd[3]), pack_bf2(gd[4], gd[5]), pack_bf2(gd[6], gd[7]));
+            else { *reinterpret_cast<float4*>(aux + co) = make_float4(gd[0], gd[1], gd[2], gd[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(gd[4], gd[5], gd[6], gd[7]); }
+        }
+    } else {
+        if (aux) {
+            if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+        }
+        if (act == P3_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+    }
+    if (dk.on) {
+        const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const uint32_t bits = drop_bits(rk, drop_colkey(dk, (uint32_t)(col + k)));
+            v[k] = drop_keep_lo(dk, bits) ? v[k] * dk.inv_keep : 0.f;
+            v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
+        }
+    }
+    if (bwd_saved) {
+        float sv[8];
+        if constexpr (sizeof(TO) == 2) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(bwd_saved + co);
+            const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sv[2 * k] = __uint_as_float(w[k] << 16); sv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+        } else {
+            const float4 r0 = *reinterpret_cast<const float4*>(bwd_saved + co);
+            const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
+            sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= gd_act_grad(sv[k], d.bwd_act) * d.bwd_scale;
+    }
+    if (has_res) {
+        const int64_t ro = (int64_t)row * d.ldr + col;
+        if (res_bf) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.residual) + ro);
+            const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+        } else {
+            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro);
+            const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+    }
+    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(C + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else static_assert(N == 0, "add the immediate");
 }
 
@@ -179,68 +244,162 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
             const float4 v1 = *reinterpret_cast<const float4*>(st + rl * EP + c8 + 4);
             if (row >= d.M || col >= d.N || ((g.ablate & 1) && v0.x != 12345.678f)) continue;
             float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
-            const int64_t co = (int64_t)row * d.ldc + col;
-            if (act == P3_ACT_GELU) {
-                float gd[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const float x = v[k]; gelu_and_grad(x, v[k], gd[k]); if (!aux_grad) gd[k] = x; }
-                if (aux) {
-                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(gd[0], gd[1]), pack_bf2(gd[2], gd[3]), pack_bf2(gd[4], gd[5]), pack_bf2(gd[6], gd[7]));
-                    else { *reinterpret_cast<float4*>(aux + co) = make_float4(gd[0], gd[1], gd[2], gd[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(gd[4], gd[5], gd[6], gd[7]); }
-                }
-            } else {
-                if (aux) {
-                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(aux + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-                    else { *reinterpret_cast<float4*>(aux + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(aux + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
-                }
-                if (act == P3_ACT_RELU) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                }
-            }
-            if (dk.on) {
-                const uint32_t rk = drop_rowkey(dk, (uint64_t)row);
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    const uint32_t bits = drop_bits(rk, drop_colkey(dk, (uint32_t)(col + k)));
-                    v[k] = drop_keep_lo(dk, bits) ? v[k] * dk.inv_keep : 0.f;
-                    v[k + 1] = drop_keep_hi(dk, bits) ? v[k + 1] * dk.inv_keep : 0.f;
-                }
-            }
-            if (bwd_saved) {
-                float sv[8];
-                if constexpr (sizeof(TO) == 2) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(bwd_saved + co);
-                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { sv[2 * k] = __uint_as_float(w[k] << 16); sv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
-                } else {
-                    const float4 r0 = *reinterpret_cast<const float4*>(bwd_saved + co);
-                    const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
-                    sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= gd_act_grad(sv[k], d.bwd_act) * d.bwd_scale;
-            }
-            if (has_res) {
-                const int64_t ro = (int64_t)row * d.ldr + col;
-                if (res_bf) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.residual) + ro);
-                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
-                } else {
-                    const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro);
-                    const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d.residual) + ro + 4);
-                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                }
-            }
-            if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(C + co) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-            else { *reinterpret_cast<float4*>(C + co) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(C + co + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+            gd_epi8<TO>(d, dk, C, aux, bwd_saved, has_res, res_bf, aux_grad, act, row, col, v);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GD_T(3);
+}
+
+// ---- persistent, wave-specialised form (variant 7 / 8) --------------------------------------------------------------------------------
+// What the per-workgroup timeline of the kernel above shows on the path's wide products (profiles/r03_gemm_dma_timeline.txt; fc1: life
+// 16.9 us = 1.2 first slice + 9.1 K loop + 6.4 epilogue, of which ~5 us is s_endpgm's implicit wait for the store acknowledgements): a
+// third of every workgroup slot's time holds registers and LDS for stores that are already on their way.  A persistent workgroup cannot
+// simply start its next tile instead: gfx950 counts loads and stores in ONE vmcnt and retires them out of order with respect to each other,
+// so the first counted wait of the next tile's loads would wait for the previous tile's stores as well.  Hence two kinds of waves:
+//   * wave 4, the LOADER, issues every LDS-DMA of the workgroup (16 instructions per 32-deep slice) and is the only wave that waits on
+//     vmcnt - its counter holds loads only, so the counted in-order wait stays exact; slices run on across tile boundaries (no prologue bubble);
+//   * waves 0-3, the COMPUTE waves (2 x 2, 64 x 64 each), meet the loader at one barrier per slice, read fragments, multiply, and at the end
+//     of a tile stage 16-row blocks through a PRIVATE LDS image and issue the stores - they never wait for them (their bias loads are issued
+//     at the start of the tile, a K loop before their first use), so the acknowledgements arrive behind the next tile's K loop.
+// LDS: NBUF-slice ring (16 KB each) + 4 x 4.5 KB epilogue images = 66 KB for NBUF = 3: two workgroups per CU, grid = 2 x CUs (or the tile count).
+// MEASURED (profiles/r03_mb_gemm_dma.txt): correct and race-free, and SLOWER than the one-tile-per-workgroup form - fc1 115 vs 90 us, qkv 82 vs 69,
+// 8192^3 664 vs 721 TF.  The K loop of every 128 x 128 variant is bound by the bytes in flight per CU (global -> LDS latency ~1.1 us under
+// load, <= 100 KB of ring / staging registers per CU): two persistent workgroups keep 64 KB in flight where four short-lived ones keep 64 KB
+// AND overlap four epilogues; hiding the store acknowledgements does not pay for the lost residency.  Kept callable (p3_gemm8 structure 7 / 8)
+// with its parity test; p3_gemm never picks it.
+template <typename TO, int NBUF>
+__global__ __launch_bounds__(320, 2) void gemm_ws_kernel(GDArgs g) {
+    constexpr int BK = 32, CPR = 4, TILE_U4 = 128 * CPR, LA = NBUF - 1, KK = 2;
+    constexpr int RING_U4 = NBUF * 2 * TILE_U4;
+    constexpr int EPR = 16, EP = 72, EPI_U4 = EPR * EP * 4 / 16;             // per compute wave: [16][72] fp32
+    __shared__ __attribute__((aligned(1024))) uint4 lds[RING_U4 + 4 * EPI_U4];
+    const p3_gemm_desc& d = g.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = g.tiles_m * g.tiles_n, G = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, G);            // logical id: the workgroups of one XCD walk consecutive tiles (one A row panel) at any time
+    const int n_my = L < ntiles ? (ntiles - L + G - 1) / G : 0;
+    const int nk = d.K / BK, total = n_my * nk;
+    if (wave == 4) {
+        // ------------------------------------------------------------------------------------------------ loader
+        const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(&lds[0]));
+        auto dma2 = [&](const bf16_t* base, uint32_t dst, uint32_t v0, uint32_t v1) __attribute__((always_inline)) {
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep) : "v"(v0), "v"(v1), "s"(base), "s"(dst) : "memory");
+        };
+        uint32_t voffA[8], voffB[8];
+        int it = 0, kt = 0, sl = 0;                     // issue pointer: tile iteration, slice of the tile, ring slot
+        auto issue = [&]() __attribute__((always_inline)) {
+            if (kt == 0) {
+                const int t = L + it * G, tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int rr = q * 16 + (lane >> 2), slot = lane & 3, c = slot ^ ((rr >> 2) & 3);
+                    const int ra = min(tm * 128 + rr, d.M - 1), rb = min(tn * 128 + rr, d.N - 1);
+                    voffA[q] = (uint32_t)(((int64_t)ra * d.lda + c * 8) * 2);
+                    voffB[q] = (uint32_t)(((int64_t)rb * d.ldb + c * 8) * 2);
+                }
+            }
+            const bf16_t* ab = g.A + (int64_t)kt * BK;
+            const bf16_t* wb = g.W + (int64_t)kt * BK;
+            const uint32_t da = lds_addr + (uint32_t)((sl * 2 + 0) * TILE_U4 * 16), db = lds_addr + (uint32_t)((sl * 2 + 1) * TILE_U4 * 16);
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) dma2(ab, da + q * 0x400, voffA[q], voffA[q + 1]);
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) dma2(wb, db + q * 0x400, voffB[q], voffB[q + 1]);
+            if (++kt == nk) { kt = 0; ++it; }
+            if (++sl == NBUF) sl = 0;
+        };
+        int issued = 0;
+        for (; issued < LA && issued < total; ++issued) issue();
+        for (int s = 0; s < total; ++s) {
+            // slices s + 1 .. may stay in flight: this wave's counter holds loads only (in-order among themselves)
+            const int ahead = min(issued - 1 - s, LA - 1);
+            if (ahead <= 0) wait_vm<0>();
+            else if (ahead == 1) wait_vm<16>();
+            else wait_vm<32>();
+            __builtin_amdgcn_s_barrier();              // slice s readable; every compute wave has consumed slice s - 1 (its ring slot is free)
+            if (issued < total) { issue(); ++issued; }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- compute waves
+    const int wr = wave >> 1, wc = wave & 1;
+    const int sw = (l31 >> 2) & 3;
+    const int arow = (wr * 64 + l31) * CPR, brow = (wc * 64 + l31) * CPR;
+    float* st = reinterpret_cast<float*>(lds + RING_U4 + wave * EPI_U4);
+    TO* C = reinterpret_cast<TO*>(g.C);
+    TO* aux = reinterpret_cast<TO*>(d.aux);
+    const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
+    const bool has_res = d.residual != nullptr, res_bf = d.dtype_res == P3_BF16, aux_grad = d.aux_mode == 1;
+    const int act = d.act;
+    const DropKey dk = drop_key(d.drop);
+    const int c8 = (lane & 7) * 8, rl0 = lane >> 3;
+    int sl = 0;
+    for (int it = 0; it < n_my; ++it) {
+        const int t = L + it * G, tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+        const int col = tn * 128 + wc * 64 + c8;
+        float bias[8];                                  // issued now, used after the K loop: the wait for them finds the previous tile's stores long retired
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bias[k] = (d.bias && col + k < d.N) ? d.bias[col + k] : 0.f;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            const uint4* abuf = lds + (sl * 2 + 0) * TILE_U4;
+            const uint4* bbuf = lds + (sl * 2 + 1) * TILE_U4;
+            if (++sl == NBUF) sl = 0;
+            uint4 af[2][KK], bfr[2][KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i][kk] = abuf[arow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
+                    bfr[i][kk] = bbuf[brow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][kk]), __builtin_bit_cast(bf16x8_t, bfr[j][kk]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // epilogue: 16-row blocks (registers 8 * hf .. 8 * hf + 7 of each 32 x 32 block) through the wave's own image; no wait for the stores
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) st[(crow32(8 * hf + r, hi) - 16 * hf) * EP + j * 32 + l31] = acc[ib][j][8 * hf + r];
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int rl = pass * 8 + rl0;
+                    const int row = tm * 128 + wr * 64 + ib * 32 + hf * 16 + rl;
+                    const float4 v0 = *reinterpret_cast<const float4*>(st + rl * EP + c8);
+                    const float4 v1 = *reinterpret_cast<const float4*>(st + rl * EP + c8 + 4);
+                    if (row >= d.M || col >= d.N) continue;
+                    float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
+                    gd_epi8<TO>(d, dk, C, aux, bwd_saved, has_res, res_bf, aux_grad, act, row, col, v);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -257,6 +416,21 @@ int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc
     { const char* e = getenv("P3_GD_TIMELINE"); g.timeline = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
     const bool bf = d->dtype_out == P3_BF16;
+    if (variant == 7 || variant == 8) {
+        static int cus = 0;
+        if (cus == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+        const int ntiles = g.tiles_m * g.tiles_n;
+        dim3 pgrid(ntiles < 2 * cus ? ntiles : 2 * cus), pblock(320);
+        if (variant == 7) {
+            if (bf) hipLaunchKernelGGL((gemm_ws_kernel<bf16_t, 3>), pgrid, pblock, 0, s, g);
+            else hipLaunchKernelGGL((gemm_ws_kernel<float, 3>), pgrid, pblock, 0, s, g);
+        } else {
+            if (bf) hipLaunchKernelGGL((gemm_ws_kernel<bf16_t, 4>), pgrid, pblock, 0, s, g);
+            else hipLaunchKernelGGL((gemm_ws_kernel<float, 4>), pgrid, pblock, 0, s, g);
+        }
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     if (variant == 4) {
         if (bf) hipLaunchKernelGGL((gemm_dma_kernel<bf16_t, 64, 2>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_dma_kernel<float, 64, 2>), grid, block, 0, s, g);
