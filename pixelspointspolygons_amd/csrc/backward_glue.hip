@@ -72,7 +72,7 @@ template <typename TS>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const TS* __restrict__ src, int src_ld,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                                                            TS* __restrict__ dsrc, float* __restrict__ dscale, float* __restrict__ dshift,
-                                                           int B, int np, int D, int rows_per_block) {
+                                                           int B, int np, int D, int rows_per_block, float* __restrict__ slab) {
     const int64_t rows = (int64_t)B * np;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
                 dsrc[(rq + q) * D + c] = Cvt<TS>::from_f(gg);
             }
         }
-        if (scale) { atomicAdd(dscale + c, a1); atomicAdd(dshift + c, a2); }
+        if (scale) {
+            // slab: this workgroup's partial row [dscale | dshift], added in workgroup order by p3_det_reduce2 instead of ~1000-deep atomic chains
+            if (slab) { slab[(int64_t)blockIdx.x * (2 * D) + c] = a1; slab[(int64_t)blockIdx.x * (2 * D) + D + c] = a2; }
+            else { atomicAdd(dscale + c, a1); atomicAdd(dshift + c, a2); }
+        }
     }
 }
 
@@ -241,12 +245,25 @@ extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_
     // workgroup; measured 8: 200 us, 16: 125, 32: 94, 64: 99, 128: 142, 192: 205
     static int rpb_env = -1;
     if (rpb_env < 0) { const char* e = getenv("P3_ASM_RPB"); rpb_env = e ? atoi(e) : 0; }
-    const int rpb = rpb_env > 0 ? rpb_env : 48;
+    // r03: with the partial sums going through the scratch slab (no atomics) short walks win: 16 rows per workgroup (P3_ASM_SLAB=0: atomics, 48 rows)
+    static int slab_env = -1;
+    if (slab_env < 0) { const char* e = getenv("P3_ASM_SLAB"); slab_env = (e && e[0] == '0') ? 0 : 1; }
+    int rpb = rpb_env > 0 ? rpb_env : 48;
+    float* slab = nullptr;
+    int64_t slab_floats = 0;
+    if (scale && slab_env) {
+        const int rpb_s = rpb_env > 0 ? rpb_env : 16;
+        const int64_t nb = p3_ceil_div((int64_t)B * np, rpb_s);
+        slab_floats = nb * 2 * D;
+        slab = p3_reduce_scratch(slab_floats + p3_ceil_div(nb, 128) * 2 * D);
+        if (slab) rpb = rpb_s;
+    }
     dim3 g(p3_ceil_div((int64_t)B * np, rpb)), b(256);
-    if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, mean, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb);
-    else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, mean, (float*)dsrc, dscale, dshift, B, np, D, rpb);
+    if (dtype_src == P3_BF16) hipLaunchKernelGGL((assemble_bwd_kernel<bf16_t>), g, b, 0, s, dx, (const bf16_t*)src, src_ld, scale, shift, mean, (bf16_t*)dsrc, dscale, dshift, B, np, D, rpb, slab);
+    else if (dtype_src == P3_F32) hipLaunchKernelGGL((assemble_bwd_kernel<float>), g, b, 0, s, dx, (const float*)src, src_ld, scale, shift, mean, (float*)dsrc, dscale, dshift, B, np, D, rpb, slab);
     else { p3_set_error("p3_tokens_assemble_bwd: dtype"); return P3_EUNSUP; }
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce2(slab, (int)g.x, 2 * D, slab + slab_floats, dscale, dshift, D, 2 * D, 1, s);
     return P3_OK;
 }
 

@@ -352,13 +352,27 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const in
 
 // BCELoss (mean): acc[0] += sum -(y*max(log p,-100) + (1-y)*max(log(1-p),-100))
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float* __restrict__ acc) {
+    // four elements per thread in flight; ONE atomic per workgroup (r03: one per wave from 1024 workgroups was a 4096-deep same-address chain
+    // - 58 us for 19 MB of input)
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float pv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; yv[u] = y[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s -= yv[u] * fmaxf(logf(pv[u]), -100.f) + (1.f - yv[u]) * fmaxf(logf(1.f - pv[u]), -100.f);
+    }
+    for (; i < n; i += stride) {
         const float pi = p[i], yi = y[i];
         s -= yi * fmaxf(logf(pi), -100.f) + (1.f - yi) * fmaxf(logf(1.f - pi), -100.f);
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, const float* __restrict__ gscale,
@@ -493,7 +507,7 @@ extern "C" int p3_ce_loss_bwd(const float* logits, int ld, const int64_t* target
 
 extern "C" int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float* acc, void* stream) {
     P3_CHECK(p && y && acc && n > 0, P3_EINVAL, "p3_bce_loss_fwd: bad arguments");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, acc);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, acc);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }
