@@ -47,6 +47,10 @@ extern "C" {
 
 int p3_version(void);
 const char* p3_last_error_string(void);
+/* Measurement hook: after p3_trace_kernels(1), p3_last_kernel() names the device kernel the calling thread's last p3_gemm launched, spelled as
+ * rocprofv3 --kernel-trace prints it after tools/kstats.py's bf16 rewrite ("gemm_dma_kernel<bf16, 32, 2>"); "" when tracing is off. */
+void p3_trace_kernels(int on);
+const char* p3_last_kernel(void);
 
 /* Deterministic reductions.  The reference seeds everything and sets cudnn.deterministic (misc/shared_utils.py:120-126, trainer.py:214);
  * here the kernels that would finish in fp32 atomicAdd's over workgroup partials (BatchNorm sums of the ScoreNet, split-M weight

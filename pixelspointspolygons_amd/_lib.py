@@ -25,6 +25,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.p3_last_error_string.restype = ctypes.c_char_p
         _lib.p3_version.restype = ctypes.c_int
+        _lib.p3_last_kernel.restype = ctypes.c_char_p
+        _lib.p3_trace_kernels.restype = None
     return _lib
 
 

@@ -11,6 +11,8 @@
 
 #include <type_traits>
 
+#include <stdio.h>
+
 #include "p3_common.h"
 
 namespace {
@@ -657,6 +659,11 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
         if (cap >= g.tiles_n && nwg > cap) nwg = cap;
     }
     dim3 grid(nwg), block(256);
+    if (p3_tracing()) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "gemm_kernel<%s, %s, %d, %d, %s>", sizeof(T) == 2 ? "bf16" : "float", sizeof(TO) == 2 ? "bf16" : "float", g.d.a_mode, BKSEL, STATS ? "true" : "false");
+        p3_note_kernel(nm);
+    }
     GemmArgs gs = g;
     const int nparts = 2 * (nwg / g.tiles_n);       // two row halves (wave rows) per workgroup
     if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
@@ -806,6 +813,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     if (!no_skinny && d->dtype_in == P3_BF16 && d->M <= 128 && d->a_mode == P3_A_PLAIN && !d->colsum && !d->aux && !d->bwd_saved &&
         !(d->drop.seed && d->drop.p > 0.f)) {
         dim3 grid(p3_ceil_div(d->N, 32), p3_ceil_div(d->M, 32));
+        if (p3_tracing()) p3_note_kernel(d->K >= 1024 ? "gemm_skinny_kernel<8>" : "gemm_skinny_kernel<1>");
         if (d->K >= 1024) {
             if (d->dtype_out == P3_BF16) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, 8>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_skinny_kernel<float, 8>), grid, dim3(512), 0, s, g);

@@ -18,6 +18,7 @@
 // DMA (phase 4's wait precedes phase 4's first barrier, the reads are in phase 1 of the next K-tile, two barriers later - still one barrier
 // late enough when the second wave group runs one barrier behind); WAR - a slot is re-staged only after a barrier that follows the
 // COMPLETION (s_waitcnt lgkmcnt(0) before the phase's first barrier) of its last reads in every wave, lagging group included.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "p3_common.h"
@@ -333,6 +334,7 @@ int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d
     g.tiles_n = p3_ceil_div(d->N, G8_BN);
     dim3 grid(g.tiles_m * g.tiles_n), block(512);
     if (structure < 0) structure = d->K >= 1024 ? 1 : 2;
+    if (p3_tracing()) { char nm[96]; snprintf(nm, sizeof(nm), "gemm8_kernel<%s, %d>", d->dtype_out == P3_BF16 ? "bf16" : "float", structure); p3_note_kernel(nm); }
     if (d->dtype_out == P3_BF16) {
         if (structure == 1) hipLaunchKernelGGL((gemm8_kernel<bf16_t, 1>), grid, block, 0, s, g);
         else if (structure == 2) hipLaunchKernelGGL((gemm8_kernel<bf16_t, 2>), grid, block, 0, s, g);

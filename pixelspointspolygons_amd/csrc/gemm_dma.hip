@@ -14,6 +14,7 @@
 //     whole slice readable and proves that slice kt - 1 has been consumed by every wave, then slice kt + NBUF - 1 is issued into that buffer;
 //   * epilogue = gemm8.hip's: wave-private fp32 staging of 32 x 64 blocks, whole 8-column chunks, 16-byte accesses.
 // BK = 32, NBUF = 3: 48 KB -> 3 workgroups / CU;  BK = 64, NBUF = 2: 64 KB -> 2 workgroups / CU.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "p3_common.h"
@@ -416,6 +417,12 @@ int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc
     { const char* e = getenv("P3_GD_TIMELINE"); g.timeline = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     dim3 grid(g.tiles_m * g.tiles_n), block(256);
     const bool bf = d->dtype_out == P3_BF16;
+    if (p3_tracing()) {
+        char nm[96];
+        if (variant == 7 || variant == 8) snprintf(nm, sizeof(nm), "gemm_ws_kernel<%s, %d>", bf ? "bf16" : "float", variant == 7 ? 3 : 4);
+        else snprintf(nm, sizeof(nm), "gemm_dma_kernel<%s, %d, %d>", bf ? "bf16" : "float", variant == 4 ? 64 : 32, variant == 5 ? 4 : (variant == 3 ? 3 : 2));
+        p3_note_kernel(nm);
+    }
     if (variant == 7 || variant == 8) {
         static int cus = 0;
         if (cus == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }

@@ -108,6 +108,8 @@ __device__ __forceinline__ float gelu_erf(float x) { float h, g; gelu_and_grad(x
 static inline int p3_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void p3_set_error(const char* msg);
+int p3_tracing(void);                     // p3_trace_kernels(1): launch sites record the kernel they picked (p3_last_kernel)
+void p3_note_kernel(const char* name);
 // deterministic reductions (det_reduce.hip): scratch for workgroup partials (NULL: atomics path) and the fixed-order float64 reduce
 float* p3_det_scratch(int64_t floats, int dtype);
 int p3_det_reduce(const float* parts, int nparts, int64_t stride, float* out, int nvals, int accumulate, hipStream_t s);

@@ -20,9 +20,11 @@ class _KernelTimer:
 
     def enable(self):
         self.on, self.pending = True, []
+        lib().p3_trace_kernels(c_int(1))          # p3_gemm records which device kernel it picked (p3_last_kernel)
 
     def disable(self):
         self.on = False
+        lib().p3_trace_kernels(c_int(0))
 
     def begin(self):
         if not self.on:
@@ -205,7 +207,8 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
             nbytes += M_ * N * eso
         if bwd is not None:
             nbytes += M_ * N * eso
-        KTIMER.end(ev, f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>", 2.0 * M_ * N * K, float(nbytes))
+        kname = lib().p3_last_kernel().decode() or f"gemm_kernel<{'bf16' if d.dtype_in == BF16 else 'f32'},{_AMODE_NAMES[a_mode]}>"
+        KTIMER.end(ev, kname, 2.0 * M_ * N * K, float(nbytes))     # the name rocprofv3 prints for the kernel p3_gemm picked
     return out
 
 
@@ -694,9 +697,12 @@ def gemm_tn(a, b, out=None, colsum_out=None):
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
     slabs, ns = _tn_slabs(N, K, a)
+    ev = KTIMER.begin()
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
                               ptr(slabs), c_int(ns), stream()), "p3_gemm_tn")
+    if ev is not None:                                          # operands once, the fp32 output tile once (split-M partials are not algorithmic)
+        KTIMER.end(ev, f"gemm_tn_kernel<{'bf16' if dt(a) == BF16 else 'float'}, 0>", 2.0 * M * N * K, float(M * (N + K) * a.element_size() + N * K * 4))
     return out
 
 

@@ -1,17 +1,21 @@
-# Round artefacts on one box: bench line, rocprofv3 kernel stats of the same command, FETCH / WRITE PMC passes (separate runs), SQ counters.
-# usage (through gpurun): bash tools/final_prof.sh r02
+# Round artefacts on one box: rocprofv3 kernel stats of the train step, FETCH / WRITE PMC passes (separate runs), THEN the bench line (so that its
+# roofline.traffic comes from this round's counters), SQ counters, the FFL line.
+# usage (through gpurun): bash tools/final_prof.sh r03
 set -x
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-python bench.py 2>&1 | tail -1 > gpurun_out/final/${R}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_stats -o st -- python bench.py --lean --steps 20 > gpurun_out/final/stats_run.log 2>&1
 find /tmp/pf_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/${R}_train_step_graph_kernel_stats.csv \;
 python tools/kstats.py gpurun_out/final/${R}_train_step_graph_kernel_stats.csv 25 60 > gpurun_out/final/${R}_train_step_graph_summary.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_fetch -o f -- python bench.py --lean --graph 0 --steps 4 --warmup 2 > gpurun_out/final/fetch_run.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pf_write -o w -- python bench.py --lean --graph 0 --steps 4 --warmup 2 > gpurun_out/final/write_run.log 2>&1
 python tools/pmc_traffic.py /tmp/pf_fetch /tmp/pf_write gpurun_out/final/${R}_pmc_traffic.json 6 > gpurun_out/final/${R}_pmc_summary.txt 2>&1
+cp gpurun_out/final/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
+python bench.py 2>&1 | tail -1 > gpurun_out/final/${R}_bench.json
+python bench.py --workload ffl_fusion --steps 10 --no-cpu-baseline --no-fp32-leg --no-predict --no-host-feed 2>&1 | tail -1 > gpurun_out/final/${R}_bench_ffl.json
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pf_sq -o q -- python bench.py --lean --graph 0 --steps 3 --warmup 2 > gpurun_out/final/sq_run.log 2>&1
 python tools/pmc_kernels.py /tmp/pf_sq > gpurun_out/final/${R}_sq_counters_summary.txt 2>&1
 tail -3 gpurun_out/final/${R}_pmc_summary.txt
-cut -c1-600 gpurun_out/final/${R}_bench.json
+cut -c1-900 gpurun_out/final/${R}_bench.json
+cut -c1-300 gpurun_out/final/${R}_bench_ffl.json
