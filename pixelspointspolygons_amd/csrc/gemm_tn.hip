@@ -423,8 +423,12 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // same-box sweep r01: 600 -> 60.1 ms, 700 -> 59.6, 768 -> 59.6, 850 -> 59.3, 950 -> 59.3; r03 (two-deep prefetch since r02, every split costs
     // N x K fp32 atomics whose lines migrate between the XCDs' L2s - 15 us of the 70 us mean launch, P3_DETERMINISTIC=2 A/B): 512 -> 39.59 ms,
     // 576 -> 39.47, 640 -> 39.05, 704 -> 39.00, 768 -> 39.39, 896 -> 39.34, 1024 -> 39.91
-    const int tgt = target_blocks > 0 ? target_blocks : 704;
+    // r03, second sweep (the first never went below 512): the best grids are the ones that fit ONE resident wave of workgroups (2 per CU = 512) -
+    // 320 -> 40.48 ms, 352 -> 40.11, 384 -> 39.89, 416 -> 39.59, 448 -> 39.41, 480 -> 39.55, 704 -> 40.33 (same box); per shape (tools/mb_tn_sweep.py)
+    // qkv 82 us at 405 workgroups, 105 at 513 (one past the wave), 93 at 704
+    const int tgt = target_blocks > 0 ? target_blocks : 448;
     int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
+    if (tgt <= 512 && splits > 1 && splits * tiles > 512) --splits;              // never one workgroup past the resident wave
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
     if (splits > max_splits) splits = max_splits;
