@@ -427,7 +427,11 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // 320 -> 40.48 ms, 352 -> 40.11, 384 -> 39.89, 416 -> 39.59, 448 -> 39.41, 480 -> 39.55, 704 -> 40.33 (same box); per shape (tools/mb_tn_sweep.py)
     // qkv 82 us at 405 workgroups, 105 at 513 (one past the wave), 93 at 704
     const int tgt = target_blocks > 0 ? target_blocks : 448;
-    int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
+    static int rule512 = -1;                         // P3_TN_RULE512=0: A/B switch of the exact-wave rule below
+    if (rule512 < 0) { const char* e = getenv("P3_TN_RULE512"); rule512 = (e && e[0] == '0') ? 0 : 1; }
+    // (measured and dropped: outputs of <= 8 tiles - the decoder's 256 x 256 projections, the head - run 18.5 instead of 27.7 us ALONE with ~192
+    // instead of 512 workgroups, tools/mb_tn_sweep.py, but the captured step got 0.2 ms slower with that rule: 39.93 vs 39.72 ms, same box)
+    int splits = (rule512 && 512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
     if (tgt <= 512 && splits > 1 && splits * tiles > 512) --splits;              // never one workgroup past the resident wave
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);
