@@ -314,7 +314,11 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     if (rpb_env < 0) { const char* e = getenv("P3_LN_RPB"); rpb_env = e ? atoi(e) : 0; }
     // rows per block trades resident waves (one row in flight per wave) against dgamma / dbeta atomics per address; same-box sweep of
     // the train step (r01, P3_LN_RPB): 16 -> 60.9 ms, 32 -> 60.2, 48 -> 59.8, 96 -> 60.3, 128 -> 60.5, 256 -> 62.7
-    const int rpb = rpb_env > 0 ? rpb_env : 48;
+    // r03, with the parameter sums going through the slab (no atomic chains to shorten): 32 -> 35.2 us, 40 -> 37.7, 48 -> 39.3, 56 -> 37.3, 64 -> 40.4
+    static int slab_on = -1;
+    if (slab_on < 0) { const char* e = getenv("P3_LN_SLAB"); slab_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool half_cols = cols == 256 || cols == 384 || cols == 768;
+    const int rpb = rpb_env > 0 ? rpb_env : (slab_on && half_cols && dgamma && p3_reduce_scratch(1) ? 32 : 48);
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
     static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)

@@ -383,8 +383,10 @@ __global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restri
 }
 
 inline int grid_rows(int64_t rows, int rows_per_block) {
+    static int cap = 0;                              // P3_RAB_GRID: workgroup cap of the grid-stride row kernels (sweeps)
+    if (cap == 0) { const char* e = getenv("P3_RAB_GRID"); cap = e ? atoi(e) : 1024; if (cap <= 0) cap = 1024; }   // r03 sweep: 1024 -> 288 / 102 us, 2048 -> 297 / 108, 3072 -> 306 / 105, 4096 -> 315 / 127
     int64_t g = (rows + rows_per_block - 1) / rows_per_block;
-    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 }  // namespace
