@@ -123,8 +123,8 @@ int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* 
  * directly for A/B measurements: same descriptor, P3_EUNSUP when the problem is not eligible (plain bf16 A, K % 64 == 0, N % 8 == 0,
  * 16-byte aligned rows, no column sums).  structure: 0 four two-barrier phases per K-tile, 1 the same with the two wave groups one barrier apart,
  * 2 one barrier per K-tile, < 0 chosen by K; 3 .. 6 = the 128 x 128-tile LDS-DMA kernel (csrc/gemm_dma.hip; 3: 32-deep slices, three in LDS,
- * 4: 64-deep, two, 5: 32-deep, four, 6: 32-deep, two = 4 workgroups / CU), which p3_gemm itself picks from M = 2048 on (K >= 1024: 4; K <= 512
- * and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in ascending k order: bit-identical outputs. */
+ * 4: 64-deep, two, 5: 32-deep, four, 6: 32-deep, two = 4 workgroups / CU), 7 / 8 its persistent wave-specialised form, 9 a 128 x 384 tile with 8 waves), which p3_gemm itself picks from M = 2048 on (N = 384 and K >= 1024: 9;
+ * other K >= 1024: 4; K <= 512 and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in ascending k order: bit-identical outputs. */
 int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -794,6 +794,15 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         // dX of fc2, linear1: 66 vs 69, 86 vs 92, 44 vs 45 us; everything else stays on the register-staged kernel), >= 3 that variant always
         const int m = gemm_dma_mode();
         int v = m >= 3 ? m : (d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0));
+        // 384-column outputs from K = 1024 on (fc2, dX of fc1 / qkv): the 128 x 384 tile - 393 workgroups = ONE resident round instead of 2.3 rounds of
+        // 128 x 128 tiles; same-box step 39.79 -> 38.78 ms (r03).  P3_GEMM_DMA=2: the rule without it.
+        if (m == 1 && d->N == 384 && d->K >= 1024) v = 9;
+        if (m == 2) v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
+        if (m == 12) { v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0); if ((d->N == 384 && d->K >= 1024) || d->N == 768) v = 9; }   // A/B: + N = 768
+        if (m == 10 || m == 11) {                                                // A/B: + the 128 x 384 tile for the 384-column outputs (11: proj too)
+            v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
+            if (d->N == 384 && (d->K >= 1024 || m == 11)) v = 9;
+        }
         if (m == 7) v = d->K >= 1024 ? 4 : 0;                                   // A/B: only the deep-K rule
         if (m == 8) v = (d->K <= 512 && d->N >= 1024) ? 6 : 0;                  //      only the wide-output rule
         if (m == 9) v = d->K >= 1024 ? (d->dtype_out == P3_BF16 ? 4 : 0) : (d->K <= 512 && d->N >= 1024 ? 6 : 0);   // deep K only with bf16 output

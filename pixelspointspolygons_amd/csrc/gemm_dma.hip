@@ -403,6 +403,115 @@ __global__ __launch_bounds__(320, 2) void gemm_ws_kernel(GDArgs g) {
     }
 }
 
+// ---- 128 x 384 tile, 8 waves (variant 9): the 384-column outputs of the ViT (proj, fc2, dX of fc1 / qkv) ----------------------------------------
+// M = 50240 makes 393 x 3 = 1179 tiles of 128 x 128: 1.5 resident waves of workgroups at 3 per CU, 2.3 at 2 per CU - the last round runs a
+// third to a half empty.  One workgroup per 128-row panel (393 workgroups: ONE round at 2 per CU) takes all 384 columns: 8 waves as 2 x 4, a wave
+// owns 64 x 96 = 2 x 3 MFMA blocks; the A panel is fetched once instead of three times.  32-deep slices, two in LDS (A 8 KB + W 24 KB each).
+template <typename TO>
+__global__ __launch_bounds__(512, 4) void gemm_dma_n384_kernel(GDArgs g) {
+    constexpr int BK = 32, CPR = 4, A_U4 = 128 * CPR, B_U4 = 384 * CPR, BUF_U4 = A_U4 + B_U4, KK = 2;
+    __shared__ __attribute__((aligned(1024))) uint4 lds[2 * BUF_U4];
+    const p3_gemm_desc& d = g.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, ntiles);
+    const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+    const int nk = d.K / BK;
+    uint32_t voffA, voffB[3];
+    {
+        const int slot = lane & 3;
+        const int ra_l = wave * 16 + (lane >> 2);
+        voffA = (uint32_t)(((int64_t)min(tm * 128 + ra_l, d.M - 1) * d.lda + (slot ^ ((ra_l >> 2) & 3)) * 8) * 2);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int rb_l = (wave * 3 + q) * 16 + (lane >> 2);
+            voffB[q] = (uint32_t)(((int64_t)min(tn * 384 + rb_l, d.N - 1) * d.ldb + (slot ^ ((rb_l >> 2) & 3)) * 8) * 2);
+        }
+    }
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(&lds[0]));
+    auto stage = [&](int kt) __attribute__((always_inline)) {
+        const int buf = kt & 1;
+        const bf16_t* ab = g.A + (int64_t)kt * BK;
+        const bf16_t* wb = g.W + (int64_t)kt * BK;
+        const uint32_t da = lds_addr + (uint32_t)((buf * BUF_U4 + wave * 64) * 16);
+        const uint32_t db = lds_addr + (uint32_t)((buf * BUF_U4 + A_U4 + wave * 3 * 64) * 16);
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "v"(voffA), "v"(voffB[0]), "v"(voffB[1]), "v"(voffB[2]), "s"(ab), "s"(wb), "s"(da), "s"(db) : "memory");
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int sw = (l31 >> 2) & 3;
+    const int arow = (wr * 64 + l31) * CPR, brow = (wc * 96 + l31) * CPR;
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                  // slice kt readable; slice kt - 1 consumed by every wave: its buffer takes slice kt + 1
+        if (kt + 1 < nk) stage(kt + 1);
+        const uint4* abuf = lds + (kt & 1) * BUF_U4;
+        const uint4* bbuf = abuf + A_U4;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {              // one 16-deep block at a time: 96 accumulator + 20 fragment registers fit 128 (4 waves / SIMD = 2 workgroups / CU)
+            uint4 af[2], bfr[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = abuf[arow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bfr[j] = bbuf[brow + j * 32 * CPR + ((2 * kk + hi) ^ sw)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // epilogue: 32 x 32 blocks through a private fp32 image [32][36]
+    constexpr int EP = 36;
+    float* st = reinterpret_cast<float*>(lds) + wave * (32 * EP);
+    TO* C = reinterpret_cast<TO*>(g.C);
+    TO* aux = reinterpret_cast<TO*>(d.aux);
+    const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
+    const bool has_res = d.residual != nullptr, res_bf = d.dtype_res == P3_BF16, aux_grad = d.aux_mode == 1;
+    const int act = d.act;
+    const DropKey dk = drop_key(d.drop);
+    const int c8 = (lane & 3) * 8, rl0 = lane >> 2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int col = tn * 384 + wc * 96 + j * 32 + c8;
+        float bias[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bias[k] = (d.bias && col + k < d.N) ? d.bias[col + k] : 0.f;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[crow32(r, hi) * EP + l31] = acc[ib][j][r];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int rl = pass * 16 + rl0;
+                const int row = tm * 128 + wr * 64 + ib * 32 + rl;
+                const float4 v0 = *reinterpret_cast<const float4*>(st + rl * EP + c8);
+                const float4 v1 = *reinterpret_cast<const float4*>(st + rl * EP + c8 + 4);
+                if (row >= d.M || col >= d.N) continue;
+                float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
+                gd_epi8<TO>(d, dk, C, aux, bwd_saved, has_res, res_bf, aux_grad, act, row, col, v);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // variant 3: BK = 32, three slices in LDS (3 workgroups / CU); 4: BK = 64, two slices (2 workgroups / CU); 5: BK = 32, four slices (2 / CU);
@@ -422,6 +531,15 @@ int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc
         if (variant == 7 || variant == 8) snprintf(nm, sizeof(nm), "gemm_ws_kernel<%s, %d>", bf ? "bf16" : "float", variant == 7 ? 3 : 4);
         else snprintf(nm, sizeof(nm), "gemm_dma_kernel<%s, %d, %d>", bf ? "bf16" : "float", variant == 4 ? 64 : 32, variant == 5 ? 4 : (variant == 3 ? 3 : 2));
         p3_note_kernel(nm);
+    }
+    if (variant == 9) {
+        g.tiles_n = p3_ceil_div(d->N, 384);
+        if (p3_tracing()) p3_note_kernel(bf ? "gemm_dma_n384_kernel<bf16>" : "gemm_dma_n384_kernel<float>");
+        dim3 ngrid(g.tiles_m * g.tiles_n), nblock(512);
+        if (bf) hipLaunchKernelGGL((gemm_dma_n384_kernel<bf16_t>), ngrid, nblock, 0, s, g);
+        else hipLaunchKernelGGL((gemm_dma_n384_kernel<float>), ngrid, nblock, 0, s, g);
+        P3_LAUNCH_CHECK();
+        return P3_OK;
     }
     if (variant == 7 || variant == 8) {
         static int cus = 0;

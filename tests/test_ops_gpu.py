@@ -100,7 +100,7 @@ def test_gemm_bf16_tall_tiles(M, N, K, epi):
         assert torch.equal(keep | (pre == 0), ref_mask | (pre == 0))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_lds_dma_kernels_equal_the_register_staged_kernel(variant):
     """csrc/gemm8.hip (256 x 256 tile, structures 0-2) and csrc/gemm_dma.hip (128 x 128 tile, LDS-DMA, variants 3-6; what p3_gemm picks
     from M = 2048 on for K >= 1024 and for wide outputs with K <= 512): every kernel adds the same 16-deep MFMA blocks in ascending k order, so

@@ -43,7 +43,7 @@ def check_variant(tag, M, N, K, **kw):
     if kw.get("drop"):
         args["drop"] = (torch.full((1,), 77, dtype=torch.int64, device="cuda"), 5, 0.1)
     outs = []
-    for f8 in (None, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+    for f8 in (None, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
         aux = torch.zeros(M, N, device="cuda", dtype=odt) if kw.get("aux") is not None else None
         o = h.gemm(a, w, out_dtype=odt, aux=aux, aux_grad=bool(kw.get("aux")), force8=f8, **args)
         outs.append((o.clone(), None if aux is None else aux.clone()))
@@ -80,7 +80,7 @@ def main():
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ref = h.gemm(a, w, bias=b).clone()
         line = f"  {tag:14s} M={M:6d} N={N:5d} K={K:5d}: "
-        sel = [("128^2", None), ("256^2 S0", 0), ("S1 stagger", 1), ("S2 1-barrier", 2), ("dma128 32x3", 3), ("dma128 64x2", 4), ("dma128 32x4", 5), ("dma128 32x2", 6), ("ws 32x3", 7), ("ws 32x4", 8)]
+        sel = [("128^2", None), ("256^2 S0", 0), ("S1 stagger", 1), ("S2 1-barrier", 2), ("dma128 32x3", 3), ("dma128 64x2", 4), ("dma128 32x4", 5), ("dma128 32x2", 6), ("ws 32x3", 7), ("ws 32x4", 8), ("n384", 9)]
         if os.environ.get("MB_ONLY_DMA"):
             sel = [x for x in sel if x[1] is None or x[1] >= 3]
         for name, f8 in sel:
