@@ -263,7 +263,7 @@ def host_feed_leg(S, args, st, dev, kind, rank):
     dt = statistics.median(times)
     img_mb = args.batch * 224 * 224 * 3 / 1e6 if kind != "lidar" else 0.0
     return {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n, "repeats": len(times),
-            "ms_per_step_all": [round(t / n * 1e3, 3) for t in times],
+            "ms_per_step_all": [round(t / n * 1e3, 3) for t in times], "min_ms_per_step": round(min(times) / n * 1e3, 3),     # host-side noise (other tenants on the box's cores) shows as spread between the repeats
             "host_bytes_per_step_mb": round(img_mb + (args.batch * args.points * 12 / 1e6 if kind != "image" else 0.0) + args.batch * (386 * 8 + 192 * 192 * 4) / 1e6, 1),
             "what": "uint8 HWC tiles + jagged points + tokens from pinned host memory (packed by a feeder thread), D4 + Normalize + HWC->CHW on the "
                     "device, persistent triple-buffered staging; median of the repeats"}

@@ -798,6 +798,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         // 128 x 128 tiles; same-box step 39.79 -> 38.78 ms (r03).  P3_GEMM_DMA=2: the rule without it.
         if (m == 1 && d->N == 384 && d->K >= 1024) v = 9;
         if (m == 2) v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
+        if (m == 13) { v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0); if (d->N == 384 && d->K >= 1024) v = 9; if (d->N == 512 && d->K <= 512) v = 6; }   // A/B: + kv_mem on 4 / CU
         if (m == 12) { v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0); if ((d->N == 384 && d->K >= 1024) || d->N == 768) v = 9; }   // A/B: + N = 768
         if (m == 10 || m == 11) {                                                // A/B: + the 128 x 384 tile for the 384-column outputs (11: proj too)
             v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);

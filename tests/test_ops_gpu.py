@@ -141,6 +141,33 @@ def test_gemm_lds_dma_kernels_equal_the_register_staged_kernel(variant):
             assert ax is None or torch.equal(ax, ref_aux), (M, N, K, variant)
 
 
+def test_kernel_trace_names_the_kernel_p3_gemm_picked(monkeypatch):
+    """bench.py's roofline object labels its HIP-event timings with p3_last_kernel() (include/p3hip.h): the name must be the kernel p3_gemm's shape
+    rule launched, spelled as rocprofv3 prints it, and empty when tracing is off."""
+    import os
+    if os.environ.get("P3_GEMM_DMA", "1") != "1":
+        pytest.skip("the shape rule is switched off in this environment")
+    h = _h()
+    from pixelspointspolygons_amd._lib import lib
+    h.KTIMER.enable()
+    try:
+        for (M, N, K), odt, want in [((4096, 1152, 384), torch.bfloat16, "gemm_dma_kernel<bf16, 32, 2>"),           # wide output, short K: 4 workgroups / CU
+                                     ((4096, 384, 1536), torch.bfloat16, "gemm_dma_n384_kernel<bf16>"),            # 384 columns, deep K: the 128 x 384 tile
+                                     ((4096, 384, 1536), torch.float32, "gemm_dma_n384_kernel<float>"),
+                                     ((4096, 256, 2048), torch.bfloat16, "gemm_dma_kernel<bf16, 64, 2>"),          # other deep K
+                                     ((4096, 384, 384), torch.bfloat16, "gemm_kernel<bf16, bf16, 0, 32, false>"),  # the register-staged kernel
+                                     ((1000, 1152, 384), torch.bfloat16, "gemm_kernel<bf16, bf16, 0, 32, false>"), # below M = 2048
+                                     ((64, 256, 256), torch.bfloat16, "gemm_skinny_kernel<1>")]:
+            a, w = _rand(M, K, seed=1).bfloat16().to(DEV), _rand(N, K, seed=2, scale=0.05).bfloat16().to(DEV)
+            h.gemm(a, w, out_dtype=odt)
+            assert lib().p3_last_kernel().decode() == want, (M, N, K)
+        names = set(h.KTIMER.summary())
+        assert "gemm_dma_n384_kernel<bf16>" in names and "gemm_skinny_kernel<1>" in names
+    finally:
+        h.KTIMER.disable()
+    assert lib().p3_last_kernel().decode() == ""
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_conv3x3_implicit(dtype):
     h = _h()
