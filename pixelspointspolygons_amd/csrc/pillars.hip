@@ -13,13 +13,19 @@
 //   5 pfn_l2_reduce    per pillar max / min over its rows (+ BN statistics, padded slot weighted by its multiplicity)
 //   6 bn_finalize      scale / shift (+ running statistics update)
 //   7 pfn_scatter      relu(scale * (scale > 0 ? hmax : hmin) + shift) -> token-major canvas (empty pillars = 0)
+#include <stdlib.h>
+
 #include "p3_common.h"
 
 namespace {
 
 constexpr int C1 = 32;      // PFN layer-0 units (feat_channels[0] / 2)
 constexpr int K2 = 64;      // layer-1 input = [x | xmax]
-constexpr int L2R_BLOCKS = 2048;   // pfn_l2_reduce grid cap (512 with per-wave atomics: 0.38 ms; see the kernel)
+// pfn_l2_reduce / pfn_bwd_l2_stats grid cap (512 with per-wave atomics: 0.38 ms; see the kernel).  P3_PFN_BLOCKS: sweeps.
+// r03 sweep (same box): reduce8 2048 -> 93 us, 1024 -> 77, 512 -> 99; bwd_l2_stats8 2048 -> 102 us, 1024 -> 83, 512 -> 70 (per-workgroup atomics on 2 C addresses)
+static int pfn_blocks(int dflt) { static int v = -1; if (v < 0) { const char* e = getenv("P3_PFN_BLOCKS"); v = e ? atoi(e) : 0; } return v > 0 ? v : dflt; }
+#define L2R_BLOCKS pfn_blocks(1024)
+#define L2S_BLOCKS pfn_blocks(512)
 constexpr int SORT_THREADS = 1024, SORT_WAVES = 16;
 constexpr int MAX_CELLS = 1900;
 // layer-0 backward accumulators: S_dyf[32][8] | S_xf[32][8] | S_f[8] | dbeta[32] | dgamma[32]
@@ -1040,11 +1046,11 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     if (phases & 1) {
     if (bf)
         if (C % 8 == 0 && C <= 512 && d->out_col_off % 8 == 0 && dcanvas_ld % 8 == 0 && ((uintptr_t)dcanvas % 16) == 0)
-            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel, dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel, dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
         else
-        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     else
-        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     P3_LAUNCH_CHECK();
     }
     if (phases & 2) {
