@@ -10,6 +10,10 @@
 #include "attn_tile.h"
 #include <type_traits>
 
+#ifndef P3_DKV32_WAVES
+#define P3_DKV32_WAVES 3     // waves / SIMD the d = 32 dK/dV kernel is compiled for (-DP3_DKV32_WAVES=4: 2.0 instead of 2.67 rounds of workgroups but 23 spilled registers - same-box step 38.28 -> 38.79 ms, r03: stays 3)
+#endif
+
 namespace {
 
 using p3attn::u32x4;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, int D, int DROP>
-__global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int QT = BF ? 64 : 32;
     using TQ = Tile<T, D, QT>;
