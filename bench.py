@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 _SCORENET_SKIPPED = 2.0 * (12.688 - 3.074)
 GFLOP_FWD_DENSE = {"fusion_s8": 85.2, "image_s8": 80.9, "image_b16": 35.13 + 10.7 + 25.4, "lidar_s8": 80.9 - 0.116 + 0.149, "ffl_fusion": 259.0}
 GFLOP_FWD = {k: (v if k == "ffl_fusion" else round(v - _SCORENET_SKIPPED, 2)) for k, v in GFLOP_FWD_DENSE.items()}
+# "fused ViT + LiDAR forward" alone (stem + fusion conv + 12 blocks + pool), the quantity north_star's >= 40 % target is defined on
+GFLOP_ENC = {"fusion_s8": 49.1, "image_s8": 2 * 22.405, "image_b16": 35.13, "lidar_s8": 2 * (22.347 + 0.0745)}
 # algorithmic HBM bytes of one train step at 64 tiles: 1.14 MB/tile of inputs + outputs, AdamW 16 B per parameter
 STEP_ALGO_BYTES = {"fusion_s8": 64 * 1.14e6 + 16 * 34.6e6}
 PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
@@ -59,13 +61,14 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency legs (profiling runs)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 parity-mode timed leg")
+    ap.add_argument("--no-ffl", action="store_true", help="skip the short FFL (configs[4]) sub-run of the default line")
     ap.add_argument("--no-predict", action="store_true", help="skip the configs[0] predict leg (image-only, batch 1, 385-step decode)")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive leg (host uint8 tiles + point lists through the device input pipeline)")
     ap.add_argument("--lean", action="store_true", help="timed loop only (= all --no-* switches; profiling / A-B runs)")
     a = ap.parse_args()
     if a.lean:
-        a.no_cpu_baseline = a.no_kernel_timing = a.no_fwd = a.no_fp32_leg = a.no_predict = a.no_host_feed = True
+        a.no_cpu_baseline = a.no_kernel_timing = a.no_fwd = a.no_fp32_leg = a.no_predict = a.no_host_feed = a.no_ffl = True
     return a
 
 
@@ -224,10 +227,13 @@ def timed_steps(st, pool, steps, warmup, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    spread = None
     if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        t = torch.tensor([dt, -dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # [max over ranks, -min over ranks]
+        dt = float(t[0])
+        spread = (-float(t[1]), float(t[0]))
+    timed_steps.rank_spread = spread
     return dt, float(out)
 
 
@@ -273,7 +279,7 @@ def _stats(samples):
     return {"min": round(min(samples), 4), "median": round(statistics.median(samples), 4), "n": len(samples)}
 
 
-def cpu_baseline(args, kind):
+def cpu_baseline(args, kind, probes=None):
     """The oracle (CPU restatement, kind = "port") timed on this box's host cores on a bounded sample of the same workload
     (SURVEY §8d protocol, bounded: forward at B in {1, 8} (>= 3 timed, min and median ms/tile), train step at B = 4 (>= 5 timed
     iterations, tiles/s = median), s/tile of the literal 385-step greedy decode).  The legs stop at a wall-clock budget once their minimum
@@ -281,6 +287,17 @@ def cpu_baseline(args, kind):
     from oracle import p3_oracle as O
     cfgv = O.VIT_S8 if args.workload != "image_b16" else O.VIT_B16
     okind = {"fusion": "fusion", "image": "image", "lidar": "lidar"}[kind]
+    # the checker's other job: `<dtype>_vs_oracle` = the MEASURED error of the bench's own model (eval mode, the first tiles of the bench batch,
+    # parity_probe) against the oracle run on the host with the same weights and inputs - so the headline states its own error
+    vs = {}
+    for name, pr in (probes or {}).items():
+        with torch.no_grad():
+            rl, rp = O.pix2poly_forward({k: v.clone() for k, v in pr["sd"].items()}, pr["y"], pr["image"], pr["lidar"], cfg=cfgv, training=False)
+        rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+        am = (pr["logits"].argmax(-1) == rl.argmax(-1))
+        vs[name] = {"tiles": int(pr["y"].shape[0]), "logits_rel": float(f"{rel(pr['logits'], rl):.3e}"), "perm_rel": float(f"{rel(pr['perm'], rp):.3e}"),
+                    "argmax_agree": round(float(am.float().mean()), 6), "argmax_positions": int(am.numel()),
+                    "what": "eval-mode forward of the bench model on tiles 0..n-1 of the bench batch vs oracle.pix2poly_forward on the host; max-abs error / max-abs reference"}
     sd = O.make_state_dict(okind, cfgv, seed=42)
 
     def inputs(B):
@@ -339,7 +356,7 @@ def cpu_baseline(args, kind):
     return {"value": round(best, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (fp32 torch CPU restatement): train step fwd+CE+10*BCE+bwd+AdamW at B = 4 (value = median of >= 5 timed iterations), forward at B = 1 and 8, "
                       f"literal greedy decode ({n_dec} of {O.MAX_LEN - 1} steps timed at B = 1, scaled); wall-clock bounded legs, iteration counts in `n`",
-            "forward": fwd, "train": train, "decode_s_per_tile": round(dec_s, 2)}
+            "forward": fwd, "train": train, "decode_s_per_tile": round(dec_s, 2), "_vs_oracle": vs}
 
 
 def pmc_step_traffic():
@@ -426,6 +443,128 @@ def roofline_leg(args, st, pool, hip, peak_tf):
                 "mfma_achieved_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak_tf, 4), **common}
     return {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach_tf / peak_tf, 4),
             "hbm_achieved_gbs": round(ach_gb, 1), "hbm_frac": round(ach_gb / peak_gb, 4), **common}
+
+
+def encoder_fwd_leg(args, model, st, pool, hip, kind, peak_tf):
+    """The quantity north_star's target is defined on: the fused ViT + LiDAR ENCODER forward alone (both stems -> fusion conv + BN + ReLU ->
+    12 blocks -> final norm -> channel pool; early_fusion_vit.py:96-127) at the bench batch, train-mode BatchNorm, no autograd, one hipGraph.
+    TFLOP/s on SURVEY §8d's count for this part (49.1 GFLOP / tile at 3 k points), + its top kernels from an instrumented eager pass."""
+    enc = model.encoder
+
+    def run():
+        s_ = st.static
+        with torch.no_grad():
+            if kind == "fusion":
+                return enc(s_["image"], st._lidar())
+            return enc(s_["image"]) if kind == "image" else enc(st._lidar())
+    st.load(pool[0])
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    graph = None
+    if st.use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+    n = max(5, min(args.steps, 20))
+    reps = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay() if graph is not None else run()
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / n * 1e3)
+    ms = statistics.median(reps)
+    gf = GFLOP_ENC[args.workload]
+    tf = gf * args.batch / (ms * 1e-3) / 1e3
+    out = {"ms_per_batch": round(ms, 3), "ms_per_tile": round(ms / args.batch, 4), "ms_per_batch_all": [round(r, 3) for r in reps], "tiles_per_s": round(args.batch / ms * 1e3, 1),
+           "gflop_per_tile": gf, "tflops": round(tf, 1), "mfma_frac": round(tf / peak_tf, 4), "mfma_peak_tflops": peak_tf, "hip_graph": graph is not None,
+           "what": "encoder only: patch-embed + pillar stem -> fusion conv + BN + ReLU -> 12 ViT blocks -> norm -> pool; train-mode BatchNorm, no autograd"}
+    if not args.no_kernel_timing:
+        hip.KTIMER.enable()
+        run()
+        torch.cuda.synchronize()
+        kt = hip.KTIMER.summary()
+        hip.KTIMER.disable()
+        tot = sum(r["ms"] for r in kt.values()) or 1.0
+        out["top_kernels"] = [{"kernel": nm, "launches": r["n"], "avg_launch_us": round(r["ms"] * 1e3 / r["n"], 2), "ms": round(r["ms"], 3),
+                               "mfma_frac": round(r["flop"] / (r["ms"] * 1e-3) / 1e12 / peak_tf, 4) if r["ms"] > 0 else None}
+                              for nm, r in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])[:3]]
+        out["bracketed_ms_eager"] = round(tot, 3)
+    return out
+
+
+def parity_probe(model, pool, kind, n=2):
+    """Device side of `<dtype>_vs_oracle`: eval-mode forward of the FIRST n tiles of the bench batch through the bench's own model (its weights
+    after the timed steps), with everything the oracle needs to repeat it on the host (inputs, state_dict) copied to host memory."""
+    b = pool[0]
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        img = b["image"][:n] if kind != "lidar" else None
+        lidar = None
+        if kind != "image":
+            off = b["lidar_offsets"][: n + 1]
+            lidar = (b["lidar_values"][: int(off[-1])].contiguous(), off.contiguous())
+        y = b["y"][:n, :-1]
+        logits, perm = model(img, lidar, y)
+    torch.cuda.synchronize()
+    model.train(was)
+    cpu = lambda t: None if t is None else t.detach().float().cpu() if t.is_floating_point() else t.detach().cpu()
+    return {"logits": cpu(logits), "perm": cpu(perm), "y": cpu(y), "image": cpu(img), "lidar": None if lidar is None else (cpu(lidar[0]), cpu(lidar[1])),
+            "sd": {k: (v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}}
+
+
+def dense_lidar_leg(args, model, S, dev, rank):
+    """SURVEY §8d's dense variant: the LiDAR stem alone (pillarize + PillarFeatureNet + scatter, pointpillars_o3d.py:85-107) at the density of
+    real tiles (40 000 points per tile, predictor.py:120-133: ~51 points per pillar, the cap of 64 binds in a share of them) beside the bench's
+    3 k-point clouds; HIP events on the launch stream, train-mode BatchNorm, no autograd.  HBM-bound sub-kernel: GB/s on its algorithmic bytes
+    (12 B per point in + the [B, 784, C] canvas out)."""
+    stem = getattr(model.encoder, "lidar_embed", None)
+    if stem is None:
+        return None
+    out = {"tiles": args.batch, "max_points_per_pillar": stem.max_points,
+           "what": "PointPillarsEncoder.forward alone: counting sort + PFN layer 0 / layer-1 GEMM / max + scatter; algorithmic bytes = points in + canvas out"}
+    for label, npts in (("bench_3k", args.points), ("dense_40k", 40000)):
+        inp = S.make_inputs(args.batch, seed=777 + rank, n_points=npts, jitter=npts // 10)
+        vals, offs = inp["lidar_values"].to(dev), inp["lidar_offsets"].to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                c = stem((vals, offs), return_flattened=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            e0.record()
+            for _ in range(n):
+                c = stem((vals, offs), return_flattened=True)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        nbytes = vals.numel() * 4 + c.numel() * c.element_size()
+        out[label] = {"points_per_tile": npts, "ms_per_batch": round(ms, 3), "mpoints_per_s": round(vals.shape[0] / ms / 1e3, 1),
+                      "algorithmic_bytes": int(nbytes), "hbm_gbs": round(nbytes / ms / 1e6, 1), "hbm_frac": round(nbytes / ms / 1e6 / 8000.0, 4)}
+        del vals, offs, c
+    return out
+
+
+def ffl_leg(args, dev, local, S, rank, world):
+    """BASELINE configs[4] driver-timed: FFL early_fusion_vit_cnn at ITS real size (ViT depth 12, 224 x 224 heads, bs 64), a short run of the same
+    step `--workload ffl_fusion` times (forward + FFL criterion + backward + AdamW under one hipGraph)."""
+    import argparse as _ap
+    a2 = _ap.Namespace(**vars(args))
+    a2.workload = "ffl_fusion"
+    _, model, opt, reducer, pool, st = build(a2, dev, local, args.precision, S, rank, world, False)
+    n = 5
+    dt, loss = timed_steps(st, pool, n, 3, 1, dev)
+    out = {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n, "warmup": 3, "dtype": "bf16" if args.precision == "bf16" else "f32",
+           "workload": f"ffl_early_fusion_vit_cnn_bs{args.batch}x1", "step": "fwd+FFL criterion+bwd+AdamW", "hip_graph": st.graph is not None,
+           "gflop_fwd_per_tile": GFLOP_FWD["ffl_fusion"], "step_mfma_frac": round(3 * GFLOP_FWD["ffl_fusion"] * args.batch / (dt / n) / 1e3 / (2500.0 if args.precision == "bf16" else 157.3), 4),
+           "final_loss": round(loss, 4)}
+    opt.close()
+    del st, reducer, opt, model, pool
+    torch.cuda.empty_cache()
+    return out
 
 
 def build(args, dev, local, precision, S, rank, world, sync_bn):
@@ -569,20 +708,31 @@ def main():
         model.train()
 
     single = world == 1 and not forced
+    rank_spread = timed_steps.rank_spread
+    peak_tf = 2500.0 if args.precision == "bf16" else 157.3
+    pix = args.workload != "ffl_fusion"
+    enc_fwd = dense = None
+    probes = {}
+    if single and rank == 0 and pix and not args.no_fwd:
+        enc_fwd = encoder_fwd_leg(args, model, st, pool, hip, kind, peak_tf)
+        dense = dense_lidar_leg(args, model, S, dev, rank)
+    if single and rank == 0 and pix and not args.no_cpu_baseline:
+        probes["bf16_vs_oracle" if args.precision == "bf16" else "fp32_vs_oracle"] = parity_probe(model, pool, kind)
     opt_buckets, early_launches, sync_calls = list(opt.buckets), reducer.early_launches, ops.SYNC_CALLS[0]
     graph_used = st.graph is not None
     feed = None
     if single and not args.no_host_feed and args.workload != "ffl_fusion":
         feed = host_feed_leg(S, args, st, dev, kind, rank)
 
-    peak_tf = 2500.0 if args.precision == "bf16" else 157.3
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
         roofline = roofline_leg(args, st, pool, hip, peak_tf)
 
     # the same step in the precision the 1e-3 parity claims hold in (every matmul on the exact fp32 MFMA path)
     fp32_leg = None
+    main_alive = True                        # the headline model / optimizer / stepper still exist
     if single and not args.no_fp32_leg and args.precision == "bf16":
+        main_alive = False
         del st, reducer
         opt.close()
         del opt, model
@@ -590,6 +740,8 @@ def main():
         _, model32, opt32, _, pool32, st32 = build(args, dev, local, "fp32", S, rank, world, False)
         n32 = max(3, min(args.steps, 6))
         dt32, loss32 = timed_steps(st32, pool32, n32, 3, 1, dev)
+        if rank == 0 and pix and not args.no_cpu_baseline:
+            probes["fp32_vs_oracle"] = parity_probe(model32, pool32, kind)
         fp32_leg = {"value": round(args.batch * n32 / dt32, 2), "unit": "tiles/s", "ms_per_step": round(dt32 / n32 * 1e3, 3), "steps": n32, "warmup": 3,
                     "dtype": "f32", "frac_of_157.3TF_fp32_mfma": round(3 * GFLOP_FWD[args.workload] * args.batch / (dt32 / n32) / 1e3 / 157.3, 4),
                     "final_loss": round(loss32, 4),
@@ -597,6 +749,16 @@ def main():
         opt32.close()
         del st32, opt32, model32, pool32
         torch.cuda.empty_cache()
+
+    ffl = None
+    if single and rank == 0 and pix and not args.no_ffl and args.workload == "fusion_s8":
+        if main_alive:
+            main_alive = False
+            del st, reducer
+            opt.close()
+            del opt, model
+            torch.cuda.empty_cache()
+        ffl = ffl_leg(args, dev, local, S, rank, world)
 
     predict = None
     if single and rank == 0 and not args.no_predict and args.workload != "ffl_fusion":
@@ -629,14 +791,25 @@ def main():
             "final_loss": round(loss_val, 4),
             "roofline": roofline,
         }
+        if enc_fwd is not None:
+            line["encoder_fwd"] = enc_fwd
+        if dense is not None:
+            line["dense_lidar"] = dense
+        if rank_spread is not None:
+            line["rank_ms_per_step"] = {"min": round(rank_spread[0] / args.steps * 1e3, 3), "max": round(rank_spread[1] / args.steps * 1e3, 3)}
         if fp32_leg is not None:
             line["fp32_parity_mode"] = fp32_leg
+        if ffl is not None:
+            line["ffl"] = ffl
         if predict is not None:
             line["predict"] = predict
         if feed is not None:
             line["pcie_inclusive"] = feed
         if not args.no_cpu_baseline and single and args.workload != "ffl_fusion":   # N = 1 only (the ranks would share the host cores)
-            line["cpu_baseline"] = cpu_baseline(args, kind)
+            cb = cpu_baseline(args, kind, probes)
+            for k_, v_ in cb.pop("_vs_oracle").items():
+                line[k_] = v_
+            line["cpu_baseline"] = cb
     if world > 1 or forced:
         dist.barrier()                                    # rank 0 runs the instrumented leg alone: leave together
         dist.destroy_process_group()

@@ -60,6 +60,13 @@ const char* p3_last_kernel(void);
  * all_dtypes = 0: only fp32 (parity-mode) launches take the path; 1: bf16 launches too.  p3_get_deterministic: 0 off, 1 fp32, 2 all. */
 int p3_set_deterministic(void* scratch, int64_t bytes, int all_dtypes);
 int p3_get_deterministic(void);
+/* More than one launch stream (r04: the independent branches of model_pix2poly.py:256-264 - scorenet1 || scorenet2 - the weight-gradient
+ * GEMMs and the pillar stem beside the patch embedding, early_fusion_vit.py:99-100, may be enqueued on side streams): the scratch is cut
+ * into `n` equal regions (p3_scratch_regions, before or after p3_set_deterministic) and the caller names the stream of the launches that
+ * follow with p3_scratch_stream (returns the region index the stream was given in first-come order, -1 = none left: those launches take
+ * their atomics path).  Single-threaded like the rest of the library. */
+int p3_scratch_regions(int n);
+int p3_scratch_stream(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[M,N] = act(A'[M,K] * W[N,K]^T + bias) + residual

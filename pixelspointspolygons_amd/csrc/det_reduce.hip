@@ -11,30 +11,58 @@
 #include "p3_common.h"
 
 static float* g_det = nullptr;
-static int64_t g_det_floats = 0;
+static int64_t g_det_floats = 0;          // floats of ONE region
 static int g_det_all = 0;
+// Launch streams: the scratch is cut into equal regions, one per stream that launches through the library (r04: ScoreNet 2 / the weight-gradient
+// GEMMs / the pillar stem may run on side streams beside the main one).  The host names the stream of the launches that follow
+// (p3_scratch_stream, called by the binding whenever its current stream changes); a stream beyond the region count gets no scratch
+// (its launches take their atomics path).  One region and one stream = the r03 behaviour.
+static int g_regions = 1, g_region = 0;
+static int64_t g_total_floats = 0;
+static void* g_streams[16];
+static int g_nstreams = 0;
 
 extern "C" int p3_set_deterministic(void* scratch, int64_t bytes, int all_dtypes) {
     P3_CHECK((scratch == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)scratch % 16) == 0, P3_EINVAL,
              "p3_set_deterministic: scratch and bytes go together, 16-byte aligned");
     g_det = (float*)scratch;
-    g_det_floats = bytes / 4;
+    g_total_floats = bytes / 4;
+    g_det_floats = (g_total_floats / g_regions) & ~(int64_t)63;
     g_det_all = all_dtypes;
     return P3_OK;
 }
 
+extern "C" int p3_scratch_regions(int n) {
+    P3_CHECK(n >= 1 && n <= 16, P3_EINVAL, "p3_scratch_regions: 1..16");
+    g_regions = n;
+    g_det_floats = (g_total_floats / g_regions) & ~(int64_t)63;
+    return P3_OK;
+}
+
+extern "C" int p3_scratch_stream(void* stream) {
+    for (int i = 0; i < g_nstreams; ++i)
+        if (g_streams[i] == stream) { g_region = i; return i; }
+    if (g_nstreams < 16) { g_streams[g_nstreams] = stream; g_region = g_nstreams; return g_nstreams++; }
+    g_region = 16;
+    return -1;
+}
+
 extern "C" int p3_get_deterministic(void) { return g_det ? (g_det_all ? 2 : 1) : 0; }
+
+static inline float* region_base(int64_t floats) {
+    if (!g_det || g_region >= g_regions || floats > g_det_floats) return nullptr;
+    return g_det + (int64_t)g_region * g_det_floats;
+}
 
 // fp32 (parity mode) launches always take the deterministic path when a scratch is registered; bf16 ones only with all_dtypes
 float* p3_det_scratch(int64_t floats, int dtype) {
-    if (!g_det || floats > g_det_floats) return nullptr;
     if (dtype != P3_F32 && !g_det_all) return nullptr;
-    return g_det;
+    return region_base(floats);
 }
 
 // any launch (bf16 included) may borrow the registered scratch for per-tile partials that replace a slower scheme (the GEMM's BatchNorm column
 // sums: gemm.hip); NULL when none is registered or it is too small - the caller then takes its other path
-float* p3_reduce_scratch(int64_t floats) { return (g_det && floats <= g_det_floats) ? g_det : nullptr; }
+float* p3_reduce_scratch(int64_t floats) { return region_base(floats); }
 
 namespace {
 // level 1 of a long reduction: tmp[chunk][i] = sum of the parts [chunk*CH, (chunk+1)*CH) (float64, part order)

@@ -40,8 +40,15 @@ class EarlyFusionViT(nn.Module):
         """-> LN'd ViT tokens [B, np+1, D] (compute dtype)."""
         B, D, g, cd = x_image.shape[0], self.D, self.g, self.cd
         canvas = torch.empty((B, g * g, 2 * D), dtype=cd, device=x_image.device)
-        canvas = self.image_embed.tokens(x_image, cd, canvas=canvas)
-        canvas = self.lidar_embed.scatter_into(x_lidar, canvas, D)
+        if ops.side_on("stem"):
+            # both stems write disjoint column halves of one canvas: the pillar stem goes to a side stream beside the patch embedding
+            with ops.on_side("stem"):
+                canvas = self.lidar_embed.scatter_into(x_lidar, canvas, D)
+            canvas = self.image_embed.tokens(x_image, cd, canvas=canvas)
+            ops.side_join("stem")
+        else:
+            canvas = self.image_embed.tokens(x_image, cd, canvas=canvas)
+            canvas = self.lidar_embed.scatter_into(x_lidar, canvas, D)
         p = self.cfg.experiment.lidar_dropout
         if p is not None:
             # one draw for the whole batch (early_fusion_vit.py:113-119); host-side RNG like the reference's .item()

@@ -78,6 +78,8 @@ def ptr(t):
 import os as _os0
 DETERMINISTIC = int(_os0.environ.get("P3_DETERMINISTIC", "1"))
 _det_state = {"buf": None}
+SIDE_STREAMS = [k for k in ("sn", "dw", "stem") if _os0.environ.get("P3_SIDE_" + k.upper(), "0") == "1"]     # ops.SIDE: branches enqueued on side streams
+SCRATCH_REGIONS = 1 + len(SIDE_STREAMS)
 _DET_SCRATCH_BYTES = int(_os0.environ.get("P3_SCRATCH_MB", "128")) << 20     # per-tile BatchNorm partials of the tall ScoreNet / FFL GEMMs: <= 103 MB
 
 
@@ -93,8 +95,11 @@ def set_deterministic(level):
         return
     buf = _det_state["buf"]
     if buf is None or buf is False:
-        buf = torch.empty(_DET_SCRATCH_BYTES, dtype=torch.uint8, device="cuda")
-    _det_state["buf"] = buf
+        buf = _det_state.get("keep")
+        if buf is None:        # one region per launch stream (SCRATCH_REGIONS: 1 + the side streams switched on, ops.SIDE)
+            buf = torch.empty(_DET_SCRATCH_BYTES * SCRATCH_REGIONS, dtype=torch.uint8, device="cuda")
+            check(lib().p3_scratch_regions(c_int(SCRATCH_REGIONS)), "p3_scratch_regions")
+    _det_state["buf"] = _det_state["keep"] = buf      # never freed: captured hipGraphs hold its address
     check(lib().p3_set_deterministic(c_void_p(buf.data_ptr()), c_int64(buf.numel()), c_int(1 if DETERMINISTIC >= 2 else 0)), "p3_set_deterministic")
 
 
@@ -103,10 +108,18 @@ def det_on(t):
     return DETERMINISTIC >= 2 or (DETERMINISTIC == 1 and t.dtype == torch.float32)
 
 
+_cur_stream = [None]
+
+
 def stream():
+    """the launch stream (torch's current stream); the library is told whenever it changes so that scratch regions follow the stream"""
     if _det_state["buf"] is None:
         set_deterministic(DETERMINISTIC)
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    h = torch.cuda.current_stream().cuda_stream
+    if h != _cur_stream[0]:
+        _cur_stream[0] = h
+        lib().p3_scratch_stream(c_void_p(h))
+    return c_void_p(h)
 
 
 def _dev(t):
@@ -316,7 +329,7 @@ def workspace(nbytes, device, tag="default"):
     grow is replaced, and the old one is kept alive for the life of the process (a graph captured at the smaller size replays into
     it; freeing it would let the caching allocator hand that memory to other tensors).  Growing DURING a capture would allocate
     from the graph's private pool and leave eager callers with a pointer the graph owns: refused."""
-    key = (str(device), tag)
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if SCRATCH_REGIONS > 1 else 0)     # a side stream's launches get buffers of their own
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
@@ -330,10 +343,11 @@ def workspace(nbytes, device, tag="default"):
 
 
 def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax, max_points, max_voxels, training,
-                col_off=0, total_points=None, keep_workspace=False, sync=None):
+                col_off=0, total_points=None, keep_workspace=False, sync=None, phases=None):
     """bn1 / bn2 = (gamma, beta, running_mean, running_var) fp32 tensors.  out: [B, ny*nx, ld] token-major canvas.
     keep_workspace: run in a workspace of its own and return (out, workspace, desc) for p3_pillar_stem_bwd.
-    sync: callable(*tensors) all-reducing statistic buffers in place (SyncBatchNorm) or None."""
+    sync: callable(*tensors) all-reducing statistic buffers in place (SyncBatchNorm) or None.
+    phases: bit mask for p3_pillar_stem_phased (1 = pillarize + layer-0 sums only: what PointPillarsEncoder.voxelize runs)."""
     _dev(values)
     d = PillarDesc()
     d.B = B
@@ -352,7 +366,9 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     ws = torch.empty(nbytes, dtype=torch.uint8, device=values.device) if keep_workspace else workspace(nbytes, values.device, "pillar")
     args = (ptr(values), ptr(offsets), ptr(w1), ptr(bn1[0]), ptr(bn1[1]), ptr(bn1[2]), ptr(bn1[3]), ptr(w2),
             ptr(bn2[0]), ptr(bn2[1]), ptr(bn2[2]), ptr(bn2[3]), ptr(out), ptr(ws), byref(d))
-    if sync is None or not training:
+    if phases is not None:
+        check(L.p3_pillar_stem_phased(*args, c_int(int(phases)), stream()), "p3_pillar_stem")
+    elif sync is None or not training:
         check(L.p3_pillar_stem(*args, stream()), "p3_pillar_stem")
     else:   # SyncBatchNorm: all-reduce the pillar count / BatchNorm sums between the phases
         sec = _pillar_sections(ws, d)
@@ -370,6 +386,19 @@ def _pillar_sections(ws, d):
     sect = lambda o, n, dtype: ws[o:o + 4 * n].view(dtype)
     return dict(totals=sect(off[13], 1, torch.int32), sums1=sect(off[14], 64, torch.float32), sums2=sect(off[15], 2 * d.C, torch.float32),
                 acc1_stat=sect(off[16] + 4 * 520, 64, torch.float32))
+
+
+def pillar_tables(ws, d):
+    """The integer outputs of the pillar sort (Open3D `PointPillars.voxelize`, pointpillars_o3d.py:92) as int32 views of a stem workspace:
+    sorted [total_points] global point ids grouped by pillar (ascending id inside a pillar), and per pillar slot b * max_voxels + s
+    (s = rank of the kept pillar in ascending hash order): vox_xy (cy * nx + cx, bit 30 = the scatter skips it because the top-z pillar
+    of the same (x, y) overwrites it), vox_start (first position in `sorted`), vox_cnt (= num_points, capped), vox_row; nvox [B]."""
+    off = (c_int64 * 17)()
+    check(lib().p3_pillar_stem_layout(byref(d), off), "p3_pillar_stem_layout")
+    nv = d.B * d.max_voxels
+    sect = lambda o, n: ws[o:o + 4 * n].view(torch.int32)
+    return dict(sorted=sect(off[0], max(int(d.total_points), 1)), vox_xy=sect(off[1], nv), vox_start=sect(off[2], nv), vox_cnt=sect(off[3], nv),
+                vox_row=sect(off[4], nv), nvox=sect(off[5], d.B))
 
 
 def pillar_stem_bwd(dcanvas, w1, g1, w2t, g2, ws, d, sync=None):

@@ -30,6 +30,61 @@ def _grad_ready(*params):
                 cb(p)
 
 
+# ---- side streams: the independent branches of the step enqueued beside the main stream ---------------------------------------------------
+# P3_SIDE_SN=1: scorenet2 (forward, and through autograd its backward) on a side stream beside scorenet1 (model_pix2poly.py:256-259);
+# P3_SIDE_DW=1: the weight-gradient GEMMs of the Linear / Mlp backward beside the dX chain, joined before AdamW; P3_SIDE_STEM=1: the pillar
+# stem beside the image patch embedding (early_fusion_vit.py:99-100).  Inside a hipGraph capture the forks / joins become graph edges.
+# Off when collectives are active (SyncBatchNorm statistics and bucket triggers are ordered on the main stream).  Measured: profiles/r04_streams_ab.txt.
+SIDE = {k: (k in hip.SIDE_STREAMS) for k in ("sn", "dw", "stem")}
+_side_streams, _side_open = {}, set()
+
+
+def side_on(name):
+    return SIDE.get(name, False) and torch.cuda.is_available() and not collectives_active()
+
+
+class on_side:
+    """with on_side(name): the launches inside go to the named side stream, ordered after everything the current stream has enqueued so far.
+    Tensors created inside belong to the side stream (allocator); join with side_join(name) before the main stream reads them."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        main = torch.cuda.current_stream()
+        s = _side_streams.get(self.name)
+        if s is None:
+            s = _side_streams[self.name] = torch.cuda.Stream()
+        s.wait_stream(main)
+        _side_open.add(self.name)
+        self.ctx = torch.cuda.stream(s)
+        self.ctx.__enter__()
+        return s
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def side_join(*names):
+    """the current stream waits for the named (default: all) side streams' work enqueued so far"""
+    main = torch.cuda.current_stream()
+    for n in (names or tuple(_side_open)):
+        if n in _side_open:
+            main.wait_stream(_side_streams[n])
+            _side_open.discard(n)
+
+
+def _tn_side(a, b, **kw):
+    """weight-gradient GEMM into the gradient arena: on the 'dw' side stream when switched on (the operands are kept from reuse until it ran)"""
+    if not side_on("dw"):
+        return hip.gemm_tn(a, b, **kw)
+    with on_side("dw") as s:
+        hip.gemm_tn(a, b, **kw)
+    a.record_stream(s)
+    b.record_stream(s)
+    return None
+
+
 _BUMPS = [None]         # list of num_batches_tracked buffers while a model forward defers their "+= 1" to one multi-tensor launch
 
 
@@ -185,6 +240,7 @@ def reset_process_state():
     _registered_T.clear()
     _shadow_cache.clear()
     _twins.clear()
+    _stream.clear()
     DIRECT_GRAD[0] = False
     GRAD_READY[0] = None
     SYNC_BN[0] = False
@@ -324,24 +380,49 @@ def clear_twins():
 # _LayerNormFork.backward (dres), _Assemble.backward (end of the chain: one cast back to fp32).  A residual pass-through (`dres = dy` in
 # _Linear / _Mlp backward) hands the carrier on untouched.
 GRAD_STREAM_BF16 = [os.environ.get("P3_GRAD_BF16", "1") == "1"]    # r03: -0.35 ms per step (ln_bwd 68.6 -> 55.8 us x 24), encoder gradient cosine at the run-to-run noise floor (tools/diag_gradstream.py)
-_stream = {}
+# Only an operator that was TOLD its input is the ViT stream emits a carrier (layernorm_fork(..., stream_grad=True) from Block.run, the final
+# norm's layernorm(..., stream_grad=True)); the generic operators never do (a carrier that reaches a consumer that cannot resolve
+# it is garbage).  A carrier's one element is NaN (a slot of a NaN-filled pool, one fill per device), so whoever reads it as data gets NaN,
+# not a plausible number; every place of this file a carrier can reach resolves it (_stream_real / _materialize).
+_stream = {}          # data_ptr of a pool slot -> real bf16 gradient
+_POOL_SLOTS = 128     # carriers alive at one time: 1-2 per ViT in a backward; a slot's old entry is dropped when the slot comes round again
+_pool = {}            # device -> [NaN tensor [_POOL_SLOTS], next slot]
 
 
 def _stream_carrier(real, shape):
-    if len(_stream) > 8:
-        _stream.clear()
-    base = torch.empty(1, dtype=torch.float32, device=real.device)
-    _stream[base.data_ptr()] = (base, real)
+    key = real.device
+    ent = _pool.get(key)
+    if ent is None:
+        ent = _pool[key] = [torch.full((_POOL_SLOTS,), float("nan"), dtype=torch.float32, device=real.device), 0]
+    base = ent[0][ent[1]:ent[1] + 1]
+    ent[1] = (ent[1] + 1) % _POOL_SLOTS
+    _stream[base.data_ptr()] = real
     return base.expand(shape)
+
+
+def _is_carrier_shaped(t):
+    return t is not None and t.dtype == torch.float32 and t.dim() > 0 and t.numel() > 1 and not any(t.stride())
 
 
 def _stream_real(t, last=False):
     """the bf16 gradient a carrier stands for, or None when `t` is an ordinary tensor; last=True: this is the carrier's final consumer
-    (the LayerNorm backward that takes it as dres, or the end of the chain) - the entry and its 38 MB are released"""
-    if t is None or not _stream or t.dtype != torch.float32 or any(t.stride()):
+    (the LayerNorm backward that takes it as dres, or the end of the chain) - the entry and its 38 MB are released.  A pool slot whose
+    entry is gone (consumed twice, or overwritten after _POOL_SLOTS further carriers) raises instead of handing NaNs on."""
+    if not _is_carrier_shaped(t):
         return None
-    ent = _stream.pop(t.data_ptr(), None) if last else _stream.get(t.data_ptr())
-    return ent[1] if ent is not None else None
+    ptr = t.data_ptr()
+    real = _stream.pop(ptr, None) if last else _stream.get(ptr)
+    if real is None:
+        ent = _pool.get(t.device)
+        if ent is not None and 0 <= ptr - ent[0].data_ptr() < 4 * _POOL_SLOTS:
+            raise RuntimeError("p3hip: a bf16 gradient-stream carrier without its tensor reached a consumer (consumed twice or dropped)")
+    return real
+
+
+def _materialize(t):
+    """`t` itself, or - when it is a carrier - the fp32 tensor it stands for (one cast pass): for consumers outside the ViT chain"""
+    real = _stream_real(t)
+    return t if real is None else hip.cast(real.view(t.shape), torch.float32)
 
 
 def _to_cd(t2, cd):
@@ -365,6 +446,7 @@ def _same_drop(a, b):
 def _to_cd_dropped(t2, cd, drop):
     """dropout backward of gradient `t2` [rows, N] in the compute dtype: the producer's masked bf16 twin when ln_bwd wrote one for exactly
     this site, the p3_dropout_apply pass (mask regenerated while casting) otherwise"""
+    t2 = _materialize(t2)
     if cd == torch.bfloat16 and t2.dtype == torch.float32:
         ent = _twins.pop(t2.data_ptr(), None)
         if ent is not None and _same_drop(ent[2], drop) and ent[1].numel() == t2.numel() and t2.is_contiguous():
@@ -396,9 +478,10 @@ class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x [.., K] compute dtype; W [N, K] fp32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows, drop, gin, gout_res, gout_x):
+    def forward(ctx, x, weight, bias, residual, act, out_dtype, cd, rows, drop, gin, gout_res, gout_x, stream_res=False):
         w = shadow(weight, cd)
         ctx.bias_param = bias
+        ctx.stream_res = stream_res                 # the residual's producer is a stream-aware LayerNorm fork (Block.run): a carrier may pass through
         ctx.gout_x = gout_x if (gout_x is not None and gout_x.armed) else None        # read before this node arms the same slot
         ctx.gin = gin if ctx.needs_input_grad[0] else None
         if ctx.gin is not None:
@@ -429,9 +512,9 @@ class _Linear(torch.autograd.Function):
         x2, weight, saved = ctx.saved_tensors
         cd = ctx.cd
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dres = dy if ctx.has_res else None
+        dres = (dy if ctx.stream_res else _materialize(dy)) if ctx.has_res else None
         if ctx.gout_res is not None:
-            ctx.gout_res.g, dres = dy, None
+            ctx.gout_res.g, dres = _materialize(dy), None
         # dpre = dy * act'(pre), in compute dtype
         drop = ctx.drop
         if ctx.act == hip.ACT_NONE:
@@ -440,7 +523,7 @@ class _Linear(torch.autograd.Function):
             else:
                 dpre = _to_cd(dy2, cd)
         else:                           # ReLU then dropout: the saved output is already masked, only the 1/(1-p) factor remains
-            dpre = hip.act_bwd(dy2, saved, ctx.act, cd, scale=1.0 / (1.0 - drop[2]) if drop is not None else 1.0)
+            dpre = hip.act_bwd(_materialize(dy2), saved, ctx.act, cd, scale=1.0 / (1.0 - drop[2]) if drop is not None else 1.0)
         dx = dw = db = None
         rows = ctx.rows
         n_true = dpre.shape[1]
@@ -464,14 +547,14 @@ class _Linear(torch.autograd.Function):
             r0, r1 = rows if rows is not None else (0, weight.shape[0])
             fuse_b = ctx.has_bias and ctx.needs_input_grad[2] and bias_p.grad is not None and ctx.needs_input_grad[1]
             if ctx.needs_input_grad[1]:     # bias gradient = column sums of dpre, folded into the same TN GEMM launch
-                hip.gemm_tn(dpre, x2, out=weight.grad[r0:r1], colsum_out=bias_p.grad[r0:r1] if fuse_b else None)
+                _tn_side(dpre, x2, out=weight.grad[r0:r1], colsum_out=bias_p.grad[r0:r1] if fuse_b else None)
             if ctx.has_bias and ctx.needs_input_grad[2] and not fuse_b:
                 if bias_p.grad is not None:
                     hip.colsum(dpre, out=bias_p.grad[r0:r1])
                 else:
                     db = hip.colsum(dpre)
             _grad_ready(weight, bias_p if ctx.has_bias else None)
-            return dx, None, db, dres, None, None, None, None, None, None, None, None
+            return dx, None, db, dres, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn(dpre, x2)[:n_true]                                      # [N, K] fp32
             if rows is not None:
@@ -484,15 +567,16 @@ class _Linear(torch.autograd.Function):
                 full = torch.zeros(weight.shape[0], dtype=torch.float32, device=db.device)
                 full[rows[0]:rows[1]] = db
                 db = full
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def linear(x, weight, bias=None, *, act=hip.ACT_NONE, residual=None, out_dtype=None, cd=torch.float32, rows=None, drop=None, gin=None,
-           gout_res=None, gout_x=None):
+           gout_res=None, gout_x=None, stream_res=False):
     """rows=(a, b): use only weight[a:b] / bias[a:b] (packed in_proj of nn.MultiheadAttention).
     drop=(seed, site, p): dropout of the activated output before the residual add (fused into the GEMM epilogue).
-    gin / gout_res / gout_x: GradSlot hand-overs of the backward (see GradSlot)."""
-    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop, gin, gout_res, gout_x)
+    gin / gout_res / gout_x: GradSlot hand-overs of the backward (see GradSlot).
+    stream_res: `residual` comes from layernorm_fork(..., stream_grad=True) (ViT block): its gradient may stay a bf16-stream carrier."""
+    return _Linear.apply(x, weight, bias, residual, act, out_dtype or cd, cd, rows, drop, gin, gout_res, gout_x, stream_res)
 
 
 def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
@@ -501,7 +585,7 @@ def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
     if DIRECT_GRAD[0] and weight.grad is not None:
         fuse_b = bias is not None and need_b and bias.grad is not None and need_w
         if need_w:
-            hip.gemm_tn(dpre, x2, out=weight.grad, colsum_out=bias.grad if fuse_b else None)
+            _tn_side(dpre, x2, out=weight.grad, colsum_out=bias.grad if fuse_b else None)
         if bias is not None and need_b and not fuse_b:
             if bias.grad is not None:
                 hip.colsum(dpre, out=bias.grad)
@@ -522,7 +606,8 @@ class _Mlp(torch.autograd.Function):
     hits HBM un-multiplied."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, act, out_dtype, cd, drop1, drop2):
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, out_dtype, cd, drop1, drop2, stream_res=False):
+        ctx.stream_res = stream_res
         ctx.res_is_x = bool(ctx.needs_input_grad[0]) and residual is not None and (residual is x or (residual.data_ptr() == x.data_ptr() and residual.shape == x.shape and residual.stride() == x.stride()))          # x + f(x): dY joins dX in the epilogue of the dX GEMM
         if w1.shape[0] % 64 or w2.shape[0] % 64:
             raise hip.P3Error("mlp: hidden / output widths must be multiples of 64")
@@ -548,7 +633,7 @@ class _Mlp(torch.autograd.Function):
         x2, h, aux, w1, w2 = ctx.saved_tensors
         act, cd, has_res, drop1, drop2, xshape = ctx.cfg
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dres = dy if has_res else None
+        dres = (dy if ctx.stream_res else _materialize(dy)) if has_res else None
         if drop2 is not None:
             dpre2 = _to_cd_dropped(dy2, cd, drop2)
         else:
@@ -562,14 +647,14 @@ class _Mlp(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())                   # [in, hidden]
-            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=dy2 if ctx.res_is_x else None).view(xshape)
+            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None).view(xshape)
             if ctx.res_is_x:
                 dres = None
-        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None, None
 
 
-def mlp(x, w1, b1, w2, b2, *, act, residual=None, out_dtype=None, cd=torch.float32, drop_act=None, drop_out=None):
-    return _Mlp.apply(x, w1, b1, w2, b2, residual, act, out_dtype or cd, cd, drop_act, drop_out)
+def mlp(x, w1, b1, w2, b2, *, act, residual=None, out_dtype=None, cd=torch.float32, drop_act=None, drop_out=None, stream_res=False):
+    return _Mlp.apply(x, w1, b1, w2, b2, residual, act, out_dtype or cd, cd, drop_act, drop_out, stream_res)
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
@@ -644,8 +729,9 @@ class _LayerNormFork(torch.autograd.Function):
     the first output and is added to the LayerNorm input gradient inside the ln_bwd kernel (no separate accumulate pass)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, out_dtype, stream_grad=False):
         ctx.beta_param = beta
+        ctx.stream = bool(stream_grad)
         if any(ctx.needs_input_grad):
             y, mean, rstd = hip.layernorm(x, gamma, beta, eps, out_dtype=out_dtype, save_stats=True)
             ctx.save_for_backward(x, gamma, mean, rstd)
@@ -658,10 +744,10 @@ class _LayerNormFork(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         beta = ctx.beta_param
         lo = dy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] in hip.LN_TWIN_COLS
-        if lo and GRAD_STREAM_BF16[0]:
+        if lo and ctx.stream and GRAD_STREAM_BF16[0]:
             if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-                return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres), None, None, None, None
-            return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres, loose=True) + (None, None)
+                return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres), None, None, None, None, None
+            return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres, loose=True) + (None, None, None)
         real = _stream_real(dres, last=True)
         if real is not None:                      # a carrier reached a fork that does not produce one (width without the half-wave kernel)
             dres = hip.cast(real.view(dres.shape), x.dtype)
@@ -673,19 +759,21 @@ class _LayerNormFork(torch.autograd.Function):
             if lo:
                 _register_twin(*dx)
                 dx = dx[0]
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
         dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=dg, dbeta=db, dres=dres, want_lo=lo)
         if lo:
             _register_twin(*dx)
             dx = dx[0]
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
-def layernorm_fork(x, gamma, beta, eps, out_dtype=None):
-    """-> (x, LN(x)); use the returned x for the residual connection of the block."""
-    return _LayerNormFork.apply(x, gamma, beta, eps, out_dtype or x.dtype)
+def layernorm_fork(x, gamma, beta, eps, out_dtype=None, stream_grad=False):
+    """-> (x, LN(x)); use the returned x for the residual connection of the block.
+    stream_grad: x is the ViT's fp32 residual stream and BOTH neighbours are stream-aware (Block.run): under GRAD_STREAM_BF16 the gradient of x
+    leaves as a bf16 carrier.  Off (the default) the gradient is an ordinary fp32 tensor (+ its bf16 twin), whatever the caller is."""
+    return _LayerNormFork.apply(x, gamma, beta, eps, out_dtype or x.dtype, stream_grad)
 
 
 # ---------------------------------------------------------------------------------------------- attention

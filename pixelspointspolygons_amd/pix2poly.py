@@ -428,6 +428,14 @@ class EncoderDecoder(nn.Module):
         """scorenet1(f) + scorenet2(f)^T (model_pix2poly.py:257-259), accumulated in place by the second ScoreNet's tail kernel."""
         B, N = features.shape[0], self.max_num_vertices
         out = torch.empty((B, N, N), dtype=torch.float32, device=features.device)
+        if ops.side_on("sn"):
+            # the two ScoreNets are independent until their sum: scorenet2 (and, through autograd, its backward) on a side stream
+            out2 = torch.empty_like(out)
+            with ops.on_side("sn"):
+                out2 = self.scorenet2.scores_into(features, out2, False)
+            out = self.scorenet1.scores_into(features, out, False)
+            ops.side_join("sn")
+            return out + out2.transpose(1, 2)
         out = self.scorenet1.scores_into(features, out, False)
         return self.scorenet2.scores_into(features, out, True)
 

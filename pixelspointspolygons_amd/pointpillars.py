@@ -69,6 +69,44 @@ class PointPillarsEncoder(nn.Module):
         return _PillarStem.apply(values.contiguous().float(), offsets.to(torch.int64), l0.linear.weight, l0.norm.weight, l0.norm.bias,
                                  l1.linear.weight, l1.norm.weight, l1.norm.bias, canvas, self, B, col_off)
 
+    @torch.no_grad()
+    def voxelize(self, x_lidar):
+        """Open3D-ML `PointPillars.voxelize` as the reference calls it (pointpillars_o3d.py:92): -> (voxels [V, max_points, 3] f32 with
+        zero-padded slots, num_points [V] int64, coors [V, 4] int64 = (batch, z, y, x)), V = kept pillars of the batch in sample order and,
+        inside a sample, ascending pillar hash.  The membership comes from the stem's own sort kernel (csrc/pillars.hip: pillar_sort_kernel,
+        the tables `hip.pillar_tables` exposes); the dense tensors are assembled with indexing ops - this is the inspection / parity entry,
+        `forward` never materialises them."""
+        values, offsets, B = jagged_parts(x_lidar)
+        values = values.contiguous().float()
+        l0, l1 = self.voxel_encoder.pfn_layers
+        dev = values.device
+        if values.shape[0] == 0:
+            return values.new_zeros((0, self.max_points, 3)), torch.zeros((0,), dtype=torch.int64, device=dev), torch.zeros((0, 4), dtype=torch.int64, device=dev)
+        canvas = torch.empty((B, self.ny * self.nx, self.C), dtype=self.cd, device=dev)
+        training = self.training
+        _, ws, d = hip.pillar_stem(values, offsets.to(torch.int64), l0.linear.weight.detach(),
+                                   (l0.norm.weight.detach(), l0.norm.bias.detach(), l0.norm.running_mean.clone(), l0.norm.running_var.clone()),
+                                   ops.shadow(l1.linear.weight, self.cd),
+                                   (l1.norm.weight.detach(), l1.norm.bias.detach(), l1.norm.running_mean.clone(), l1.norm.running_var.clone()),
+                                   canvas, B=B, grid=(self.nx, self.ny), voxel=self.voxel, zmax=self.zmax, max_points=self.max_points,
+                                   max_voxels=self.max_voxels[0] if training else self.max_voxels[1], training=training, keep_workspace=True,
+                                   phases=1)
+        t = hip.pillar_tables(ws, d)
+        mv, mp = d.max_voxels, self.max_points
+        slot = torch.arange(B * mv, device=dev)
+        keep = (slot % mv) < t["nvox"].long()[slot // mv]
+        slot = slot[keep]
+        cnt, start = t["vox_cnt"].long()[slot], t["vox_start"].long()[slot]
+        k = torch.arange(mp, device=dev)
+        valid = k[None, :] < cnt[:, None]
+        pid = t["sorted"].long()[(start[:, None] + k[None, :]).clamp_(max=values.shape[0] - 1)]
+        voxels = torch.where(valid[..., None], values[pid], values.new_zeros(()))
+        xy = t["vox_xy"].long()[slot] & ((1 << 30) - 1)
+        first = values[t["sorted"].long()[start.clamp(max=values.shape[0] - 1)]]
+        cz = (first[:, 2] * torch.tensor(1.0 / self.voxel[2], dtype=torch.float32, device=dev)).to(torch.int64)
+        coors = torch.stack([slot // mv, cz, xy // self.nx, xy % self.nx], 1)
+        return voxels, cnt, coors
+
     def forward(self, x_lidar, return_flattened=True):
         _, _, B = jagged_parts(x_lidar)
         dev = self.voxel_encoder.pfn_layers[0].linear.weight.device

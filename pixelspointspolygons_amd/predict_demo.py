@@ -72,14 +72,19 @@ def demo_model(device, precision="fp32", state_dict=None, fixture=None):
 
 def predict_leg(device, repeats=5):
     """bench.py `predict` object: s/tile of the whole predict path at batch 1 (graphs on: first call eager, second captures the 385
-    per-step graphs, later calls replay), in the fp32 parity mode and in bf16."""
+    per-step graphs, later calls replay), in the fp32 parity mode and in bf16.  The model is the one tests/test_predict_demo_gpu.py checks
+    against the oracle: seed-42 weights (synthetic.make_state_dict) + the fixture's planted, CPU-fitted output layer, so the decode ends in a
+    real EOS and the timed tail (2 x ScoreNet, Hungarian assignment, polygon assembly) works on real polygons."""
+    from . import synthetic
     tile, fx = demo_tile()
     out = {"tile": "demo_data/image0_CH_val.tif (pixel bytes from tests/golden/demo_tile.npz)" if fx is not None else "synthetic (fixture missing)",
            "batch": 1, "decode_steps": 385, "what": "image prep + ViT-S/8 encoder + KV-cached greedy decode (one hipGraph per step) + 2x ScoreNet + "
-           "device Hungarian assignment + polygon assembly; random-init weights (seed 42: the time does not depend on the token values; "
-           "token / polygon parity on this tile is tests/test_predict_demo_gpu.py)"}
+           "device Hungarian assignment + polygon assembly; seed-42 weights with the demo fixture's planted output layer (trained-like logits, "
+           "a real EOS, non-trivial polygons; token / polygon parity of exactly this model: tests/test_predict_demo_gpu.py)"}
+    sd = synthetic.make_state_dict("image", seed=42) if fx is not None else None
+    want = torch.from_numpy(fx["tokens"]) if fx is not None else None
     for prec in ("fp32", "bf16"):
-        model, tk = demo_model(device, prec)
+        model, tk = demo_model(device, prec, state_dict=sd, fixture=fx)
         for _ in range(3):
             polys, tokens = predict_tile(model, tk, tile)
         torch.cuda.synchronize()
@@ -89,7 +94,12 @@ def predict_leg(device, repeats=5):
             polys, tokens = predict_tile(model, tk, tile)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+        has_eos = bool((tokens[0] == tk.EOS_code).any())
+        eos = int((tokens[0] == tk.EOS_code).nonzero()[0]) if has_eos else None
         out[prec] = {"s_per_tile": round(float(np.median(ts)), 4), "min_s_per_tile": round(min(ts), 4), "polygons": len(polys),
-                     "eos_at": int((tokens[0] == tk.EOS_code).nonzero()[0]) if bool((tokens[0] == tk.EOS_code).any()) else None}
+                     "vertices": int(sum(len(p) for p in polys)), "eos_at": eos}
+        if want is not None and eos is not None:      # tokens up to the planted EOS against the fixture (the oracle's sequence)
+            n = int((want[0] == tk.EOS_code).nonzero()[0]) + 1
+            out[prec]["tokens_equal_fixture_upto_eos"] = bool(torch.equal(tokens[0, :n], want[0, :n]))
         del model
     return out

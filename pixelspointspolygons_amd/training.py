@@ -205,6 +205,7 @@ class FlatAdamW:
     def apply(self, grad_scale=1.0):
         """device side (capturable): schedule kernel + one fused update kernel over the arena (which also refreshes the bf16 shadow),
         then the transposed / re-laid-out weight copies are rewritten in place."""
+        ops.side_join()                          # side-stream branches (ops.SIDE) write into the gradient arena too
         if not self._host_fed:
             if self._sched_sent is None:         # apply() without prepare_step() (tests): upload once, outside any capture
                 self._sched_sent = (float(self.lr), float(self._sched[0]), float(self._sched[1]), float(self._sched[2]))

@@ -51,6 +51,7 @@ class _PatchGemm(torch.autograd.Function):
         D = w2.shape[0]
         ctx.save_for_backward(patches)
         ctx.wshape, ctx.D = weight.shape, D
+        ctx.chain = canvas is not None and canvas.requires_grad      # the pillar stem wrote into this canvas first: hand its gradient on
         if canvas is None:
             return hip.gemm(patches, w2, bias=bias, out_dtype=cd)
         hip.gemm(patches, w2, bias=bias, out=canvas[..., :D])
@@ -65,7 +66,7 @@ class _PatchGemm(torch.autograd.Function):
             dy2 = hip.cast(dy2.contiguous(), patches.dtype)
         dw = hip.gemm_tn(dy2, patches).view(ctx.wshape)
         db = hip.colsum(dy2)
-        return None, dw, db, None, None, None
+        return None, dw, db, None, dy if ctx.chain else None, None
 
 
 class Attention(nn.Module):
@@ -99,13 +100,15 @@ class Block(nn.Module):
     def run(self, x, cd):
         """x: residual stream [B, L, D] - fp32 (default), or the compute dtype under RESIDUAL_IN_CD (experiment switch P3_RES_BF16=1)."""
         rdt = cd if RESIDUAL_IN_CD[0] else torch.float32
-        x, h = ops.layernorm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd)
+        # stream_grad / stream_res: this chain (fork -> proj residual -> fork -> fc2 residual -> next block's fork ... -> _Assemble) is the one
+        # place where the gradient of the fp32 stream may travel as a bf16 carrier (ops.GRAD_STREAM_BF16): every link resolves it
+        x, h = ops.layernorm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=cd, stream_grad=True)
         qkv = ops.linear(h, self.attn.qkv.weight, self.attn.qkv.bias, cd=cd)
         a = ops.self_attention(qkv, self.attn.num_heads)
-        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=rdt, cd=cd)
-        x, h = ops.layernorm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd)
+        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, out_dtype=rdt, cd=cd, stream_res=True)
+        x, h = ops.layernorm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd, stream_grad=True)
         return ops.mlp(h, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, act=hip.ACT_GELU, residual=x,
-                       out_dtype=rdt, cd=cd)
+                       out_dtype=rdt, cd=cd, stream_res=True)
 
 
 _TIMM_SHAPES = {  # model_name prefix -> (dim, depth, heads)

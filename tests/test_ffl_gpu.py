@@ -138,3 +138,42 @@ def test_ffl_backward_vs_oracle_autograd(training):
         if not e < 1.5e-2:
             bad[k] = e
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+FULL = dict(dim=384, depth=12, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_ffl_full_batch_is_batch_independent_and_matches_the_oracle(precision):
+    """BASELINE configs[4] at its REAL size (model_ffl.py:28-104 over early_fusion_vit_cnn.py:87-104): ViT depth 12, 64 tiles of 224 x 224 +
+    3 k points.  Eval mode: tile b of the batch of 64 == the same tile run alone, bit for bit (row-independent implicit-GEMM convs, per-tile
+    upsample / pillar sort), and two of the 64 tiles are checked against the oracle."""
+    from oracle import p3_oracle as O
+    m, sd, cfg = _model("early_fusion_vit_cnn", precision, "fusion", FULL, vit_depth=12, batch_size=64)
+    m.eval()
+    B = 64
+    inp = O.make_inputs(B, seed=1234)
+    off = inp["lidar_offsets"]
+    img, lv, lo = inp["image"].cuda(), inp["lidar_values"].cuda(), inp["lidar_offsets"].cuda()
+    with torch.no_grad():
+        out = m({"image": img, "lidar": torch.nested.nested_tensor_from_jagged(lv, lo)})
+        seg, cf = out["seg"], out["crossfield"]
+        assert seg.shape == (B, 1, 224, 224) and cf.shape == (B, 4, 224, 224)
+        assert torch.isfinite(seg).all() and torch.isfinite(cf).all()
+        assert float(seg.min()) >= 0.0 and float(seg.max()) <= 1.0 and float(cf.abs().max()) <= 2.0      # sigmoid / 2 * tanh ranges (model_ffl.py:87-93)
+        for b in (0, 29, 63):
+            vals = lv[off[b]:off[b + 1]].contiguous()
+            offs = torch.tensor([0, int(off[b + 1] - off[b])], device="cuda")
+            o1 = m({"image": img[b:b + 1], "lidar": torch.nested.nested_tensor_from_jagged(vals, offs)})
+            assert torch.equal(o1["seg"][0], seg[b]) and torch.equal(o1["crossfield"][0], cf[b]), b
+        for b in (29, 63):
+            l0, l1 = int(off[b]), int(off[b + 1])
+            ref, _ = O.ffl_forward({k: v.clone() for k, v in sd.items()}, inp["image"][b:b + 1],
+                                   (inp["lidar_values"][l0:l1], torch.tensor([0, l1 - l0])), FULL, 224, False)
+            if precision == "fp32":
+                assert rel_err(seg[b:b + 1].float().cpu(), ref["seg"]) < 1e-3
+                assert rel_err(cf[b:b + 1].float().cpu(), ref["crossfield"]) < 1e-3
+            else:
+                l2 = lambda a, r: float((a.double() - r.double()).norm() / r.double().norm())
+                assert l2(seg[b:b + 1].float().cpu(), ref["seg"]) < 2e-2 and l2(cf[b:b + 1].float().cpu(), ref["crossfield"]) < 2e-2
+                assert rel_err(cf[b:b + 1].float().cpu(), ref["crossfield"]) < 0.2

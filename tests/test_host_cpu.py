@@ -282,6 +282,14 @@ def test_product_synthetic_generator_equals_the_oracles():
     assert (S.NUM_BINS, S.BOS, S.EOS, S.PAD) == (O.NUM_BINS, O.BOS, O.EOS, O.PAD)
 
 
+@pytest.mark.parametrize("kind", ["image", "fusion", "lidar"])
+def test_product_synthetic_weights_equal_the_oracles(kind):
+    """bench.py's `predict` leg plants tests/golden/demo_tile.npz (fitted on the oracle's seed-42 weights) on the product generator's seed 42."""
+    from pixelspointspolygons_amd import synthetic as S
+    a, b = S.make_state_dict(kind, seed=42), O.make_state_dict(kind, seed=42)
+    assert list(a) == list(b) and all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a)
+
+
 def test_only_checkers_import_the_oracle():
     """the product package, bench.py outside its cpu_baseline leg, and tools/ never import oracle/."""
     import re

@@ -16,6 +16,11 @@ TOL32 = 1e-3      # BASELINE.json north_star: "fp logits within 1e-3 rel"
 TOL16 = 6e-2      # bf16 storage through 12 + 6 layers (documented in DESIGN.md)
 
 
+def perm_tol(tol):
+    """the permutation matrix is held to the SAME 1e-3 as the logits in the fp32 parity mode (measured 2e-6); the bf16 mode keeps 5 x its tolerance"""
+    return tol if tol <= TOL32 else tol * 5
+
+
 def _model(kind, precision, sd=None, **kw):
     from pixelspointspolygons_amd.config import make_config
     from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
@@ -48,7 +53,7 @@ def test_pix2poly_forward_eval_vs_oracle(kind, precision, tol):
         logits, perm = m(d["image"] if img is not None else None, lj, d["y"][:, :-1])
     assert logits.shape == ref_logits.shape and perm.shape == ref_perm.shape
     assert rel_err(logits.float().cpu(), ref_logits) < tol
-    assert rel_err(perm.float().cpu(), ref_perm) < tol * 5
+    assert rel_err(perm.float().cpu(), ref_perm) < perm_tol(tol)
     if precision == "fp32":   # bit-exact token indices
         assert torch.equal(logits.float().cpu().argmax(-1), ref_logits.argmax(-1))
 
@@ -101,7 +106,7 @@ def test_forward_train_mode_batchnorm_statistics(precision, tol):
         d = _to_dev(inp)
         logits, perm = m(d["image"], (d["lidar_values"], d["lidar_offsets"]), d["y"][:, :-1])
     assert rel_err(logits.float().cpu(), ref_logits) < tol
-    assert rel_err(perm.float().cpu(), ref_perm) < tol * 5
+    assert rel_err(perm.float().cpu(), ref_perm) < perm_tol(tol)
     new = m.state_dict()
     for k in ("encoder.fusion_layer.1.running_mean", "encoder.fusion_layer.1.running_var", "scorenet1.bn2.running_var",
               "encoder.lidar_embed.voxel_encoder.pfn_layers.1.norm.running_mean", "scorenet2.bn3.running_mean"):
@@ -199,7 +204,7 @@ def test_pix2poly_vit_b16_forward_vs_oracle(precision, tol):
         d = _to_dev(inp)
         logits, perm = m(d["image"], None, d["y"][:, :-1])
     assert rel_err(logits.float().cpu(), ref_logits) < tol
-    assert rel_err(perm.float().cpu(), ref_perm) < tol * 5
+    assert rel_err(perm.float().cpu(), ref_perm) < perm_tol(tol)
     if precision == "fp32":
         assert torch.equal(logits.float().cpu().argmax(-1), ref_logits.argmax(-1))
 
@@ -368,6 +373,6 @@ def test_full_bench_batch_is_batch_independent_and_matches_the_oracle(precision)
             lo, hi = int(off[b]), int(off[b + 1])
             rl, rp = O.pix2poly_forward({k: v.clone() for k, v in sd.items()}, inp["y"][b:b + 1, :-1], inp["image"][b:b + 1],
                                         (inp["lidar_values"][lo:hi], torch.tensor([0, hi - lo])))
-            assert rel_err(logits[b:b + 1].float().cpu(), rl) < tol and rel_err(perm[b:b + 1].float().cpu(), rp) < tol * 5
+            assert rel_err(logits[b:b + 1].float().cpu(), rl) < tol and rel_err(perm[b:b + 1].float().cpu(), rp) < perm_tol(tol)
             if precision == "fp32":
                 assert torch.equal(logits[b:b + 1].float().cpu().argmax(-1), rl.argmax(-1))

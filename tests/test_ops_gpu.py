@@ -262,10 +262,57 @@ def test_residual_gradient_twin_replaces_the_cast_pass():
             if not use_twin:
                 ops._register_twin = reg
         return x.grad.clone(), lin.weight.grad.clone(), len(ops._twins)
+    assert ops.GRAD_STREAM_BF16[0]                      # the default: the generic fork must not emit a carrier all the same (opt-in)
     gx1, gw1, left1 = run(True)
     gx0, gw0, _ = run(False)
     assert left1 == 0                                   # the twin was consumed by the Linear's backward
     assert torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
+    assert torch.isfinite(gx1).all() and not ops._stream
+    was = ops.GRAD_STREAM_BF16[0]
+    ops.GRAD_STREAM_BF16[0] = False                     # and the switch changes nothing for callers that did not opt in
+    try:
+        gx2, gw2, _ = run(True)
+    finally:
+        ops.GRAD_STREAM_BF16[0] = was
+    assert torch.equal(gx1, gx2) and torch.equal(gw1, gw2)
+
+
+def test_gradient_stream_carriers_stay_inside_the_vit_chain():
+    """a carrier (zero-stride fp32 stand-in of the bf16 residual gradient) is emitted only by operators told their input is
+    the ViT stream, every consumer on that chain resolves it, its element is NaN, and a consumer outside the chain gets a real tensor."""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.vision_transformer import VisionTransformer
+    torch.manual_seed(1)
+    vit = VisionTransformer(64, 8, 384, 2, 6, None, cd=torch.bfloat16).to(DEV)
+    img = torch.rand(2, 3, 64, 64, device=DEV)
+
+    def grads(stream):
+        was, ops.GRAD_STREAM_BF16[0] = ops.GRAD_STREAM_BF16[0], stream
+        try:
+            ops.clear_twins()
+            for p_ in vit.parameters():
+                p_.grad = None
+            y = vit(img)
+            (y.float() ** 2).sum().backward()
+            return {k: p_.grad.clone() for k, p_ in vit.named_parameters()}
+        finally:
+            ops.GRAD_STREAM_BF16[0] = was
+    g1, g0 = grads(True), grads(False)
+    assert not ops._stream                              # every carrier of the backward was consumed
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        cos = float((g1[k].double() * g0[k].double()).sum() / (g1[k].double().norm() * g0[k].double().norm()).clamp_min(1e-30))
+        assert cos > 0.999, (k, cos)
+    # a carrier's own element is NaN, and _materialize hands a consumer outside the chain the real values
+    real = torch.randn(3, 5, 384, device=DEV).bfloat16()
+    car = ops._stream_carrier(real, real.shape)
+    assert car.shape == real.shape and not any(car.stride()) and bool(torch.isnan(car).all())
+    assert torch.equal(ops._materialize(car), real.float())
+    assert ops._stream_real(car, last=True) is real
+    with pytest.raises(RuntimeError):
+        ops._stream_real(car)                           # consumed twice: loud, not NaNs handed on
+    plain = torch.ones(1, device=DEV).expand(3, 5)     # an ordinary expanded gradient (d/dx of sum) is not mistaken for a carrier
+    assert ops._stream_real(plain) is None and ops._materialize(plain) is plain
 
 
 @pytest.mark.parametrize("cols", [256, 384, 768])

@@ -1,0 +1,113 @@
+"""Row a-4a: the INTEGER outputs of the pillar sort against the oracle's `pillarize` (Open3D `PointPillars.voxelize`,
+models/pointpillars/pointpillars_o3d.py:92 `voxels, num_points, coors = self.voxelize(x_lidar)`): pillar coordinates, `num_points`
+and the kept point indices bit for bit - not through the float canvas.  Two routes are checked: `PointPillarsEncoder.voxelize`
+(the reference's call) and the tables the stem's own forward call leaves in its workspace (`hip.pillar_tables`)."""
+import pytest
+import torch
+
+from oracle import p3_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _encoder(max_points=64, max_voxels=784, precision="fp32"):
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pointpillars import PointPillarsEncoder
+    cfg = make_config("early_fusion_vit", precision=precision, device=DEV)
+    enc = cfg.experiment.encoder
+    enc.max_num_points_per_voxel = max_points
+    enc.max_num_voxels.train = enc.max_num_voxels.test = max_voxels
+    m = PointPillarsEncoder(cfg).to(DEV)
+    return m.eval()
+
+
+def _oracle(vals, offs, max_points, max_voxels):
+    return O.pillarize(vals, offs, (8.0, 8.0, 100.0), (0, 0, 0), (224.0, 224.0, 100.0), max_points, max_voxels)
+
+
+def _check(vals, offs, max_points=64, max_voxels=784, precision="fp32"):
+    from pixelspointspolygons_amd import hip, ops
+    m = _encoder(max_points, max_voxels, precision)
+    r_vox, r_np, r_coors, r_pidx = _oracle(vals, offs, max_points, max_voxels)
+    dv, do = vals.to(DEV), offs.to(DEV)
+    voxels, num_points, coors = m.voxelize((dv, do))
+    assert coors.dtype == torch.int64 and num_points.dtype == torch.int64
+    assert torch.equal(coors.cpu(), r_coors), "pillar coordinates (b, z, y, x)"
+    assert torch.equal(num_points.cpu(), r_np), "num_points"
+    assert torch.equal(voxels.cpu(), r_vox), "gathered voxels (kept points in slot order, zero padding)"
+    # the tables of the product's own forward call (the workspace `forward` hands to its backward)
+    B = offs.shape[0] - 1
+    l0, l1 = m.voxel_encoder.pfn_layers
+    canvas = torch.empty((B, 784, 384), dtype=m.cd, device=DEV)
+    _, ws, d = hip.pillar_stem(dv, do, l0.linear.weight.detach(), (l0.norm.weight.detach(), l0.norm.bias.detach(), l0.norm.running_mean, l0.norm.running_var),
+                               ops.shadow(l1.linear.weight, m.cd), (l1.norm.weight.detach(), l1.norm.bias.detach(), l1.norm.running_mean, l1.norm.running_var),
+                               canvas, B=B, grid=(28, 28), voxel=(8.0, 8.0, 100.0), zmax=100.0, max_points=max_points, max_voxels=max_voxels,
+                               training=False, keep_workspace=True)
+    t = {k: v.cpu().long() for k, v in hip.pillar_tables(ws, d).items()}
+    assert int(t["nvox"].sum()) == r_coors.shape[0]
+    v = 0
+    offl = offs.tolist()
+    for b in range(B):
+        for s in range(int(t["nvox"][b])):
+            i = b * max_voxels + s
+            xy = int(t["vox_xy"][i]) & ((1 << 30) - 1)
+            assert (b, xy // 28, xy % 28) == (int(r_coors[v, 0]), int(r_coors[v, 2]), int(r_coors[v, 3]))
+            c = int(t["vox_cnt"][i])
+            assert c == int(r_np[v])
+            kept = t["sorted"][int(t["vox_start"][i]): int(t["vox_start"][i]) + c] - offl[b]
+            assert torch.equal(kept, r_pidx[v, :c]), f"kept point indices of pillar {v}"
+            # bit 30: a z == zmax pillar of the same (x, y) comes later in scatter order and overwrites this one (a-4c)
+            over = bool(int(t["vox_xy"][i]) >> 30)
+            same = (r_coors[:, 0] == b) & (r_coors[:, 2] == xy // 28) & (r_coors[:, 3] == xy % 28)
+            assert over == (int(r_coors[v, 1]) == 0 and int(same.sum()) == 2)
+            v += 1
+    return r_coors.shape[0]
+
+
+def test_pillar_membership_bit_exact_bench_cloud():
+    """the bench's 3 k-point clouds (SURVEY §8d inputs): ~3.8 points per pillar, no cap"""
+    inp = O.make_inputs(4, seed=1234, n_points=3000)
+    V = _check(inp["lidar_values"], inp["lidar_offsets"])
+    assert V > 4 * 700
+
+
+@pytest.mark.parametrize("max_points", [8, 64, 128])
+def test_pillar_membership_bit_exact_dense_cap(max_points):
+    """20 000 points on a 60 x 60 px corner (~350 per pillar): the per-pillar cap keeps the LOWEST point indices; the density-ablation caps"""
+    g = torch.Generator().manual_seed(3)
+    dense = torch.rand(20000, 3, generator=g) * torch.tensor([60.0, 60.0, 99.0])
+    sparse = torch.rand(2500, 3, generator=g) * torch.tensor([223.9, 223.9, 99.9])
+    vals = torch.cat([dense, sparse])
+    offs = torch.tensor([0, 20000, 22500])
+    _check(vals, offs, max_points=max_points)
+
+
+def test_pillar_membership_bit_exact_real_density():
+    """40 000 points per tile (real tiles: predictor.py:120-133): ~51 per pillar, a share of the pillars over the cap of 64"""
+    g = torch.Generator().manual_seed(11)
+    vals = torch.rand(80000, 3, generator=g) * torch.tensor([223.99, 223.99, 99.99])
+    vals[::1000, 2] = 100.0                                        # MinMax-scaled z: the top point of a tile sits exactly at 100
+    _check(vals, torch.tensor([0, 40000, 80000]))
+
+
+def test_pillar_membership_bit_exact_boundaries_and_empty_sample():
+    """x == 224 / y == 224 (out-of-grid cell, filtered but counted), z == 100 (top-z pillar), out-of-range points, an empty sample"""
+    g = torch.Generator().manual_seed(5)
+    edge = torch.tensor([[224.0, 10.0, 5.0], [10.0, 224.0, 5.0], [224.0, 224.0, 100.0], [100.0, 100.0, 100.0], [100.5, 100.5, 50.0],
+                         [101.0, 100.0, 100.0], [-0.1, 5.0, 5.0], [5.0, 5.0, 100.1], [5.0, -1e-7, 5.0], [223.99, 223.99, 99.99], [0.0, 0.0, 0.0],
+                         [8.0, 8.0, 0.0], [7.9999995, 16.0, 0.0], [216.0, 223.99998, 100.0]])
+    rnd = torch.rand(300, 3, generator=g) * torch.tensor([224.0, 224.0, 100.0])
+    rnd[::7, 0] = 224.0
+    rnd[::11, 2] = 100.0
+    vals = torch.cat([edge, rnd, torch.rand(50, 3, generator=g) * 200])
+    offs = torch.tensor([0, 14, 314, 314, 364])                      # sample 2 is empty
+    _check(vals, offs)
+
+
+def test_pillar_membership_bit_exact_max_voxels():
+    """max_num_voxels below the number of non-empty cells: the lowest hashes survive, and the cap counts BEFORE the bounds filter"""
+    g = torch.Generator().manual_seed(9)
+    vals = torch.rand(6000, 3, generator=g) * torch.tensor([224.0, 224.0, 100.0])
+    vals[::5, 0] = 224.0                                             # column 28 cells take max_voxels slots and are then filtered
+    _check(vals, torch.tensor([0, 3000, 6000]), max_voxels=300)

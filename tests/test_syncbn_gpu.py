@@ -90,7 +90,7 @@ def test_two_ranks_with_sync_batchnorm_equal_the_oracle_on_the_whole_batch(preci
     (sum(losses) / world).backward()
     for r in range(world):
         assert rel_err(res[r]["logits"], logits[2 * r:2 * r + 2].detach()) < 1e-3
-        assert rel_err(res[r]["perm"], perm[2 * r:2 * r + 2].detach()) < 5e-3
+        assert rel_err(res[r]["perm"], perm[2 * r:2 * r + 2].detach()) < (1e-3 if precision == "fp32" else 5e-3)
         assert abs(res[r]["loss"] - float(losses[r])) < 2e-3 * abs(float(losses[r]))
     assert torch.equal(res[0]["rmean"], res[1]["rmean"])        # identical running statistics on both ranks
     assert rel_err(res[0]["rmean"], p["encoder.fusion_layer.1.running_mean"]) < 1e-4
