@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "p3_common.h"
+#include "sinkhorn_tile.h"
 
 namespace {
 
@@ -20,13 +21,14 @@ __device__ __forceinline__ float lse_wave(float mx_local, float (&vals)[8], int 
     return mx + __logf(s);
 }
 
+template <int RA, int CB>
 __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                         int iters, float* __restrict__ perm, float* __restrict__ zfull,
                                                         float* __restrict__ uv_hist, int force_log) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1;
-    float* Z = sm;                 // [M1][N1]
-    float* u = sm + M1 * N1;       // [M1]
+    float* Z = sm;                 // [M1][N1]; the linear-domain path reuses the space as its column-partial slab once E sits in registers
+    float* u = sm + max(M1 * N1, sk::Slab<CB>::FLOATS);       // [M1]
     float* v = u + M1;             // [N1]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float alpha = alpha_p[0];
@@ -74,63 +76,90 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
     }
     const bool fast = !__syncthreads_or(wide) && !force_log && iters > 0;     // iters == 0: u = v = 0 stay log-domain quantities
     if (fast) {
-        for (int i = tid; i < M1 * N1; i += 1024) { const int r = i / N1; Z[i] = __expf(Z[i] - rmax[r]); }
-        for (int i = tid; i < N1; i += 1024) v[i] = 1.f;
+        // register tiling (sinkhorn_tile.h): thread (ty, tx) owns rows ty + 64 a, columns tx + 16 b of E
+        const int tx = tid & 15, ty = tid >> 4;
+        float e[RA][CB], rmx[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            const int i = ty + 64 * a;
+            rmx[a] = i < M1 ? rmax[i] : 0.f;
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) {
+                const int j = tx + 16 * bb;
+                e[a][bb] = (i < M1 && j < N1) ? __expf(Z[i * N1 + j] - rmx[a]) : 0.f;
+            }
+        }
+        __syncthreads();                    // Z is dead from here on
+        float* P = sm;
+        float vr[CB], ur[RA];
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) vr[bb] = (tx + 16 * bb < N1) ? 1.f : 0.f;
+#pragma unroll
+        for (int a = 0; a < RA; ++a) ur[a] = 0.f;
         const float mu = 1.f / (float)(m + n), mu_last = (float)n / (float)(m + n), nu_last = (float)m / (float)(m + n);
-        __syncthreads();
+        const int rc = tid >> 2, rp = tid & 3;               // the column this thread helps to reduce, and its part of the 64 partials
         for (int it = 0; it < iters; ++it) {
-            {   // U_i = mu_i / sum_j E_ij V_j
-                float sacc = 0.f;
-                if (idx < M1) {
-                    const int c0 = part * chj, c1 = min(N1, c0 + chj);
-                    const float* zr = Z + idx * N1;
-                    for (int c = c0; c < c1; ++c) sacc = fmaf(zr[c], v[c], sacc);
-                }
-                ps[part * 256 + idx] = sacc;
+            float* h = uv_hist ? uv_hist + ((int64_t)b * iters + it) * (M1 + N1) : nullptr;
+            // U_i = mu_i / sum_j E_ij V_j: the 16 lanes of a DPP row share the row, every lane ends with the same U_i
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                float p = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < CB; ++bb) p = fmaf(e[a][bb], vr[bb], p);
+                p = sk::row16_sum(p);
+                const int i = ty + 64 * a;
+                ur[a] = i < M1 ? (i < m ? mu : mu_last) / p : 0.f;
+                if (h && tx == 0 && i < M1) h[i] = __logf(ur[a]) - rmx[a];        // the backward pass reads log-domain duals
+            }
+            // V_j = nu_j / sum_i E_ij U_i
+            float q[CB];
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) {
+                float t = 0.f;
+#pragma unroll
+                for (int a = 0; a < RA; ++a) t = fmaf(e[a][bb], ur[a], t);
+                q[bb] = t;
+            }
+            const float cs = sk::col_reduce<CB>(P, q, tid, N1);
+            if (rp == 0 && rc < N1) {
+                const float vn = (rc < n ? mu : nu_last) / cs;
+                v[rc] = vn;
+                if (h) h[M1 + rc] = __logf(vn);
             }
             __syncthreads();
-            if (tid < M1) u[tid] = (tid < m ? mu : mu_last) / ((ps[tid] + ps[256 + tid]) + (ps[512 + tid] + ps[768 + tid]));
-            __syncthreads();
-            {   // V_j = nu_j / sum_i E_ij U_i
-                float sacc = 0.f;
-                if (idx < N1) {
-                    const int r0 = part * chi, r1 = min(M1, r0 + chi);
-                    for (int r = r0; r < r1; ++r) sacc = fmaf(Z[r * N1 + idx], u[r], sacc);
-                }
-                ps[part * 256 + idx] = sacc;
-            }
-            __syncthreads();
-            if (tid < N1) v[tid] = (tid < n ? mu : nu_last) / ((ps[tid] + ps[256 + tid]) + (ps[512 + tid] + ps[768 + tid]));
-            __syncthreads();
-            if (uv_hist) {                      // the backward pass reads log-domain duals
-                float* h = uv_hist + ((int64_t)b * iters + it) * (M1 + N1);
-                for (int i = tid; i < M1; i += 1024) h[i] = __logf(u[i]) - rmax[i];
-                for (int i = tid; i < N1; i += 1024) h[M1 + i] = __logf(v[i]);
-            }
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) { const int j = tx + 16 * bb; vr[bb] = j < N1 ? v[j] : 0.f; }
         }
         if (zfull) {
-            for (int i = tid; i < M1 * N1; i += 1024) {
-                const int r = i / N1, c = i - r * N1;
-                const float z0 = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
-                zfull[(int64_t)b * M1 * N1 + i] = z0 + (__logf(u[r]) - rmax[r]) + __logf(v[c]) - norm;
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                const int i = ty + 64 * a;
+#pragma unroll
+                for (int bb = 0; bb < CB; ++bb) {
+                    const int j = tx + 16 * bb;
+                    if (i < M1 && j < N1) {
+                        const float z0 = (i < m && j < n) ? scores[((int64_t)b * m + i) * n + j] : alpha;
+                        zfull[(int64_t)b * M1 * N1 + i * N1 + j] = z0 + (__logf(ur[a]) - rmx[a]) + __logf(vr[bb]) - norm;
+                    }
+                }
             }
         }
-        if (perm) {                             // softmax_j(Z_ij + v_j) = E_ij V_j / sum_j E_ij V_j
-            const int nc = (n + 63) / 64;
-            for (int r = w; r < m; r += 16) {
-                float vals[8]; float ssum = 0.f;
+        if (perm) {                             // softmax_j(Z_ij + v_j) = E_ij V_j / sum_{j < n} E_ij V_j
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int c = lane + 64 * k;
-                    vals[k] = (k < nc && c < n) ? Z[r * N1 + c] * v[c] : 0.f;
-                    ssum += vals[k];
+            for (int a = 0; a < RA; ++a) {
+                const int i = ty + 64 * a;
+                float vals[CB], ssum = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < CB; ++bb) {
+                    vals[bb] = (tx + 16 * bb < n) ? e[a][bb] * vr[bb] : 0.f;
+                    ssum += vals[bb];
                 }
-                ssum = wave_sum(ssum);
+                ssum = sk::row16_sum(ssum);
                 const float inv = 1.f / ssum;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int c = lane + 64 * k;
-                    if (k < nc && c < n) perm[((int64_t)b * m + r) * n + c] = vals[k] * inv;
+                for (int bb = 0; bb < CB; ++bb) {
+                    const int j = tx + 16 * bb;
+                    if (i < m && j < n) perm[((int64_t)b * m + i) * n + j] = vals[bb] * inv;
                 }
             }
         }
@@ -220,17 +249,31 @@ extern "C" int p3_sinkhorn(const float* scores, const float* alpha, int B, int m
                            float* uv_hist, void* stream) {
     P3_CHECK(scores && alpha && B > 0 && m > 0 && n > 0 && iters >= 0, P3_EINVAL, "p3_sinkhorn: bad arguments");
     P3_CHECK(m < 255 && n < 255, P3_EUNSUP, "p3_sinkhorn: m, n must be < 255");
-    const size_t lds = ((size_t)(m + 1) * (n + 1) + 2 * (size_t)(m + 1) + (n + 1) + 2048) * sizeof(float);
-    P3_CHECK(lds <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn: coupling matrix does not fit the 160 KB LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
     static int force_log = -1;                        // P3_SINKHORN_LOG=1: always the log-domain loop (A/B, tests of the fallback)
     if (force_log < 0) { const char* e = getenv("P3_SINKHORN_LOG"); force_log = (e && e[0] == '1') ? 1 : 0; }
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, scores, alpha, m, n, iters, perm, z_full, uv_hist, force_log);
+    hipStream_t s = (hipStream_t)stream;
+    // register tile of the linear-domain path: RA rows (64 apart) x CB columns (16 apart) per thread; the smallest instantiation that covers
+    // (m + 1) x (n + 1) - 4 x 13 for the reference's 193 x 193 (config/model/pix2poly.yaml:13), 1 x 4 for debug_rgd.yaml's 61 x 61
+#define P3_SK_LAUNCH(RA, CB)                                                                                                              \
+    do {                                                                                                                                  \
+        const size_t zf = (size_t)(m + 1) * (n + 1) > (size_t)sk::Slab<CB>::FLOATS ? (size_t)(m + 1) * (n + 1) : (size_t)sk::Slab<CB>::FLOATS; \
+        const size_t lds = (zf + 2 * (size_t)(m + 1) + (n + 1) + 2048) * sizeof(float);                                                   \
+        P3_CHECK(lds <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn: coupling matrix does not fit the 160 KB LDS");                         \
+        static bool attr_set = false;                                                                                                     \
+        if (!attr_set) {                                                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_kernel<RA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }                                                   \
+            attr_set = true;                                                                                                              \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((sinkhorn_kernel<RA, CB>), dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, z_full, uv_hist, force_log); \
+    } while (0)
+    const int M1 = m + 1, N1 = n + 1;
+    if (M1 <= 64 && N1 <= 32) P3_SK_LAUNCH(1, 2);
+    else if (M1 <= 64 && N1 <= 64) P3_SK_LAUNCH(1, 4);
+    else if (M1 <= 128 && N1 <= 128) P3_SK_LAUNCH(2, 8);
+    else if (M1 <= 256 && N1 <= 208) P3_SK_LAUNCH(4, 13);
+    else P3_SK_LAUNCH(4, 16);
+#undef P3_SK_LAUNCH
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

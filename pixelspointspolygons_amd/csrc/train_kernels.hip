@@ -2,6 +2,7 @@
 #include <stdlib.h>
 
 #include "p3_common.h"
+#include "sinkhorn_tile.h"
 
 namespace {
 
@@ -135,25 +136,24 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
 // as the forward kernel - and the 37 k-element gradient dZ = G - E (sum_t A^t B^t^T + D^t C^t^T) is accumulated ONCE at the end
 // from the per-iteration vectors (kept in a global scratch slab, 309 KB per tile, L2 resident) instead of being read-modify-written
 // in registers twice per iteration (r01: 1.49 ms for that form, 1.72 ms for the log-domain one, 64 x 192 x 192 x 100).
+// r04: E lives in REGISTERS in the 64 x 16 thread tiling of sinkhorn_tile.h (row products by DPP, column products through a small LDS
+// slab; r03 read E and the vector from LDS for every FMA and was bound by the ds_read_b32 rate: 730 us).
+template <int RA, int CB>
 __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                                  int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
                                                                  const float* __restrict__ dperm, float* __restrict__ dscores,
                                                                  float* __restrict__ dalpha, int* __restrict__ tile_flags, float* __restrict__ vecs,
-                                                                 int forced) {
+                                                                 float* __restrict__ rmax_out, int forced) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1, VS = 2 * (M1 + N1);
-    float* E = sm;                   // [M1][N1]
-    float* rmax = sm + M1 * N1;      // [M1]
-    float* Ai = rmax + M1;           // [M1] exp(u_t + rmax)
-    float* Di = Ai + M1;             // [M1] Ai / mu_i * du_i
-    float* Bj = Di + M1;             // [N1] exp(v_t - log_nu) * dv
-    float* Cj = Bj + N1;             // [N1] exp(v_{t-1})
-    float* dv = Cj + N1;             // [N1]
-    float* pm = dv + N1;             // [1024] partials
+    float* E = sm;                   // [M1][N1] while the tile is loaded and tested; then the column-partial slab
+    float* rmax = sm + max(M1 * N1, sk::Slab<CB>::FLOATS);      // [M1]
+    float* Bl = rmax + M1;           // [N1] B_j of the current iteration
+    float* pm = Bl + N1;             // [1024] partials
     float* ps = pm + 1024;           // [1024] partials
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int idx = tid & 255, part = tid >> 8;
-    const int chj = (N1 + 3) / 4, chi = (M1 + 3) / 4;
+    const int chj = (N1 + 3) / 4;
     // forced (kernel argument; P3_SINKHORN_LOG=1): leave every tile to the log-domain kernel.  tile_flags is WRITE-only here: r03's
     // rocprofv3 runs of the captured step showed the flags non-zero on entry (a memset node ahead of this kernel had cleared them before:
     // every tile then took the 1.2 ms log-domain path under the profiler only) - nothing is read that this launch did not write
@@ -162,7 +162,6 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
         const int r = i / N1, c = i - r * N1;
         E[i] = (r < m && c < n) ? scores[((int64_t)b * m + r) * n + c] : alpha;
     }
-    for (int i = tid; i < N1; i += 1024) dv[i] = 0.f;
     const float norm = -logf((float)(m + n));
     const float b_last = logf((float)m) + norm;
     const float inv_mu = (float)(m + n), inv_mu_last = (float)(m + n) / (float)n;      // 1 / exp(log_mu)
@@ -187,120 +186,189 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
     const bool wide_tile = __syncthreads_or(wide);
     if (tid == 0) tile_flags[b] = wide_tile ? 1 : 0;
     if (wide_tile) return;
-    for (int i = tid; i < M1 * N1; i += 1024) { const int r = i / N1; E[i] = __expf(E[i] - rmax[r]); }
-    // ---- softmax backward: G = perm * (dperm - rowdot); dv[j] = sum_i G_ij (G itself is rebuilt in the last phase)
-    for (int i = w; i < m; i += 16) {
-        float pv[SK_MAXC], gv[SK_MAXC];
-        float dot = 0.f;
+    if (tid < M1) rmax_out[(int64_t)b * M1 + tid] = rmax[tid];      // sinkhorn_bwd_dz_kernel rebuilds E from the scores
+    const int tx = tid & 15, ty = tid >> 4;
+    const int rc = tid >> 2, rp = tid & 3;                   // reducer role: column rc, part rp of its 64 partials
+    // tile bases are wave-uniform (SGPR pair) and element offsets 32-bit: one address VGPR per load instead of a 64-bit pair (the 104
+    // perm / dperm loads of a thread otherwise spill)
+    const float* __restrict__ permb = perm + (int64_t)b * m * n;
+    const float* __restrict__ dpermb = dperm + (int64_t)b * m * n;
+    float* __restrict__ dscb = dscores + (int64_t)b * m * n;
+    float e[RA][CB], rmx[RA];
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) {
-            const int j = lane + 64 * c;
-            const bool ok = j < n;
-            pv[c] = ok ? perm[((int64_t)b * m + i) * n + j] : 0.f;
-            gv[c] = ok ? dperm[((int64_t)b * m + i) * n + j] : 0.f;
-            dot += pv[c] * gv[c];
-        }
-        dot = wave_sum(dot);
+    for (int a = 0; a < RA; ++a) {
+        const int i = ty + 64 * a;
+        rmx[a] = i < M1 ? rmax[i] : 0.f;
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) {
-            const int j = lane + 64 * c;
-            const float G = pv[c] * (gv[c] - dot);
-            if (j < n && G != 0.f) atomicAdd(&dv[j], G);
+        for (int bb = 0; bb < CB; ++bb) {
+            const int j = tx + 16 * bb;
+            e[a][bb] = (i < M1 && j < N1) ? __expf(E[i * N1 + j] - rmx[a]) : 0.f;
         }
     }
-    __syncthreads();
+    __syncthreads();                        // the LDS image is dead: its space is the slab now
+    float* P = sm;
+    // ---- softmax backward: G = perm * (dperm - rowdot); dv[j] = sum_i G_ij (G itself is rebuilt in the last phase)
+    float dvj;                              // reducer threads: dv of column rc
+    {
+        float gq[CB];
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) gq[bb] = 0.f;
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            const int i = ty + 64 * a;
+            float pv[CB], gv[CB], dot = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) {
+                const int j = tx + 16 * bb;
+                const bool ok = i < m && j < n;
+                const uint32_t off = ok ? (uint32_t)(i * n + j) * 4u : 0u;
+                pv[bb] = sk::ld_off(permb, off); gv[bb] = sk::ld_off(dpermb, off);
+                if (!ok) { pv[bb] = 0.f; gv[bb] = 0.f; }
+                dot = fmaf(pv[bb], gv[bb], dot);
+            }
+            dot = sk::row16_sum(dot);
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) gq[bb] += pv[bb] * (gv[bb] - dot);
+            asm volatile("" ::: "memory");      // one row's 2 CB loads in flight at a time (hoisting all RA rows' loads spills)
+        }
+        dvj = sk::col_reduce<CB>(P, gq, tid, N1);
+        if (rc >= n) dvj = 0.f;             // the dustbin column takes no softmax gradient
+    }
     float* vt_all = vecs + (int64_t)b * iters * VS;
     for (int t = iters; t >= 1; --t) {
         const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
         float* vs = vt_all + (int64_t)(t - 1) * VS;            // [A (M1) | D (M1) | B (N1) | C (N1)] of this iteration
-        if (tid < M1) { const float a = __expf(h[tid] + rmax[tid]); Ai[tid] = a; vs[tid] = a; }
-        if (tid < N1) {
-            const float bj = __expf(h[M1 + tid] - (tid < n ? norm : b_last)) * dv[tid];
-            const float cj = t > 1 ? __expf(h[M1 + tid - (M1 + N1)]) : 1.f;                        // v_0 = 0
-            Bj[tid] = bj; Cj[tid] = cj; vs[2 * M1 + tid] = bj; vs[2 * M1 + N1 + tid] = cj;
+        float hu[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) { const int i = ty + 64 * a; hu[a] = i < M1 ? h[i] : 0.f; }      // in flight across the barrier
+        float cj = 1.f;
+        if (rc < N1) {
+            const float bj = __expf(h[M1 + rc] - (rc < n ? norm : b_last)) * dvj;
+            if (t > 1) cj = __expf(h[M1 + rc - (M1 + N1)]);                                            // v_0 = 0
+            if (rp == 0) { Bl[rc] = bj; vs[2 * M1 + rc] = bj; vs[2 * M1 + N1 + rc] = cj; }
         }
-        __syncthreads();
-        {   // s_i = sum_j E_ij B_j
+        __syncthreads();                    // also separates this iteration's slab use from the previous one's
+        float br[CB];
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) { const int j = tx + 16 * bb; br[bb] = j < N1 ? Bl[j] : 0.f; }
+        // s_i = sum_j E_ij B_j;  du_i = -A_i s_i;  D_i = A_i / mu_i * du_i
+        float dr[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            const int i = ty + 64 * a;
             float sacc = 0.f;
-            if (idx < M1) {
-                const int c0 = part * chj, c1 = min(N1, c0 + chj);
-                const float* er = E + idx * N1;
-                for (int c = c0; c < c1; ++c) sacc = fmaf(er[c], Bj[c], sacc);
-            }
-            ps[part * 256 + idx] = sacc;
+#pragma unroll
+            for (int bb = 0; bb < CB; ++bb) sacc = fmaf(e[a][bb], br[bb], sacc);
+            sacc = sk::row16_sum(sacc);
+            const float ai = __expf(hu[a] + rmx[a]);
+            const float du = -ai * sacc;
+            dr[a] = i < M1 ? ai * (i < m ? inv_mu : inv_mu_last) * du : 0.f;
+            if (tx == 0 && i < M1) { vs[i] = ai; vs[M1 + i] = dr[a]; }
         }
-        __syncthreads();
-        if (tid < M1) {
-            const float du = -Ai[tid] * ((ps[tid] + ps[256 + tid]) + (ps[512 + tid] + ps[768 + tid]));
-            const float d = Ai[tid] * (tid < m ? inv_mu : inv_mu_last) * du;
-            Di[tid] = d; vs[M1 + tid] = d;
+        // w_j = sum_i E_ij D_i;  dv_{t-1}[j] = -C_j w_j
+        float q[CB];
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) {
+            float w_ = 0.f;
+#pragma unroll
+            for (int a = 0; a < RA; ++a) w_ = fmaf(e[a][bb], dr[a], w_);
+            q[bb] = w_;
         }
-        __syncthreads();
-        {   // w_j = sum_i E_ij D_i
-            float sacc = 0.f;
-            if (idx < N1) {
-                const int r0 = part * chi, r1 = min(M1, r0 + chi);
-                for (int r = r0; r < r1; ++r) sacc = fmaf(E[r * N1 + idx], Di[r], sacc);
-            }
-            pm[part * 256 + idx] = sacc;
-        }
-        __syncthreads();
-        if (tid < N1) dv[tid] = -Cj[tid] * ((pm[tid] + pm[256 + tid]) + (pm[512 + tid] + pm[768 + tid]));
-        // no barrier needed here: dv[tid] is read by the same thread next iteration; Ai/Bj/Cj/Di writes of the next iteration come
-        // after this iteration's last reads of them (before the barrier above) except Cj, read just now by its own writer thread
+        dvj = -cj * sk::col_reduce<CB>(P, q, tid, N1);
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---- dZ = G - E * sum_t (A^t_i B^t_j + D^t_i C^t_j); rows w, w + 16, ..., columns lane, lane + 64, ...
-    float acc[13][SK_MAXC];
+}
+
+// ---- dZ = G - E * sum_t (A^t_i B^t_j + D^t_i C^t_j) from the sweep's per-iteration vectors: no sequential dependency, so this half runs on
+// the WHOLE chip (8 row blocks per tile: 512 workgroups for 64 tiles) instead of on the 64 CUs the sweep occupies.  A workgroup = 16 x 16
+// threads over its row block x all columns (rows r0 + ty + 16 a, columns tx + 16 b); the vectors of 16 iterations at a time are staged through
+// LDS with coalesced loads, E_ij = exp(Z_ij - rowmax_i) is rebuilt from the scores, G from perm / dperm (rowdot by DPP).
+constexpr int SK_RS = 8, SK_TC = 16;
+template <int RA2, int CB>
+__global__ __launch_bounds__(256) void sinkhorn_bwd_dz_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n, int iters,
+                                                              const float* __restrict__ perm, const float* __restrict__ dperm, float* __restrict__ dscores,
+                                                              float* __restrict__ dalpha, const int* __restrict__ tile_flags, const float* __restrict__ vecs,
+                                                              const float* __restrict__ rmax_in) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x / SK_RS, rs = blockIdx.x - b * SK_RS;
+    if (tile_flags[b] != 0) return;                       // a wide tile: the log-domain kernel computes it
+    const int M1 = m + 1, N1 = n + 1, VS = 2 * (M1 + N1);
+    const int RPW = (M1 + SK_RS - 1) / SK_RS, r0 = rs * RPW, nr = min(M1 - r0, RPW);
+    if (nr <= 0) return;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int W = 2 * RPW + 2 * N1;                       // floats staged per iteration: [A rows | D rows | B | C]
+    const float* vt_all = vecs + (int64_t)b * iters * VS;
+    float acc[RA2][CB];
 #pragma unroll
-    for (int k = 0; k < 13; ++k)
+    for (int a = 0; a < RA2; ++a)
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) acc[k][c] = 0.f;
-    for (int t = 0; t < iters; ++t) {
-        const float* vs = vt_all + (int64_t)t * VS;
-        float bb[SK_MAXC], cc[SK_MAXC];
+        for (int bb = 0; bb < CB; ++bb) acc[a][bb] = 0.f;
+    // LDS offsets of this thread's rows / columns inside one iteration's record; rows / columns past the end read a valid word (their
+    // products are never stored)
+    int la[RA2], lb[CB];
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) {
-            const int j = lane + 64 * c;
-            bb[c] = j < N1 ? vs[2 * M1 + j] : 0.f;
-            cc[c] = j < N1 ? vs[2 * M1 + N1 + j] : 0.f;
+    for (int a = 0; a < RA2; ++a) la[a] = min(ty + 16 * a, nr - 1);
+#pragma unroll
+    for (int bb = 0; bb < CB; ++bb) lb[bb] = 2 * RPW + min(tx + 16 * bb, N1 - 1);
+    for (int t0 = 0; t0 < iters; t0 += SK_TC) {
+        const int tc = min(SK_TC, iters - t0);
+        __syncthreads();
+        for (int x = tid; x < tc * W; x += 256) {
+            const int t = x / W, kk = x - t * W;
+            const float* vs = vt_all + (int64_t)(t0 + t) * VS;
+            float val;
+            if (kk < RPW) val = kk < nr ? vs[r0 + kk] : 0.f;
+            else if (kk < 2 * RPW) val = (kk - RPW) < nr ? vs[M1 + r0 + kk - RPW] : 0.f;
+            else val = vs[2 * M1 + kk - 2 * RPW];
+            sm[x] = val;
         }
+        __syncthreads();
+        for (int t = 0; t < tc; ++t) {
+            const float* L = sm + t * W;
+            float av[RA2], dd[RA2];
 #pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            const int i = w + 16 * k;
-            const float a = i < M1 ? vs[i] : 0.f, d = i < M1 ? vs[M1 + i] : 0.f;
+            for (int a = 0; a < RA2; ++a) { av[a] = L[la[a]]; dd[a] = L[RPW + la[a]]; }
 #pragma unroll
-            for (int c = 0; c < SK_MAXC; ++c) acc[k][c] = fmaf(a, bb[c], fmaf(d, cc[c], acc[k][c]));
+            for (int bb = 0; bb < CB; ++bb) {
+                const float bj = L[lb[bb]], cc = L[N1 + lb[bb]];
+#pragma unroll
+                for (int a = 0; a < RA2; ++a) acc[a][bb] = fmaf(av[a], bj, fmaf(dd[a], cc, acc[a][bb]));
+            }
         }
     }
+    const float alpha = alpha_p[0];
+    const float* __restrict__ permb = perm + (int64_t)b * m * n;
+    const float* __restrict__ dpermb = dperm + (int64_t)b * m * n;
+    const float* __restrict__ scb = scores + (int64_t)b * m * n;
+    float* __restrict__ dscb = dscores + (int64_t)b * m * n;
     float da = 0.f;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const int i = w + 16 * k;
-        float pv[SK_MAXC], gv[SK_MAXC];
-        float dot = 0.f;
+    for (int a = 0; a < RA2; ++a) {
+        const int li = ty + 16 * a, i = r0 + li;
+        const bool rok = li < nr;
+        const float rm = rok ? rmax_in[(int64_t)b * M1 + i] : 0.f;
+        float pv[CB], gv[CB], zz[CB], dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) {
-            const int j = lane + 64 * c;
-            const bool ok = i < m && j < n;
-            pv[c] = ok ? perm[((int64_t)b * m + i) * n + j] : 0.f;
-            gv[c] = ok ? dperm[((int64_t)b * m + i) * n + j] : 0.f;
-            dot += pv[c] * gv[c];
+        for (int bb = 0; bb < CB; ++bb) {
+            const int j = tx + 16 * bb;
+            const bool ok = rok && i < m && j < n;
+            const uint32_t off = ok ? (uint32_t)(i * n + j) * 4u : 0u;
+            pv[bb] = sk::ld_off(permb, off); gv[bb] = sk::ld_off(dpermb, off); zz[bb] = sk::ld_off(scb, off);
+            if (!ok) { pv[bb] = 0.f; gv[bb] = 0.f; zz[bb] = alpha; }
+            dot = fmaf(pv[bb], gv[bb], dot);
         }
-        dot = wave_sum(dot);
+        dot = sk::row16_sum(dot);
 #pragma unroll
-        for (int c = 0; c < SK_MAXC; ++c) {
-            const int j = lane + 64 * c;
-            if (i < M1 && j < N1) {
-                const float dz = pv[c] * (gv[c] - dot) - E[i * N1 + j] * acc[k][c];
-                if (i < m && j < n) dscores[((int64_t)b * m + i) * n + j] = dz;
+        for (int bb = 0; bb < CB; ++bb) {
+            const int j = tx + 16 * bb;
+            if (rok && j < N1) {
+                const float dz = pv[bb] * (gv[bb] - dot) - __expf(zz[bb] - rm) * acc[a][bb];
+                if (i < m && j < n) sk::st_off(dscb, (uint32_t)(i * n + j) * 4u, dz);
                 else da += dz;
             }
         }
     }
     da = wave_sum(da);
-    if (lane == 0 && da != 0.f) atomicAdd(dalpha, da);
+    if ((tid & 63) == 0 && da != 0.f) atomicAdd(dalpha, da);
 }
 
 // ------------------------------------------------------------------------------------------------ losses
@@ -454,7 +522,8 @@ extern "C" int p3_adamw_schedule_dev(long long* step, float* hyper, const float*
 }
 
 extern "C" int64_t p3_sinkhorn_bwd_workspace_bytes(int B, int m, int n, int iters) {
-    return 256 + ((int64_t)B * 4 + 255) / 256 * 256 + (int64_t)B * iters * 2 * (m + n + 2) * 4;
+    // [tile flags | per-iteration vectors A, D, B, C of every tile | row maxima]
+    return 256 + ((int64_t)B * 4 + 255) / 256 * 256 + (int64_t)B * iters * 2 * (m + n + 2) * 4 + (int64_t)B * (m + 1) * 4 + 256;
 }
 
 extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, int m, int n, int iters, const float* perm,
@@ -462,14 +531,12 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
     P3_CHECK(scores && alpha && perm && uv_hist && dperm && dscores && dalpha && workspace && B > 0, P3_EINVAL, "p3_sinkhorn_bwd: bad arguments");
     P3_CHECK(m + 1 <= 16 * SK_MAXK && n + 1 <= 64 * SK_MAXC, P3_EUNSUP, "p3_sinkhorn_bwd: m <= 207, n <= 255");
     const size_t lds = ((size_t)(m + 1) * (n + 1) + 2 * (size_t)(m + 1) + 4 * (size_t)(n + 1)) * sizeof(float);
-    const size_t lds_fast = ((size_t)(m + 1) * (n + 1) + 3 * (size_t)(m + 1) + 3 * (size_t)(n + 1) + 2048) * sizeof(float);
-    P3_CHECK(lds <= 160 * 1024 && lds_fast <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
+    P3_CHECK(lds <= 160 * 1024, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");
     static int force_log = -1;                        // P3_SINKHORN_LOG=1: log-domain loop only (A/B, tests of the fallback)
     if (force_log < 0) { const char* e = getenv("P3_SINKHORN_LOG"); force_log = (e && e[0] == '1') ? 1 : 0; }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sinkhorn_bwd_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
@@ -478,7 +545,34 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
     float* vecs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)B * 4 + 255) / 256 * 256);
     // two launches: the linear-domain kernel takes every tile whose row spread allows it and flags the others for the log-domain
     // kernel, which returns at once for the tiles already done (one kernel holding both loops spilled 40 more registers)
-    hipLaunchKernelGGL(sinkhorn_bwd_fast_kernel, dim3(B), dim3(1024), lds_fast, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags, vecs, force_log);
+    float* rmaxs = vecs + (int64_t)B * iters * 2 * (m + n + 2);
+#define P3_SKB_LAUNCH(RA, CB, RA2)                                                                                                        \
+    do {                                                                                                                                  \
+        const size_t zf = (size_t)(m + 1) * (n + 1) > (size_t)sk::Slab<CB>::FLOATS ? (size_t)(m + 1) * (n + 1) : (size_t)sk::Slab<CB>::FLOATS; \
+        const size_t lds_fast = (zf + (size_t)(m + 1) + (size_t)(n + 1) + 2048) * sizeof(float);                                          \
+        P3_CHECK(lds_fast <= 160 * 1024 - 512, P3_EUNSUP, "p3_sinkhorn_bwd: does not fit the 160 KB LDS");                                \
+        static bool fattr = false;                                                                                                        \
+        if (!fattr) {                                                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void*)sinkhorn_bwd_fast_kernel<RA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }                                                   \
+            fattr = true;                                                                                                                 \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((sinkhorn_bwd_fast_kernel<RA, CB>), dim3(B), dim3(1024), lds_fast, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, \
+                           dalpha, tile_flags, vecs, rmaxs, force_log);                                                                   \
+        const int rpw = (m + 1 + SK_RS - 1) / SK_RS;                                                                                      \
+        const size_t lds_dz = (size_t)SK_TC * (2 * rpw + 2 * (n + 1)) * sizeof(float);                                                    \
+        hipLaunchKernelGGL((sinkhorn_bwd_dz_kernel<RA2, CB>), dim3(B * SK_RS), dim3(256), lds_dz, s, scores, alpha, m, n, iters, perm, dperm, dscores, \
+                           dalpha, tile_flags, vecs, rmaxs);                                                                              \
+    } while (0)
+    {
+        const int M1 = m + 1, N1 = n + 1;      // RA2 = ceil(ceil(M1 / 8) / 16)
+        if (M1 <= 64 && N1 <= 32) P3_SKB_LAUNCH(1, 2, 1);
+        else if (M1 <= 64 && N1 <= 64) P3_SKB_LAUNCH(1, 4, 1);
+        else if (M1 <= 128 && N1 <= 128) P3_SKB_LAUNCH(2, 8, 1);
+        else if (M1 <= 256 && N1 <= 208) P3_SKB_LAUNCH(4, 13, 2);
+        else P3_SKB_LAUNCH(4, 16, 2);
+    }
+#undef P3_SKB_LAUNCH
     hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
     P3_LAUNCH_CHECK();
     return P3_OK;

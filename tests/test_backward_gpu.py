@@ -113,6 +113,31 @@ def test_sinkhorn_backward_vs_autograd():
         assert abs(float(ad.grad.cpu()) - float(alpha.grad)) < 2e-3 * max(1.0, abs(float(alpha.grad)))
 
 
+@pytest.mark.parametrize("m,n", [(20, 20), (60, 60), (70, 100), (100, 70), (127, 127), (192, 192), (140, 254), (254, 140), (33, 254)])
+def test_sinkhorn_register_tilings_forward_backward(m, n):
+    """every instantiation of the register-tiled linear-domain kernels (sinkhorn_tile.h: RA x CB = 1x2, 1x4, 2x8, 4x13, 4x16) incl. non-square
+    couplings and sizes one short of a tile edge: Z + u + v - norm, the row softmax and both gradients against autograd of the oracle"""
+    import pixelspointspolygons_amd.hip as h
+    iters = 25
+    s = (_rand(2, m, n, seed=m + n) * 2).requires_grad_(True)
+    alpha = torch.tensor(0.9, requires_grad=True)
+    z = O.log_optimal_transport(s, alpha, iters)
+    perm = torch.softmax(z[:, :m, :n], -1)
+    g = _rand(2, m, n, seed=7)
+    perm.backward(g)
+    sd, ad = s.detach().to(DEV), alpha.detach().to(DEV).reshape(1)
+    pd, zf, hist = h.sinkhorn(sd, ad, iters, want_perm=True, want_z=True, want_hist=True)
+    assert rel_err(zf.cpu(), z.detach()) < 1e-5
+    assert rel_err(pd.cpu(), perm.detach()) < 1e-4
+    ds, da = h.sinkhorn_bwd(sd, ad, pd, hist, g.to(DEV), iters)
+    assert rel_err(ds.cpu(), s.grad) < 2e-3
+    assert abs(float(da.cpu()) - float(alpha.grad)) < 2e-3 * max(1.0, abs(float(alpha.grad)))
+    # run-to-run bit-reproducible (fixed reduction order everywhere but the dustbin scalar)
+    pd2, _, hist2 = h.sinkhorn(sd, ad, iters, want_perm=True, want_hist=True)
+    ds2, _ = h.sinkhorn_bwd(sd, ad, pd2, hist2, g.to(DEV), iters)
+    assert torch.equal(pd, pd2) and torch.equal(hist, hist2) and torch.equal(ds, ds2)
+
+
 def test_sinkhorn_wide_range_scores_take_the_log_domain_path():
     """Rows whose scores span more than 60 (exp(Z - rowmax) would underflow) fall back to the log-domain loop; tiles below the
     threshold run the linear-domain iterations: both against the oracle's log_optimal_transport, values and gradients."""
