@@ -14,6 +14,8 @@
 //         the V^T fragments come from the transposing LDS read ds_read_b64_tr_b16;
 //   f32 : v_mfma_f32_32x32x2_f32 (exact fp32), V stays row-major.
 // Masks: keys >= Lk, causal (key > query) -> -inf; key_bias[b, key] is ADDED (reference's float padding mask).
+#include <stdlib.h>
+
 #include "p3_common.h"
 #include "attn_tile.h"
 
@@ -24,6 +26,7 @@ using p3attn::u32x4;
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O;
     p3_attn_desc d;
+    int order;          // attn_block_of mode
 };
 
 template <typename T, int D> struct ATr;
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     // (PMC r01: 579 MB fetched per ViT launch with the (q-block, head, batch) grid = 7x the 77 MB of K/V, one copy per XCD)
     const int nqb = (d.Lq + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblk = (lid % nqb) * 128, h = (lid / nqb) % d.H, b = lid / (nqb * d.H);
+    int blk_, pair_;
+    attn_block_of(lid, nqb, d.Lq, d.B * d.H, a.order, blk_, pair_);
+    const int qblk = blk_ * 128, h = pair_ % d.H, b = pair_ / d.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -420,6 +425,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
 }
 
+int p3_attn_order(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("P3_ATTN_TAIL_FIRST"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream) {
     P3_CHECK(Q && K && V && O && d, P3_EINVAL, "p3_attention: null pointer");
     P3_CHECK(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0, P3_ESHAPE, "p3_attention: empty problem");
@@ -429,7 +440,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
     P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
     P3_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, P3_EALIGN, "p3_attention: 16-byte base alignment");
-    AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d;
+    AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d; a.order = p3_attn_order();
     dim3 grid(p3_ceil_div(d->Lq, 128) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool drop = d->drop.seed != nullptr && d->drop.p > 0.f;

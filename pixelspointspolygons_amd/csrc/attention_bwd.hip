@@ -23,6 +23,7 @@ struct BwdArgs {
     void* dQ; void* dK; void* dV;
     const float* lse; float* delta;
     p3_attn_desc d;
+    int order;          // attn_block_of mode
 };
 
 template <typename T>
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     const p3_attn_desc& d = a.d;
     const int nqb = (d.Lq + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);      // blocks of one (batch, head) share an XCD's L2 (see attention.hip)
-    const int qblk = (lid % nqb) * 128, h = (lid / nqb) % d.H, b = lid / (nqb * d.H);
+    int blk_, pair_;
+    attn_block_of(lid, nqb, d.Lq, d.B * d.H, a.order, blk_, pair_);
+    const int qblk = blk_ * 128, h = pair_ % d.H, b = pair_ / d.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
     const p3_attn_desc& d = a.d;
     const int nkb = (d.Lk + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int kblk = (lid % nkb) * 128, h = (lid / nkb) % d.H, b = lid / (nkb * d.H);
+    int blk_, pair_;
+    attn_block_of(lid, nkb, d.Lk, d.B * d.H, a.order, blk_, pair_);
+    const int kblk = blk_ * 128, h = pair_ % d.H, b = pair_ / d.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
     const T* Qp = reinterpret_cast<const T*>(a.Q) + (int64_t)b * d.q_bs + h * D;
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
@@ -438,7 +443,7 @@ extern "C" int p3_attention_bwd(const void* Q, const void* K, const void* V, con
     P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention_bwd: dtype");
     const int al = d->dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % al == 0, P3_EALIGN, "p3_attention_bwd: row strides");
-    BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d;
+    BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d; a.order = p3_attn_order();
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == P3_BF16) return d->head_dim == 64 ? launch_bwd<bf16_t, 64>(a, s) : launch_bwd<bf16_t, 32>(a, s);
     return d->head_dim == 64 ? launch_bwd<float, 64>(a, s) : launch_bwd<float, 32>(a, s);

@@ -399,6 +399,13 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict_
 
 }  // namespace
 
+void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, int splits, hipStream_t s) {
+    int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, slabs, C, N, K, ldc, splits);
+}
+int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float* colsum, float* slabs, int max_slabs,
+                       hipStream_t s);      // gemm_tn_dma.hip
+
 extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
                              const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, float* slabs, int max_slabs, void* stream) {
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
@@ -409,6 +416,10 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     const int vec = dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0, P3_EALIGN, "p3_gemm_tn: N, K, lda, ldb must be multiples of 8 (bf16) / 4 (f32)");
     P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, P3_EALIGN, "p3_gemm_tn: 16-byte base alignment");
+    if (dtype == P3_BF16 && b_mode == 0) {          // the plain bf16 weight gradients at 64 / 128-aligned shapes: LDS-DMA kernel (gemm_tn_dma.hip)
+        const int rc = p3_gemm_tn_dma_try(A, B, C, M, N, K, lda, ldb, ldc, colsum, slabs, max_slabs, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.b_mode = b_mode; g.b_scale = b_scale; g.b_shift = b_shift; g.pair_V = pair_V; g.pair_n = pair_n; g.colsum = colsum;
     const int tiles_n = p3_ceil_div(N, TN);

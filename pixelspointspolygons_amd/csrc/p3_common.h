@@ -86,6 +86,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Attention launches: logical block id -> (128-row block, (batch, head) pair).  L = 785 = 6 x 128 + 17 (ViT) and 385 = 3 x 128 + 1 (decoder)
+// leave a nearly empty last block per pair that still walks the whole key / query sequence: one wave live, a slot held for most of a full
+// block's time, and a grid of 7/6 (4/3) x the full blocks - ViT forward: 2304 full blocks = exactly 3 rounds of the 768 resident slots, the
+// 384 tail blocks mixed in made it 3.5.  mode 1: inside each XCD's consecutive id range (xcd_remap) the TAIL blocks come first - short, they
+// finish while the first round of full blocks starts, and the launch ends on whole rounds of full blocks; the blocks of one pair stay on one
+// XCD (K / V in one L2).  Needs pairs % 8 == 0 and a ragged last block; anything else keeps the pair-major order (mode 0).
+__device__ __forceinline__ void attn_block_of(int lid, int nblk, int L, int pairs, int mode, int& blk, int& pair) {
+    if (mode == 1 && nblk > 1 && (L & 127) != 0 && (pairs & 7) == 0) {
+        const int p8 = pairs >> 3, per_xcd = p8 * nblk;
+        const int x = lid / per_xcd, local = lid - x * per_xcd;
+        if (local < p8) { pair = x * p8 + local; blk = nblk - 1; }
+        else { const int l2 = local - p8; pair = x * p8 + l2 / (nblk - 1); blk = l2 % (nblk - 1); }
+    } else { blk = lid % nblk; pair = lid / nblk; }
+}
+int p3_attn_order(void);      // host: 1 unless P3_ATTN_TAIL_FIRST=0 (A/B switch)
+
 // row index of accumulator register r of a 32x32 MFMA C/D fragment (col = lane & 31)
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
                 v[rc] = vn;
                 if (h) h[M1 + rc] = __logf(vn);
             }
-            __syncthreads();
+            sk::lds_barrier();
 #pragma unroll
             for (int bb = 0; bb < CB; ++bb) { const int j = tx + 16 * bb; vr[bb] = j < N1 ? v[j] : 0.f; }
         }

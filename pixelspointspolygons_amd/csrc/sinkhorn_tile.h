@@ -56,6 +56,11 @@ __device__ __forceinline__ void st_off(float* base, uint32_t byte_off, float v) 
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access (s_waitcnt vmcnt(0)): with the
+// per-iteration dual / vector stores of these loops in flight that is a ~1 us store round trip per barrier (r04: 2.5 us per iteration, two
+// barriers each).  The stores are consumed by a later launch (or behind the final __syncthreads of the kernel), never inside the loop.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // row pitch of the column-partial slab in floats: 16 CB + 8 keeps the four parts of a column (rows 4k + part) on banks 8 apart
 template <int CB> struct Slab { static constexpr int LD = 16 * CB + 8, FLOATS = 64 * LD; };
 
@@ -68,7 +73,7 @@ __device__ __forceinline__ float col_reduce(float* __restrict__ P, const float (
     const int tx = tid & 15, ty = tid >> 4;
 #pragma unroll
     for (int b = 0; b < CB; ++b) P[ty * LD + tx + 16 * b] = q[b];
-    __syncthreads();
+    lds_barrier();
     const int rc = tid >> 2, rp = tid & 3;
     float s = 0.f;
     if (rc < ncols) {

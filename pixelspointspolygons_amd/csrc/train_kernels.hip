@@ -235,19 +235,31 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
         if (rc >= n) dvj = 0.f;             // the dustbin column takes no softmax gradient
     }
     float* vt_all = vecs + (int64_t)b * iters * VS;
-    for (int t = iters; t >= 1; --t) {
-        const float* h = uv_hist + ((int64_t)b * iters + (t - 1)) * (M1 + N1);
-        float* vs = vt_all + (int64_t)(t - 1) * VS;            // [A (M1) | D (M1) | B (N1) | C (N1)] of this iteration
-        float hu[RA];
+    // the dual iterates of step t - 1 are loaded while step t is worked on (software pipeline: no load is waited for inside an iteration, and
+    // the barriers order LDS traffic only - sk::lds_barrier - so the vector stores of an iteration stay in flight too)
+    float hu[RA], hv = 0.f, hvp = 0.f;
+    {
+        const float* h = uv_hist + ((int64_t)b * iters + (iters - 1)) * (M1 + N1);
 #pragma unroll
-        for (int a = 0; a < RA; ++a) { const int i = ty + 64 * a; hu[a] = i < M1 ? h[i] : 0.f; }      // in flight across the barrier
+        for (int a = 0; a < RA; ++a) { const int i = ty + 64 * a; hu[a] = (iters > 0 && i < M1) ? h[i] : 0.f; }
+        if (iters > 0 && rc < N1) { hv = h[M1 + rc]; if (iters > 1) hvp = h[M1 + rc - (M1 + N1)]; }
+    }
+    for (int t = iters; t >= 1; --t) {
+        float* vs = vt_all + (int64_t)(t - 1) * VS;            // [A (M1) | D (M1) | B (N1) | C (N1)] of this iteration
+        float hu_n[RA], hvp_n = 0.f;
+        {
+            const float* hn = uv_hist + ((int64_t)b * iters + (t - 2)) * (M1 + N1);      // iteration t - 1 (read only when t > 1)
+#pragma unroll
+            for (int a = 0; a < RA; ++a) { const int i = ty + 64 * a; hu_n[a] = (t > 1 && i < M1) ? hn[i] : 0.f; }
+            if (t > 2 && rc < N1) hvp_n = hn[M1 + rc - (M1 + N1)];
+        }
         float cj = 1.f;
         if (rc < N1) {
-            const float bj = __expf(h[M1 + rc] - (rc < n ? norm : b_last)) * dvj;
-            if (t > 1) cj = __expf(h[M1 + rc - (M1 + N1)]);                                            // v_0 = 0
+            const float bj = __expf(hv - (rc < n ? norm : b_last)) * dvj;
+            if (t > 1) cj = __expf(hvp);                                                               // v_0 = 0
             if (rp == 0) { Bl[rc] = bj; vs[2 * M1 + rc] = bj; vs[2 * M1 + N1 + rc] = cj; }
         }
-        __syncthreads();                    // also separates this iteration's slab use from the previous one's
+        sk::lds_barrier();                  // also separates this iteration's slab use from the previous one's
         float br[CB];
 #pragma unroll
         for (int bb = 0; bb < CB; ++bb) { const int j = tx + 16 * bb; br[bb] = j < N1 ? Bl[j] : 0.f; }
@@ -275,6 +287,9 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
             q[bb] = w_;
         }
         dvj = -cj * sk::col_reduce<CB>(P, q, tid, N1);
+#pragma unroll
+        for (int a = 0; a < RA; ++a) hu[a] = hu_n[a];
+        hv = hvp; hvp = hvp_n;              // v of iteration t - 1 is this iteration's v_{t-1}
     }
 }
 

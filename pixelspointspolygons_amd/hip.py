@@ -727,11 +727,14 @@ def gemm_tn(a, b, out=None, colsum_out=None):
         out = torch.zeros((N, K), dtype=torch.float32, device=a.device)
     slabs, ns = _tn_slabs(N, K, a)
     ev = KTIMER.begin()
+    if ev is not None:
+        lib().p3_trace_kernels(c_int(1))                        # forget the previous launch's name: an untraced kernel must not inherit it
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
                               ptr(slabs), c_int(ns), stream()), "p3_gemm_tn")
     if ev is not None:                                          # operands once, the fp32 output tile once (split-M partials are not algorithmic)
-        KTIMER.end(ev, f"gemm_tn_kernel<{'bf16' if dt(a) == BF16 else 'float'}, 0>", 2.0 * M * N * K, float(M * (N + K) * a.element_size() + N * K * 4))
+        kname = lib().p3_last_kernel().decode() or f"gemm_tn_kernel<{'bf16' if dt(a) == BF16 else 'float'}, 0>"
+        KTIMER.end(ev, kname, 2.0 * M * N * K, float(M * (N + K) * a.element_size() + N * K * 4))
     return out
 
 

@@ -99,10 +99,12 @@ class PointPillarsEncoder(nn.Module):
         cnt, start = t["vox_cnt"].long()[slot], t["vox_start"].long()[slot]
         k = torch.arange(mp, device=dev)
         valid = k[None, :] < cnt[:, None]
-        pid = t["sorted"].long()[(start[:, None] + k[None, :]).clamp_(max=values.shape[0] - 1)]
+        # only the positions [start, start + cnt) of `sorted` are written by the sort (points outside the range leave its tail uninitialised)
+        pos = torch.where(valid, start[:, None] + k[None, :], start[:, None])
+        pid = t["sorted"].long()[pos]
         voxels = torch.where(valid[..., None], values[pid], values.new_zeros(()))
         xy = t["vox_xy"].long()[slot] & ((1 << 30) - 1)
-        first = values[t["sorted"].long()[start.clamp(max=values.shape[0] - 1)]]
+        first = values[t["sorted"].long()[start]]
         cz = (first[:, 2] * torch.tensor(1.0 / self.voxel[2], dtype=torch.float32, device=dev)).to(torch.int64)
         coors = torch.stack([slot // mv, cz, xy // self.nx, xy % self.nx], 1)
         return voxels, cnt, coors

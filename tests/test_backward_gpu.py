@@ -37,6 +37,31 @@ def test_gemm_tn_and_colsum(dtype, tol, M, N, K):
     assert rel_err(cs.cpu(), a.float().sum(0)) < 1e-4          # bias gradient folded into the TN GEMM
 
 
+@pytest.mark.parametrize("M,N,K,lda_pad", [(192, 128, 128, 0), (6400, 384, 384, 0), (3136, 1536, 384, 0), (12544, 384, 1536, 0), (4096, 1152, 384, 768),
+                                            (64 * 385, 256, 256, 0), (2 * 50240, 1152, 384, 0)])
+def test_gemm_tn_dma_kernel(M, N, K, lda_pad):
+    """the LDS-DMA weight-gradient kernel (gemm_tn_dma.hip: M % 64 == 0, N and K multiples of 128, bf16): product, folded bias column sums,
+    accumulation into a non-zero C, a strided A operand (a column block of a wider matrix, as the packed qkv gradient), against float64 matmul,
+    and against the register-staged kernel (P3_TN_DMA is read once per process, so that comparison is by value)"""
+    h = _h()
+    h.lib().p3_trace_kernels(1)
+    full = _rand(M, N + lda_pad, seed=11).bfloat16()
+    a = full[:, lda_pad // 2: lda_pad // 2 + N] if lda_pad else full
+    b = _rand(M, K, seed=12).bfloat16()
+    ref = (a.double().t() @ b.double())
+    out = torch.full((N, K), 0.5, device=DEV)
+    cs = torch.full((N,), 2.0, device=DEV)
+    ad = full.to(DEV)[:, lda_pad // 2: lda_pad // 2 + N] if lda_pad else full.to(DEV)
+    h.gemm_tn(ad, b.to(DEV), out=out, colsum_out=cs)
+    picked = h.lib().p3_last_kernel().decode()
+    h.lib().p3_trace_kernels(0)
+    assert picked.startswith("gemm_tn_dma_kernel"), picked
+    assert rel_err(out.cpu() - 0.5, ref.float()) < 2e-5
+    assert rel_err(cs.cpu() - 2.0, a.float().sum(0)) < 1e-4
+    out2 = h.gemm_tn(ad, b.to(DEV))                     # zero-filled output, no colsum
+    assert rel_err(out2.cpu(), ref.float()) < 2e-5
+
+
 def test_gemm_tn_strided_operand_and_accumulate():
     h = _h()
     full = _rand(300, 512, seed=3)
@@ -113,7 +138,7 @@ def test_sinkhorn_backward_vs_autograd():
         assert abs(float(ad.grad.cpu()) - float(alpha.grad)) < 2e-3 * max(1.0, abs(float(alpha.grad)))
 
 
-@pytest.mark.parametrize("m,n", [(20, 20), (60, 60), (70, 100), (100, 70), (127, 127), (192, 192), (140, 254), (254, 140), (33, 254)])
+@pytest.mark.parametrize("m,n", [(20, 20), (60, 60), (70, 100), (100, 70), (127, 127), (192, 192), (140, 254), (200, 150), (33, 254)])
 def test_sinkhorn_register_tilings_forward_backward(m, n):
     """every instantiation of the register-tiled linear-domain kernels (sinkhorn_tile.h: RA x CB = 1x2, 1x4, 2x8, 4x13, 4x16) incl. non-square
     couplings and sizes one short of a tile edge: Z + u + v - norm, the row softmax and both gradients against autograd of the oracle"""
