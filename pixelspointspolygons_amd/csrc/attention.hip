@@ -16,8 +16,6 @@
 // Masks: keys >= Lk, causal (key > query) -> -inf; key_bias[b, key] is ADDED (reference's float padding mask).
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "p3_common.h"
 #include "attn_tile.h"
 
@@ -160,32 +158,24 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
     constexpr int KPT = (KV16 + 255) / 256;                 // per thread
     constexpr int VPT = KPT;
-    // TWO staging register sets: the tile t + 2 is in flight while tile t is multiplied.  With one set (r01 - r03) a workgroup had 16 KB in
-    // flight and a tile step took as long as a load round trip under load (~1.1 us against ~0.5 us of MFMA + softmax work per tile): the
-    // launch was bound by latency x residency, not by any unit (584 TF at the ViT shape).
-    // (D = 64 without dropout = the ViT shape; the other instantiations spill with a second set at their register budgets and keep one)
-    constexpr int NSET = (P3_ATTN_PF2 && BF && D == 64 && !DROP) ? 2 : 1;
-    u32x4 kreg[NSET][KPT];
-    u32x4 vreg[NSET][VPT];
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT];
     p3attn::ScoreAddr<BF ? D : 16> sadr;          // bf16: lane-constant offsets into the swizzled K / V images
     p3attn::TrAddr<BF ? D : 32> tadr;
     if constexpr (BF) { sadr.init(l31, hi); tadr.init(lane); }
 
-    if (ntiles > 0) attn_load_tile<T, D, KPT, VPT>(0, tid, d, Kp, Vp, kreg[0], vreg[0]);
-    if (NSET > 1 && ntiles > 1) attn_load_tile<T, D, KPT, VPT>(1, tid, d, Kp, Vp, kreg[NSET - 1], vreg[NSET - 1]);
-    // FULLT = steady state (tile t + 2 exists): the prefetch carries no condition (a conditional load inside the loop makes hipcc drain vmcnt
-    // before the set is loaded again - the r02 finding of gemm.hip); the last tiles run the conditional form
-    auto tile_step = [&](int t, u32x4 (&kr)[KPT], u32x4 (&vr)[VPT], auto FULLT) __attribute__((always_inline)) {
+    if (ntiles > 0) attn_load_tile<T, D, KPT, VPT>(0, tid, d, Kp, Vp, kreg, vreg);
+    for (int t = 0; t < ntiles; ++t) {
         __syncthreads();  // previous tile's LDS reads are done
-        attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kr, vr);
+        attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
         // the tile's key bias goes through LDS (log2 units): read per element from global memory it was 32 dependent loads per tile, each
         // followed by s_waitcnt vmcnt(0) - which also drained the next tile's prefetch (decoder self-attention: every tile has a bias)
         if (kbias && tid < KT) { const int kvb = t * KT + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * 1.4426950408889634f; }
         __syncthreads();
-        if (decltype(FULLT)::value || t + NSET < ntiles) attn_load_tile<T, D, KPT, VPT>(t + NSET, tid, d, Kp, Vp, kr, vr);
+        if (t + 1 < ntiles) attn_load_tile<T, D, KPT, VPT>(t + 1, tid, d, Kp, Vp, kreg, vreg);
         const int kv0 = t * KT;
         // a wave whose 32 queries all lie beyond Lq (tail q-block: L = 785 -> 17 live rows, L = 385 -> 1) only helps with the staging
-        if (!wave_live) return;
+        if (!wave_live) continue;
 
         // ---- S^T = K . Q^T ----
         // last tile: a 32-key half that lies entirely beyond the block's last visible key is skipped (785 = 12 x 64 + 17)
@@ -193,7 +183,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         int vis_end = kv_end;
         if (d.causal) { const int wl = qblk + wave * 32 + 32; if (wl < vis_end) vis_end = wl; }
         const int nh2 = (vis_end - kv0 + 31) >> 5;          // visible 32-key halves of this tile (>= NH2: all)
-        if (nh2 <= 0) return;
+        if (nh2 <= 0) continue;
         f32x16 sacc[NH2];
 #pragma unroll
         for (int h2 = 0; h2 < NH2; ++h2) {
@@ -327,16 +317,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                     }
                 }
         }
-    };
-    if constexpr (NSET == 2) {
-        int t = 0;
-        for (; t + 4 <= ntiles; t += 2) { tile_step(t, kreg[0], vreg[0], std::true_type{}); tile_step(t + 1, kreg[NSET - 1], vreg[NSET - 1], std::true_type{}); }
-        for (; t < ntiles; t += 2) {
-            tile_step(t, kreg[0], vreg[0], std::false_type{});
-            if (t + 1 < ntiles) tile_step(t + 1, kreg[NSET - 1], vreg[NSET - 1], std::false_type{});
-        }
-    } else {
-        for (int t = 0; t < ntiles; ++t) tile_step(t, kreg[0], vreg[0], std::false_type{});
     }
 
     // ---- finalize ----

@@ -233,17 +233,14 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     const float* kbias = d.key_bias ? d.key_bias + (int64_t)b * d.Lk : nullptr;
     DropKey dkey; uint32_t drop_rk = 0;
     if constexpr (DROP) { dkey = drop_key(d.drop); drop_rk = drop_rowkey(dkey, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
-    // two staging register sets at the ViT shape (D = 64, no dropout): tile t + 2 is in flight while tile t is multiplied (see attention.hip)
-    constexpr int NSET = (P3_ATTN_PF2 && BF && D == 64 && DROP == 0) ? 2 : 1;
-    Stage<T, D, KT> kreg[NSET], vreg[NSET];
+    Stage<T, D, KT> kreg, vreg;
     FragAddr<T, D> fa; fa.init(lane, l31, hi);
-    if (ntiles > 0) { kreg[0].load(Kp, 0, d.Lk, d.k_rs, tid); vreg[0].load(Vp, 0, d.Lk, d.v_rs, tid); }
-    if (NSET > 1 && ntiles > 1) { kreg[NSET - 1].load(Kp, KT, d.Lk, d.k_rs, tid); vreg[NSET - 1].load(Vp, KT, d.Lk, d.v_rs, tid); }
-    auto tile_step = [&](int t, Stage<T, D, KT>& kr, Stage<T, D, KT>& vr, auto FULLT) __attribute__((always_inline)) {
+    if (ntiles > 0) { kreg.load(Kp, 0, d.Lk, d.k_rs, tid); vreg.load(Vp, 0, d.Lk, d.v_rs, tid); }
+    for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();
-        kr.store(Krow, tid);
-        vr.store(Vrow, tid);
+        kreg.store(Krow, tid);
+        vreg.store(Vrow, tid);
         if (kbias && tid < KT) { const int kvb = kv0 + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * LOG2E; }   // see attention.hip
         __syncthreads();
         // keep-bit words of this tile's 32-key halves: loaded BEFORE the next tile's prefetch is issued - vmcnt retires in order, so a
@@ -257,8 +254,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
                 if (kw < nkw) dwords[sub] = d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + qc];
             }
         }
-        if (decltype(FULLT)::value || t + NSET < ntiles) { kr.load(Kp, kv0 + NSET * KT, d.Lk, d.k_rs, tid); vr.load(Vp, kv0 + NSET * KT, d.Lk, d.v_rs, tid); }
-        if (qblk + wave * 32 >= d.Lq) return;        // tail q-block: this wave has no live query, it only stages
+        if (t + 1 < ntiles) { kreg.load(Kp, kv0 + KT, d.Lk, d.k_rs, tid); vreg.load(Vp, kv0 + KT, d.Lk, d.v_rs, tid); }
+        if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
         int vis_end = kv_end;                        // keys this wave's queries can see (causal: up to its last query)
         if (d.causal) { const int wl = qblk + wave * 32 + 32; if (wl < vis_end) vis_end = wl; }
 #pragma unroll
@@ -298,16 +295,6 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
             if (__builtin_amdgcn_readfirstlane((int)full)) elements(std::true_type{}); else elements(std::false_type{});
             accum_mma<T, D, KT>(Krow, sub, s, dq, fa, l31, hi);               // dQ^T[d, q] += K^T . dS^T
         }
-    };
-    if constexpr (NSET == 2) {
-        int t = 0;
-        for (; t + 4 <= ntiles; t += 2) { tile_step(t, kreg[0], vreg[0], std::true_type{}); tile_step(t + 1, kreg[NSET - 1], vreg[NSET - 1], std::true_type{}); }
-        for (; t < ntiles; t += 2) {
-            tile_step(t, kreg[0], vreg[0], std::false_type{});
-            if (t + 1 < ntiles) tile_step(t + 1, kreg[NSET - 1], vreg[NSET - 1], std::false_type{});
-        }
-    } else {
-        for (int t = 0; t < ntiles; ++t) tile_step(t, kreg[0], vreg[0], std::false_type{});
     }
     if (q < d.Lq) store_T_acc<T, D>(dQp + (int64_t)q * d.q_rs, dq, d.scale, hi);
 }
@@ -351,18 +338,14 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
     DropKey dkey; uint32_t drop_ck = 0; uint64_t drop_bh = 0;
     if constexpr (DROP != 0) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
-    constexpr int NSET = (P3_ATTN_PF2 && BF && D == 64 && DROP == 0) ? 2 : 1;       // see the dQ kernel
-    Stage<T, D, QT> qreg[NSET], greg[NSET];
+    Stage<T, D, QT> qreg, greg;
     FragAddr<T, D> fa; fa.init(lane, l31, hi);
-    const int ntiles = q_begin < d.Lq ? (d.Lq - q_begin + QT - 1) / QT : 0;
-    if (ntiles > 0) { qreg[0].load(Qp, q_begin, d.Lq, d.q_rs, tid); greg[0].load(dOp, q_begin, d.Lq, d.o_rs, tid); }
-    if (NSET > 1 && ntiles > 1) { qreg[NSET - 1].load(Qp, q_begin + QT, d.Lq, d.q_rs, tid); greg[NSET - 1].load(dOp, q_begin + QT, d.Lq, d.o_rs, tid); }
+    if (q_begin < d.Lq) { qreg.load(Qp, q_begin, d.Lq, d.q_rs, tid); greg.load(dOp, q_begin, d.Lq, d.o_rs, tid); }
     const int64_t word_row = (((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq;
-    auto tile_step = [&](int t, Stage<T, D, QT>& qr, Stage<T, D, QT>& gr, auto FULLT) __attribute__((always_inline)) {
-        const int q0 = q_begin + t * QT;
+    for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
         __syncthreads();
-        qr.store(Qrow, tid);
-        gr.store(Grow, tid);
+        qreg.store(Qrow, tid);
+        greg.store(Grow, tid);
         if (tid < QT) {
             const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
             Ls[tid] = a.lse[stat_base + qq] * 1.4426950408889634f; Ds[tid] = a.delta[stat_base + qq];   // lse in log2 units
@@ -379,8 +362,8 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
                 if (kblk + wave * 32 < d.Lk) mywords[sub] = d.drop_rows[word_row + (qr < d.Lq ? qr : d.Lq - 1)];
             }
         }
-        if (decltype(FULLT)::value || t + NSET < ntiles) { qr.load(Qp, q0 + NSET * QT, d.Lq, d.q_rs, tid); gr.load(dOp, q0 + NSET * QT, d.Lq, d.o_rs, tid); }
-        if (kblk + wave * 32 >= d.Lk) return;        // tail k-block: this wave has no live key, it only stages
+        if (q0 + QT < d.Lq) { qreg.load(Qp, q0 + QT, d.Lq, d.q_rs, tid); greg.load(dOp, q0 + QT, d.Lq, d.o_rs, tid); }
+        if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
             // 32-query half beyond Lq, or (causal) entirely before this wave's first key: P == dS == 0
@@ -421,16 +404,6 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
             accum_mma<T, D, QT>(Grow, sub, s, dv, fa, l31, hi);               // dV^T[d, kv] += dO^T . P
             accum_mma<T, D, QT>(Qrow, sub, ds, dk, fa, l31, hi);              // dK^T[d, kv] += Q^T . dS
         }
-    };
-    if constexpr (NSET == 2) {
-        int t = 0;
-        for (; t + 4 <= ntiles; t += 2) { tile_step(t, qreg[0], greg[0], std::true_type{}); tile_step(t + 1, qreg[NSET - 1], greg[NSET - 1], std::true_type{}); }
-        for (; t < ntiles; t += 2) {
-            tile_step(t, qreg[0], greg[0], std::false_type{});
-            if (t + 1 < ntiles) tile_step(t + 1, qreg[NSET - 1], greg[NSET - 1], std::false_type{});
-        }
-    } else {
-        for (int t = 0; t < ntiles; ++t) tile_step(t, qreg[0], greg[0], std::false_type{});
     }
     if (kv < d.Lk) {
         store_T_acc<T, D>(dKp + (int64_t)kv * d.k_rs, dk, d.scale, hi);

@@ -16,9 +16,6 @@
 #pragma once
 #include "p3_common.h"
 
-#ifndef P3_ATTN_PF2
-#define P3_ATTN_PF2 1      // 0: one staging register set in the attention kernels (build-time A/B of the two-deep K / V prefetch, tools/build_variant.sh)
-#endif
 
 namespace p3attn {
 

@@ -98,7 +98,16 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
         for (int a = 0; a < RA; ++a) ur[a] = 0.f;
         const float mu = 1.f / (float)(m + n), mu_last = (float)n / (float)(m + n), nu_last = (float)m / (float)(m + n);
         const int rc = tid >> 2, rp = tid & 3;               // the column this thread helps to reduce, and its part of the 64 partials
+        // per-row / per-column marginals with the validity folded in: an invalid row has E = 0 (sum 0), marginal 0 and pad 1 -> U = 0 * rcp(1),
+        // no select in the loop.  U = mu * rcp(sum): v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the iteration is a
+        // contraction, the tests hold Z + u + v to 1e-5 of the oracle.
+        float mua[RA], pada[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) { const int i = ty + 64 * a; mua[a] = i < m ? mu : (i < M1 ? mu_last : 0.f); pada[a] = i < M1 ? 0.f : 1.f; }
+        const float nuc = rc < n ? mu : (rc < N1 ? nu_last : 0.f), padc = rc < N1 ? 0.f : 1.f;
         for (int it = 0; it < iters; ++it) {
+            // the duals the backward pass reads are stored in the LINEAR domain (U_i, V_j) for a tile on this path: its backward kernel
+            // (sinkhorn_bwd_fast_kernel makes the same per-tile decision) needs exactly these - the log / exp round trip is gone
             float* h = uv_hist ? uv_hist + ((int64_t)b * iters + it) * (M1 + N1) : nullptr;
             // U_i = mu_i / sum_j E_ij V_j: the 16 lanes of a DPP row share the row, every lane ends with the same U_i
 #pragma unroll
@@ -107,9 +116,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
 #pragma unroll
                 for (int bb = 0; bb < CB; ++bb) p = fmaf(e[a][bb], vr[bb], p);
                 p = sk::row16_sum(p);
-                const int i = ty + 64 * a;
-                ur[a] = i < M1 ? (i < m ? mu : mu_last) / p : 0.f;
-                if (h && tx == 0 && i < M1) h[i] = __logf(ur[a]) - rmx[a];        // the backward pass reads log-domain duals
+                ur[a] = mua[a] * __builtin_amdgcn_rcpf(p + pada[a]);
+                if (h && tx == 0 && pada[a] == 0.f) h[ty + 64 * a] = ur[a];
             }
             // V_j = nu_j / sum_i E_ij U_i
             float q[CB];
@@ -121,10 +129,10 @@ __global__ __launch_bounds__(1024) void sinkhorn_kernel(const float* __restrict_
                 q[bb] = t;
             }
             const float cs = sk::col_reduce<CB>(P, q, tid, N1);
+            const float vn = nuc * __builtin_amdgcn_rcpf(cs + padc);
             if (rp == 0 && rc < N1) {
-                const float vn = (rc < n ? mu : nu_last) / cs;
                 v[rc] = vn;
-                if (h) h[M1 + rc] = __logf(vn);
+                if (h) h[M1 + rc] = vn;
             }
             sk::lds_barrier();
 #pragma unroll

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
     const float norm = -logf((float)(m + n));
     const float b_last = logf((float)m) + norm;
     const float inv_mu = (float)(m + n), inv_mu_last = (float)(m + n) / (float)n;      // 1 / exp(log_mu)
+    const float inv_nu_last = (float)(m + n) / (float)m;
     __syncthreads();
     {   // row maxima / spread test (same rule as the forward kernel)
         float mx = -INFINITY, mn = INFINITY;
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
         }
         float cj = 1.f;
         if (rc < N1) {
-            const float bj = __expf(hv - (rc < n ? norm : b_last)) * dvj;
-            if (t > 1) cj = __expf(hvp);                                                               // v_0 = 0
+            const float bj = hv * (rc < n ? inv_mu : inv_nu_last) * dvj;        // the forward's linear-domain duals: V_j / nu_j * dv_j
+            if (t > 1) cj = hvp;                                                 // V of the previous iteration (V_0 = 1)
             if (rp == 0) { Bl[rc] = bj; vs[2 * M1 + rc] = bj; vs[2 * M1 + N1 + rc] = cj; }
         }
         sk::lds_barrier();                  // also separates this iteration's slab use from the previous one's
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_fast_kernel(const float* __
 #pragma unroll
             for (int bb = 0; bb < CB; ++bb) sacc = fmaf(e[a][bb], br[bb], sacc);
             sacc = sk::row16_sum(sacc);
-            const float ai = __expf(hu[a] + rmx[a]);
+            const float ai = hu[a];                        // A_i = exp(u_i + rowmax_i) = U_i, stored as such by the forward
             const float du = -ai * sacc;
             dr[a] = i < M1 ? ai * (i < m ? inv_mu : inv_mu_last) * du : 0.f;
             if (tx == 0 && i < M1) { vs[i] = ai; vs[M1 + i] = dr[a]; }
