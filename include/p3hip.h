@@ -62,10 +62,12 @@ int p3_set_deterministic(void* scratch, int64_t bytes, int all_dtypes);
 int p3_get_deterministic(void);
 /* More than one launch stream (r04: the independent branches of model_pix2poly.py:256-264 - scorenet1 || scorenet2 - the weight-gradient
  * GEMMs and the pillar stem beside the patch embedding, early_fusion_vit.py:99-100, may be enqueued on side streams): the scratch is cut
- * into `n` equal regions (p3_scratch_regions, before or after p3_set_deterministic) and the caller names the stream of the launches that
- * follow with p3_scratch_stream (returns the region index the stream was given in first-come order, -1 = none left: those launches take
- * their atomics path).  Single-threaded like the rest of the library. */
+ * into `n` equal regions (p3_scratch_regions, before or after p3_set_deterministic).  Region 0 serves every stream that is not registered
+ * (default stream, hipGraph capture streams); p3_scratch_side_stream registers a side stream (returns its region 1 .. 15) and
+ * p3_scratch_stream names the stream of the launches that follow (returns the region, -1 = a side stream beyond the region count: those
+ * launches take their atomics path).  Single-threaded like the rest of the library. */
 int p3_scratch_regions(int n);
+int p3_scratch_side_stream(void* stream);
 int p3_scratch_stream(void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -126,13 +128,12 @@ typedef struct {
                            * without bounds checks; conv_H / conv_W stay the OUTPUT size */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
-/* The 256 x 256-tile kernel behind p3_gemm for wide plain bf16 products (csrc/gemm8.hip: 8 waves, LDS-DMA staging, phased K loop), callable
- * directly for A/B measurements: same descriptor, P3_EUNSUP when the problem is not eligible (plain bf16 A, K % 64 == 0, N % 8 == 0,
- * 16-byte aligned rows, no column sums).  structure: 0 four two-barrier phases per K-tile, 1 the same with the two wave groups one barrier apart,
- * 2 one barrier per K-tile, < 0 chosen by K; 3 .. 6 = the 128 x 128-tile LDS-DMA kernel (csrc/gemm_dma.hip; 3: 32-deep slices, three in LDS,
- * 4: 64-deep, two, 5: 32-deep, four, 6: 32-deep, two = 4 workgroups / CU), 7 / 8 its persistent wave-specialised form, 9 a 128 x 384 tile with 8 waves), which p3_gemm itself picks from M = 2048 on (N = 384 and K >= 1024: 9;
- * other K >= 1024: 4; K <= 512 and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in ascending k order: bit-identical outputs. */
-int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, void* stream);
+/* The LDS-DMA kernels behind p3_gemm for the plain bf16 products (csrc/gemm_dma.hip), callable directly for A/B measurements and parity tests: same
+ * descriptor, P3_EUNSUP when the problem is not eligible (plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums).  variant 4: 128 x 128
+ * tile, 64-deep slices, two in LDS; 6: 32-deep, two = 4 workgroups / CU; 9: 128 x 384 tile with 8 waves.  p3_gemm itself picks them from M = 2048 on (N = 384
+ * and K >= 1024: 9; other K >= 1024: 4; K <= 512 and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in
+ * ascending k order as the register-staged kernel: bit-identical outputs. */
+int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim:  y = (x - mean) / sqrt(var + eps) * gamma + beta

@@ -243,16 +243,12 @@ extern "C" int p3_tokens_assemble_bwd(const float* dx, const void* src, int src_
     hipStream_t s = (hipStream_t)stream;
     // rows per workgroup (P3_ASM_RPB): fewer rows = more same-address atomics on the per-channel sums, more rows = a longer serial walk per
     // workgroup; measured 8: 200 us, 16: 125, 32: 94, 64: 99, 128: 142, 192: 205
-    static int rpb_env = -1;
-    if (rpb_env < 0) { const char* e = getenv("P3_ASM_RPB"); rpb_env = e ? atoi(e) : 0; }
-    // r03: with the partial sums going through the scratch slab (no atomics) short walks win: 16 rows per workgroup (P3_ASM_SLAB=0: atomics, 48 rows)
-    static int slab_env = -1;
-    if (slab_env < 0) { const char* e = getenv("P3_ASM_SLAB"); slab_env = (e && e[0] == '0') ? 0 : 1; }
-    int rpb = rpb_env > 0 ? rpb_env : 48;
+    // r03: with the partial sums going through the scratch slab (no atomics) short walks win: 16 rows per workgroup (no scratch: atomics, 48 rows)
+    int rpb = 48;
     float* slab = nullptr;
     int64_t slab_floats = 0;
-    if (scale && slab_env) {
-        const int rpb_s = rpb_env > 0 ? rpb_env : 16;
+    if (scale) {
+        const int rpb_s = 16;
         const int64_t nb = p3_ceil_div((int64_t)B * np, rpb_s);
         slab_floats = nb * 2 * D;
         slab = p3_reduce_scratch(slab_floats + p3_ceil_div(nb, 128) * 2 * D);

@@ -13,14 +13,16 @@
 static float* g_det = nullptr;
 static int64_t g_det_floats = 0;          // floats of ONE region
 static int g_det_all = 0;
-// Launch streams: the scratch is cut into equal regions, one per stream that launches through the library (r04: ScoreNet 2 / the weight-gradient
-// GEMMs / the pillar stem may run on side streams beside the main one).  The host names the stream of the launches that follow
-// (p3_scratch_stream, called by the binding whenever its current stream changes); a stream beyond the region count gets no scratch
-// (its launches take their atomics path).  One region and one stream = the r03 behaviour.
+// Launch streams: the scratch is cut into equal regions: region 0 serves every stream that was not registered as a SIDE stream (the default
+// stream, and the capture stream torch.cuda.graph() runs a step on - r04: keying regions on "streams in first-come order" sent the captured
+// step's launches to a region that did not exist, i.e. silently back to the atomics paths: ln_bwd 34 -> 55 us), region 1 + i the i-th registered
+// side stream (r04: ScoreNet 2 / the weight-gradient GEMMs / the pillar stem may run beside the main stream, ops.SIDE).  The host names the
+// stream of the launches that follow (p3_scratch_stream, called by the binding whenever its current stream changes); a side stream beyond the
+// region count gets no scratch (its launches take their atomics path).
 static int g_regions = 1, g_region = 0;
 static int64_t g_total_floats = 0;
-static void* g_streams[16];
-static int g_nstreams = 0;
+static void* g_side[15];
+static int g_nside = 0;
 
 extern "C" int p3_set_deterministic(void* scratch, int64_t bytes, int all_dtypes) {
     P3_CHECK((scratch == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)scratch % 16) == 0, P3_EINVAL,
@@ -39,12 +41,19 @@ extern "C" int p3_scratch_regions(int n) {
     return P3_OK;
 }
 
+extern "C" int p3_scratch_side_stream(void* stream) {
+    for (int i = 0; i < g_nside; ++i)
+        if (g_side[i] == stream) return i + 1;
+    P3_CHECK(g_nside < 15, P3_EINVAL, "p3_scratch_side_stream: too many side streams");
+    g_side[g_nside++] = stream;
+    return g_nside;
+}
+
 extern "C" int p3_scratch_stream(void* stream) {
-    for (int i = 0; i < g_nstreams; ++i)
-        if (g_streams[i] == stream) { g_region = i; return i; }
-    if (g_nstreams < 16) { g_streams[g_nstreams] = stream; g_region = g_nstreams; return g_nstreams++; }
-    g_region = 16;
-    return -1;
+    g_region = 0;
+    for (int i = 0; i < g_nside; ++i)
+        if (g_side[i] == stream) { g_region = i + 1; break; }
+    return g_region < g_regions ? g_region : -1;
 }
 
 extern "C" int p3_get_deterministic(void) { return g_det ? (g_det_all ? 2 : 1) : 0; }
@@ -134,8 +143,7 @@ int p3_det_reduce2(const float* parts, int nparts, int64_t stride, float* tmp, f
     const float* src = parts;
     int n = nparts;
     int64_t st = stride;
-    static int one_level = -1;                      // parts up to which one 16-lane pass does it (P3_DET_1LVL; r03 A/B on the LayerNorm partials)
-    if (one_level < 0) { const char* e = getenv("P3_DET_1LVL"); one_level = e ? atoi(e) : 16 * CH; }
+    constexpr int one_level = 16 * CH;              // parts up to which one 16-lane pass does it (r03 A/B on the LayerNorm partials)
     if (nparts > one_level) {
         const int nch = (nparts + CH - 1) / CH;
         hipLaunchKernelGGL(det_reduce_chunk_kernel, dim3((nvals + 63) / 64, nch), dim3(256), 0, s, parts, nparts, stride, tmp, nvals, CH);

@@ -23,7 +23,6 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
     float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2 row halves][2][N] partials of (colsum, colsumsq) instead of atomics
-    int col_major;      // STATS walk: tiles in column-major order (every workgroup of the chip on ONE column panel of W at a time)
     float* tile_stats;  // non-STATS launch that still owes BatchNorm column sums: [tiles_m][2 row halves][2][N] per-tile partials (see launch_bk)
 };
 
@@ -200,23 +199,6 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
     // STATS mode: gridDim.x is a multiple of tiles_n, so tn stays fixed along a workgroup's walk
     const int bid = STATS ? vb : xcd_remap(vb, ntiles);
     int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
-    if constexpr (STATS) {
-        // col_major (a weight matrix larger than one XCD's L2: the fusion conv's 5.3 MB): all resident workgroups sit on the same 128-column
-        // panel of W, which then stays in every L2 (r02 PMC: 2.14 GB fetched per launch in row-major order, the panels evicting each other);
-        // the A rows are read once per panel instead.  A workgroup's walk then crosses panels: its column sums are flushed at the crossing.
-        if (g.col_major) {
-            tn = bid / g.tiles_m; tm = bid - tn * g.tiles_m;
-            if (tn != tn_stats && vb != (int)blockIdx.x) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = tn_stats * BN + wn * 64 + j * 32 + l31;
-                    const float s1 = cs1[j] + __shfl_xor(cs1[j], 32, 64), s2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-                    if (hi == 0 && col < d.N) { atomicAdd(d.colsum + col, s1); atomicAdd(d.colsumsq + col, s2); }
-                    cs1[j] = 0.f; cs2[j] = 0.f;
-                }
-            }
-        }
-    }
     tn_stats = tn;
     RowSrc arow[NPASS];
     int64_t wrow[NPASS];
@@ -667,12 +649,8 @@ int launch_bk2(const GemmArgs& g, hipStream_t s) {
     GemmArgs gs = g;
     const int nparts = 2 * (nwg / g.tiles_n);       // two row halves (wave rows) per workgroup
     if (STATS) gs.stat_slab = (nwg % g.tiles_n == 0) ? p3_det_scratch((int64_t)nparts * 2 * g.d.N, g.d.dtype_in) : nullptr;
-    // column-major walk when W (N x K) cannot stay in a 4 MB L2 next to the A stream; the deterministic (slab) form keeps the row-major walk.
-    // P3_GEMM_COLMAJOR=1 switches it on: measured on the fusion conv (r03, rocprofv3 same box) 408 us row-major vs 423 us column-major - the
-    // weight re-fetch the PMC pass shows (2.1 GB per launch) is served by the MALL and is not what bounds the launch; default off.
-    static int cm_env = -1;
-    if (cm_env < 0) { const char* e = getenv("P3_GEMM_COLMAJOR"); cm_env = (e && e[0] == '1') ? 1 : 0; }
-    gs.col_major = (STATS && cm_env && !gs.stat_slab && g.tiles_n > 1 && (int64_t)g.d.N * g.d.K * (int)sizeof(T) > (3ll << 20)) ? 1 : 0;
+    // (a column-major tile walk for weight matrices larger than one XCD's L2 - the fusion conv's 5.3 MB - measured SLOWER, 408 -> 423 us: the
+    // re-fetch the PMC pass shows is served by the MALL and does not bound the launch; r03, removed in r04)
     {
     const GemmArgs& g = gs;
     switch (g.d.a_mode) {
@@ -699,12 +677,10 @@ int launch_bk(const GemmArgs& g, hipStream_t s) {
     // BatchNorm column sums.  Preferred form (r03): the ordinary one-tile-per-workgroup kernel (3 workgroups / CU, single-pass bf16 epilogue)
     // writes per-tile, per-row-half partial sums into the registered scratch and a two-level fixed-order float64 reduction adds them -
     // tools/mb_sn_fwd.py: the persistent register-resident form below costs 573 vs 431 us (ScoreNet conv2) and 391 vs 215 us (conv3) over the
-    // same product without sums.  Also bit-reproducible in bf16.  P3_GEMM_TILESTATS=0, or no / too small a scratch: the persistent form.
-    static int ts_env = -1;
-    if (ts_env < 0) { const char* e = getenv("P3_GEMM_TILESTATS"); ts_env = (e && e[0] == '0') ? 0 : 1; }
+    // same product without sums.  Also bit-reproducible in bf16.  No / too small a scratch: the persistent form.
     const int nparts = g.tiles_m * 2, nch = (nparts + 127) / 128;
     const int64_t slab_f = (int64_t)nparts * 2 * g.d.N;
-    float* scratch = ts_env ? p3_reduce_scratch(slab_f + (int64_t)nch * 2 * g.d.N) : nullptr;
+    float* scratch = p3_reduce_scratch(slab_f + (int64_t)nch * 2 * g.d.N);
     if (!scratch) return launch_bk2<T, TO, BKSEL, true>(g, s);
     GemmArgs gt = g;
     gt.tile_stats = scratch;
@@ -717,12 +693,9 @@ int launch_bk(const GemmArgs& g, hipStream_t s) {
 template <typename T, typename TO>
 int launch_mode(const GemmArgs& g, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        static int force = -1;                        // P3_GEMM_BK=32|64 forces one variant (A/B sweeps)
-        if (force < 0) { const char* e = getenv("P3_GEMM_BK"); force = e ? atoi(e) : 0; }
         const bool conv = g.d.a_mode == P3_A_CONV3X3 || g.d.a_mode == P3_A_CONV3X3_AFFINE_RELU;
         const bool can64 = g.d.K % 64 == 0 && (!conv || g.d.conv_C % 64 == 0);
-        const int thr = force > 64 ? force : (force == 64 ? 0 : 2047);   // P3_GEMM_BK=<threshold>: BK = 64 only for K above it
-        const bool deep = force == 32 ? false : (can64 && g.d.K > thr);
+        const bool deep = can64 && g.d.K >= 2048;       // 64-deep K slices from K = 2048 on (r01 sweep)
         return deep ? launch_bk<T, TO, 64>(g, s) : launch_bk<T, TO, 32>(g, s);
     } else {
         return launch_bk<T, TO, 16>(g, s);
@@ -731,26 +704,18 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
-// gemm8.hip: 256 x 256 tile, LDS-DMA, phased K loop
-int p3_gemm8_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
-int p3_gemm8_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, hipStream_t s);
-// gemm_dma.hip: 128 x 128 tile, LDS-DMA, 2 - 3 workgroups / CU (variants 3 / 4 / 5)
+// gemm_dma.hip: LDS-DMA kernels for the plain bf16 products (variant 4: 128 x 128 tile, 64-deep slices, two in LDS; 6: 32-deep, two = 4 workgroups / CU;
+// 9: 128 x 384 tile, 8 waves)
+int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
-static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = e ? atoi(e) : 1; } return m; }
+static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
 
-// P3_GEMM8: 0 (default) never, 1 by the shape rule below, 2 whenever eligible (A/B sweeps); P3_GEMM8_STRUCT=0|1|2 forces a loop structure.
-// Default OFF: same-box A/B of the whole train step (r03): 42.55 ms without, 43.35 ms with it - on the path's shapes (K = 384 .. 1536, output
-// 116 - 154 MB per launch) a tile's life is bounded by its epilogue and HBM, not by the K loop the 256^2 structure speeds up (8192^3: 1097 vs
-// 880 TF); profiles/r03_g8_probe.txt has the ablation (epilogue + prologue alone = 26 of 67 us on the qkv shape).
-static int gemm8_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM8"); m = e ? atoi(e) : 0; } return m; }
-static int gemm8_struct() { static int m = -2; if (m < -1) { const char* e = getenv("P3_GEMM8_STRUCT"); m = e ? atoi(e) : -1; } return m; }
-
-extern "C" int p3_gemm8(const void* A, const void* W, void* C, const p3_gemm_desc* d, int structure, void* stream) {
-    P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm8: null pointer");
-    P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm8: empty problem");
-    P3_CHECK(p3_gemm8_eligible(d, A, W, C), P3_EUNSUP, "p3_gemm8: plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums");
-    if (structure >= 3) return p3_gemm_dma_launch(A, W, C, d, structure, (hipStream_t)stream);
-    return p3_gemm8_launch(A, W, C, d, structure, (hipStream_t)stream);
+extern "C" int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream) {
+    P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm_dma: null pointer");
+    P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm_dma: empty problem");
+    P3_CHECK(variant == 4 || variant == 6 || variant == 9, P3_EINVAL, "p3_gemm_dma: variant 4, 6 or 9");
+    P3_CHECK(p3_gemm_dma_eligible(d, A, W, C), P3_EUNSUP, "p3_gemm_dma: plain bf16 A, K % 64 == 0, N % 8 == 0, 16-byte aligned rows, no column sums");
+    return p3_gemm_dma_launch(A, W, C, d, variant, (hipStream_t)stream);
 }
 
 extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
@@ -777,7 +742,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
     P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
     GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.col_major = 0; g.tile_stats = nullptr;
+    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.tile_stats = nullptr;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
     {
@@ -788,35 +753,15 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
-        // P3_GEMM_DMA: 0 never, 1 (default; same-box A/B of the train step r03: 40.60 -> 40.15 ms) by shape (tools/mb_gemm8.py: the 64-deep two-slice form from K = 1024 on - fc2, dX of fc1 / qkv, decoder
-        // linear2: 74 vs 87, 59 vs 67, 33 vs 42 us; the 32-deep two-slice form, 4 workgroups / CU, on wide outputs with K <= 512 - qkv, fc1,
-        // dX of fc2, linear1: 66 vs 69, 86 vs 92, 44 vs 45 us; everything else stays on the register-staged kernel), >= 3 that variant always
-        const int m = gemm_dma_mode();
-        int v = m >= 3 ? m : (d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0));
-        // 384-column outputs from K = 1024 on (fc2, dX of fc1 / qkv): the 128 x 384 tile - 393 workgroups = ONE resident round instead of 2.3 rounds of
-        // 128 x 128 tiles; same-box step 39.79 -> 38.78 ms (r03).  P3_GEMM_DMA=2: the rule without it.
-        if (m == 1 && d->N == 384 && d->K >= 1024) v = 9;
-        if (m == 2) v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
-        if (m == 13) { v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0); if (d->N == 384 && d->K >= 1024) v = 9; if (d->N == 512 && d->K <= 512) v = 6; }   // A/B: + kv_mem on 4 / CU
-        if (m == 12) { v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0); if ((d->N == 384 && d->K >= 1024) || d->N == 768) v = 9; }   // A/B: + N = 768
-        if (m == 10 || m == 11) {                                                // A/B: + the 128 x 384 tile for the 384-column outputs (11: proj too)
-            v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
-            if (d->N == 384 && (d->K >= 1024 || m == 11)) v = 9;
-        }
-        if (m == 7) v = d->K >= 1024 ? 4 : 0;                                   // A/B: only the deep-K rule
-        if (m == 8) v = (d->K <= 512 && d->N >= 1024) ? 6 : 0;                  //      only the wide-output rule
-        if (m == 9) v = d->K >= 1024 ? (d->dtype_out == P3_BF16 ? 4 : 0) : (d->K <= 512 && d->N >= 1024 ? 6 : 0);   // deep K only with bf16 output
+    if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm_dma_eligible(d, A, W, C)) {
+        // P3_GEMM_DMA=0 switches the rule off (everything on the register-staged kernel).  The rule (r03, tools/mb_gemm_shapes.py + same-box A/B of the
+        // train step 40.60 -> 40.15 -> 38.78 ms): the 64-deep two-slice form from K = 1024 on (dX of fc1 / qkv, decoder linear2: 74 vs 87, 59 vs 67, 33 vs
+        // 42 us); the 32-deep two-slice form, 4 workgroups / CU, on wide outputs with K <= 512 (qkv, fc1, dX of fc2, linear1: 66 vs 69, 86 vs 92, 44 vs 45 us);
+        // the 128 x 384 tile for the 384-column outputs from K = 1024 on (fc2, dX of fc1 / qkv: 393 workgroups = ONE resident round instead of 2.3 rounds
+        // of 128 x 128 tiles); everything else stays on the register-staged kernel.
+        int v = d->K >= 1024 ? 4 : (d->K <= 512 && d->N >= 1024 ? 6 : 0);
+        if (d->N == 384 && d->K >= 1024) v = 9;
         if (v) return p3_gemm_dma_launch(A, W, C, d, v, s);
-    }
-    if (gemm8_mode() > 0 && d->M >= 2048 && p3_gemm8_eligible(d, A, W, C)) {
-        // where it measured faster than the 128^2 kernel (tools/mb_gemm8.py, profiles/r03_mb_gemm8.txt): the ViT's wide products (N >= 1152:
-        // qkv, fc1, dX of fc2; <= 12 % padding columns) and from K = 1024 on also its 384-column ones (fc2, dX of fc1 / qkv); the decoder's
-        // shapes (M = 24640 / 50176, K = 256 or N = 256) stay on the 128^2 kernel, which is up to 1.5x faster there
-        const int tn = (d->N + 255) / 256;
-        const bool fits = tn * 256 * 8 <= d->N * 9 || d->N == 384;
-        const bool win = d->M >= 32768 && fits && ((d->N >= 1152 && d->K >= 384) || (d->N >= 384 && d->K >= 1024));
-        if (gemm8_mode() >= 2 || win) return p3_gemm8_launch(A, W, C, d, gemm8_struct(), s);
     }
     static int no_skinny = -1;                        // P3_NO_SKINNY=1: A/B switch
     if (no_skinny < 0) { const char* e = getenv("P3_NO_SKINNY"); no_skinny = (e && e[0] == '1') ? 1 : 0; }

@@ -13,7 +13,9 @@
 //   * NBUF slices in LDS, NBUF - 1 in flight: iteration kt waits (counted vmcnt) for this wave's pieces of slice kt, one barrier makes the
 //     whole slice readable and proves that slice kt - 1 has been consumed by every wave, then slice kt + NBUF - 1 is issued into that buffer;
 //   * epilogue = gemm8.hip's: wave-private fp32 staging of 32 x 64 blocks, whole 8-column chunks, 16-byte accesses.
-// BK = 32, NBUF = 3: 48 KB -> 3 workgroups / CU;  BK = 64, NBUF = 2: 64 KB -> 2 workgroups / CU.
+// Shipped instantiations: BK = 64, NBUF = 2 (64 KB -> 2 workgroups / CU) for K >= 1024; BK = 32, NBUF = 2 (36 KB -> 4 workgroups / CU) for wide outputs with
+// K <= 512.  (Measured and dropped, r03: three / four 32-deep slices, a persistent wave-specialised form - tools/probe/gemm_ws_kernel.hip.txt - and the
+// 256 x 256 tile of tools/probe/gemm8_probe.hip.)
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -25,8 +27,8 @@ struct GDArgs {
     const bf16_t* A; const bf16_t* W; void* C;
     p3_gemm_desc d;
     int tiles_m, tiles_n;
-    long long* timeline;        // diagnostic (P3_GD_TIMELINE=<device address>, tools/mb_gemm_dma_timeline.py): per workgroup {start, first slice readable, loop end, end} at 100 MHz + HW_ID + XCC_ID
-    int ablate;                 // diagnostic (P3_GD_ABLATE, tools/mb_gemm8.py): 1 no C / aux stores, 2 no MFMAs, 4 only the first slices are loaded
+    long long* timeline;        // diagnostic (-DP3_GD_DIAG build, P3_GD_TIMELINE=<device address>, tools/mb_gemm_dma_timeline.py): per workgroup {start, first slice readable, loop end, end} at 100 MHz + HW_ID + XCC_ID
+    int ablate;                 // diagnostic (-DP3_GD_DIAG build, P3_GD_ABLATE): 1 no C / aux stores, 2 no MFMAs, 4 only the first slices are loaded
 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -252,157 +254,6 @@ __global__ __launch_bounds__(256, BK == 32 ? (NBUF == 2 ? 4 : 3) : 2) void gemm_
     GD_T(3);
 }
 
-// ---- persistent, wave-specialised form (variant 7 / 8) --------------------------------------------------------------------------------
-// What the per-workgroup timeline of the kernel above shows on the path's wide products (profiles/r03_gemm_dma_timeline.txt; fc1: life
-// 16.9 us = 1.2 first slice + 9.1 K loop + 6.4 epilogue, of which ~5 us is s_endpgm's implicit wait for the store acknowledgements): a
-// third of every workgroup slot's time holds registers and LDS for stores that are already on their way.  A persistent workgroup cannot
-// simply start its next tile instead: gfx950 counts loads and stores in ONE vmcnt and retires them out of order with respect to each other,
-// so the first counted wait of the next tile's loads would wait for the previous tile's stores as well.  Hence two kinds of waves:
-//   * wave 4, the LOADER, issues every LDS-DMA of the workgroup (16 instructions per 32-deep slice) and is the only wave that waits on
-//     vmcnt - its counter holds loads only, so the counted in-order wait stays exact; slices run on across tile boundaries (no prologue bubble);
-//   * waves 0-3, the COMPUTE waves (2 x 2, 64 x 64 each), meet the loader at one barrier per slice, read fragments, multiply, and at the end
-//     of a tile stage 16-row blocks through a PRIVATE LDS image and issue the stores - they never wait for them (their bias loads are issued
-//     at the start of the tile, a K loop before their first use), so the acknowledgements arrive behind the next tile's K loop.
-// LDS: NBUF-slice ring (16 KB each) + 4 x 4.5 KB epilogue images = 66 KB for NBUF = 3: two workgroups per CU, grid = 2 x CUs (or the tile count).
-// MEASURED (profiles/r03_mb_gemm_dma.txt): correct and race-free, and SLOWER than the one-tile-per-workgroup form - fc1 115 vs 90 us, qkv 82 vs 69,
-// 8192^3 664 vs 721 TF.  The K loop of every 128 x 128 variant is bound by the bytes in flight per CU (global -> LDS latency ~1.1 us under
-// load, <= 100 KB of ring / staging registers per CU): two persistent workgroups keep 64 KB in flight where four short-lived ones keep 64 KB
-// AND overlap four epilogues; hiding the store acknowledgements does not pay for the lost residency.  Kept callable (p3_gemm8 structure 7 / 8)
-// with its parity test; p3_gemm never picks it.
-template <typename TO, int NBUF>
-__global__ __launch_bounds__(320, 2) void gemm_ws_kernel(GDArgs g) {
-    constexpr int BK = 32, CPR = 4, TILE_U4 = 128 * CPR, LA = NBUF - 1, KK = 2;
-    constexpr int RING_U4 = NBUF * 2 * TILE_U4;
-    constexpr int EPR = 16, EP = 72, EPI_U4 = EPR * EP * 4 / 16;             // per compute wave: [16][72] fp32
-    __shared__ __attribute__((aligned(1024))) uint4 lds[RING_U4 + 4 * EPI_U4];
-    const p3_gemm_desc& d = g.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    const int ntiles = g.tiles_m * g.tiles_n, G = gridDim.x;
-    const int L = xcd_remap(blockIdx.x, G);            // logical id: the workgroups of one XCD walk consecutive tiles (one A row panel) at any time
-    const int n_my = L < ntiles ? (ntiles - L + G - 1) / G : 0;
-    const int nk = d.K / BK, total = n_my * nk;
-    if (wave == 4) {
-        // ------------------------------------------------------------------------------------------------ loader
-        const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(&lds[0]));
-        auto dma2 = [&](const bf16_t* base, uint32_t dst, uint32_t v0, uint32_t v1) __attribute__((always_inline)) {
-            uint32_t keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep) : "v"(v0), "v"(v1), "s"(base), "s"(dst) : "memory");
-        };
-        uint32_t voffA[8], voffB[8];
-        int it = 0, kt = 0, sl = 0;                     // issue pointer: tile iteration, slice of the tile, ring slot
-        auto issue = [&]() __attribute__((always_inline)) {
-            if (kt == 0) {
-                const int t = L + it * G, tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int rr = q * 16 + (lane >> 2), slot = lane & 3, c = slot ^ ((rr >> 2) & 3);
-                    const int ra = min(tm * 128 + rr, d.M - 1), rb = min(tn * 128 + rr, d.N - 1);
-                    voffA[q] = (uint32_t)(((int64_t)ra * d.lda + c * 8) * 2);
-                    voffB[q] = (uint32_t)(((int64_t)rb * d.ldb + c * 8) * 2);
-                }
-            }
-            const bf16_t* ab = g.A + (int64_t)kt * BK;
-            const bf16_t* wb = g.W + (int64_t)kt * BK;
-            const uint32_t da = lds_addr + (uint32_t)((sl * 2 + 0) * TILE_U4 * 16), db = lds_addr + (uint32_t)((sl * 2 + 1) * TILE_U4 * 16);
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) dma2(ab, da + q * 0x400, voffA[q], voffA[q + 1]);
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) dma2(wb, db + q * 0x400, voffB[q], voffB[q + 1]);
-            if (++kt == nk) { kt = 0; ++it; }
-            if (++sl == NBUF) sl = 0;
-        };
-        int issued = 0;
-        for (; issued < LA && issued < total; ++issued) issue();
-        for (int s = 0; s < total; ++s) {
-            // slices s + 1 .. may stay in flight: this wave's counter holds loads only (in-order among themselves)
-            const int ahead = min(issued - 1 - s, LA - 1);
-            if (ahead <= 0) wait_vm<0>();
-            else if (ahead == 1) wait_vm<16>();
-            else wait_vm<32>();
-            __builtin_amdgcn_s_barrier();              // slice s readable; every compute wave has consumed slice s - 1 (its ring slot is free)
-            if (issued < total) { issue(); ++issued; }
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------------------------------------- compute waves
-    const int wr = wave >> 1, wc = wave & 1;
-    const int sw = (l31 >> 2) & 3;
-    const int arow = (wr * 64 + l31) * CPR, brow = (wc * 64 + l31) * CPR;
-    float* st = reinterpret_cast<float*>(lds + RING_U4 + wave * EPI_U4);
-    TO* C = reinterpret_cast<TO*>(g.C);
-    TO* aux = reinterpret_cast<TO*>(d.aux);
-    const TO* bwd_saved = reinterpret_cast<const TO*>(d.bwd_saved);
-    const bool has_res = d.residual != nullptr, res_bf = d.dtype_res == P3_BF16, aux_grad = d.aux_mode == 1;
-    const int act = d.act;
-    const DropKey dk = drop_key(d.drop);
-    const int c8 = (lane & 7) * 8, rl0 = lane >> 3;
-    int sl = 0;
-    for (int it = 0; it < n_my; ++it) {
-        const int t = L + it * G, tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-        const int col = tn * 128 + wc * 64 + c8;
-        float bias[8];                                  // issued now, used after the K loop: the wait for them finds the previous tile's stores long retired
-#pragma unroll
-        for (int k = 0; k < 8; ++k) bias[k] = (d.bias && col + k < d.N) ? d.bias[col + k] : 0.f;
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            __builtin_amdgcn_s_barrier();
-            const uint4* abuf = lds + (sl * 2 + 0) * TILE_U4;
-            const uint4* bbuf = lds + (sl * 2 + 1) * TILE_U4;
-            if (++sl == NBUF) sl = 0;
-            uint4 af[2][KK], bfr[2][KK];
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i][kk] = abuf[arow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
-                    bfr[i][kk] = bbuf[brow + i * 32 * CPR + ((2 * kk + hi) ^ sw)];
-                }
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][kk]), __builtin_bit_cast(bf16x8_t, bfr[j][kk]), acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        // epilogue: 16-row blocks (registers 8 * hf .. 8 * hf + 7 of each 32 x 32 block) through the wave's own image; no wait for the stores
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) st[(crow32(8 * hf + r, hi) - 16 * hf) * EP + j * 32 + l31] = acc[ib][j][8 * hf + r];
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int rl = pass * 8 + rl0;
-                    const int row = tm * 128 + wr * 64 + ib * 32 + hf * 16 + rl;
-                    const float4 v0 = *reinterpret_cast<const float4*>(st + rl * EP + c8);
-                    const float4 v1 = *reinterpret_cast<const float4*>(st + rl * EP + c8 + 4);
-                    if (row >= d.M || col >= d.N) continue;
-                    float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
-                    gd_epi8<TO>(d, dk, C, aux, bwd_saved, has_res, res_bf, aux_grad, act, row, col, v);
-                }
-            }
-        }
-    }
-}
-
 // ---- 128 x 384 tile, 8 waves (variant 9): the 384-column outputs of the ViT (proj, fc2, dX of fc1 / qkv) ----------------------------------------
 // M = 50240 makes 393 x 3 = 1179 tiles of 128 x 128: 1.5 resident waves of workgroups at 3 per CU, 2.3 at 2 per CU - the last round runs a
 // third to a half empty.  One workgroup per 128-row panel (393 workgroups: ONE round at 2 per CU) takes all 384 columns: 8 waves as 2 x 4, a wave
@@ -514,24 +365,30 @@ __global__ __launch_bounds__(512, 4) void gemm_dma_n384_kernel(GDArgs g) {
 
 }  // namespace
 
-// variant 3: BK = 32, three slices in LDS (3 workgroups / CU); 4: BK = 64, two slices (2 workgroups / CU); 5: BK = 32, four slices (2 / CU);
-// 6: BK = 32, two slices (36 KB = the epilogue image: 4 / CU).
-// Same eligibility as the 256 x 256 kernel (p3_gemm8_eligible: K % 64 == 0 covers every slice depth here).
+int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C) {
+    if (d->dtype_in != P3_BF16 || d->a_mode != P3_A_PLAIN || d->colsum) return 0;
+    if (d->K % 64 != 0 || d->N % 8 != 0 || d->lda % 8 != 0 || d->ldb % 8 != 0) return 0;
+    const int vo = d->dtype_out == P3_BF16 ? 8 : 4;
+    if (d->ldc % vo != 0 || ((uintptr_t)C % 16) != 0 || ((uintptr_t)A % 16) != 0 || ((uintptr_t)W % 16) != 0) return 0;
+    if (d->aux && (uintptr_t)d->aux % 16 != 0) return 0;
+    if (d->bwd_saved && (uintptr_t)d->bwd_saved % 16 != 0) return 0;
+    if (d->residual) { const int vr = d->dtype_res == P3_BF16 ? 8 : 4; if (d->ldr % vr != 0 || (uintptr_t)d->residual % 16 != 0) return 0; }
+    if ((int64_t)d->M * d->lda * 2 >= (1ll << 31) || (int64_t)d->N * d->ldb * 2 >= (1ll << 31)) return 0;      // 32-bit DMA source offsets
+    return 1;
+}
+
+// variant 4: 128 x 128 tile, BK = 64, two slices in LDS (2 workgroups / CU); 6: BK = 32, two slices (36 KB = the epilogue image: 4 / CU); 9: 128 x 384 tile
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s) {
     GDArgs g;
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.d = *d;
     g.tiles_m = p3_ceil_div(d->M, 128);
     g.tiles_n = p3_ceil_div(d->N, 128);
+    g.ablate = 0; g.timeline = nullptr;
+#ifdef P3_GD_DIAG
     { const char* e = getenv("P3_GD_ABLATE"); g.ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("P3_GD_TIMELINE"); g.timeline = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-    dim3 grid(g.tiles_m * g.tiles_n), block(256);
+#endif
     const bool bf = d->dtype_out == P3_BF16;
-    if (p3_tracing()) {
-        char nm[96];
-        if (variant == 7 || variant == 8) snprintf(nm, sizeof(nm), "gemm_ws_kernel<%s, %d>", bf ? "bf16" : "float", variant == 7 ? 3 : 4);
-        else snprintf(nm, sizeof(nm), "gemm_dma_kernel<%s, %d, %d>", bf ? "bf16" : "float", variant == 4 ? 64 : 32, variant == 5 ? 4 : (variant == 3 ? 3 : 2));
-        p3_note_kernel(nm);
-    }
     if (variant == 9) {
         g.tiles_n = p3_ceil_div(d->N, 384);
         if (p3_tracing()) p3_note_kernel(bf ? "gemm_dma_n384_kernel<bf16>" : "gemm_dma_n384_kernel<float>");
@@ -541,33 +398,18 @@ int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc
         P3_LAUNCH_CHECK();
         return P3_OK;
     }
-    if (variant == 7 || variant == 8) {
-        static int cus = 0;
-        if (cus == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-        const int ntiles = g.tiles_m * g.tiles_n;
-        dim3 pgrid(ntiles < 2 * cus ? ntiles : 2 * cus), pblock(320);
-        if (variant == 7) {
-            if (bf) hipLaunchKernelGGL((gemm_ws_kernel<bf16_t, 3>), pgrid, pblock, 0, s, g);
-            else hipLaunchKernelGGL((gemm_ws_kernel<float, 3>), pgrid, pblock, 0, s, g);
-        } else {
-            if (bf) hipLaunchKernelGGL((gemm_ws_kernel<bf16_t, 4>), pgrid, pblock, 0, s, g);
-            else hipLaunchKernelGGL((gemm_ws_kernel<float, 4>), pgrid, pblock, 0, s, g);
-        }
-        P3_LAUNCH_CHECK();
-        return P3_OK;
+    dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    if (p3_tracing()) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "gemm_dma_kernel<%s, %d, 2>", bf ? "bf16" : "float", variant == 4 ? 64 : 32);
+        p3_note_kernel(nm);
     }
     if (variant == 4) {
         if (bf) hipLaunchKernelGGL((gemm_dma_kernel<bf16_t, 64, 2>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_dma_kernel<float, 64, 2>), grid, block, 0, s, g);
-    } else if (variant == 6) {
+    } else {
         if (bf) hipLaunchKernelGGL((gemm_dma_kernel<bf16_t, 32, 2>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_dma_kernel<float, 32, 2>), grid, block, 0, s, g);
-    } else if (variant == 5) {
-        if (bf) hipLaunchKernelGGL((gemm_dma_kernel<bf16_t, 32, 4>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_dma_kernel<float, 32, 4>), grid, block, 0, s, g);
-    } else {
-        if (bf) hipLaunchKernelGGL((gemm_dma_kernel<bf16_t, 32, 3>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_dma_kernel<float, 32, 3>), grid, block, 0, s, g);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

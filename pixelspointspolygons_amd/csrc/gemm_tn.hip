@@ -429,20 +429,16 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // M-split count (measured r01, tools/mb_tn.py sweep 512..2048): ~768 workgroups (1.5 x the 512 that fit the chip at 2 per CU)
     // balances per-block prologue / atomic-epilogue overhead against tail imbalance: +8..13 % over 1024; exactly one full wave of
     // 512 blocks is better still when the tile count divides it (decoder linear1: 64 vs 82 us).  P3_TN_BLOCKS overrides for sweeps.
-    static int target_blocks = 0;
-    if (target_blocks == 0) { const char* e = getenv("P3_TN_BLOCKS"); target_blocks = e ? atoi(e) : -1; if (target_blocks == 0) target_blocks = -1; }
     // same-box sweep r01: 600 -> 60.1 ms, 700 -> 59.6, 768 -> 59.6, 850 -> 59.3, 950 -> 59.3; r03 (two-deep prefetch since r02, every split costs
     // N x K fp32 atomics whose lines migrate between the XCDs' L2s - 15 us of the 70 us mean launch, P3_DETERMINISTIC=2 A/B): 512 -> 39.59 ms,
     // 576 -> 39.47, 640 -> 39.05, 704 -> 39.00, 768 -> 39.39, 896 -> 39.34, 1024 -> 39.91
     // r03, second sweep (the first never went below 512): the best grids are the ones that fit ONE resident wave of workgroups (2 per CU = 512) -
     // 320 -> 40.48 ms, 352 -> 40.11, 384 -> 39.89, 416 -> 39.59, 448 -> 39.41, 480 -> 39.55, 704 -> 40.33 (same box); per shape (tools/mb_tn_sweep.py)
     // qkv 82 us at 405 workgroups, 105 at 513 (one past the wave), 93 at 704
-    const int tgt = target_blocks > 0 ? target_blocks : 448;
-    static int rule512 = -1;                         // P3_TN_RULE512=0: A/B switch of the exact-wave rule below
-    if (rule512 < 0) { const char* e = getenv("P3_TN_RULE512"); rule512 = (e && e[0] == '0') ? 0 : 1; }
+    const int tgt = 448;
     // (measured and dropped: outputs of <= 8 tiles - the decoder's 256 x 256 projections, the head - run 18.5 instead of 27.7 us ALONE with ~192
     // instead of 512 workgroups, tools/mb_tn_sweep.py, but the captured step got 0.2 ms slower with that rule: 39.93 vs 39.72 ms, same box)
-    int splits = (rule512 && 512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
+    int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
     if (tgt <= 512 && splits > 1 && splits * tiles > 512) --splits;              // never one workgroup past the resident wave
     if (slabs && splits > max_slabs) splits = max_slabs;
     int max_splits = p3_ceil_div(M, 4 * bm);

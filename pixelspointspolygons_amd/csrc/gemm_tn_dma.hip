@@ -120,6 +120,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(TdArgs g) {
 #pragma unroll
     for (int p = 0; p < LA; ++p)
         if (p < nsteps) stage(p);
+    // (r04, measured and dropped: a software pipeline over the steps - the fragments of step s + 1 read from LDS while the MFMAs of step s run
+    // from a second fragment register set, 240 VGPRs - ran 8 - 11 % SLOWER on every shape: fc1 94 vs 85 us, qkv 71 vs 64)
     for (int st = 0; st < nsteps; ++st) {
         // RAW: this wave's pieces of step st have landed once at most (LA - 1) younger steps stay in flight (loads retire in order; nothing else
         // is outstanding); the barrier extends that to every wave's pieces.  WAR: a wave reaches the barrier after its reads of step st - 1, whose
@@ -225,12 +227,8 @@ void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, in
 // returns P3_OK when the launch was taken, 1 when the shape / mode is not this kernel's (the caller then runs gemm_tn.hip's kernel)
 int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float* colsum, float* slabs, int max_slabs,
                        hipStream_t s) {
-    static int on = -1, nbuf_env = 0, blocks_env = 0;
-    if (on < 0) {
-        const char* e = getenv("P3_TN_DMA"); on = (e && e[0] == '0') ? 0 : 1;
-        e = getenv("P3_TN_DMA_NBUF"); nbuf_env = e ? atoi(e) : 0;
-        e = getenv("P3_TN_DMA_BLOCKS"); blocks_env = e ? atoi(e) : 0;
-    }
+    static int on = -1;                              // P3_TN_DMA=0: every weight gradient on gemm_tn.hip's register-staged kernel (A/B: profiles/r04_mb_tn.txt)
+    if (on < 0) { const char* e = getenv("P3_TN_DMA"); on = (e && e[0] == '0') ? 0 : 1; }
     if (!on || M % TD_BM != 0 || N % 128 != 0 || K % 128 != 0 || lda % 8 != 0 || ldb % 8 != 0) return 1;
     if (((uintptr_t)A % 16) != 0 || ((uintptr_t)B % 16) != 0) return 1;
     if ((int64_t)TD_BM * lda * 2 + 256 >= (1ll << 31) || (int64_t)TD_BM * ldb * 2 + 256 >= (1ll << 31)) return 1;     // 32-bit DMA offsets inside a step
@@ -242,8 +240,7 @@ int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int
     if (tiles > 256) return 1;
     // one workgroup per CU: splits = 256 / tiles (the r03 finding for the register-staged kernel - the best grids fill ONE resident round -
     // holds here by construction); never fewer than 2 steps per split
-    const int target = blocks_env > 0 ? blocks_env : 256;
-    int splits = target / tiles;
+    int splits = 256 / tiles;
     if (splits < 1) splits = 1;
     const int max_splits = M / (2 * TD_BM) > 0 ? M / (2 * TD_BM) : 1;
     if (splits > max_splits) splits = max_splits;
@@ -253,20 +250,16 @@ int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int
     g.splits = splits;
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
     g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, P3_BF16) : nullptr;
-    const int nbuf = nbuf_env >= 2 && nbuf_env <= 4 ? nbuf_env : 4;
-    const size_t lds = (size_t)nbuf * TD_STEP_BYTES > 65536 ? (size_t)nbuf * TD_STEP_BYTES : 65536;      // the fold needs 8 x 8 KB
+    constexpr int NBUF = 4;                          // three steps in flight (NBUF = 3 measured 2 % slower, profiles/r04_mb_tn.txt)
+    const size_t lds = (size_t)NBUF * TD_STEP_BYTES;       // >= the 64 KB the fold needs
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     dim3 grid(tiles * splits), block(512);
-    if (nbuf == 4) hipLaunchKernelGGL(gemm_tn_dma_kernel<4>, grid, block, lds, s, g);
-    else if (nbuf == 3) hipLaunchKernelGGL(gemm_tn_dma_kernel<3>, grid, block, lds, s, g);
-    else hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid, block, lds, s, g);
+    hipLaunchKernelGGL(gemm_tn_dma_kernel<NBUF>, grid, block, lds, s, g);
     if (p3_tracing()) p3_note_kernel("gemm_tn_dma_kernel<4>");
     if (g.slabs) p3_tn_reduce_launch(g.slabs, C, N, K, ldc, splits, s);
     P3_LAUNCH_CHECK();

@@ -310,26 +310,18 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0, P3_ESHAPE, "p3_layernorm_bwd: cols must be <=1024 and %4");
     P3_CHECK((dgamma == nullptr) == (dbeta == nullptr), P3_EINVAL, "p3_layernorm_bwd: dgamma/dbeta go together");
     if (rows <= 0) return P3_OK;
-    static int rpb_env = -1;
-    if (rpb_env < 0) { const char* e = getenv("P3_LN_RPB"); rpb_env = e ? atoi(e) : 0; }
     // rows per block trades resident waves (one row in flight per wave) against dgamma / dbeta atomics per address; same-box sweep of
     // the train step (r01, P3_LN_RPB): 16 -> 60.9 ms, 32 -> 60.2, 48 -> 59.8, 96 -> 60.3, 128 -> 60.5, 256 -> 62.7
     // r03, with the parameter sums going through the slab (no atomic chains to shorten): 32 -> 35.2 us, 40 -> 37.7, 48 -> 39.3, 56 -> 37.3, 64 -> 40.4
-    static int slab_on = -1;
-    if (slab_on < 0) { const char* e = getenv("P3_LN_SLAB"); slab_on = (e && e[0] == '0') ? 0 : 1; }
     const bool half_cols = cols == 256 || cols == 384 || cols == 768;
-    const int rpb = rpb_env > 0 ? rpb_env : (slab_on && half_cols && dgamma && p3_reduce_scratch(1) ? 32 : 48);
+    const int rpb = (half_cols && dgamma && p3_reduce_scratch(1)) ? 32 : 48;
     dim3 grid(p3_ceil_div(rows, rpb)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    static int half_env = -1;                         // P3_LN_HALF=0: the one-wave-per-row kernel (A/B)
-    if (half_env < 0) { const char* e = getenv("P3_LN_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
-    // dgamma / dbeta partials of the half-wave kernel through the registered scratch (P3_LN_SLAB=0: atomics)
-    static int slab_env = -1;
-    if (slab_env < 0) { const char* e = getenv("P3_LN_SLAB"); slab_env = (e && e[0] == '0') ? 0 : 1; }
-    const bool halfk = (lod || half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768);
+    // dgamma / dbeta partials of the half-wave kernel go through the registered scratch (none registered / too small: atomics)
+    const bool halfk = half_cols;
     const int nblk = (int)grid.x;
     const int64_t slab_floats = (int64_t)nblk * 2 * cols, tmp_floats = (int64_t)p3_ceil_div(nblk, 128) * 2 * cols;
-    float* slab = (halfk && dgamma && slab_env && nblk > 8) ? p3_reduce_scratch(slab_floats + tmp_floats) : nullptr;
+    float* slab = (halfk && dgamma && nblk > 8) ? p3_reduce_scratch(slab_floats + tmp_floats) : nullptr;
     auto finish = [&]() { return slab ? p3_det_reduce2(slab, nblk, 2 * cols, slab + slab_floats, dgamma, dbeta, cols, 2 * cols, 1, s) : P3_OK; };
     if (lod) {
 #define LNH_D(CPL) hipLaunchKernelGGL((ln_bwd_half_kernel<bf16_t, float, float, CPL, false, true>), grid, block, 0, s, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const float*)nullptr, (float*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab, *lo_drop)
@@ -338,7 +330,7 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
         P3_LAUNCH_CHECK();
         return finish();
     }
-    if ((half_env || dx_lo) && (cols == 256 || cols == 384 || cols == 768)) {
+    if (half_cols) {
 #define LNH_R(TDY, TX, TDX, CPL, RES) \
     hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab)
 #define LNH_C(TDY, TX, TDX, CPL) \

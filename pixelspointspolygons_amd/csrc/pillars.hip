@@ -23,9 +23,8 @@ constexpr int C1 = 32;      // PFN layer-0 units (feat_channels[0] / 2)
 constexpr int K2 = 64;      // layer-1 input = [x | xmax]
 // pfn_l2_reduce / pfn_bwd_l2_stats grid cap (512 with per-wave atomics: 0.38 ms; see the kernel).  P3_PFN_BLOCKS: sweeps.
 // r03 sweep (same box): reduce8 2048 -> 93 us, 1024 -> 77, 512 -> 99; bwd_l2_stats8 2048 -> 102 us, 1024 -> 83, 512 -> 70 (per-workgroup atomics on 2 C addresses)
-static int pfn_blocks(int dflt) { static int v = -1; if (v < 0) { const char* e = getenv("P3_PFN_BLOCKS"); v = e ? atoi(e) : 0; } return v > 0 ? v : dflt; }
-#define L2R_BLOCKS pfn_blocks(1024)
-#define L2S_BLOCKS pfn_blocks(512)
+#define L2R_BLOCKS 1024
+#define L2S_BLOCKS 512
 constexpr int SORT_THREADS = 1024, SORT_WAVES = 16;
 constexpr int MAX_CELLS = 1900;
 // layer-0 backward accumulators: S_dyf[32][8] | S_xf[32][8] | S_f[8] | dbeta[32] | dgamma[32]

@@ -383,8 +383,7 @@ __global__ void pair_stats_bwd_kernel(const T* __restrict__ U, const T* __restri
 }
 
 inline int grid_rows(int64_t rows, int rows_per_block) {
-    static int cap = 0;                              // P3_RAB_GRID: workgroup cap of the grid-stride row kernels (sweeps)
-    if (cap == 0) { const char* e = getenv("P3_RAB_GRID"); cap = e ? atoi(e) : 1024; if (cap <= 0) cap = 1024; }   // r03 sweep: 1024 -> 288 / 102 us, 2048 -> 297 / 108, 3072 -> 306 / 105, 4096 -> 315 / 127
+    constexpr int cap = 1024;                        // workgroup cap of the grid-stride row kernels; r03 sweep: 1024 -> 288 / 102 us, 2048 -> 297 / 108, 3072 -> 306 / 105, 4096 -> 315 / 127
     int64_t g = (rows + rows_per_block - 1) / rows_per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
@@ -468,24 +467,18 @@ static int pair_bwd_impl(const void* dA, const void* U, const void* V, const flo
     P3_CHECK(dA && U && V && scale && shift && mean && dU && dV && acc && B > 0, P3_EINVAL, "p3_pair_bwd: bad arguments");
     P3_CHECK(C == 256, P3_EUNSUP, "p3_pair_bwd: ScoreNet conv1 width must be 256 (model_pix2poly.py:74)");
     hipStream_t s = (hipStream_t)stream;
-    static int ic_env = -1;
-    if (ic_env < 0) { const char* e = getenv("P3_PAIR_IC"); ic_env = e ? atoi(e) : 0; }
-    const int ic = ic_env > 0 ? ic_env : 16;     // rows i per block: dV gets N/IC atomic adds per element (same-box sweep r01: 4 -> 60.2 ms, 8 -> 58.0, 12 -> 57.7, 16 -> 57.6)
+    const int ic = 16;     // rows i per block: dV gets N/IC atomic adds per element (same-box sweep r01: 4 -> 60.2 ms, 8 -> 58.0, 12 -> 57.7, 16 -> 57.6)
 #define PB(T, IC) do { nblk = (N + IC - 1) / IC; acc_slab = p3_det_scratch((int64_t)B * nblk * 2 * C, dtype); if (!acc_slab) dslab = nullptr; \
                        hipLaunchKernelGGL((pair_bwd_kernel<T, IC>), dim3(nblk, B), dim3(256), 0, s, (const T*)dA, (const T*)U, (const T*)V, scale, shift, mean, dU, dV, acc, N, C, dslab, acc_slab); } while (0)
     int nblk = 0;
     float* acc_slab = nullptr;
     float* dslab = slab;          // the plain forms use the dV slab only together with the deterministic (dscale, dshift) partials
-    static int wide = -1;                             // P3_PAIR_WIDE=0: the 8-byte form (A/B switch)
-    if (wide < 0) { const char* e = getenv("P3_PAIR_WIDE"); wide = e ? atoi(e) : 1; }   // 0: 8-byte form
-    if (dtype == P3_BF16 && wide && ic_env <= 0) {
+    if (dtype == P3_BF16) {
         // IC = 12 rows i per block (6 per half-wave): the register budget of two waves per SIMD without spills (IC = 16 spills 270 B / lane)
         // 8 rows i per block (4 per half-wave) with the next step's rows prefetched: 238 VGPRs, no spills (the 12-row form needs 256 + 35
         // spilled and cannot hold a second register set).  rocprofv3 A/B (r03): 592 -> 348 us per launch, the dV slab sum 44 -> 68 us.
-        // P3_PAIR_IC16=12 selects the old form.
-        static int ic16 = -1;
-        if (ic16 < 0) { const char* e = getenv("P3_PAIR_IC16"); ic16 = e ? atoi(e) : 8; }
-        const int icb = (ic16 == 8 && slab) ? 8 : 12;
+        // Without a dV slab (caller's choice) the 12-row form runs.
+        const int icb = slab ? 8 : 12;
         nblk = (N + icb - 1) / icb;
         acc_slab = p3_det_scratch((int64_t)B * nblk * 2 * C, dtype);
         if (icb == 8) hipLaunchKernelGGL((pair_bwd_kernel16<8, true>), dim3(nblk, B), dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)U, (const bf16_t*)V, scale, shift,

@@ -19,7 +19,7 @@ from .pointpillars import PointPillarsViT
 from .vision_transformer import ViT, compute_dtype
 
 import os
-LDF = int(os.environ.get("P3_FFL_LDF", "320"))   # row stride of the padded conv-input image: 256 features + 1 seg channel, padded to a multiple of the GEMM's K slice (A/B: 288)
+LDF = 320   # row stride of the padded conv-input image: 256 features + 1 seg channel, padded to a multiple of the GEMM's K slice (288 measured slower)
 
 
 def _khwc(w, cpad=None):

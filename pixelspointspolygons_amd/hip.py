@@ -111,6 +111,11 @@ def det_on(t):
 _cur_stream = [None]
 
 
+def register_side_stream(s):
+    check(0 if lib().p3_scratch_side_stream(c_void_p(s.cuda_stream)) > 0 else -1, "p3_scratch_side_stream")
+    _cur_stream[0] = None
+
+
 def stream():
     """the launch stream (torch's current stream); the library is told whenever it changes so that scratch regions follow the stream"""
     if _det_state["buf"] is None:
@@ -151,10 +156,9 @@ class GemmDesc(Structure):
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, force8=None):
+         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, variant=None):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p).
-    force8 = 0 | 1 | 2: call the 256 x 256-tile kernel (p3_gemm8, loop structure 0 / 1 / 2), 3 .. 6: the 128 x 128-tile LDS-DMA kernel (gemm_dma.hip),
-    directly instead of p3_gemm's own choice (A/B tools, tests)."""
+    variant = 4 | 6 | 9: call that LDS-DMA kernel (p3_gemm_dma, csrc/gemm_dma.hip) directly instead of p3_gemm's own choice (A/B tools, tests)."""
     _dev(a)
     N, K = w.shape
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
@@ -199,8 +203,8 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
             raise P3Error("gemm: bwd_saved must match the output's dtype and row stride")
         d.bwd_saved, d.bwd_act, d.bwd_scale = sv.data_ptr(), bact, bscale
     ev = KTIMER.begin()
-    if force8 is not None:
-        check(lib().p3_gemm8(ptr(a), ptr(w), ptr(out), byref(d), c_int(int(force8)), stream()), "p3_gemm8")
+    if variant is not None:
+        check(lib().p3_gemm_dma(ptr(a), ptr(w), ptr(out), byref(d), c_int(int(variant)), stream()), "p3_gemm_dma")
     else:
         check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
     if ev is not None:
@@ -701,20 +705,16 @@ def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None
     return dq, dk, dv
 
 
-import os as _os
-TN_MAX_SLABS = int(_os.environ.get("P3_TN_SLABS", "0"))     # > 0: store split-M partials in scratch slabs + reduce instead of fp32 atomics
-
-
-TN_SLAB_MAX_NK = int(_os.environ.get("P3_TN_SLAB_NK", "0"))    # slabs only for outputs of at most this many elements (0: every output)
+TN_MAX_SLABS = 0     # > 0 (tools/mb_tn.py): store split-M partials in scratch slabs + reduce instead of fp32 atomics also outside deterministic launches
 
 
 def _tn_slabs(N, K, a):
     """(scratch, max slabs) for the split-M partial tiles of the weight-gradient GEMM: stored + summed in split order by tn_reduce_kernel
-    instead of fp32 atomics.  Always in deterministic launches (hip.det_on); P3_TN_SLABS forces it elsewhere (A/B switch)."""
+    instead of fp32 atomics.  Always in deterministic launches (hip.det_on); TN_MAX_SLABS forces it elsewhere (r02 A/B: 43.3 ms with atomics, 43.7 - 48 with slabs)."""
     if det_on(a):
         ns = max(8, min(512, (64 << 20) // (N * K * 4)))         # <= 64 MB of slabs, at least 8
         return workspace(ns * N * K * 4 + 16, a.device, "tn_slabs"), ns
-    if TN_MAX_SLABS <= 0 or (TN_SLAB_MAX_NK > 0 and N * K > TN_SLAB_MAX_NK):
+    if TN_MAX_SLABS <= 0:
         return None, 0
     return workspace(TN_MAX_SLABS * N * K * 4 + 16, a.device, "tn_slabs"), TN_MAX_SLABS
 
@@ -898,9 +898,8 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
     dU = torch.empty((B * N, C), dtype=torch.float32, device=U.device)
     dV = torch.zeros((B * N, C), dtype=torch.float32, device=U.device)
     L = lib()
-    import os
     # dV partials through a scratch slab instead of global atomics: the bf16 form always, the fp32 one in deterministic launches
-    if (dt(U) == BF16 and os.environ.get("P3_PAIR_SLAB", "1") != "0") or (dt(U) == F32 and det_on(U)):
+    if dt(U) == BF16 or (dt(U) == F32 and det_on(U)):
         L.p3_pair_bwd_workspace_bytes_dt.restype = c_int64
         ws = workspace(L.p3_pair_bwd_workspace_bytes_dt(c_int(B), c_int(N), c_int(C), c_int(dt(U))), U.device, "pair_bwd")
         check(L.p3_pair_bwd_ws(ptr(dA), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N), c_int(C),

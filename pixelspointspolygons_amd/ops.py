@@ -55,6 +55,7 @@ class on_side:
         s = _side_streams.get(self.name)
         if s is None:
             s = _side_streams[self.name] = torch.cuda.Stream()
+            hip.register_side_stream(s)          # a scratch region of its own (csrc/det_reduce.hip)
         s.wait_stream(main)
         _side_open.add(self.name)
         self.ctx = torch.cuda.stream(s)

@@ -129,7 +129,7 @@ class FlatAdamW:
         """bf16 W^T copies ([in, out]) of every 2-D weight whose dX GEMM reads the plain transpose (out % 64 == 0): one arena, one
         table, refreshed by ONE kernel after each AdamW step instead of one strided copy per weight per step."""
         self.shadow_T, self.t_table, self.t_entries, self.t_tiles = None, None, 0, 0
-        if self.shadow is None or os.environ.get("P3_NO_WT") == "1":     # P3_NO_WT=1: A/B switch (per-weight strided copies instead)
+        if self.shadow is None:
             return
         import struct
         recs, total, tiles = [], 0, 0

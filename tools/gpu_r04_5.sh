@@ -5,3 +5,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_stats -o st -- p
 find /tmp/pf_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04/r04_mid_kernel_stats.csv \;
 python tools/kstats.py gpurun_out/r04/r04_mid_kernel_stats.csv 25 70 > gpurun_out/r04/r04_mid_summary.txt
 cat gpurun_out/r04/r04_mid_summary.txt
+python -m pytest tests/test_backward_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "sinkhorn" 2>&1 | tail -4
+python tools/mb_sinkhorn.py

@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 import torch
 
 import pixelspointspolygons_amd.hip as h
-from tools.mb_gemm8 import rnd
+from tools.probe.mb_gemm8 import rnd
 
 
 def main():
@@ -21,11 +21,11 @@ def main():
     for v in variants:
         os.environ.pop("P3_GD_TIMELINE", None)
         for _ in range(3):
-            h.gemm(a, w, bias=b, out=out, force8=v)
+            h.gemm(a, w, bias=b, out=out, variant=v)
         torch.cuda.synchronize()
         os.environ["P3_GD_TIMELINE"] = str(tl.data_ptr())
         tl.zero_()
-        h.gemm(a, w, bias=b, out=out, force8=v)
+        h.gemm(a, w, bias=b, out=out, variant=v)
         torch.cuda.synchronize()
         os.environ.pop("P3_GD_TIMELINE", None)
         t = tl.view(nwg, 6).cpu().double()

@@ -1,3 +1,5 @@
+// r03 probe, moved out of the product library in r04 (default-off since it lost the step-level A/B: 42.55 ms without, 43.35 ms with it): the 256 x 256-tile,
+// 8-wave LDS-DMA GEMM with a phased K loop.  It includes csrc/p3_common.h and links against libp3hip objects; numbers: profiles/r03_mb_gemm8.txt, r03_g8_probe.txt.
 // p3hip GEMM, 256 x 256 tile, 8 waves, LDS-DMA staging, phased K loop (bf16 in, fp32 accumulate) for the wide plain GEMMs of the path:
 //   C[M,N] = epilogue(A[M,K] * W[N,K]^T)            (timm Block: qkv / fc1, their dX products; decoder linear1 / linear2 ...)
 //

@@ -1,3 +1,4 @@
+# r03 tool of the 256 x 256-tile probe (tools/probe/gemm8_probe.hip): it drove p3_gemm8 / force8, which left the product library in r04; kept for the record.
 """256 x 256-tile GEMM (csrc/gemm8.hip) against the 128 x 128 kernel on the path's plain bf16 shapes: bit-equality of the outputs (both add
 the same 16-deep MFMA blocks in ascending k order), repeat-run race screen, HIP-event timing.   P3_GEMM8=0 python tools/mb_gemm8.py"""
 import os
