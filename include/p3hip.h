@@ -407,6 +407,14 @@ int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C);
 int64_t p3_pair_bwd_workspace_bytes_dt(int B, int N, int C, int dtype);   /* per dtype: the fp32 form takes smaller row chunks (more slabs) */
 int p3_pair_bwd_ws(const void* dA, const void* U, const void* V, const float* scale, const float* shift, const float* mean, float* dU, float* dV,
                    float* acc, int B, int N, int C, int dtype, void* workspace, void* stream);
+/* p3_gemm (dA2 = dH2 . W2, the input gradient of ScoreNet.conv2, model_pix2poly.py:76) and p3_pair_bwd in ONE launch (bf16; csrc/pair_bwd_mma.hip): a
+ * workgroup owns (tile, 8 rows i, all j), the 128 x 256 product tiles of dA2 stay in its MFMA accumulators and are masked / summed there - the
+ * [B N^2, 256] gradient (1.2 GB per net at B = 64, N = 192) is neither written nor read.  dH2 [B N^2, 128] bf16 (dense), W2t = conv2.weight transposed
+ * [256, 128] bf16, U / V [B N, 256] bf16, scale / shift / mean [256] fp32; outputs as p3_pair_bwd: dU (=), dV (+=, zero it first), acc[0:256] += centred
+ * scale sums, acc[256:512] += shift sums.  workspace: p3_pair_bwd_fused_workspace_bytes(B, N) bytes (dV partial rows of the N / 8 row blocks). */
+int64_t p3_pair_bwd_fused_workspace_bytes(int B, int N);
+int p3_pair_bwd_fused(const void* dH2, const void* W2t, const void* U, const void* V, const float* scale, const float* shift, const float* mean,
+                      float* dU, float* dV, float* acc, int B, int N, void* workspace, void* stream);
 int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
                       void* stream);
 

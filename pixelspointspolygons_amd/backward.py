@@ -4,6 +4,8 @@ PillarFeatureNet backward in csrc/pillars.hip: p3_pillar_stem_bwd.)  No PyTorch 
 """
 import torch
 
+FUSED_PAIR = [True]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
+
 
 def scorenet_backward(net, feats, keep, dout, transpose_acc):
     """Native backward over the tensors the forward kept (U, V, H2, H3, BN triples); see csrc/scorenet_bwd.hip."""
@@ -44,9 +46,13 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dW2 = hip.gemm_tn_ex(dH2, U, wout("conv2", 128, 256), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)
     db2 = ops.bias_grad_before_bn(dH2, training, net.conv2.bias)
     w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
-    dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                                  # [R, 256]
     acc1 = torch.zeros(2 * 256, **f32)
-    dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
+    if cd == torch.bfloat16 and FUSED_PAIR[0]:
+        # dA2 = dH2 W2 ([R, 256]: 1.2 GB per net) is formed tile by tile inside the pair kernel and never stored (csrc/pair_bwd_mma.hip)
+        dU, dV = hip.pair_bwd_fused(dH2, w2t, U, V, sc1, sh1, m1, B, N, acc1)
+    else:
+        dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                              # [R, 256]
+        dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
     dg1, dbt1, a1, b1 = ops.bn_backward_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training, params=(net.bn1.weight, net.bn1.bias))
     if training:
         hip.pair_stats_bwd(U, V, a1, b1, dU, dV, B, N)

@@ -442,6 +442,11 @@ extern "C" int p3_affine_fix_ld(void* dH, const void* H, int ldh, const float* a
     return P3_OK;
 }
 
+void p3_pair_dv_reduce_launch(const float* slab, float* dV, int nblk, int B, int N, int C, hipStream_t s) {
+    const int64_t per = (int64_t)N * C / 4, total = (int64_t)B * per;
+    hipLaunchKernelGGL(pair_dv_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, slab, dV, nblk, per, total);
+}
+
 extern "C" int64_t p3_pair_bwd_workspace_bytes(int B, int N, int C) { return (int64_t)B * ((N + 11) / 12) * N * C * 4; }
 // per dtype: the fp32 kernel takes 8 rows i per block (more, smaller slabs), the bf16 one 12
 extern "C" int64_t p3_pair_bwd_workspace_bytes_dt(int B, int N, int C, int dtype) {

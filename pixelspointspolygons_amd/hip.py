@@ -910,6 +910,20 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
     return dU, dV
 
 
+def pair_bwd_fused(dH2, w2t, U, V, scale, shift, mean, B, N, acc):
+    """conv2's input gradient + pair_bwd in one launch (bf16): dA2 = dH2 @ w2t^T never touches memory.  -> (dU, dV) fp32 [B N, 256]"""
+    if dt(dH2) != BF16 or dt(U) != BF16 or w2t.shape != (256, 128) or not w2t.is_contiguous() or not dH2.is_contiguous():
+        raise P3Error("pair_bwd_fused: bf16, contiguous dH2 [B N N, 128] and w2t [256, 128]")
+    dU = torch.empty((B * N, 256), dtype=torch.float32, device=U.device)
+    dV = torch.zeros((B * N, 256), dtype=torch.float32, device=U.device)
+    L = lib()
+    L.p3_pair_bwd_fused_workspace_bytes.restype = c_int64
+    ws = workspace(L.p3_pair_bwd_fused_workspace_bytes(c_int(B), c_int(N)), U.device, "pair_bwd")
+    check(L.p3_pair_bwd_fused(ptr(dH2), ptr(w2t), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N),
+                              ptr(ws), stream()), "p3_pair_bwd_fused")
+    return dU, dV
+
+
 def pair_stats_bwd(U, V, a, b, dU, dV, B, N):
     check(lib().p3_pair_stats_bwd(ptr(U), ptr(V), ptr(a), ptr(b), ptr(dU), ptr(dV), c_int(B), c_int(N), c_int(U.shape[1]), c_int(dt(U)),
                                   stream()), "p3_pair_stats_bwd")

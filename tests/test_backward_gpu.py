@@ -526,6 +526,39 @@ def _assert_kink_only(decisions, zs, limit=4e-6, count=64):
             assert nd <= count and (nd == 0 or float(z[diff].abs().max()) < limit), (pre, li, nd, float(z[diff].abs().max()) if nd else 0.0)
 
 
+@pytest.mark.parametrize("B,N", [(2, 192), (3, 60), (2, 24), (1, 13), (1, 16)])
+def test_pair_bwd_fused_vs_float64_and_the_two_launch_form(B, N):
+    """csrc/pair_bwd_mma.hip: conv2's input gradient dA2 = dH2 W2 formed in the MFMA accumulators of the pair kernel (never stored) - dU, dV and the
+    BatchNorm sums against float64 on the host, and against p3_gemm + p3_pair_bwd (which round dA2 to bf16 in between); N = 60 / 24 / 13: ragged
+    row blocks (N % 8) and ragged 16-column steps."""
+    h = _h()
+    R = B * N * N
+    dH2 = (_rand(R, 128, seed=1) * 0.5).bfloat16()
+    w2t = (_rand(256, 128, seed=2) * 0.1).bfloat16()
+    U, V = _rand(B * N, 256, seed=3).bfloat16(), _rand(B * N, 256, seed=4).bfloat16()
+    sc, sh, mu = 0.5 + _rand(256, seed=5).abs(), _rand(256, seed=6) * 0.3, _rand(256, seed=7)
+    dA = (dH2.double() @ w2t.double().t()).view(B, N, N, 256)
+    pre = U.double().view(B, N, 1, 256) + V.double().view(B, 1, N, 256)
+    on = (pre.float() * sc + sh > 0)                      # the decision in fp32, as the kernels take it
+    dz = dA * on
+    acc_ref = torch.cat([(dz * (pre - mu.double())).sum((0, 1, 2)), dz.sum((0, 1, 2))])
+    dU_ref = (dz * sc.double()).sum(2).reshape(B * N, 256)
+    dV_ref = (dz * sc.double()).sum(1).reshape(B * N, 256)
+    d = lambda t: t.to(DEV)
+    acc = torch.zeros(512, device=DEV)
+    dU, dV = h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, acc)
+    assert l2_err(dU.cpu(), dU_ref) < 2e-3 and l2_err(dV.cpu(), dV_ref) < 2e-3
+    assert l2_err(acc.cpu(), acc_ref) < 2e-3
+    dA2 = h.gemm(d(dH2), d(w2t), out_dtype=torch.bfloat16)
+    acc2 = torch.zeros(512, device=DEV)
+    dU2, dV2 = h.pair_bwd(dA2, d(U), d(V), d(sc), d(sh), d(mu), B, N, acc2)
+    assert l2_err(dU.cpu(), dU2.cpu()) < 5e-3 and l2_err(dV.cpu(), dV2.cpu()) < 5e-3 and l2_err(acc.cpu(), acc2.cpu()) < 5e-3
+    # run-to-run bit-reproducible (slab partials, fixed-order folds; the BatchNorm sums too when deterministic reductions cover bf16)
+    acc3 = torch.zeros(512, device=DEV)
+    dU3, dV3 = h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, acc3)
+    assert torch.equal(dU, dU3) and torch.equal(dV, dV3)
+
+
 @pytest.mark.parametrize("transpose,train,N,B", [(False, True, 24, 3), (True, True, 24, 3), (False, False, 24, 3), (True, False, 24, 3),
                                                   (False, True, 192, 2), (False, False, 192, 2)])
 def test_scorenet_backward_native_vs_oracle_autograd(transpose, train, N, B):
