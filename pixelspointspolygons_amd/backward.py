@@ -4,7 +4,7 @@ PillarFeatureNet backward in csrc/pillars.hip: p3_pillar_stem_bwd.)  No PyTorch 
 """
 import torch
 
-FUSED_PAIR = [True]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
+FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
 
 
 def scorenet_backward(net, feats, keep, dout, transpose_acc):
