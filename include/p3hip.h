@@ -43,6 +43,9 @@ extern "C" {
 #define P3_A_CONV3X3 1 /* A is an NHWC map [B,H,W,lda]; K = 9*C, zero padding 1 (implicit GEMM) */
 #define P3_A_AFFINE_RELU 2 /* A'[m,k] = relu(A[m,k]*a_scale[k] + a_shift[k])  (BN+ReLU folded into the load) */
 #define P3_A_PAIR_AFFINE_RELU 3 /* A'[(b,i,j),k] = relu((U[b,i,k]+V[b,j,k])*a_scale[k]+a_shift[k]) ScoreNet conv1 */
+#define P3_A_AFFINE_MASK2 5 /* p3_gemm_tn_ex only: B'[m, k] = [y > 0] for k < K and [y > 0] * B[m, k - K] for K <= k < 2K, y = B[m, k]*b_scale[k]+b_shift[k]:
+                              * ONE pass over (A, B) gives G = A^T [y > 0] and G2 = A^T ([y > 0] B) - a BatchNorm/ReLU layer's weight gradient AND the sums
+                              * of its input gradient's BatchNorm backward (p3_bn_sums_from_g); C is [N, 2K] */
 #define P3_A_CONV3X3_AFFINE_RELU 4 /* CONV3X3 over relu(A*a_scale[c]+a_shift[c]) (a_scale/a_shift indexed by input channel): FFL heads */
 
 int p3_version(void);
@@ -412,6 +415,12 @@ int p3_pair_bwd_ws(const void* dA, const void* U, const void* V, const float* sc
  * [B N^2, 256] gradient (1.2 GB per net at B = 64, N = 192) is neither written nor read.  dH2 [B N^2, 128] bf16 (dense), W2t = conv2.weight transposed
  * [256, 128] bf16, U / V [B N, 256] bf16, scale / shift / mean [256] fp32; outputs as p3_pair_bwd: dU (=), dV (+=, zero it first), acc[0:256] += centred
  * scale sums, acc[256:512] += shift sums.  workspace: p3_pair_bwd_fused_workspace_bytes(B, N) bytes (dV partial rows of the N / 8 row blocks). */
+/* From G [N, 2K] = p3_gemm_tn_ex(dH [M, N], H [M, K], P3_A_AFFINE_MASK2) (G | G2 side by side, row stride ldg) and W [N, K] fp32 (the weight of the layer
+ * dH belongs to, e.g. ScoreNet.conv3.weight, model_pix2poly.py:78): dW [N, K] += scale G2 + shift G (that layer's weight gradient over relu(bn(H))), and
+ * acc[0:K] += sum dz (H - mean), acc[K:2K] += sum dz for dz = [bn(H) > 0] (dH W) - the BatchNorm backward sums of the layer below, WITHOUT a pass over
+ * the [M, K] input gradient (r01 - r03: p3_row_affine_bwd pass 1, 290 us per ScoreNet at B = 64). */
+int p3_bn_sums_from_g(const float* G, int ldg, const float* W, const float* scale, const float* shift, const float* mean, float* dW, float* acc,
+                      int N, int K, void* stream);
 int64_t p3_pair_bwd_fused_workspace_bytes(int B, int N);
 int p3_pair_bwd_fused(const void* dH2, const void* W2t, const void* U, const void* V, const float* scale, const float* shift, const float* mean,
                       float* dU, float* dV, float* acc, int B, int N, void* workspace, void* stream);

@@ -4,6 +4,7 @@ PillarFeatureNet backward in csrc/pillars.hip: p3_pillar_stem_bwd.)  No PyTorch 
 """
 import torch
 
+SUMS_FROM_G = [__import__("os").environ.get("P3_SUMS_FROM_G", "1") != "0"]    # BatchNorm-2 backward sums from the dual-operand weight-gradient GEMM (A/B switch)
 FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
 
 
@@ -33,12 +34,21 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     # weight gradients: the split-M atomics of the TN GEMMs accumulate straight into the gradient arena in direct-gradient mode
     gw = {n: ops.direct_grads(getattr(net, n).weight) for n in ("conv1", "conv2", "conv3")}
     wout = lambda n, r, c: gw[n][0].view(r, c) if gw[n] is not None else torch.zeros(r, c, **f32)
-    dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
     db3 = ops.bias_grad_before_bn(dH3, training, net.conv3.bias)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
     dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
-    dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
+    if training and SUMS_FROM_G[0]:
+        # ONE pass over (dH3, H2) gives G = dH3^T [bn2(H2) > 0] and G2 = dH3^T ([bn2(H2) > 0] H2): conv3's weight gradient AND the BatchNorm-2 backward
+        # sums of dA3 follow from the two 64 x 128 matrices (p3_bn_sums_from_g) - the sums pass over the [R, 128] gradient (290 us per net) is gone
+        G = torch.zeros((64, 256), **f32)
+        hip.gemm_tn_ex(dH3, H2, G, hip.A_AFFINE_MASK2, sc2, sh2)
+        dW3 = wout("conv3", 64, 128)
+        hip.bn_sums_from_g(G, net.conv3.weight.detach().reshape(64, 128), sc2, sh2, m2, dW3, acc2)
+        dH2 = None
+    else:
+        dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
+        dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
     dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training, params=(net.bn2.weight, net.bn2.bias))
     if training:
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))

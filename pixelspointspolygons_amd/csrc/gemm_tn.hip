@@ -20,7 +20,8 @@ struct TnArgs {
     const void* A; const void* B; float* C;
     int M, N, K, lda, ldb, ldc, rows_per_split, tiles_k, splits;
     // optional generated B operand (ScoreNet backward): B'[m,k] = relu((B[m',k] (+ V[m'',k])) * b_scale[k] + b_shift[k])
-    int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j)
+    int Kb;                     // columns of B in memory (== K but for P3_A_AFFINE_MASK2: K = 2 Kb output columns)
+    int b_mode;                 // 0 plain, P3_A_AFFINE_RELU, P3_A_PAIR_AFFINE_RELU (m = (b,i,j): B row b*n+i, V row b*n+j), P3_A_AFFINE_MASK2
     const float* b_scale; const float* b_shift; const void* pair_V; int pair_n;
     float* slabs;               // optional [splits][N][K] fp32: partial tiles are STORED here (coalesced) and summed by tn_reduce_kernel
                                 // instead of splits x N x K fp32 atomics on C (measured: the atomics, not the MFMAs, bounded this kernel)
@@ -47,7 +48,7 @@ template <typename T, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
-    constexpr bool GENB = BMODE != 0, PAIR = BMODE == P3_A_PAIR_AFFINE_RELU;
+    constexpr bool GENB = BMODE != 0, PAIR = BMODE == P3_A_PAIR_AFFINE_RELU, GMASK2 = BMODE == P3_A_AFFINE_MASK2;
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;          // byte offset of the tile buffers inside the LDS aperture (inline-asm reads)
@@ -86,14 +87,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     uint32_t rok[2];                              // generated B: bit i = row i of the set lies inside [m_beg, m_end)
     const int coln = tn * TN + cv, colk = tk * TK + cv;
     const bool okn = coln < g.N, okk = colk < g.K;  // N, K are multiples of VEC (checked on the host)
+    // GMASK2: output columns [Kb, 2 Kb) are a second generated operand over the SAME columns of B (block-uniform: Kb is a multiple of VEC)
+    const bool second = GMASK2 && colk >= g.Kb;
+    const int colb = second ? colk - g.Kb : colk;
     float bsc[GENB ? VEC : 1], bsh[GENB ? VEC : 1];
     if constexpr (GENB) {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) { bsc[q] = okk ? g.b_scale[colk + q] : 0.f; bsh[q] = okk ? g.b_shift[colk + q] : 0.f; }
+        for (int q = 0; q < VEC; ++q) { bsc[q] = okk ? g.b_scale[colb + q] : 0.f; bsh[q] = okk ? g.b_shift[colb + q] : 0.f; }
     }
 
     // vector part of the operand addresses (thread row rt, column chunk); the step / pass part (m0 + 16 i) * ld is wave-uniform
-    const int64_t abase = (int64_t)rt * g.lda + (okn ? coln : 0), bbase = (int64_t)rt * g.ldb + (okk ? colk : 0);
+    const int64_t abase = (int64_t)rt * g.lda + (okn ? coln : 0), bbase = (int64_t)rt * g.ldb + (okk ? colb : 0);
     auto load_step = [&](auto SET, auto INRANGE, int m0) __attribute__((always_inline)) {
         constexpr int ss = decltype(SET)::value;
         u32x4 (&ra)[NLOAD] = rsa[ss];
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                     const int bb = rowc / nn, p = rowc - bb * nn, ii = p / n, jj = p - ii * n;
                     r1 = (int64_t)bb * n + ii; r2 = (int64_t)bb * n + jj;
                 }
-                rb[i] = *reinterpret_cast<const u32x4*>(B + r1 * g.ldb + (okk ? colk : 0));
-                if constexpr (PAIR) rsy[ss][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.pair_V) + r2 * g.ldb + (okk ? colk : 0));
+                rb[i] = *reinterpret_cast<const u32x4*>(B + r1 * g.ldb + (okk ? colb : 0));
+                if constexpr (PAIR) rsy[ss][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.pair_V) + r2 * g.ldb + (okk ? colb : 0));
                 if (i == 0) rok[ss] = 0;
                 rok[ss] |= (uint32_t)(okr && okk) << i;
             }
@@ -181,7 +185,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                 }
                 const bool ok = (rok[ss] >> i) & 1u;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) v[q] = ok ? fmaxf(v[q] * bsc[q] + bsh[q], 0.f) : 0.f;
+                for (int q = 0; q < VEC; ++q) {
+                    if constexpr (GMASK2) { const bool on = ok && (v[q] * bsc[q] + bsh[q] > 0.f); v[q] = on ? (second ? v[q] : 1.f) : 0.f; }
+                    else v[q] = ok ? fmaxf(v[q] * bsc[q] + bsh[q], 0.f) : 0.f;
+                }
                 u32x4 r;
                 if constexpr (BF) {
 #pragma unroll
@@ -409,7 +416,8 @@ int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int
 extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
                              const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, float* slabs, int max_slabs, void* stream) {
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
-    P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU, P3_EINVAL, "p3_gemm_tn: b_mode");
+    P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU || b_mode == P3_A_AFFINE_MASK2, P3_EINVAL, "p3_gemm_tn: b_mode");
+    P3_CHECK(b_mode != P3_A_AFFINE_MASK2 || ldc >= 2 * K, P3_ESHAPE, "p3_gemm_tn: P3_A_AFFINE_MASK2 writes [N, 2K]");
     P3_CHECK(b_mode == 0 || (b_scale && b_shift), P3_EINVAL, "p3_gemm_tn: generated B operand needs b_scale / b_shift");
     P3_CHECK(b_mode != P3_A_PAIR_AFFINE_RELU || (pair_V && pair_n > 0 && M % (pair_n * pair_n) == 0), P3_ESHAPE, "p3_gemm_tn: pair mode needs V and M == B*n*n");
     P3_CHECK(dtype == P3_F32 || dtype == P3_BF16, P3_EUNSUP, "p3_gemm_tn: dtype");
@@ -421,6 +429,8 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
         if (rc != 1) return rc;
     }
     TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.Kb = K;
+    if (b_mode == P3_A_AFFINE_MASK2) { K *= 2; g.K = K; }       // two generated operands side by side
     g.b_mode = b_mode; g.b_scale = b_scale; g.b_shift = b_shift; g.pair_V = pair_V; g.pair_n = pair_n; g.colsum = colsum;
     const int tiles_n = p3_ceil_div(N, TN);
     g.tiles_k = p3_ceil_div(K, TK);
@@ -458,6 +468,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     } while (0)
     if (g.b_mode == 0) P3_TN_LAUNCH(0);
     else if (g.b_mode == P3_A_AFFINE_RELU) P3_TN_LAUNCH(P3_A_AFFINE_RELU);
+    else if (g.b_mode == P3_A_AFFINE_MASK2) P3_TN_LAUNCH(P3_A_AFFINE_MASK2);
     else P3_TN_LAUNCH(P3_A_PAIR_AFFINE_RELU);
 #undef P3_TN_LAUNCH
     if (g.slabs) {

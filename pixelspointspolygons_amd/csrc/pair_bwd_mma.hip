@@ -13,7 +13,7 @@
 //   * 256-byte operand rows: chunk c of row r sits at slot c ^ (r & 15) (applied on the DMA's source address) - ds_read_b128 fragment reads conflict free;
 //   * vmcnt counts loads AND stores and retires them out of order against each other on gfx950, so the wait at the top of a step is vmcnt(0); the dV
 //     partial stores of step s are therefore issued at the START of step s + 1 (right after its DMA): they have a whole step to retire.
-// 8 waves, acc 64 registers; MFMA 128 x 256 x 128 per step (2061 CU cycles) against ~64 masked elements per lane of epilogue VALU.
+// 8 waves, acc 64 registers; MFMA 128 x 256 x 128 per step (2061 CU cycles) against 64 masked elements per lane of epilogue VALU (5 operations each).
 #include <stdlib.h>
 
 #include "p3_common.h"
@@ -53,19 +53,21 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_mma_kernel(PfArgs g) {
         const int p = wave * 8 + q, row = p * 4 + (lane >> 4), slot = lane & 15;
         dma1(g.W2t, lds_addr + (uint32_t)(p * 1024), (uint32_t)((row * 128 + ((slot ^ (row & 15)) * 8)) * 2));
     }
-    // ---- per-lane constants: the two 32-column blocks of this wave's 64 columns
-    float s_[2], h_[2], mu_[2], u_[2][4];
-    bool iok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) iok[q] = i0 + q + 4 * hi < N;
+    // ---- per-lane constants: the two 32-column blocks of this wave's 64 columns.  us = U_i * scale + shift, so that the ReLU decision of an element
+    // is fma(V_j, scale, us) > 0; a row i beyond N gets us = -inf (never on).  The BatchNorm sums are rebuilt from the dU / dV partial sums at the end:
+    //   sum dz (p - mean) = sum_i (U_i - mean) sum_j dz  +  sum_j V_j sum_i dz        (p = U_i + V_j)
+    // - five VALU operations per element (fma, compare, select, two adds) instead of twelve.
+    float s_[2], mu_[2], u_[2][4], us_[2][4];
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         const int c = wc * 64 + jb * 32 + l31;
-        s_[jb] = g.sc[c]; h_[jb] = g.sh[c]; mu_[jb] = g.mean[c];
+        s_[jb] = g.sc[c]; mu_[jb] = g.mean[c];
+        const float hh = g.sh[c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = min(i0 + q + 4 * hi, N - 1);
-            u_[jb][q] = bf2f(g.U[((int64_t)b * N + i) * 256 + c]);
+            const int i = i0 + q + 4 * hi;
+            u_[jb][q] = bf2f(g.U[((int64_t)b * N + min(i, N - 1)) * 256 + c]);
+            us_[jb][q] = i < N ? fmaf(u_[jb][q], s_[jb], hh) : -INFINITY;
         }
     }
     // ---- staging of a step: dH2 tile rows (jj, ii) -> tile row jj * 8 + ii (4 pieces per wave), V rows of the 16 j (1 piece = 2 rows per wave)
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_mma_kernel(PfArgs g) {
         dma1(Vb, dv + (uint32_t)(wave * 1024), (uint32_t)((jv * 256 + (lane & 31) * 8) * 2));
     };
     const int nsteps = (N + PF_JT - 1) / PF_JT;
-    float du[2][4], a_sc[2], a_sh[2], dvp[2][2][4];
+    float du[2][4], a_v[2], dvp[2][2][4];         // du: RAW sums of dz over j (scaled at the end); a_v = sum_j V_j sum_i dz
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
-        a_sc[jb] = 0.f; a_sh[jb] = 0.f;
+        a_v[jb] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { du[jb][q] = 0.f; dvp[jb][0][q] = 0.f; dvp[jb][1][q] = 0.f; }
     }
@@ -137,28 +139,29 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_mma_kernel(PfArgs g) {
                 for (int jb = 0; jb < 2; ++jb)
                     acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ib]), __builtin_bit_cast(bf16x8_t, bf[jb]), acc[ib][jb], 0, 0, 0);
         }
-        // ---- epilogue: mask with relu'(bn1(U_i + V_j)), BatchNorm sums, dU over j (registers), dV over the 8 i (4 here + the other half-wave)
+        // ---- epilogue: mask with relu'(bn1(U_i + V_j)); dz summed over j (registers, per i) and over the 8 i (4 here + the other half-wave, per j)
         const int j0 = st * PF_JT;
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int jj = wr * 8 + ib * 4 + q4;
-                const bool jok = j0 + jj < N;
+                if (j0 + jj < N) {                                    // wave-uniform (ragged last step only)
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
-                    const float v = bf2f(*reinterpret_cast<const bf16_t*>(Vt + jj * 512 + (wc * 64 + jb * 32 + l31) * 2));
-                    float dvs = 0.f;
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const float v = bf2f(*reinterpret_cast<const bf16_t*>(Vt + jj * 512 + (wc * 64 + jb * 32 + l31) * 2));
+                        float dvs = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float p = u_[jb][q] + v;
-                        const bool on = jok && iok[q] && (p * s_[jb] + h_[jb] > 0.f);
-                        const float dz = on ? acc[ib][jb][q4 * 4 + q] : 0.f;
-                        a_sc[jb] += dz * (p - mu_[jb]); a_sh[jb] += dz;
-                        const float t = dz * s_[jb];
-                        du[jb][q] += t; dvs += t;
+                        for (int q = 0; q < 4; ++q) {
+                            const float dz = fmaf(v, s_[jb], us_[jb][q]) > 0.f ? acc[ib][jb][q4 * 4 + q] : 0.f;
+                            du[jb][q] += dz; dvs += dz;
+                        }
+                        dvs += __shfl_xor(dvs, 32, 64);
+                        a_v[jb] = fmaf(v, dvs, a_v[jb]);              // the folded sum: both half-waves hold the same a_v
+                        dvp[jb][ib][q4] = dvs * s_[jb];
                     }
-                    dvp[jb][ib][q4] = dvs + __shfl_xor(dvs, 32, 64);
+                } else {
+                    dvp[0][ib][q4] = 0.f; dvp[1][ib][q4] = 0.f;
                 }
             }
     }
@@ -171,9 +174,16 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_mma_kernel(PfArgs g) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         const int c = wc * 64 + jb * 32 + l31;
+        float t_sh = 0.f, t_sc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[(wr * 8 + q + 4 * hi) * 256 + c] = du[jb][q];
-        const float t_sc = a_sc[jb] + __shfl_xor(a_sc[jb], 32, 64), t_sh = a_sh[jb] + __shfl_xor(a_sh[jb], 32, 64);
+        for (int q = 0; q < 4; ++q) {
+            red[(wr * 8 + q + 4 * hi) * 256 + c] = du[jb][q] * s_[jb];
+            t_sh += du[jb][q];
+            t_sc = fmaf(u_[jb][q] - mu_[jb], du[jb][q], t_sc);
+        }
+        t_sh += __shfl_xor(t_sh, 32, 64);
+        t_sc += __shfl_xor(t_sc, 32, 64);
+        t_sc += a_v[jb];                                              // sum_j V_j sum_i dz: computed from the folded sums, the same in both half-waves
         if (hi == 0) { red2[(wr * 2 + 0) * 256 + c] = t_sc; red2[(wr * 2 + 1) * 256 + c] = t_sh; }
     }
     __syncthreads();

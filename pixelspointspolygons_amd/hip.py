@@ -851,10 +851,20 @@ def adamw(params, grads, m, v, hyper, beta1, beta2, eps, wd, grad_scale=1.0, sha
 
 
 # ------------------------------------------------------------------------------------------ ScoreNet backward
+A_AFFINE_MASK2 = 5
+
+
+def bn_sums_from_g(G, W, scale, shift, mean, dW, acc):
+    """see p3_bn_sums_from_g: G [N, 2K] fp32 from gemm_tn_ex(..., A_AFFINE_MASK2); dW [N, K] and acc [2K] are accumulated into"""
+    N, K = W.shape
+    check(lib().p3_bn_sums_from_g(ptr(G), c_int(G.stride(0)), ptr(W), ptr(scale), ptr(shift), ptr(mean), ptr(dW), ptr(acc), c_int(N), c_int(K), stream()),
+          "p3_bn_sums_from_g")
+
+
 def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=None):
     M_ = a.shape[0] if M is None else M
     N, K = a.shape[1], b.shape[1]
-    slabs, ns = _tn_slabs(N, K, a)
+    slabs, ns = _tn_slabs(N, K * (2 if b_mode == A_AFFINE_MASK2 else 1), a)
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
                               c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
                               ptr(None), ptr(slabs), c_int(ns), stream()), "p3_gemm_tn_ex")

@@ -526,6 +526,36 @@ def _assert_kink_only(decisions, zs, limit=4e-6, count=64):
             assert nd <= count and (nd == 0 or float(z[diff].abs().max()) < limit), (pre, li, nd, float(z[diff].abs().max()) if nd else 0.0)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-3), (torch.float32, 2e-5)])
+def test_bn_sums_from_the_dual_operand_weight_gradient(dtype, tol):
+    """p3_gemm_tn_ex(P3_A_AFFINE_MASK2) + p3_bn_sums_from_g: conv3's weight gradient over relu(bn2(H2)) and the BatchNorm-2 backward sums of
+    dA3 = dH3 W3 from ONE pass over (dH3, H2) - against float64, and against the sums pass it replaces (p3_row_affine_bwd over the stored dA3)."""
+    h = _h()
+    R = 7000
+    dH3 = (_rand(R, 64, seed=1) * 0.3).to(dtype)
+    H2 = _rand(R, 128, seed=2).to(dtype)
+    W3 = _rand(64, 128, seed=3) * 0.1
+    sc, sh, mu = 0.5 + _rand(128, seed=4).abs(), _rand(128, seed=5) * 0.3, _rand(128, seed=6) * 0.2
+    on = (H2.float() * sc + sh > 0)
+    dA3 = dH3.double() @ W3.double()
+    dz = dA3 * on
+    s1_ref, s2_ref = dz.sum(0), (dz * (H2.double() - mu.double())).sum(0)
+    dW_ref = dH3.double().t() @ torch.relu(H2.double() * sc.double() + sh.double())
+    d = lambda t: t.to(DEV)
+    G = torch.zeros(64, 256, device=DEV)
+    h.gemm_tn_ex(d(dH3), d(H2), G, h.A_AFFINE_MASK2, d(sc), d(sh))
+    dW = torch.full((64, 128), 0.25, device=DEV)
+    acc = torch.zeros(256, device=DEV)
+    h.bn_sums_from_g(G, d(W3), d(sc), d(sh), d(mu), dW, acc)
+    assert l2_err(acc[:128].cpu(), s2_ref) < tol and l2_err(acc[128:].cpu(), s1_ref) < tol
+    assert l2_err(dW.cpu() - 0.25, dW_ref) < tol
+    if dtype == torch.bfloat16:            # the pass it replaces works on the bf16-rounded dA3: same sums to that rounding
+        dA3d = h.gemm(d(dH3), d(W3.t().contiguous().to(dtype)), out_dtype=dtype)
+        acc_old = torch.zeros(256, device=DEV)
+        h.row_affine_bwd(d(H2), d(sc), d(sh), d(mu), acc_old, dA=dA3d, store=False)
+        assert l2_err(acc.cpu(), acc_old.cpu()) < 5e-3
+
+
 @pytest.mark.parametrize("B,N", [(2, 192), (3, 60), (2, 24), (1, 13), (1, 16)])
 def test_pair_bwd_fused_vs_float64_and_the_two_launch_form(B, N):
     """csrc/pair_bwd_mma.hip: conv2's input gradient dA2 = dH2 W2 formed in the MFMA accumulators of the pair kernel (never stored) - dU, dV and the
