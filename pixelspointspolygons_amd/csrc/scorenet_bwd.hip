@@ -421,27 +421,37 @@ extern "C" int p3_row_affine_bwd2(const void* dA, const float* dS, const void* H
 // G = A^T [y > 0], G2 = A^T ([y > 0] H) from p3_gemm_tn_ex(P3_A_AFFINE_MASK2) -> the weight gradient of the layer behind the BatchNorm / ReLU
 // (dW[k, c] += scale[c] G2[k, c] + shift[c] G[k, c]  =  A^T relu(H scale + shift)) and the two sums the BatchNorm backward of the layer's INPUT gradient
 // dA = A W needs (dz = [y > 0] dA):  sum_r dz = sum_k W[k, c] G[k, c],  sum_r dz (H - mean) = sum_k W[k, c] (G2[k, c] - mean[c] G[k, c]).
-// One thread per channel c; float64 accumulation in k order (bit-reproducible).
-__global__ void bn_sums_from_g_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ W, const float* __restrict__ sc, const float* __restrict__ sh,
-                                      const float* __restrict__ mean, float* __restrict__ dW, float* __restrict__ acc, int N, int K) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= K) return;
-    const float s = sc[c], h = sh[c], mu = mean[c];
+// A workgroup = 16 channels x 16 row lanes (row lane q takes k = q, q + 16, ...); float64 partials folded in lane order (bit-reproducible).
+__global__ __launch_bounds__(256) void bn_sums_from_g_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ W, const float* __restrict__ sc,
+                                                             const float* __restrict__ sh, const float* __restrict__ mean, float* __restrict__ dW,
+                                                             float* __restrict__ acc, int N, int K) {
+    __shared__ double r1[16][16], r2[16][16];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < N; ++k) {
-        const float g = G[(int64_t)k * ldg + c], g2 = G[(int64_t)k * ldg + K + c], w = W[(int64_t)k * K + c];
-        s1 += (double)w * (double)g;
-        s2 += (double)w * ((double)g2 - (double)mu * (double)g);
-        dW[(int64_t)k * K + c] += s * g2 + h * g;
+    if (c < K) {
+        const float s = sc[c], h = sh[c], mu = mean[c];
+        for (int k = q; k < N; k += 16) {
+            const float g = G[(int64_t)k * ldg + c], g2 = G[(int64_t)k * ldg + K + c], w = W[(int64_t)k * K + c];
+            s1 += (double)w * (double)g;
+            s2 += (double)w * ((double)g2 - (double)mu * (double)g);
+            dW[(int64_t)k * K + c] += s * g2 + h * g;
+        }
     }
-    acc[c] += (float)s2;            // centred scale sums
-    acc[K + c] += (float)s1;        // shift sums
+    r1[q][cl] = s1; r2[q][cl] = s2;
+    __syncthreads();
+    if (q == 0 && c < K) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a1 += r1[i][cl]; a2 += r2[i][cl]; }
+        acc[c] += (float)a2;            // centred scale sums
+        acc[K + c] += (float)a1;        // shift sums
+    }
 }
 
 extern "C" int p3_bn_sums_from_g(const float* G, int ldg, const float* W, const float* scale, const float* shift, const float* mean, float* dW, float* acc,
                                  int N, int K, void* stream) {
     P3_CHECK(G && W && scale && shift && mean && dW && acc && N > 0 && K > 0 && ldg >= 2 * K, P3_EINVAL, "p3_bn_sums_from_g: bad arguments");
-    hipLaunchKernelGGL(bn_sums_from_g_kernel, dim3((K + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, ldg, W, scale, shift, mean, dW, acc, N, K);
+    hipLaunchKernelGGL(bn_sums_from_g_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, G, ldg, W, scale, shift, mean, dW, acc, N, K);
     P3_LAUNCH_CHECK();
     return P3_OK;
 }

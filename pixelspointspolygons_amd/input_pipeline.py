@@ -84,6 +84,31 @@ def pack_lidar(clouds, values_out=None, offsets_out=None):
     return values, offsets
 
 
+def _stop_feeder(stop, free):
+    stop.set()
+    free.put(None)                   # wakes a feeder parked on free.get()
+
+
+def _feeder_loop(ref, it, free, ready, stop, device):
+    try:
+        torch.cuda.set_device(device)
+        for host in it:
+            s = free.get()
+            if stop.is_set() or s is None:
+                return
+            pf = ref()
+            if pf is None:
+                return
+            if s["copied"] is not None:
+                s["copied"].synchronize()                  # the H2D copies that last read this set's pinned buffers are done
+            out, rdy = pf._upload(s, pf._stage(s, host))
+            del pf
+            ready.put((s, out, rdy, None))
+        ready.put((None, None, None, StopIteration()))
+    except BaseException as e:                             # surface feeder errors in the consumer's thread
+        ready.put((None, None, None, e))
+
+
 class DevicePrefetcher:
     """Triple-buffered host->device feeder.  Wraps an iterable of HOST batches (dicts):
          "image"  uint8 [B,H,W,C] tensor / array (optional)       "lidar"  list of [n_i,3] float32 clouds (optional)
@@ -116,8 +141,14 @@ class DevicePrefetcher:
         for _ in range(max(2, depth)):
             self.free.put({"pin": {}, "dev": {}, "copied": None, "consumed": None})
         self.current = None
-        self._stop = False
-        self.thread = threading.Thread(target=self._feed, name="p3-feeder", daemon=True)
+        # The feeder thread must not keep the prefetcher alive (with a bound method as its target an abandoned iterator was never
+        # collected, so nothing ever stopped the thread or released the pinned / device staging).  It holds a weak reference, takes a strong one
+        # only while it packs a batch, and a finalizer - run by close(), by garbage collection or at interpreter exit - wakes and stops it.
+        import weakref
+        self._stop = threading.Event()
+        self._finalizer = weakref.finalize(self, _stop_feeder, self._stop, self.free)
+        self.thread = threading.Thread(target=_feeder_loop, args=(weakref.ref(self), self.it, self.free, self.ready, self._stop, self.device),
+                                       name="p3-feeder", daemon=True)
         self.thread.start()
 
     # ---- persistent buffers of one staging set
@@ -188,27 +219,9 @@ class DevicePrefetcher:
             ready.record(self.stream)
         return out, ready
 
-    def _feed(self):
-        try:
-            torch.cuda.set_device(self.device)
-            for host in self.it:
-                s = self.free.get()
-                if self._stop:
-                    return
-                if s["copied"] is not None:
-                    s["copied"].synchronize()                  # the H2D copies that last read this set's pinned buffers are done
-                out, ready = self._upload(s, self._stage(s, host))
-                self.ready.put((s, out, ready, None))
-            self.ready.put((None, None, None, StopIteration()))
-        except BaseException as e:                             # surface feeder errors in the consumer's thread
-            self.ready.put((None, None, None, e))
-
     def close(self):
         """stop the feeder thread (it may be parked on free.get()) and drop the pinned / device staging; idempotent"""
-        if self._stop:
-            return
-        self._stop = True
-        self.free.put({"pin": {}, "dev": {}, "copied": None, "consumed": None})
+        self._finalizer()
 
     def __enter__(self):
         return self
@@ -216,12 +229,6 @@ class DevicePrefetcher:
     def __exit__(self, *exc):
         self.close()
         return False
-
-    def __del__(self):                       # an abandoned iterator must not leave the thread blocked holding pinned + device buffers
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def __iter__(self):
         return self

@@ -178,3 +178,25 @@ def test_prefetcher_prepares_ffl_ground_truth():
         assert np.array_equal(b["gt_crossfield_angle"][i, 0].cpu().numpy(), O.ffl_angle_from_u8(O.d4_image(ang[i][..., None], e)[..., 0], e))
         assert torch.equal(b["image"][i].cpu(), O.normalize_to_tensor(O.d4_image(host["image"][i].numpy(), e)))
     assert torch.equal(b["class_freq"].cpu(), host["class_freq"])
+
+
+def test_an_abandoned_prefetcher_stops_its_feeder_thread():
+    """the feeder thread holds only a weak reference to the prefetcher - dropping an iterator mid-way (a temporary `next(DevicePrefetcher(...))`,
+    an early `break`) lets it be collected, and the finalizer wakes and ends the thread parked on the free queue (its pinned / device staging goes with it)."""
+    import gc
+    g = torch.Generator().manual_seed(0)
+    host = [{"image": torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=g)} for _ in range(8)]
+    pf = DevicePrefetcher(iter(host), DEV)
+    b = next(pf)
+    th = pf.thread
+    assert th.is_alive()
+    del pf
+    gc.collect()
+    th.join(timeout=10)
+    assert not th.is_alive()
+    assert b["image"].shape == (2, 3, 224, 224) and torch.isfinite(b["image"]).all()      # the batch already handed out stays valid
+    with DevicePrefetcher(iter(host), DEV) as pf2:                                          # close() / context exit: the same path
+        next(pf2)
+        th2 = pf2.thread
+    th2.join(timeout=10)
+    assert not th2.is_alive()
