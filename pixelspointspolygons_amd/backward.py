@@ -10,6 +10,13 @@ FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # 
 
 def scorenet_backward(net, feats, keep, dout, transpose_acc):
     """Native backward over the tensors the forward kept (U, V, H2, H3, BN triples); see csrc/scorenet_bwd.hip."""
+    from . import ops
+    return ops.drive_steps([scorenet_backward_steps(net, feats, keep, dout, transpose_acc)])[0]
+
+
+def scorenet_backward_steps(net, feats, keep, dout, transpose_acc):
+    """scorenet_backward as a generator that stops at its three SyncBatchNorm exchanges (ops.bn_backward_coeffs_steps): scorenet1 / scorenet2 run
+    in lockstep and share one message per depth (ops.drive_steps)."""
     from . import hip, ops
     cd, N, training = net.cd, net.n_vertices, net.training
     B, L, D = feats.shape
@@ -27,7 +34,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     dS, w4 = dout.contiguous(), net.conv4.weight.detach().reshape(-1)
     dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, acc3, dS=dS, w4=w4, N=N, transpose=transpose_acc, store=not training)
     dw4, db4 = acc3[128:192].view(1, 64, 1, 1), acc3[192:193]
-    dg3, dbt3, a3, b3 = ops.bn_backward_coeffs(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training, params=(net.bn3.weight, net.bn3.bias))
+    dg3, dbt3, a3, b3 = yield from ops.bn_backward_coeffs_steps(acc3[:64], acc3[64:128], net.bn3.weight.detach(), m3, r3, cnt, training, params=(net.bn3.weight, net.bn3.bias))
     if training:
         dH3 = hip.row_affine_bwd(H3, sc3, sh3, m3, None, dS=dS, w4=w4, N=N, transpose=transpose_acc, fix=(a3, b3))
     # ---- conv3 (+ BN2/ReLU in front of it)
@@ -49,7 +56,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     else:
         dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
-    dg2, dbt2, a2, b2 = ops.bn_backward_coeffs(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training, params=(net.bn2.weight, net.bn2.bias))
+    dg2, dbt2, a2, b2 = yield from ops.bn_backward_coeffs_steps(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training, params=(net.bn2.weight, net.bn2.bias))
     if training:
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
@@ -63,7 +70,7 @@ def scorenet_backward(net, feats, keep, dout, transpose_acc):
     else:
         dA2 = hip.gemm(dH2, w2t, out_dtype=cd)                                                              # [R, 256]
         dU, dV = hip.pair_bwd(dA2, U, V, sc1, sh1, m1, B, N, acc1)
-    dg1, dbt1, a1, b1 = ops.bn_backward_coeffs(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training, params=(net.bn1.weight, net.bn1.bias))
+    dg1, dbt1, a1, b1 = yield from ops.bn_backward_coeffs_steps(acc1[:256], acc1[256:], net.bn1.weight.detach(), m1, r1, cnt, training, params=(net.bn1.weight, net.bn1.bias))
     if training:
         hip.pair_stats_bwd(U, V, a1, b1, dU, dV, B, N)
     # ---- conv1 (separable): U = F W1a^T + b1, V = F W1b^T

@@ -189,6 +189,52 @@ def bn_backward_coeffs(dscale, dshift, gamma, mean, rstd, count, training, param
     return dg, dbt, a, b
 
 
+def bn_backward_coeffs_steps(dscale, dshift, gamma, mean, rstd, count, training, params=None):
+    """bn_backward_coeffs as a generator: yields the statistic tensors SyncBatchNorm must all-reduce (None: nothing to exchange), is sent the
+    world size, returns (dgamma, dbeta, a, b) - so that a caller can put the exchanges of several independent BatchNorm sites (scorenet1 /
+    scorenet2 at equal depth) into ONE message (drive_steps)."""
+    acc = direct_grads(*params) if params is not None else None
+    dg, dbt, a, b = hip.bn_bwd_coeffs(dscale, dshift, gamma, mean, rstd, count, training, acc=acc)
+    if acc is not None:
+        _grad_ready(*params)
+    if training and sync_active():
+        gs, gh = dscale.clone(), dshift.clone()
+        w = yield (gs, gh)
+        _, _, a, b = hip.bn_bwd_coeffs(gs, gh, gamma, mean, rstd, count * w, training)
+    else:
+        yield None
+    return dg, dbt, a, b
+
+
+def drive_steps(gens):
+    """Run generators in lockstep: whatever they yield at one stop (statistic tensors, tuples of them, or None) is all-reduced in ONE packed
+    sync_stats call, the world size is sent back.  Returns the generators' return values."""
+    gens = list(gens)
+    results = [None] * len(gens)
+    live = list(range(len(gens)))
+    pending = {}
+    for i in live:
+        try:
+            pending[i] = next(gens[i])
+        except StopIteration as e:
+            results[i] = e.value
+    while pending:
+        flat = []
+        for v in pending.values():
+            if v is None:
+                continue
+            flat.extend(v if isinstance(v, (tuple, list)) else (v,))
+        w = sync_stats(*flat) if flat else 1
+        nxt = {}
+        for i in list(pending):
+            try:
+                nxt[i] = gens[i].send(w)
+            except StopIteration as e:
+                results[i] = e.value
+        pending = nxt
+    return results
+
+
 _rng = {}
 
 

@@ -94,6 +94,11 @@ def log_optimal_transport(scores, alpha, iters):
 
 
 # ------------------------------------------------------------------------------------------------ ScoreNet
+PAIR_SCORENETS = [None]     # EncoderDecoder.perm_scores: both ScoreNets as one lockstep autograd node.  None = exactly when SyncBatchNorm exchanges
+                            # statistics (one message per depth for both nets); a single process keeps net-after-net order (each net's tensors
+                            # stay hot in L2 / MALL between its launches).  Tests force True / False to compare.
+
+
 class ScoreNet(nn.Module):
     def __init__(self, n_vertices, in_channels=512, token_mode=2):
         super().__init__()
@@ -122,9 +127,9 @@ class ScoreNet(nn.Module):
         return self.scores_into(feats if feats.dtype == self.cd else hip.cast(feats.contiguous(), self.cd), out, False)
 
 
-def _bn_scale_shift(sums, count, bn, training, save=False):
+def _bn_scale_shift(sums, count, bn, training, save=False, world=None):
     if training:
-        count = count * ops.sync_stats(sums)        # SyncBatchNorm: global sums / global count
+        count = count * (ops.sync_stats(sums) if world is None else world)        # SyncBatchNorm: global sums / global count
     r = hip.bn_finalize(sums, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                         training, save=save)
     if training:
@@ -134,6 +139,12 @@ def _bn_scale_shift(sums, count, bn, training, save=False):
 
 def scorenet_forward(net, feats, out, transpose_acc, keep=None):
     """feats [B, L, D] (compute dtype) -> raw scores written / transposed-accumulated into `out` [B, N, N]."""
+    return ops.drive_steps([scorenet_forward_steps(net, feats, out, transpose_acc, keep)])[0]
+
+
+def scorenet_forward_steps(net, feats, out, transpose_acc, keep=None):
+    """scorenet_forward as a generator that stops at its three BatchNorm statistic exchanges (yields the sums, is sent the world size): the two
+    ScoreNets of the model run in lockstep and exchange the sums of equal depth in ONE message (ops.drive_steps; 6 -> 3 collectives per forward)."""
     cd, N, training = net.cd, net.n_vertices, net.training
     B, L, D = feats.shape
     dev = feats.device
@@ -146,21 +157,51 @@ def scorenet_forward(net, feats, out, transpose_acc, keep=None):
     if training:
         s1 = torch.zeros(512, dtype=torch.float32, device=dev)
         hip.pair_stats(U, V, B, N, s1)
-    sc1, sh1, m1, r1 = _bn_scale_shift(s1, cnt, net.bn1, training, save=True)
+    w_ = yield (s1 if training else None)
+    sc1, sh1, m1, r1 = _bn_scale_shift(s1, cnt, net.bn1, training, save=True, world=w_)
     w2 = ops.shadow(net.conv2.weight, cd, key="2d", fn=lambda t: t.reshape(t.shape[0], -1))
     s2 = torch.zeros(256, dtype=torch.float32, device=dev) if training else None
     H2 = hip.gemm(U, w2, bias=net.conv2.bias.detach(), a_mode=hip.A_PAIR_AFFINE_RELU, M=B * N * N, pair_v=V, pair_n=N, a_scale=sc1,
                   a_shift=sh1, out_dtype=cd, colsum=s2[:128] if training else None, colsumsq=s2[128:] if training else None)
-    sc2, sh2, m2, r2 = _bn_scale_shift(s2, cnt, net.bn2, training, save=True)
+    w_ = yield (s2 if training else None)
+    sc2, sh2, m2, r2 = _bn_scale_shift(s2, cnt, net.bn2, training, save=True, world=w_)
     w3 = ops.shadow(net.conv3.weight, cd, key="2d", fn=lambda t: t.reshape(t.shape[0], -1))
     s3 = torch.zeros(128, dtype=torch.float32, device=dev) if training else None
     H3 = hip.gemm(H2, w3, bias=net.conv3.bias.detach(), a_mode=hip.A_AFFINE_RELU, a_scale=sc2, a_shift=sh2, out_dtype=cd,
                   colsum=s3[:64] if training else None, colsumsq=s3[64:] if training else None)
-    sc3, sh3, m3, r3 = _bn_scale_shift(s3, cnt, net.bn3, training, save=True)
+    w_ = yield (s3 if training else None)
+    sc3, sh3, m3, r3 = _bn_scale_shift(s3, cnt, net.bn3, training, save=True, world=w_)
     hip.score_out(H3, sc3, sh3, net.conv4.weight.detach().reshape(-1), net.conv4.bias.detach(), out, B, N, transpose_acc)
     if keep is not None:
         keep.update(F=F, U=U, V=V, H2=H2, H3=H3, bn=((sc1, sh1, m1, r1), (sc2, sh2, m2, r2), (sc3, sh3, m3, r3)))
     return out
+
+
+class _ScoreNetPairFn(torch.autograd.Function):
+    """scorenet1(f) + scorenet2(f)^T (model_pix2poly.py:257-259) as ONE autograd node: forward and backward of the two nets advance in lockstep,
+    so that under SyncBatchNorm (convert_sync_batchnorm, model_pix2poly.py:326) the statistic exchanges of equal depth share one message."""
+
+    @staticmethod
+    def forward(ctx, feats, net1, net2, out, n1, *params):
+        k1 = {} if any(ctx.needs_input_grad) else None
+        k2 = {} if any(ctx.needs_input_grad) else None
+        ops.drive_steps([scorenet_forward_steps(net1, feats, out, False, k1), scorenet_forward_steps(net2, feats, out, True, k2)])
+        for net, k in ((net1, k1), (net2, k2)):
+            if k is not None and getattr(net, "debug_keep", False):
+                net._last_keep = dict(k)
+        ctx.nets, ctx.keeps, ctx.n1 = (net1, net2), (k1, k2), n1
+        ctx.save_for_backward(feats)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .backward import scorenet_backward_steps
+        (feats,) = ctx.saved_tensors
+        (net1, net2), (k1, k2) = ctx.nets, ctx.keeps
+        (df1, dp1), (df2, dp2) = ops.drive_steps([scorenet_backward_steps(net1, feats, k1, dout, False), scorenet_backward_steps(net2, feats, k2, dout, True)])
+        dfeats = df1 + df2
+        return (dfeats, None, None, None, None, *dp1, *dp2)
 
 
 class _ScoreNetFn(torch.autograd.Function):
@@ -436,6 +477,10 @@ class EncoderDecoder(nn.Module):
             out = self.scorenet1.scores_into(features, out, False)
             ops.side_join("sn")
             return out + out2.transpose(1, 2)
+        pair = ops.sync_active() if PAIR_SCORENETS[0] is None else PAIR_SCORENETS[0]
+        if pair and self.scorenet1.token_mode == 2 and self.scorenet2.token_mode == 2:
+            p1, p2 = list(self.scorenet1.parameters()), list(self.scorenet2.parameters())
+            return _ScoreNetPairFn.apply(features, self.scorenet1, self.scorenet2, out, len(p1), *p1, *p2)
         out = self.scorenet1.scores_into(features, out, False)
         return self.scorenet2.scores_into(features, out, True)
 

@@ -526,6 +526,42 @@ def _assert_kink_only(decisions, zs, limit=4e-6, count=64):
             assert nd <= count and (nd == 0 or float(z[diff].abs().max()) < limit), (pre, li, nd, float(z[diff].abs().max()) if nd else 0.0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_scorenet_pair_node_equals_the_two_single_nodes(precision):
+    """EncoderDecoder.perm_scores: scorenet1 / scorenet2 as ONE lockstep autograd node (pix2poly._ScoreNetPairFn: under SyncBatchNorm the two nets
+    share one statistic message per depth) against the two separate nodes: the same launches in another interleaving - outputs, the feature
+    gradient and every parameter gradient (fp32: bit for bit; bf16: atomics in the weight gradients, so to rounding)."""
+    from pixelspointspolygons_amd import pix2poly
+    from pixelspointspolygons_amd.config import make_config
+    cfg = make_config("vit", precision=precision, device=DEV)
+    torch.manual_seed(3)
+    m = pix2poly.Pix2PolyModel(cfg, pix2poly.Tokenizer(cfg).vocab_size, 0).train()
+    cd = torch.float32 if precision == "fp32" else torch.bfloat16
+    feats0 = (_rand(2, 385, 256, seed=8) * 0.5).to(cd).to(DEV)
+    gup = _rand(2, 192, 192, seed=9).to(DEV)
+
+    def run(pair):
+        was, pix2poly.PAIR_SCORENETS[0] = pix2poly.PAIR_SCORENETS[0], pair
+        try:
+            for p_ in m.parameters():
+                p_.grad = None
+            f = feats0.clone().requires_grad_(True)
+            out = m.perm_scores(f)
+            (out * gup).sum().backward()
+            return out.detach().clone(), f.grad.clone(), {k: p_.grad.clone() for k, p_ in m.named_parameters() if k.startswith("scorenet") and p_.grad is not None}
+        finally:
+            pix2poly.PAIR_SCORENETS[0] = was
+    o1, g1, p1 = run(True)
+    o0, g0, p0 = run(False)
+    assert p1.keys() == p0.keys() and len(p1) >= 2 * 14
+    if precision == "fp32":
+        assert torch.equal(o1, o0) and torch.equal(g1, g0)
+        assert all(torch.equal(p1[k], p0[k]) for k in p1)
+    else:
+        assert torch.equal(o1, o0) and rel_err(g1.float().cpu(), g0.float().cpu()) < 2e-2
+        assert all(l2_err(p1[k].cpu(), p0[k].cpu()) < 1e-2 for k in p1)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-3), (torch.float32, 2e-5)])
 def test_bn_sums_from_the_dual_operand_weight_gradient(dtype, tol):
     """p3_gemm_tn_ex(P3_A_AFFINE_MASK2) + p3_bn_sums_from_g: conv3's weight gradient over relu(bn2(H2)) and the BatchNorm-2 backward sums of

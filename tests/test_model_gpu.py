@@ -265,7 +265,21 @@ def test_kv_cached_generate_full_model(precision):
             ftoks, ffeats = m.generate(enc)
             torch.cuda.synchronize(); t_fused = time.time() - t0
             print(f"\n[fp32] fused decode layer: {t_fused:.2f} s against the launch chain's {t_cached:.2f} s")
-            assert torch.equal(ftoks[:, :60], toks[:, :60]) and rel_err(ffeats[:, :59].cpu(), feats[:, :59].cpu()) < 1e-4
+            # FULL-length comparison: the fused layer sums its dot products in another order (features agree to ~2e-5), so a greedy
+            # step whose two best logits lie closer than that may pick the other token - and only such a step may: the first divergence of every
+            # sequence is located and the launch chain's own top-2 logit margin there must be a near-tie; up to it tokens are equal bit for bit
+            for b_ in range(toks.shape[0]):
+                diff = (ftoks[b_] != toks[b_]).nonzero()
+                if diff.numel() == 0:
+                    assert rel_err(ffeats[b_:b_ + 1].cpu(), feats[b_:b_ + 1].cpu()) < 1e-4
+                    continue
+                k = int(diff[0])                                     # token k was chosen from the logits of position k - 1
+                lg, _ = m.decoder.predict(enc[b_:b_ + 1], toks[b_:b_ + 1, :k])
+                top2 = lg[0].float().topk(2).values
+                margin = float(top2[0] - top2[1])
+                print(f"\n[fp32] tile {b_}: fused decode leaves the launch chain's sequence at step {k} of 385, top-2 logit margin there {margin:.2e}")
+                assert margin < 2e-4 * max(1.0, float(top2[0].abs())), (b_, k, margin)
+                assert k >= 2 and torch.equal(ftoks[b_, :k], toks[b_, :k]) and rel_err(ffeats[b_:b_ + 1, :k - 1].cpu(), feats[b_:b_ + 1, :k - 1].cpu()) < 1e-4
         torch.cuda.synchronize(); t0 = time.time()
         ref_toks, ref_feats = m.generate(enc, steps=24, use_cache=False)
         torch.cuda.synchronize(); t_full24 = time.time() - t0
