@@ -38,6 +38,9 @@ extern "C" {
 #define P3_ACT_GELU 1 /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
 #define P3_ACT_RELU 2
 #define P3_ACT_MUL 3  /* p3_gemm_desc.bwd_act only: the saved tensor already holds act'(pre) (aux_mode = 1): plain multiply */
+#define P3_ACT_BN_RELU 4 /* p3_gemm_desc.bwd_act only: bwd_saved = H, the input of a train-mode BatchNorm + ReLU whose OUTPUT this GEMM's product is the gradient
+                          * of: C = [H*bn[0] + bn[1] > 0] * (A'W^T) * bn[0] + bn[2] + bn[3] * H  with bwd_bn = four rows of N floats (scale, shift, and the a / b
+                          * of p3_bn_bwd_coeffs) - the whole BatchNorm backward of the layer in front, no [M,N] gradient stored in between */
 
 #define P3_A_PLAIN 0
 #define P3_A_CONV3X3 1 /* A is an NHWC map [B,H,W,lda]; K = 9*C, zero padding 1 (implicit GEMM) */
@@ -129,6 +132,7 @@ typedef struct {
                            * activation from the same erf / exp), so that backward is a multiply with no transcendental */
     int conv_pad;         /* P3_A_CONV3X3: 1 = A is a zero-bordered image [B, conv_H+2, conv_W+2, lda] (p3_pad_nhwc): taps are read
                            * without bounds checks; conv_H / conv_W stay the OUTPUT size */
+    const float* bwd_bn;  /* bwd_act = P3_ACT_BN_RELU: [4, N] floats (scale | shift | a | b) */
 } p3_gemm_desc;
 int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream);
 /* The LDS-DMA kernels behind p3_gemm for the plain bf16 products (csrc/gemm_dma.hip), callable directly for A/B measurements and parity tests: same

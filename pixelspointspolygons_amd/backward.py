@@ -5,6 +5,7 @@ PillarFeatureNet backward in csrc/pillars.hip: p3_pillar_stem_bwd.)  No PyTorch 
 import torch
 
 SUMS_FROM_G = [__import__("os").environ.get("P3_SUMS_FROM_G", "1") != "0"]    # BatchNorm-2 backward sums from the dual-operand weight-gradient GEMM (A/B switch)
+FUSED_BN2 = [__import__("os").environ.get("P3_BN2_FUSED", "1") != "0"]        # conv3 input gradient with the BatchNorm-2 / ReLU backward as its epilogue (needs SUMS_FROM_G)
 FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
 
 
@@ -43,8 +44,9 @@ def scorenet_backward_steps(net, feats, keep, dout, transpose_acc):
     wout = lambda n, r, c: gw[n][0].view(r, c) if gw[n] is not None else torch.zeros(r, c, **f32)
     db3 = ops.bias_grad_before_bn(dH3, training, net.conv3.bias)
     w3t = ops.shadow(net.conv3.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [128, 64]
-    dA3 = hip.gemm(dH3, w3t, out_dtype=cd)                                                                  # [R, 128]
     acc2 = torch.zeros(2 * 128, **f32)
+    fused2 = training and SUMS_FROM_G[0] and FUSED_BN2[0]
+    dA3 = None if fused2 else hip.gemm(dH3, w3t, out_dtype=cd)                                              # [R, 128]
     if training and SUMS_FROM_G[0]:
         # ONE pass over (dH3, H2) gives G = dH3^T [bn2(H2) > 0] and G2 = dH3^T ([bn2(H2) > 0] H2): conv3's weight gradient AND the BatchNorm-2 backward
         # sums of dA3 follow from the two 64 x 128 matrices (p3_bn_sums_from_g) - the sums pass over the [R, 128] gradient (290 us per net) is gone
@@ -57,7 +59,11 @@ def scorenet_backward_steps(net, feats, keep, dout, transpose_acc):
         dW3 = hip.gemm_tn_ex(dH3, H2, wout("conv3", 64, 128), hip.A_AFFINE_RELU, sc2, sh2)
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, acc2, dA=dA3, out=dA3, store=not training)
     dg2, dbt2, a2, b2 = yield from ops.bn_backward_coeffs_steps(acc2[:128], acc2[128:], net.bn2.weight.detach(), m2, r2, cnt, training, params=(net.bn2.weight, net.bn2.bias))
-    if training:
+    if fused2:
+        # dA3 = dH3 W3 is never stored: the BatchNorm-2 / ReLU backward ([y > 0] dA3 scale + a + b H2) is the epilogue of the product (P3_ACT_BN_RELU) -
+        # one [R, 128] write + read less per net than "product, then row_affine_bwd pass 2"
+        dH2 = hip.gemm(dH3, w3t, out_dtype=cd, bwd=(H2, hip.ACT_BN_RELU, torch.stack([sc2, sh2, a2, b2])))
+    elif training:
         dH2 = hip.row_affine_bwd(H2, sc2, sh2, m2, None, dA=dA3, out=dA3, fix=(a2, b2))
     # ---- conv2 (+ BN1/ReLU over the pair grid in front of it)
     dW2 = hip.gemm_tn_ex(dH2, U, wout("conv2", 128, 256), hip.A_PAIR_AFFINE_RELU, sc1, sh1, pair_v=V, pair_n=N, M=R)

@@ -491,8 +491,17 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                         const float4 r1 = *reinterpret_cast<const float4*>(bwd_saved + co + 4);
                         sv[0] = r0.x; sv[1] = r0.y; sv[2] = r0.z; sv[3] = r0.w; sv[4] = r1.x; sv[5] = r1.y; sv[6] = r1.z; sv[7] = r1.w;
                     }
+                    if (d.bwd_act == P3_ACT_BN_RELU) {
+                        const float* bn = d.bwd_bn + col;
     #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= act_grad(sv[k], d.bwd_act) * d.bwd_scale;
+                        for (int k = 0; k < 8; ++k) {
+                            const float sc_ = bn[k];
+                            v[k] = (sv[k] * sc_ + bn[d.N + k] > 0.f ? v[k] * sc_ : 0.f) + bn[2 * d.N + k] + bn[3 * d.N + k] * sv[k];
+                        }
+                    } else {
+    #pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] *= act_grad(sv[k], d.bwd_act) * d.bwd_scale;
+                    }
                 }
                 if (has_res) {
                     const int64_t ro = (int64_t)row * d.ldr + col;
@@ -521,7 +530,11 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_ker
                         if (act == P3_ACT_RELU) x = fmaxf(x, 0.f);
                     }
                     if (dk.on) x = drop_keep(dk, (uint64_t)row, (uint32_t)(col + k)) ? x * dk.inv_keep : 0.f;
-                    if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
+                    if (bwd_saved && d.bwd_act == P3_ACT_BN_RELU) {
+                        const float hv = Cvt<TO>::to_f(bwd_saved[co + k]);
+                        const float* bn = d.bwd_bn + col + k;
+                        x = (hv * bn[0] + bn[d.N] > 0.f ? x * bn[0] : 0.f) + bn[2 * d.N] + bn[3 * d.N] * hv;
+                    } else if (bwd_saved) x *= act_grad(Cvt<TO>::to_f(bwd_saved[co + k]), d.bwd_act) * d.bwd_scale;
                     if (has_res) {
                         const int64_t ri = (int64_t)row * d.ldr + col + k;
                         x += res_bf ? bf2f(reinterpret_cast<const bf16_t*>(d.residual)[ri]) : reinterpret_cast<const float*>(d.residual)[ri];
@@ -706,6 +719,7 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 
 // gemm_dma.hip: LDS-DMA kernels for the plain bf16 products (variant 4: 128 x 128 tile, 64-deep slices, two in LDS; 6: 32-deep, two = 4 workgroups / CU;
 // 9: 128 x 384 tile, 8 waves)
+int p3_rows_gemm_try(const void* A, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);   // rows_gemm.hip: 0x7fffffff = not one of its shapes
 int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
 static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
@@ -740,7 +754,9 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     if (d->a_mode == P3_A_PAIR_AFFINE_RELU)
         P3_CHECK(d->pair_V && d->pair_n > 0 && d->M % (d->pair_n * d->pair_n) == 0, P3_ESHAPE, "p3_gemm: pair mode needs V and M == B*n*n");
     P3_CHECK((d->colsum == nullptr) == (d->colsumsq == nullptr), P3_EINVAL, "p3_gemm: colsum and colsumsq go together");
-    P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL, P3_EINVAL, "p3_gemm: bwd_saved needs bwd_act = GELU, RELU or MUL");
+    P3_CHECK(!d->bwd_saved || d->bwd_act == P3_ACT_GELU || d->bwd_act == P3_ACT_RELU || d->bwd_act == P3_ACT_MUL || d->bwd_act == P3_ACT_BN_RELU, P3_EINVAL,
+             "p3_gemm: bwd_saved needs bwd_act = GELU, RELU, MUL or BN_RELU");
+    P3_CHECK(!(d->bwd_saved && d->bwd_act == P3_ACT_BN_RELU) || d->bwd_bn, P3_EINVAL, "p3_gemm: P3_ACT_BN_RELU needs bwd_bn");
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.tile_stats = nullptr;
     g.tiles_m = p3_ceil_div(d->M, BM);
@@ -753,6 +769,10 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
+    {   // the ScoreNet's thin 1x1 convolutions over millions of rows: weight-stationary streaming kernels (rows_gemm.hip)
+        const int rc = p3_rows_gemm_try(A, W, C, d, s);
+        if (rc != 0x7fffffff) return rc;
+    }
     if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm_dma_eligible(d, A, W, C)) {
         // P3_GEMM_DMA=0 switches the rule off (everything on the register-staged kernel).  The rule (r03, tools/mb_gemm_shapes.py + same-box A/B of the
         // train step 40.60 -> 40.15 -> 38.78 ms): the 64-deep two-slice form from K = 1024 on (dX of fc1 / qkv, decoder linear2: 74 vs 87, 59 vs 67, 33 vs

@@ -371,7 +371,7 @@ int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, co
     const int vo = d->dtype_out == P3_BF16 ? 8 : 4;
     if (d->ldc % vo != 0 || ((uintptr_t)C % 16) != 0 || ((uintptr_t)A % 16) != 0 || ((uintptr_t)W % 16) != 0) return 0;
     if (d->aux && (uintptr_t)d->aux % 16 != 0) return 0;
-    if (d->bwd_saved && (uintptr_t)d->bwd_saved % 16 != 0) return 0;
+    if (d->bwd_saved && ((uintptr_t)d->bwd_saved % 16 != 0 || d->bwd_act == P3_ACT_BN_RELU)) return 0;
     if (d->residual) { const int vr = d->dtype_res == P3_BF16 ? 8 : 4; if (d->ldr % vr != 0 || (uintptr_t)d->residual % 16 != 0) return 0; }
     if ((int64_t)d->M * d->lda * 2 >= (1ll << 31) || (int64_t)d->N * d->ldb * 2 >= (1ll << 31)) return 0;      // 32-bit DMA source offsets
     return 1;

@@ -8,7 +8,7 @@ import torch
 from ._lib import P3Error, check, lib
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL, ACT_BN_RELU = 0, 1, 2, 3, 4
 A_PLAIN, A_CONV3X3, A_AFFINE_RELU, A_PAIR_AFFINE_RELU = 0, 1, 2, 3
 
 
@@ -151,7 +151,8 @@ class GemmDesc(Structure):
                 ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
                 ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout),
-                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int), ("conv_pad", c_int)]
+                ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int), ("conv_pad", c_int),
+                ("bwd_bn", c_void_p)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
@@ -201,7 +202,13 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         sv, bact, bscale = bwd
         if sv.dtype != out.dtype or sv.stride(-2) != out.stride(-2):
             raise P3Error("gemm: bwd_saved must match the output's dtype and row stride")
-        d.bwd_saved, d.bwd_act, d.bwd_scale = sv.data_ptr(), bact, bscale
+        d.bwd_saved, d.bwd_act = sv.data_ptr(), bact
+        if bact == ACT_BN_RELU:    # bscale = the [4, N] float table (scale | shift | a | b): the BatchNorm + ReLU backward of the layer in front
+            if bscale.dtype != torch.float32 or tuple(bscale.shape) != (4, N) or not bscale.is_contiguous():
+                raise P3Error("gemm: ACT_BN_RELU needs a contiguous float32 [4, N] table")
+            d.bwd_bn, d.bwd_scale = bscale.data_ptr(), 1.0
+        else:
+            d.bwd_scale = bscale
     ev = KTIMER.begin()
     if variant is not None:
         check(lib().p3_gemm_dma(ptr(a), ptr(w), ptr(out), byref(d), c_int(int(variant)), stream()), "p3_gemm_dma")

@@ -199,6 +199,76 @@ def test_gemm_affine_and_pair_modes():
     assert rel_err(out2, ref2) < 3e-6
 
 
+def _bn_relu_bwd_ref(A, W, H, tab):
+    """float64 [H s + h > 0] (A W^T) s + a + b H, and the elements away from the ReLU kink (|H s + h| > 1e-4: the kernel's fused multiply-add may
+    decide the others either way)."""
+    z = H.double() * tab[0].double() + tab[1].double()
+    ref = torch.where(z > 0, (A.double() @ W.double().t()) * tab[0].double(), torch.zeros((), dtype=torch.float64)) + tab[2].double() + tab[3].double() * H.double()
+    return ref.float(), z.abs() > 1e-4
+
+
+def test_rows_gemm_kernels_of_the_scorenet_conv3():
+    """csrc/rows_gemm.hip (weight-stationary streaming kernels p3_gemm picks for bf16, M % 32 == 0, M >= 4096): conv3 forward (K = 128 -> N = 64 with the
+    BatchNorm-2 / ReLU A operand, bias, BatchNorm-3 column sums) and its input gradient (K = 64 -> N = 128 with the P3_ACT_BN_RELU epilogue), against
+    float64 from the same bf16 operands; the kernel trace names them; sums and outputs bit-reproducible."""
+    hip = _h()
+    M = 32 * 2311                        # 2311 row groups over 512 x 4 waves: ragged walk
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, 128, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(64, 128, generator=g) * 0.1).bfloat16()
+    bias, sc, sh = torch.randn(64, generator=g), torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    from pixelspointspolygons_amd._lib import lib
+    last_kernel = lambda: lib().p3_last_kernel().decode()
+    hip.KTIMER.enable()
+    try:
+        def fwd():
+            sums = torch.zeros(128, device=DEV)
+            y = hip.gemm(x.to(DEV), w.to(DEV), bias=bias.to(DEV), a_mode=hip.A_AFFINE_RELU, a_scale=sc.to(DEV), a_shift=sh.to(DEV), out_dtype=torch.bfloat16,
+                         colsum=sums[:64], colsumsq=sums[64:])
+            return y, sums, last_kernel()
+        y, sums, name = fwd()
+        y2, sums2, _ = fwd()
+        assert name == "rows_gemm_kernel<128, 64, 0>", name
+        assert torch.equal(y, y2) and torch.equal(sums, sums2)
+        a_ref = torch.relu(torch.addcmul(sh, x.float(), sc)).bfloat16().double()        # fma like the kernel, rounded to the MFMA operand
+        ref = a_ref @ w.double().t() + bias.double()
+        assert rel_err(y.float().cpu(), ref.float()) < 3e-3                             # bf16 output rounding
+        assert rel_err(sums[:64].cpu(), ref.sum(0).float()) < 1e-5 and rel_err(sums[64:].cpu(), (ref * ref).sum(0).float()) < 1e-5
+        ye = hip.gemm(x.to(DEV), w.to(DEV), bias=bias.to(DEV), a_mode=hip.A_AFFINE_RELU, a_scale=sc.to(DEV), a_shift=sh.to(DEV), out_dtype=torch.bfloat16)
+        assert torch.equal(ye, y) and last_kernel() == "rows_gemm_kernel<128, 64, 0>"        # eval form: no sums
+        # input gradient with the BatchNorm-2 / ReLU backward epilogue
+        dy = (torch.randn(M, 64, generator=g) * 0.5).bfloat16()
+        w3t = (torch.randn(128, 64, generator=g) * 0.1).bfloat16()
+        H = torch.randn(M, 128, generator=g).bfloat16()
+        tab = torch.stack([torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3, torch.randn(128, generator=g) * 0.1,
+                           torch.randn(128, generator=g) * 0.1]).contiguous()
+        dx = hip.gemm(dy.to(DEV), w3t.to(DEV), out_dtype=torch.bfloat16, bwd=(H.to(DEV), hip.ACT_BN_RELU, tab.to(DEV)))
+        assert last_kernel() == "rows_gemm_kernel<64, 128, 1>", last_kernel()
+        ref, far = _bn_relu_bwd_ref(dy, w3t, H, tab)
+        out = dx.float().cpu()
+        assert rel_err(torch.where(far, out, torch.zeros(())), torch.where(far, ref, torch.zeros(()))) < 3e-3
+        assert (~far).float().mean() < 2e-4                      # the excluded kink band is a handful of the 9.5 M elements
+    finally:
+        hip.KTIMER.disable()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 6e-3), (torch.float32, 2e-6)])
+@pytest.mark.parametrize("N", [128, 132])
+def test_gemm_batchnorm_relu_backward_epilogue(dtype, tol, N):
+    """p3_gemm with bwd_act = P3_ACT_BN_RELU: the train-mode BatchNorm + ReLU backward of the layer in front as the epilogue of the input-gradient
+    product (ScoreNet conv3 -> bn2: model_pix2poly.py:88-93 differentiated): C = [H s + h > 0] (A W^T) s + a + b H against float64 at the kernel's own
+    ReLU decisions.  N = 132: the scalar (unaligned rows) epilogue; ragged M."""
+    hip = _h()
+    M, K = 1000, 64
+    A, W, H = _rand(M, K, seed=1).to(dtype), (_rand(N, K, seed=2) * 0.2).to(dtype), _rand(M, N, seed=3).to(dtype)
+    tab = torch.stack([_rand(N, seed=4).abs() + 0.5, _rand(N, seed=5) * 0.3, _rand(N, seed=6) * 0.1, _rand(N, seed=7) * 0.1]).contiguous()
+    out = hip.gemm(A.to(DEV), W.to(DEV), out_dtype=dtype, bwd=(H.to(DEV), hip.ACT_BN_RELU, tab.to(DEV))).float().cpu()
+    ref, far = _bn_relu_bwd_ref(A, W, H, tab)
+    assert rel_err(torch.where(far, out, torch.zeros(())), torch.where(far, ref, torch.zeros(()))) < tol
+    with pytest.raises(hip.P3Error):
+        hip.gemm(A.to(DEV), W.to(DEV), out_dtype=dtype, bwd=(H.to(DEV), hip.ACT_BN_RELU, tab[:3].contiguous().to(DEV)))
+
+
 def test_gemm_rejects_bad_shapes():
     h = _h()
     from pixelspointspolygons_amd._lib import P3Error
