@@ -42,7 +42,7 @@ GFLOP_FWD = {k: (v if k == "ffl_fusion" else round(v - _SCORENET_SKIPPED, 2)) fo
 GFLOP_ENC = {"fusion_s8": 49.1, "image_s8": 2 * 22.405, "image_b16": 35.13, "lidar_s8": 2 * (22.347 + 0.0745)}
 # algorithmic HBM bytes of one train step at 64 tiles: 1.14 MB/tile of inputs + outputs, AdamW 16 B per parameter
 STEP_ALGO_BYTES = {"fusion_s8": 64 * 1.14e6 + 16 * 34.6e6}
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():

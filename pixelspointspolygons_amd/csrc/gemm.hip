@@ -163,7 +163,7 @@ __device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v)
 // one per 128-row tile: the tall-skinny ScoreNet / FFL GEMMs have 18 000 - 25 000 row tiles, and 37 000 same-address atomics are a
 // 0.4 ms serial chain (r01: conv3 of the ScoreNet 906 us for 39 GFLOP).
 template <typename T, typename TO, int AMODE, int BKSEL, bool STATS>
-__global__ __launch_bounds__(256, (BKSEL == 32 && !STATS ? 3 : 2)) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_AFFINE_RELU ? 3 : 2)) void gemm_kernel(GemmArgs g) {
     using TR = Tr<T, BKSEL>;
     constexpr int BK = TR::BK, PITCH = TR::PITCH, VEC = TR::VEC, LDSE = TR::LDS_ELEMS;
     constexpr int EPI_PASSES = BKSEL == 32 ? 2 : 1;  // epilogue staged through LDS in 1 pass of 128 rows or 2 passes of 64
@@ -720,6 +720,7 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 // gemm_dma.hip: LDS-DMA kernels for the plain bf16 products (variant 4: 128 x 128 tile, 64-deep slices, two in LDS; 6: 32-deep, two = 4 workgroups / CU;
 // 9: 128 x 384 tile, 8 waves)
 int p3_rows_gemm_try(const void* A, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);   // rows_gemm.hip: 0x7fffffff = not one of its shapes
+int p3_pair_fwd_try(const void* U, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);    // pair_fwd_mma.hip: same convention
 int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
 static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
@@ -769,8 +770,11 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         g.vec_epi = ok ? 1 : 0;
     }
     hipStream_t s = (hipStream_t)stream;
-    {   // the ScoreNet's thin 1x1 convolutions over millions of rows: weight-stationary streaming kernels (rows_gemm.hip)
-        const int rc = p3_rows_gemm_try(A, W, C, d, s);
+    {   // the ScoreNet's thin 1x1 convolutions over millions of rows: weight-stationary streaming kernels (rows_gemm.hip); its conv2 over the pair
+        // grid: pair_fwd_mma.hip
+        int rc = p3_rows_gemm_try(A, W, C, d, s);
+        if (rc != 0x7fffffff) return rc;
+        rc = p3_pair_fwd_try(A, W, C, d, s);
         if (rc != 0x7fffffff) return rc;
     }
     if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm_dma_eligible(d, A, W, C)) {

@@ -207,6 +207,41 @@ def _bn_relu_bwd_ref(A, W, H, tab):
     return ref.float(), z.abs() > 1e-4
 
 
+@pytest.mark.parametrize("Bn,n", [(3, 64), (2, 40), (1, 192)])
+def test_pair_forward_kernel_of_the_scorenet_conv2(Bn, n):
+    """csrc/pair_fwd_mma.hip (p3_gemm's P3_A_PAIR_AFFINE_RELU at the ScoreNet conv2 shape K = 256 -> N = 128, bf16, n % 8 == 0): relu(bn1(U_i + V_j)) W2^T + bias
+    with the BatchNorm-2 column sums, against float64 from the same bf16 operands (the generated operand rounded to bf16 like the kernel's MFMA input) and
+    against the tile kernel (n = 20: not a multiple of 8); bit-reproducible; n = 40: ragged last 32-column step."""
+    hip = _h()
+    from pixelspointspolygons_amd._lib import lib
+    g = torch.Generator().manual_seed(7)
+    U, V = (torch.randn(Bn * n, 256, generator=g) * 0.7).bfloat16(), (torch.randn(Bn * n, 256, generator=g) * 0.7).bfloat16()
+    w = (torch.randn(128, 256, generator=g) * 0.08).bfloat16()
+    bias, sc, sh = torch.randn(128, generator=g), torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+    hip.KTIMER.enable()
+    try:
+        def run():
+            sums = torch.zeros(256, device=DEV)
+            y = hip.gemm(U.to(DEV), w.to(DEV), bias=bias.to(DEV), a_mode=hip.A_PAIR_AFFINE_RELU, M=Bn * n * n, pair_v=V.to(DEV), pair_n=n, a_scale=sc.to(DEV),
+                         a_shift=sh.to(DEV), out_dtype=torch.bfloat16, colsum=sums[:128], colsumsq=sums[128:])
+            return y, sums, lib().p3_last_kernel().decode()
+        y, sums, name = run()
+        y2, sums2, _ = run()
+    finally:
+        hip.KTIMER.disable()
+    assert name == "pair_fwd_mma_kernel", name
+    assert torch.equal(y, y2) and torch.equal(sums, sums2)
+    pair = (U.float().view(Bn, n, 1, 256) + V.float().view(Bn, 1, n, 256)).reshape(-1, 256)
+    a_ref = torch.relu(pair * sc + sh).bfloat16().double()
+    ref = a_ref @ w.double().t() + bias.double()
+    # the generated operand may round to the neighbouring bf16 value where the kernel's fma order differs from this expression: 1e-3, not bf16's 4e-3
+    assert rel_err(y.float().cpu(), ref.float()) < 4e-3
+    assert rel_err(sums[:128].cpu(), ref.sum(0).float()) < 1e-3 and rel_err(sums[128:].cpu(), (ref * ref).sum(0).float()) < 1e-3
+    ye = hip.gemm(U.to(DEV), w.to(DEV), bias=bias.to(DEV), a_mode=hip.A_PAIR_AFFINE_RELU, M=Bn * n * n, pair_v=V.to(DEV), pair_n=n, a_scale=sc.to(DEV),
+                  a_shift=sh.to(DEV), out_dtype=torch.bfloat16)
+    assert torch.equal(ye, y)                                       # eval form (no sums)
+
+
 def test_rows_gemm_kernels_of_the_scorenet_conv3():
     """csrc/rows_gemm.hip (weight-stationary streaming kernels p3_gemm picks for bf16, M % 32 == 0, M >= 4096): conv3 forward (K = 128 -> N = 64 with the
     BatchNorm-2 / ReLU A operand, bias, BatchNorm-3 column sums) and its input gradient (K = 64 -> N = 128 with the P3_ACT_BN_RELU epilogue), against

@@ -16,6 +16,9 @@ python bench.py 2>&1 | tail -1 > gpurun_out/final/${R}_bench.json
 python bench.py --workload ffl_fusion --steps 10 --no-cpu-baseline --no-fp32-leg --no-predict --no-host-feed 2>&1 | tail -1 > gpurun_out/final/${R}_bench_ffl.json
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pf_sq -o q -- python bench.py --lean --graph 0 --steps 3 --warmup 2 > gpurun_out/final/sq_run.log 2>&1
 python tools/pmc_kernels.py /tmp/pf_sq > gpurun_out/final/${R}_sq_counters_summary.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_fp32 -o st32 -- python bench.py --lean --precision fp32 --steps 6 --warmup 2 > gpurun_out/final/fp32_run.log 2>&1
+find /tmp/pf_fp32 -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/${R}_fp32_step_kernel_stats.csv \;
+python tools/kstats.py gpurun_out/final/${R}_fp32_step_kernel_stats.csv 9 40 > gpurun_out/final/${R}_fp32_step_summary.txt
 tail -3 gpurun_out/final/${R}_pmc_summary.txt
 cut -c1-900 gpurun_out/final/${R}_bench.json
 cut -c1-300 gpurun_out/final/${R}_bench_ffl.json

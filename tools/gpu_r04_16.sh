@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_ops_gpu.py -q -m gpu -k "pair_forward or affine_and_pair or rows_gemm" 2>&1 | tail -12
+python -m pytest tests/test_backward_gpu.py -x -q -m gpu -k "scorenet or train_step or pair" 2>&1 | tail -4
+python bench.py --lean --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pair fwd kernel ms/step', d['ms_per_step'], d['final_loss'])"
+P3_PAIR_FWD=0 python bench.py --lean --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('tile kernel     ms/step', d['ms_per_step'], d['final_loss'])"
+python bench.py --lean --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pair fwd kernel ms/step', d['ms_per_step'], d['final_loss'])"
