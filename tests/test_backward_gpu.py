@@ -62,6 +62,30 @@ def test_gemm_tn_dma_kernel(M, N, K, lda_pad):
     assert rel_err(out2.cpu(), ref.float()) < 2e-5
 
 
+@pytest.mark.parametrize("Bn,n", [(3, 48), (1, 192), (40, 16)])
+def test_pair_weight_gradient_kernel_of_the_scorenet_conv2(Bn, n):
+    """csrc/pair_dw_mma.hip (p3_gemm_tn_ex in pair mode at the ScoreNet conv2 shape, bf16, n % 16 == 0): dW2 += dH2^T relu(bn1(U_i + V_j)) against float64 with
+    the generated operand rounded to bf16 like the kernel's MFMA input, accumulated into a non-zero C; (40, 16): more units than one round of workgroups
+    walks at once (several units per workgroup, unit changes inside the DMA pipeline); n = 24 stays on gemm_tn.hip and must agree with it."""
+    h = _h()
+    g = torch.Generator().manual_seed(13)
+    R = Bn * n * n
+    dH = (torch.randn(R, 128, generator=g) * 0.3).bfloat16()
+    U, V = (torch.randn(Bn * n, 256, generator=g) * 0.7).bfloat16(), (torch.randn(Bn * n, 256, generator=g) * 0.7).bfloat16()
+    sc, sh = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+    h.lib().p3_trace_kernels(1)
+    out = torch.full((128, 256), 0.25, device=DEV)
+    h.gemm_tn_ex(dH.to(DEV), U.to(DEV), out, h.A_PAIR_AFFINE_RELU, sc.to(DEV), sh.to(DEV), pair_v=V.to(DEV), pair_n=n, M=R)
+    picked = h.lib().p3_last_kernel().decode()
+    h.lib().p3_trace_kernels(0)
+    assert picked == "pair_dw_mma_kernel", picked
+    pair = (U.float().view(Bn, n, 1, 256) + V.float().view(Bn, 1, n, 256)).reshape(-1, 256)
+    a1 = torch.relu(pair * sc + sh).bfloat16().double()
+    ref = dH.double().t() @ a1
+    # the kernel's fma order may round a generated element to the neighbouring bf16 value: 2e-4 (measured ~3e-5), not the 2e-5 of a plain product
+    assert rel_err(out.cpu() - 0.25, ref.float()) < 2e-4
+
+
 def test_gemm_tn_strided_operand_and_accumulate():
     h = _h()
     full = _rand(300, 512, seed=3)
