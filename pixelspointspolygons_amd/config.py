@@ -40,7 +40,8 @@ def make_config(encoder="early_fusion_vit", model="pix2poly", *, in_size=224, pa
                 vit_depth=12, vit_heads=6, vit_mlp=None, max_num_vertices=192, out_feature_dim=256,
                 max_num_points_per_voxel=64, sinkhorn_iterations=100, device="cuda", multi_gpu=False,
                 lidar_dropout=None, precision="bf16", batch_size=16):
-    """precision: 'bf16' (bf16 storage, fp32 accumulate; throughput mode) or 'fp32' (exact fp32 MFMA; parity mode)."""
+    """precision: 'bf16' (bf16 storage, fp32 accumulate; throughput mode), 'fp32' (exact fp32 MFMA; parity mode) or 'fp32x3' (fp32 storage, GEMMs as bf16 x 3 on
+    the bf16 MFMA: 2^-17 per product - the north star's 1e-3 at a multiple of the exact mode's throughput)."""
     if encoder not in _ENCODERS:
         raise NotImplementedError(f"Encoder {encoder} not implemented")
     g = in_size // patch_size

@@ -36,6 +36,11 @@ constexpr int BM = 128, BN = 128;
 template <typename T, int BKSEL> struct Tr;
 template <int BKSEL> struct Tr<bf16_t, BKSEL> { static constexpr int BK = BKSEL, PITCH = BKSEL + 8, VEC = 8, LDS_ELEMS = BM * (BKSEL + 8); };
 template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
+// BKSEL == BK_SPLIT (T = float): fp32 operands multiplied as bf16 x 3 (r04, p3_set_gemm_split): a value x is split into hi = bf16(x) and lo = bf16(x - hi)
+// when its slice is stored to LDS (two bf16 images [128 rows][16 k], 48-byte rows: conflict-free 16-byte fragment reads) and the product is
+// a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA (2^-17 relative per product; the dropped a_lo b_lo term is 2^-18) - 16 x the fp32 MFMA rate for 3 x the issues.
+constexpr int BK_SPLIT = 17, SPLIT_PITCH_B = 48, SPLIT_IMG_B = 128 * SPLIT_PITCH_B;
+template <> struct Tr<float, BK_SPLIT> { static constexpr int BK = 16, PITCH = 24, VEC = 4, LDS_ELEMS = 2 * SPLIT_IMG_B / 4; };
 template <typename T> struct VecOf { static constexpr int VEC = 16 / (int)sizeof(T); };
 
 // ---- per-thread A-row descriptor (fixed over the K loop) -------------------------------------
@@ -158,6 +163,17 @@ __device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v)
     }
 }
 
+// split form: 4 consecutive k of one row -> 8 bytes into the hi image and 8 into the lo image
+__device__ __forceinline__ void lds_put_split(float* buf, int row, int kq, const uint4& v) {
+    const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    float h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = bf2f(f2bf(x[e])); l[e] = x[e] - h[e]; }
+    unsigned char* b = reinterpret_cast<unsigned char*>(buf) + row * SPLIT_PITCH_B + kq * 2;
+    *reinterpret_cast<uint2*>(b) = make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
+    *reinterpret_cast<uint2*>(b + SPLIT_IMG_B) = make_uint2(pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3]));
+}
+
 // STATS = true (BatchNorm column sums requested): persistent workgroups walk the tiles vb, vb + gridDim.x, ... of ONE tile column
 // and keep the per-column sum / sum-of-squares in registers across them, so each column gets gridDim.x / tiles_n atomics instead of
 // one per 128-row tile: the tall-skinny ScoreNet / FFL GEMMs have 18 000 - 25 000 row tiles, and 37 000 same-address atomics are a
@@ -234,9 +250,14 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
     auto load_v = [&](int p, int k) __attribute__((always_inline)) {
         return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(d.pair_V) + arow[p].off2 + k);
     };
+    constexpr bool SPLIT = sizeof(T) == 4 && BKSEL == BK_SPLIT;
+    auto put = [&](T* buf, int row, const uint4& v) __attribute__((always_inline)) {
+        if constexpr (SPLIT) lds_put_split(reinterpret_cast<float*>(buf), row, kq, v);
+        else lds_put<T, PITCH>(buf, row, kq, v);
+    };
     auto put_a = [&](T* buf, int set, int p, int k) __attribute__((always_inline)) {
-        if constexpr (XF) lds_put<T, PITCH>(buf, r0 + p * ROWS_PER_PASS, kq, xform_a<T, AMODE>(ra[set][p], rv[PAIRA ? set : 0][PAIRA ? p : 0], xsc, xsh, k));
-        else lds_put<T, PITCH>(buf, r0 + p * ROWS_PER_PASS, kq, ra[set][p]);
+        if constexpr (XF) put(buf, r0 + p * ROWS_PER_PASS, xform_a<T, AMODE>(ra[set][p], rv[PAIRA ? set : 0][PAIRA ? p : 0], xsc, xsh, k));
+        else put(buf, r0 + p * ROWS_PER_PASS, ra[set][p]);
     };
     const int nk = d.K / BK;
 #pragma unroll
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
         }
     }
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { put_a(lds, 0, p, kq); lds_put<T, PITCH>(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, kq, rb[0][p]); }
+    for (int p = 0; p < NPASS; ++p) { put_a(lds, 0, p, kq); put(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, rb[0][p]); }
     __syncthreads();
 
     // FULL = steady state (slices t+1 and t+2 exist): no conditions around the loads / LDS stores.  With the conditions inside the loop the
@@ -290,6 +311,25 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
                             __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), af[i]),
                             __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), bf[j]), acc[i][j], 0, 0, 0);
             }
+        } else if constexpr (SPLIT) {
+            const unsigned char* ab = reinterpret_cast<const unsigned char*>(as);
+            const unsigned char* bb = reinterpret_cast<const unsigned char*>(bs);
+            typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+            bfx8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ao = (wm * 64 + i * 32 + l31) * SPLIT_PITCH_B + 16 * hi, bo = (wn * 64 + i * 32 + l31) * SPLIT_PITCH_B + 16 * hi;
+                ah[i] = *reinterpret_cast<const bfx8*>(ab + ao); al[i] = *reinterpret_cast<const bfx8*>(ab + SPLIT_IMG_B + ao);
+                bh[i] = *reinterpret_cast<const bfx8*>(bb + bo); bl[i] = *reinterpret_cast<const bfx8*>(bb + SPLIT_IMG_B + bo);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {      // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
@@ -309,7 +349,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { put_a(an, s0 ^ 1, p, (t + 1) * BK + kq); lds_put<T, PITCH>(bn, r0 + p * ROWS_PER_PASS, kq, rb[s0 ^ 1][p]); }
+            for (int p = 0; p < NPASS; ++p) { put_a(an, s0 ^ 1, p, (t + 1) * BK + kq); put(bn, r0 + p * ROWS_PER_PASS, rb[s0 ^ 1][p]); }
         }
         __syncthreads();
     };
@@ -703,6 +743,8 @@ int launch_bk(const GemmArgs& g, hipStream_t s) {
     return p3_det_reduce2(scratch, nparts, 2 * (int64_t)g.d.N, scratch + slab_f, g.d.colsum, g.d.colsumsq, g.d.N, 2 * g.d.N, 1, s);   // (sum | sum of squares) in one go
 }
 
+int g_gemm_split = 0;      // p3_set_gemm_split: fp32 products on the bf16 x 3 path
+
 template <typename T, typename TO>
 int launch_mode(const GemmArgs& g, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
@@ -711,7 +753,7 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
         const bool deep = can64 && g.d.K >= 2048;       // 64-deep K slices from K = 2048 on (r01 sweep)
         return deep ? launch_bk<T, TO, 64>(g, s) : launch_bk<T, TO, 32>(g, s);
     } else {
-        return launch_bk<T, TO, 16>(g, s);
+        return g_gemm_split ? launch_bk<T, TO, BK_SPLIT>(g, s) : launch_bk<T, TO, 16>(g, s);
     }
 }
 
@@ -724,6 +766,9 @@ int p3_pair_fwd_try(const void* U, const void* W, void* C, const p3_gemm_desc* d
 int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
 static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
+
+extern "C" int p3_set_gemm_split(int on) { const int was = g_gemm_split; g_gemm_split = on ? 1 : 0; return was; }
+extern "C" int p3_get_gemm_split(void) { return g_gemm_split; }
 
 extern "C" int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream) {
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm_dma: null pointer");

@@ -44,9 +44,13 @@ template <> struct TTr<float> { static constexpr int BM = 16, PITCH = 132, ELEMS
 // P3_A_PAIR_AFFINE_RELU: generated B operand - the raw rows (and, pair mode, the V rows) are LOADED in load_step like any operand and
 // turned into relu(scale * (x [+ y]) + shift) when they are stored to LDS (the transform at load time consumed every load at once:
 // vmcnt(0) inside the step, no prefetch at all; 519 us per ScoreNet weight gradient in r02).
-template <typename T, int BMODE>
+// SPLIT (T = float, p3_set_gemm_split): the fp32 operands are split into bf16 hi / lo images when a step is stored to LDS ([16 rows][160] bf16 each, the bf16
+// path's pitch) and multiplied as a_lo b_hi + a_hi b_lo + a_hi b_hi from transposing reads - see gemm.hip BK_SPLIT.
+constexpr int TS_PITCH = 160, TS_IMG_B = 16 * TS_PITCH * 2, TS_ELEMS = 2 * TS_IMG_B / 4;
+template <typename T, int BMODE, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
-    constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = TTr<T>::ELEMS;
+    static_assert(!SPLIT || sizeof(T) == 4, "the split form is the fp32 operands' path");
+    constexpr int BM = TTr<T>::BM, PITCH = TTr<T>::PITCH, ELEMS = SPLIT ? TS_ELEMS : TTr<T>::ELEMS;
     constexpr bool BF = sizeof(T) == 2;
     constexpr bool GENB = BMODE != 0, PAIR = BMODE == P3_A_PAIR_AFFINE_RELU, GMASK2 = BMODE == P3_A_AFFINE_MASK2;
     __shared__ __attribute__((aligned(16))) T lds[4 * ELEMS];
@@ -208,6 +212,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                 *reinterpret_cast<u32x4*>(as + (rt + 16 * i) * PITCH + cv) = ra[i];
                 *reinterpret_cast<u32x4*>(bs + (rt + 16 * i) * PITCH + cv) = rb[i];
             }
+        } else if constexpr (SPLIT) {
+            auto put = [&](T* img, int row, const u32x4& v) __attribute__((always_inline)) {
+                float h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float x = __uint_as_float(v[q]); h[q] = bf2f(f2bf(x)); l[q] = x - h[q]; }
+                unsigned char* b = reinterpret_cast<unsigned char*>(img) + (row * TS_PITCH + cv) * 2;
+                *reinterpret_cast<u32x2*>(b) = u32x2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+                *reinterpret_cast<u32x2*>(b + TS_IMG_B) = u32x2{pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3])};
+            };
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) { put(as, rt + 8 * i, ra[i]); put(bs, rt + 8 * i, rb[i]); }
         } else {
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
@@ -277,6 +292,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
                             __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), bf[j]), acc[i][j], 0, 0, 0);
                 if (kk + 1 < BM / 16) wait(sl ^ 1);
             }
+        } else if constexpr (SPLIT) {
+            const int g4 = lane >> 4, li = lane & 15;
+            const uint32_t lane_off = (uint32_t)((((g4 >> 1) * 8 + (li >> 2)) * TS_PITCH + (g4 & 1) * 16 + (li & 3) * 4) * 2);
+            const uint32_t abase = lds_base + (uint32_t)(cur * ELEMS * 4) + lane_off + (uint32_t)(wm * 64 * 2);
+            const uint32_t bbase = lds_base + (uint32_t)((2 + cur) * ELEMS * 4) + lane_off + (uint32_t)(wn * 64 * 2);
+            u32x2 fa[2][2][2], fb[2][2][2];          // [hi | lo image][32-column block][rows +0..3 | +4..7]
+#pragma unroll
+            for (int im = 0; im < 2; ++im)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t off = (uint32_t)(im * TS_IMG_B + (hh * 4 * TS_PITCH + i * 32) * 2);
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fa[im][i][hh]) : "v"(abase + off));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fb[im][i][hh]) : "v"(bbase + off));
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]),
+                           "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]));
+            typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+            bfx8 af[2][2], bf[2][2];                 // [image][block]
+#pragma unroll
+            for (int im = 0; im < 2; ++im)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[im][i] = __builtin_bit_cast(bfx8, u32x4{fa[im][i][0].x, fa[im][i][0].y, fa[im][i][1].x, fa[im][i][1].y});
+                    bf[im][i] = __builtin_bit_cast(bfx8, u32x4{fb[im][i][0].x, fb[im][i][0].y, fb[im][i][1].x, fb[im][i][1].y});
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BM / 2; ++kk) {
@@ -471,6 +522,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
 #define P3_TN_LAUNCH(MODE)                                                                            \
     do {                                                                                              \
         if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, MODE>), grid, block, 0, s, g); \
+        else if (p3_get_gemm_split()) hipLaunchKernelGGL((gemm_tn_kernel<float, MODE, true>), grid, block, 0, s, g); \
         else hipLaunchKernelGGL((gemm_tn_kernel<float, MODE>), grid, block, 0, s, g);                  \
     } while (0)
     if (g.b_mode == 0) P3_TN_LAUNCH(0);

@@ -868,6 +868,25 @@ def bn_sums_from_g(G, W, scale, shift, mean, dW, acc):
           "p3_bn_sums_from_g")
 
 
+class gemm_split:
+    """`with hip.gemm_split(True):` fp32 products on the bf16 x 3 MFMA path (p3_set_gemm_split) inside the block; the previous setting comes back after it."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.was = lib().p3_set_gemm_split(c_int(int(self.on)))
+        return self
+
+    def __exit__(self, *exc):
+        lib().p3_set_gemm_split(c_int(self.was))
+        return False
+
+
+def set_gemm_split(on):
+    return bool(lib().p3_set_gemm_split(c_int(int(bool(on)))))
+
+
 def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=None):
     M_ = a.shape[0] if M is None else M
     N, K = a.shape[1], b.shape[1]

@@ -15,8 +15,14 @@ from . import hip, ops
 
 
 def compute_dtype(cfg):
+    """precision -> storage dtype.  'fp32x3' (r04) = fp32 storage with every GEMM on the bf16 x 3 MFMA path (hip.set_gemm_split): the switch is process-global,
+    so the fp32-family model constructed LAST decides it ('fp32' switches it off again); bf16 models do not touch it."""
     p = getattr(cfg, "precision", "bf16")
-    return torch.float32 if p in ("fp32", "float32", "exact") else torch.bfloat16
+    if p in ("fp32", "float32", "exact", "fp32x3"):
+        if str(getattr(cfg, "device", "cuda")).startswith("cuda") and torch.cuda.is_available():
+            hip.set_gemm_split(p == "fp32x3")
+        return torch.float32
+    return torch.bfloat16
 
 
 class PatchEmbed(nn.Module):

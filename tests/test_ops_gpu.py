@@ -304,6 +304,28 @@ def test_gemm_batchnorm_relu_backward_epilogue(dtype, tol, N):
         hip.gemm(A.to(DEV), W.to(DEV), out_dtype=dtype, bwd=(H.to(DEV), hip.ACT_BN_RELU, tab[:3].contiguous().to(DEV)))
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (4200, 1536, 384), (512, 227, 256), (777, 256, 2048)])
+def test_gemm_fp32_operands_as_bf16x3(M, N, K):
+    """p3_set_gemm_split (include/p3hip.h): fp32 operands split into bf16 hi + lo while staged, a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA.  Against float64:
+    1e-5 (2^-17 per product, fp32 accumulation) - two orders tighter than a plain bf16 product, one looser than the exact fp32 MFMA path (checked in the same test);
+    epilogues (bias + GELU + aux + residual, ReLU gradient) ride on the unchanged fp32 code."""
+    hip = _h()
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1)
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    ref = a.double() @ w.double().t()
+    exact = hip.gemm(a.to(DEV), w.to(DEV)).cpu()
+    with hip.gemm_split(True):
+        split = hip.gemm(a.to(DEV), w.to(DEV)).cpu()
+        aux = torch.empty(M, N, device=DEV)
+        full = hip.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=hip.ACT_GELU, aux=aux, residual=res.to(DEV)).cpu()
+    assert not hip.lib().p3_get_gemm_split()
+    e_exact, e_split = rel_err(exact, ref.float()), rel_err(split, ref.float())
+    assert e_exact < 2e-6 and e_split < 1e-5, (e_exact, e_split)
+    pre = ref + bias.double()
+    assert rel_err(full, (F.gelu(pre) + res.double()).float()) < 1e-5 and rel_err(aux.cpu(), pre.float()) < 1e-5
+    assert not torch.equal(split, exact)                     # it really is another arithmetic
+
+
 def test_gemm_rejects_bad_shapes():
     h = _h()
     from pixelspointspolygons_amd._lib import P3Error
