@@ -37,10 +37,10 @@ template <typename T, int BKSEL> struct Tr;
 template <int BKSEL> struct Tr<bf16_t, BKSEL> { static constexpr int BK = BKSEL, PITCH = BKSEL + 8, VEC = 8, LDS_ELEMS = BM * (BKSEL + 8); };
 template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
 // BKSEL == BK_SPLIT (T = float): fp32 operands multiplied as bf16 x 3 (r04, p3_set_gemm_split): a value x is split into hi = bf16(x) and lo = bf16(x - hi)
-// when its slice is stored to LDS (two bf16 images [128 rows][16 k], 48-byte rows: conflict-free 16-byte fragment reads) and the product is
+// when its slice is stored to LDS (two bf16 images [128 rows][32 k], 80-byte rows: conflict-free 16-byte fragment reads) and the product is
 // a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA (2^-17 relative per product; the dropped a_lo b_lo term is 2^-18) - 16 x the fp32 MFMA rate for 3 x the issues.
-constexpr int BK_SPLIT = 17, SPLIT_PITCH_B = 48, SPLIT_IMG_B = 128 * SPLIT_PITCH_B;
-template <> struct Tr<float, BK_SPLIT> { static constexpr int BK = 16, PITCH = 24, VEC = 4, LDS_ELEMS = 2 * SPLIT_IMG_B / 4; };
+constexpr int BK_SPLIT = 17, SPLIT_BK = 32, SPLIT_PITCH_B = (SPLIT_BK + 8) * 2, SPLIT_IMG_B = 128 * SPLIT_PITCH_B;      // 80-byte rows: 8 consecutive rows cover all 32 banks
+template <> struct Tr<float, BK_SPLIT> { static constexpr int BK = SPLIT_BK, PITCH = SPLIT_BK + 8, VEC = 4, LDS_ELEMS = 2 * SPLIT_IMG_B / 4; };
 template <typename T> struct VecOf { static constexpr int VEC = 16 / (int)sizeof(T); };
 
 // ---- per-thread A-row descriptor (fixed over the K loop) -------------------------------------
@@ -315,21 +315,24 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
             const unsigned char* ab = reinterpret_cast<const unsigned char*>(as);
             const unsigned char* bb = reinterpret_cast<const unsigned char*>(bs);
             typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
-            bfx8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ao = (wm * 64 + i * 32 + l31) * SPLIT_PITCH_B + 16 * hi, bo = (wn * 64 + i * 32 + l31) * SPLIT_PITCH_B + 16 * hi;
-                ah[i] = *reinterpret_cast<const bfx8*>(ab + ao); al[i] = *reinterpret_cast<const bfx8*>(ab + SPLIT_IMG_B + ao);
-                bh[i] = *reinterpret_cast<const bfx8*>(bb + bo); bl[i] = *reinterpret_cast<const bfx8*>(bb + SPLIT_IMG_B + bo);
-            }
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bfx8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {      // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    const int ao = (wm * 64 + i * 32 + l31) * SPLIT_PITCH_B + 32 * kk + 16 * hi, bo = (wn * 64 + i * 32 + l31) * SPLIT_PITCH_B + 32 * kk + 16 * hi;
+                    ah[i] = *reinterpret_cast<const bfx8*>(ab + ao); al[i] = *reinterpret_cast<const bfx8*>(ab + SPLIT_IMG_B + ao);
+                    bh[i] = *reinterpret_cast<const bfx8*>(bb + bo); bl[i] = *reinterpret_cast<const bfx8*>(bb + SPLIT_IMG_B + bo);
                 }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {      // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
@@ -753,7 +756,10 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
         const bool deep = can64 && g.d.K >= 2048;       // 64-deep K slices from K = 2048 on (r01 sweep)
         return deep ? launch_bk<T, TO, 64>(g, s) : launch_bk<T, TO, 32>(g, s);
     } else {
-        return g_gemm_split ? launch_bk<T, TO, BK_SPLIT>(g, s) : launch_bk<T, TO, 16>(g, s);
+        // the split form walks K in 32-deep slices; a K (or conv channel count) that is only a multiple of 16 stays on the exact kernel
+        const bool conv = g.d.a_mode == P3_A_CONV3X3 || g.d.a_mode == P3_A_CONV3X3_AFFINE_RELU;
+        const bool can_split = g_gemm_split && g.d.K % SPLIT_BK == 0 && (!conv || g.d.conv_C % SPLIT_BK == 0);
+        return can_split ? launch_bk<T, TO, BK_SPLIT>(g, s) : launch_bk<T, TO, 16>(g, s);
     }
 }
 
