@@ -141,7 +141,7 @@ int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* 
  * and K >= 1024: 9; other K >= 1024: 4; K <= 512 and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in
  * ascending k order as the register-staged kernel: bit-identical outputs. */
 int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream);
-/* fp32 products as bf16 x 3 (r04): with the switch on, every p3_gemm / p3_gemm_tn launch whose operands are fp32 splits each value into hi = bf16(x) and
+/* fp32 products as bf16 x 3 (r04): with the switch on, every p3_gemm / p3_gemm_tn / p3_attention / p3_attention_bwd launch whose operands are fp32 splits each value into hi = bf16(x) and
  * lo = bf16(x - hi) while staging it and accumulates a_lo b_hi + a_hi b_lo + a_hi b_hi in fp32 on the bf16 MFMA (error 2^-17 relative per product instead of the
  * exact fp32 MFMA's 2^-24; storage, epilogues and every non-GEMM kernel stay fp32).  Process-global (one model per process sets it before its first launch and
  * before a hipGraph capture); returns the previous setting.  The precision mode "fp32x3" of the Python host: tests hold it to the north star's 1e-3. */

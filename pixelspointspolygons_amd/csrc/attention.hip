@@ -22,6 +22,8 @@
 namespace {
 
 using p3attn::u32x4;
+using p3attn::f32s;
+using p3attn::Kind;
 
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O;
@@ -32,6 +34,10 @@ struct AttnArgs {
 template <typename T, int D> struct ATr;
 template <int D> struct ATr<bf16_t, D> {
     static constexpr int KT = 64, PK = D, PV = D;           // K [KT][D] ; V [KT][D], both swizzled (attn_tile.h)
+    static constexpr int K_ELEMS = KT * D, V_ELEMS = KT * D;
+};
+template <int D> struct ATr<f32s, D> {                        // fp32x3 mode: two swizzled bf16 images (hi | lo) per tile, in units of 4-byte elements
+    static constexpr int KT = 64, PK = D, PV = D;
     static constexpr int K_ELEMS = KT * D, V_ELEMS = KT * D;
 };
 template <int D> struct ATr<float, D> {
@@ -102,10 +108,10 @@ __device__ __forceinline__ void attn_store_tile(int tid, T* Ks, T* Vs, const u32
 }
 
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(AttnArgs a) {
     using TR = ATr<T, D>;
     constexpr int KT = TR::KT, PK = TR::PK, PV = TR::PV, NH2 = KT / 32, NDJ = D / 32;
-    constexpr bool BF = sizeof(T) == 2;
+    constexpr bool BF = Kind<T>::BF, X3 = Kind<T>::X3, IMG = Kind<T>::IMG;
     __shared__ __attribute__((aligned(16))) T Ks[TR::K_ELEMS];
     __shared__ __attribute__((aligned(16))) T Vs[TR::V_ELEMS];
     __shared__ float Kb[KT];
@@ -129,12 +135,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     const int qc = q < d.Lq ? q : d.Lq - 1;        // clamped for loads
 
     // ---- Q fragments (B operand of S^T) ----
-    s16x8 qb[BF ? D / 16 : 1];
-    float qf[BF ? 1 : D / 2];
+    s16x8 qb[IMG ? D / 16 : 1], ql[X3 ? D / 16 : 1];
+    float qf[IMG ? 1 : D / 2];
     if constexpr (BF) {
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks)
             qb[ks] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qc * d.q_rs + ks * 16 + 8 * hi);
+    } else if constexpr (X3) {
+        const float* qr = reinterpret_cast<const float*>(Qp) + (int64_t)qc * d.q_rs + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const float4 x0 = *reinterpret_cast<const float4*>(qr + ks * 16), x1 = *reinterpret_cast<const float4*>(qr + ks * 16 + 4);
+            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            p3attn::split8(x, qb[ks], ql[ks]);
+        }
     } else {
 #pragma unroll
         for (int ks = 0; ks < D / 2; ++ks) qf[ks] = Qp[(int64_t)qc * d.q_rs + 2 * ks + hi];
@@ -158,21 +172,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
     constexpr int KPT = (KV16 + 255) / 256;                 // per thread
     constexpr int VPT = KPT;
-    u32x4 kreg[KPT];
-    u32x4 vreg[VPT];
-    p3attn::ScoreAddr<BF ? D : 16> sadr;          // bf16: lane-constant offsets into the swizzled K / V images
-    p3attn::TrAddr<BF ? D : 32> tadr;
-    if constexpr (BF) { sadr.init(l31, hi); tadr.init(lane); }
+    u32x4 kreg[X3 ? 1 : KPT];
+    u32x4 vreg[X3 ? 1 : VPT];
+    p3attn::SplitStage<D, KT> ksp, vsp;           // fp32x3: fp32 rows in flight, split into the hi / lo images at store time
+    p3attn::ScoreAddr<IMG ? D : 16> sadr;         // bf16 / fp32x3: lane-constant offsets into the swizzled K / V images
+    p3attn::TrAddr<IMG ? D : 32> tadr;
+    if constexpr (IMG) { sadr.init(l31, hi); tadr.init(lane); }
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            ksp.load(reinterpret_cast<const float*>(Kp), t * KT, d.Lk, d.k_rs, tid);
+            vsp.load(reinterpret_cast<const float*>(Vp), t * KT, d.Lk, d.v_rs, tid);
+        } else {
+            attn_load_tile<T, D, KPT, VPT>(t, tid, d, Kp, Vp, kreg, vreg);
+        }
+    };
 
-    if (ntiles > 0) attn_load_tile<T, D, KPT, VPT>(0, tid, d, Kp, Vp, kreg, vreg);
+    if (ntiles > 0) load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();  // previous tile's LDS reads are done
-        attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
+        if constexpr (X3) { ksp.store(reinterpret_cast<bf16_t*>(Ks), tid); vsp.store(reinterpret_cast<bf16_t*>(Vs), tid); }
+        else attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
         // the tile's key bias goes through LDS (log2 units): read per element from global memory it was 32 dependent loads per tile, each
         // followed by s_waitcnt vmcnt(0) - which also drained the next tile's prefetch (decoder self-attention: every tile has a bias)
         if (kbias && tid < KT) { const int kvb = t * KT + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * 1.4426950408889634f; }
         __syncthreads();
-        if (t + 1 < ntiles) attn_load_tile<T, D, KPT, VPT>(t + 1, tid, d, Kp, Vp, kreg, vreg);
+        if (t + 1 < ntiles) load_tile(t + 1);
         const int kv0 = t * KT;
         // a wave whose 32 queries all lie beyond Lq (tail q-block: L = 785 -> 17 live rows, L = 385 -> 1) only helps with the staging
         if (!wave_live) continue;
@@ -194,6 +218,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks)
                     sacc[h2] = p3attn::mfma_bf16(sadr.frag(reinterpret_cast<const bf16_t*>(Ks), h2, ks), qb[ks], sacc[h2]);
+            } else if constexpr (X3) {
+                const bf16_t* kh = reinterpret_cast<const bf16_t*>(Ks);
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {      // small terms first
+                    const s16x8 xh = sadr.frag(kh, h2, ks), xl = sadr.frag(kh + KT * D, h2, ks);
+                    sacc[h2] = p3attn::mfma_bf16(xl, qb[ks], sacc[h2]);
+                    sacc[h2] = p3attn::mfma_bf16(xh, ql[ks], sacc[h2]);
+                    sacc[h2] = p3attn::mfma_bf16(xh, qb[ks], sacc[h2]);
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < D / 2; ++ks) {
@@ -301,6 +334,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int j = 0; j < NDJ; ++j)      // V^T[d, keys 4hi + {0..3, 8..11}] of the 16-key group: the keys this lane's P registers hold
                         oacc[j] = p3attn::mfma_bf16(tadr.frag(reinterpret_cast<const bf16_t*>(Vs), h2 * 32 + 16 * c2, j), pb, oacc[j]);
+                }
+            }
+        } else if constexpr (X3) {
+            const bf16_t* vh = reinterpret_cast<const bf16_t*>(Vs);
+#pragma unroll
+            for (int h2 = 0; h2 < NH2; ++h2) {
+                if (h2 >= nh2) continue;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float pv8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pv8[i] = sacc[h2][8 * c2 + i];
+                    s16x8 ph, pl;
+                    p3attn::split8(pv8, ph, pl);
+#pragma unroll
+                    for (int j = 0; j < NDJ; ++j) {
+                        const s16x8 xh = tadr.frag(vh, h2 * 32 + 16 * c2, j), xl = tadr.frag(vh + KT * D, h2 * 32 + 16 * c2, j);
+                        oacc[j] = p3attn::mfma_bf16(xl, ph, oacc[j]);
+                        oacc[j] = p3attn::mfma_bf16(xh, pl, oacc[j]);
+                        oacc[j] = p3attn::mfma_bf16(xh, ph, oacc[j]);
+                    }
                 }
             }
         } else {
@@ -461,6 +515,8 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     } while (0)
     if (d->dtype == P3_BF16) {
         if (d->head_dim == 64) P3_ATTN_FWD(bf16_t, 64); else P3_ATTN_FWD(bf16_t, 32);
+    } else if (p3_get_gemm_split()) {                    // fp32x3 mode: bf16 x 3 products on split images (attn_tile.h)
+        if (d->head_dim == 64) P3_ATTN_FWD(f32s, 64); else P3_ATTN_FWD(f32s, 32);
     } else {
         if (d->head_dim == 64) P3_ATTN_FWD(float, 64); else P3_ATTN_FWD(float, 32);
     }

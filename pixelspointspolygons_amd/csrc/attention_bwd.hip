@@ -17,6 +17,8 @@
 namespace {
 
 using p3attn::u32x4;
+using p3attn::f32s;
+using p3attn::Kind;
 
 struct BwdArgs {
     const void* Q; const void* K; const void* V; const void* O; const void* dO;
@@ -43,9 +45,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(BwdArgs a, int D) {
 
 // ---- LDS tile: R rows x D.  bf16: ONE swizzled row image (attn_tile.h) serves both the score products (ds_read_b128) and the
 // accumulate products (transposing ds_read_b64_tr_b16); f32: row image [R][D + 1].
+// f32s (fp32x3 mode): TWO swizzled bf16 images, hi at the tile's start and lo R * D bf16 behind it (R * D elements of 4 bytes in all).
 template <typename T, int D, int R> struct Tile {
-    static constexpr bool BF = sizeof(T) == 2;
-    static constexpr int PR = BF ? D : D + 1;
+    static constexpr bool BF = Kind<T>::BF, X3 = Kind<T>::X3, IMG = Kind<T>::IMG;
+    static constexpr int PR = IMG ? D : D + 1;
     static constexpr int ROW_ELEMS = R * PR;
 };
 
@@ -83,6 +86,14 @@ template <int D, int R> struct Stage<float, D, R> {
     }
 };
 
+template <int D, int R> struct Stage<f32s, D, R> {
+    p3attn::SplitStage<D, R> st;
+    __device__ __forceinline__ void load(const f32s* __restrict__ src, int row0, int nvalid, int64_t row_stride, int tid) {
+        st.load(reinterpret_cast<const float*>(src), row0, nvalid, row_stride, tid);
+    }
+    __device__ __forceinline__ void store(f32s* rowimg, int tid) const { st.store(reinterpret_cast<bf16_t*>(rowimg), tid); }
+};
+
 // lane-constant LDS offsets of the bf16 fragment reads (empty for f32)
 template <typename T, int D> struct FragAddr { __device__ __forceinline__ void init(int, int, int) {} };
 template <int D> struct FragAddr<bf16_t, D> {
@@ -90,11 +101,12 @@ template <int D> struct FragAddr<bf16_t, D> {
     p3attn::TrAddr<D> t;
     __device__ __forceinline__ void init(int lane, int l31, int hi) { s.init(l31, hi); t.init(lane); }
 };
+template <int D> struct FragAddr<f32s, D> : FragAddr<bf16_t, D> {};
 
 // score-like product: acc[rows32 x cols32] = X[rows from LDS row image] . Y[cols held in regs]^T   (contract over D)
 template <typename T, int D, int R>
-__device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], const float (&yf)[D / 2],
-                                            const FragAddr<T, D>& fa, int l31, int hi) {
+__device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], const s16x8 (&yl)[D / 16 > 0 ? D / 16 : 1],
+                                            const float (&yf)[D / 2], const FragAddr<T, D>& fa, int l31, int hi) {
     using TL = Tile<T, D, R>;
     f32x16 acc;
 #pragma unroll
@@ -102,6 +114,16 @@ __device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x
     if constexpr (TL::BF) {
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) acc = p3attn::mfma_bf16(fa.s.frag(rowimg, sub, ks), yb[ks], acc);
+    } else if constexpr (TL::X3) {
+        const bf16_t* ih = reinterpret_cast<const bf16_t*>(rowimg);
+        const bf16_t* il = ih + R * D;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {          // small terms first
+            const s16x8 xh = fa.s.frag(ih, sub, ks), xl = fa.s.frag(il, sub, ks);
+            acc = p3attn::mfma_bf16(xl, yb[ks], acc);
+            acc = p3attn::mfma_bf16(xh, yl[ks], acc);
+            acc = p3attn::mfma_bf16(xh, yb[ks], acc);
+        }
     } else {
 #pragma unroll
         for (int ks = 0; ks < D / 2; ++ks) {
@@ -127,6 +149,24 @@ __device__ __forceinline__ void accum_mma(const T* rowimg, int sub, const f32x16
             for (int j = 0; j < D / 32; ++j)      // X^T[d, rows 4hi + {0..3, 8..11}] of the 16-row group: the rows whose W this lane holds
                 out[j] = p3attn::mfma_bf16(fa.t.frag(rowimg, sub * 32 + 16 * c2, j), wb, out[j]);
         }
+    } else if constexpr (TL::X3) {
+        const bf16_t* ih = reinterpret_cast<const bf16_t*>(rowimg);
+        const bf16_t* il = ih + R * D;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = w[8 * c2 + i];
+            s16x8 wh, wl;
+            p3attn::split8(wv, wh, wl);
+#pragma unroll
+            for (int j = 0; j < D / 32; ++j) {
+                const s16x8 xh = fa.t.frag(ih, sub * 32 + 16 * c2, j), xl = fa.t.frag(il, sub * 32 + 16 * c2, j);
+                out[j] = p3attn::mfma_bf16(xl, wh, out[j]);
+                out[j] = p3attn::mfma_bf16(xh, wl, out[j]);
+                out[j] = p3attn::mfma_bf16(xh, wh, out[j]);
+            }
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -141,10 +181,19 @@ __device__ __forceinline__ void accum_mma(const T* rowimg, int sub, const f32x16
 }
 
 template <typename T, int D>
-__device__ __forceinline__ void load_rowfrags(const T* base, int64_t row, int row_stride, s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], float (&yf)[D / 2], int hi) {
-    if constexpr (sizeof(T) == 2) {
+__device__ __forceinline__ void load_rowfrags(const T* base, int64_t row, int row_stride, s16x8 (&yb)[D / 16 > 0 ? D / 16 : 1], s16x8 (&yl)[D / 16 > 0 ? D / 16 : 1],
+                                              float (&yf)[D / 2], int hi) {
+    if constexpr (Kind<T>::BF) {
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) yb[ks] = *reinterpret_cast<const s16x8*>(base + row * row_stride + ks * 16 + 8 * hi);
+    } else if constexpr (Kind<T>::X3) {
+        const float* fb = reinterpret_cast<const float*>(base) + row * row_stride + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(fb + ks * 16), b = *reinterpret_cast<const float4*>(fb + ks * 16 + 4);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            p3attn::split8(x, yb[ks], yl[ks]);
+        }
     } else {
 #pragma unroll
         for (int ks = 0; ks < D / 2; ++ks) yf[ks] = base[row * row_stride + 2 * ks + hi];
@@ -162,7 +211,7 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = acc[j][4 * rg + i] * mul;
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (Kind<T>::BF) {
                 uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
                 *reinterpret_cast<uint2*>(dst_row + dd) = pk;
             } else {
@@ -173,9 +222,9 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <typename T, int D, int DROP>
-__global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(BwdArgs a) {
-    constexpr bool BF = sizeof(T) == 2;
-    constexpr int KT = BF ? 64 : 32;
+__global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? 3 : 2)) void attn_bwd_dq_kernel(BwdArgs a) {
+    constexpr bool BF = Kind<T>::BF, X3 = Kind<T>::X3;
+    constexpr int KT = Kind<T>::IMG ? 64 : 32;
     using TK = Tile<T, D, KT>;
     __shared__ __attribute__((aligned(16))) T Krow[TK::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Vrow[TK::ROW_ELEMS];
@@ -194,10 +243,10 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
     T* dQp = reinterpret_cast<T*>(a.dQ) + (int64_t)b * d.q_bs + h * D;
     const int q = qblk + wave * 32 + l31;
     const int qc = q < d.Lq ? q : d.Lq - 1;
-    s16x8 qb[D / 16], gb[D / 16];
+    s16x8 qb[D / 16], gb[D / 16], ql[D / 16], gl[D / 16];       // ql / gl: the lo fragments of the fp32x3 mode
     float qf[D / 2], gf[D / 2];
-    load_rowfrags<T, D>(Qp, qc, d.q_rs, qb, qf, hi);
-    load_rowfrags<T, D>(dOp, qc, d.o_rs, gb, gf, hi);
+    load_rowfrags<T, D>(Qp, qc, d.q_rs, qb, ql, qf, hi);
+    load_rowfrags<T, D>(dOp, qc, d.o_rs, gb, gl, gf, hi);
     constexpr float LOG2E = 1.4426950408889634f;
     const float lse2 = a.lse[((int64_t)b * d.H + h) * d.Lq + qc] * LOG2E;    // log2 domain: p = exp2(s*scale*log2e + bias*log2e - lse2)
     const float c2 = d.scale * LOG2E;
@@ -215,6 +264,12 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
 #pragma unroll
                 for (int e = 0; e < 8; ++e) part += bf2f((bf16_t)ob[e]) * bf2f((bf16_t)gb[ks][e]);
             }
+        } else if constexpr (X3) {                      // dO = hi + lo (to 2^-18), O read as fp32
+            const float* of = reinterpret_cast<const float*>(Op) + (int64_t)qc * d.o_rs + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += of[ks * 16 + e] * (bf2f((bf16_t)gb[ks][e]) + bf2f((bf16_t)gl[ks][e]));
         } else {
 #pragma unroll
             for (int ks = 0; ks < D / 2; ++ks) part += Op[(int64_t)qc * d.o_rs + 2 * ks + hi] * gf[ks];
@@ -261,8 +316,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             if (kv0 + sub * 32 >= vis_end) continue;                          // 32-key half with no visible key: dS == 0
-            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, qf, fa, l31, hi);   // S^T[kv, q]
-            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gf, fa, l31, hi);  // dP^T[kv, q]
+            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, ql, qf, fa, l31, hi);   // S^T[kv, q]
+            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gl, gf, fa, l31, hi);  // dP^T[kv, q]
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
             const uint32_t dword = dwords[sub];
@@ -301,9 +356,8 @@ __global__ __launch_bounds__(256, (D == 32 ? 3 : 2)) void attn_bwd_dq_kernel(Bwd
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, int D, int DROP>
-__global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
-    constexpr bool BF = sizeof(T) == 2;
-    constexpr int QT = BF ? 64 : 32;
+__global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)) void attn_bwd_dkv_kernel(BwdArgs a) {
+    constexpr int QT = Kind<T>::IMG ? 64 : 32;
     using TQ = Tile<T, D, QT>;
     __shared__ __attribute__((aligned(16))) T Qrow[TQ::ROW_ELEMS];
     __shared__ __attribute__((aligned(16))) T Grow[TQ::ROW_ELEMS];
@@ -323,10 +377,10 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
     T* dVp = reinterpret_cast<T*>(a.dV) + (int64_t)b * d.v_bs + h * D;
     const int kv = kblk + wave * 32 + l31;
     const int kvc = kv < d.Lk ? kv : d.Lk - 1;
-    s16x8 kb[D / 16], vb[D / 16];
+    s16x8 kb[D / 16], vb[D / 16], kl[D / 16], vl[D / 16];
     float kf[D / 2], vf[D / 2];
-    load_rowfrags<T, D>(Kp, kvc, d.k_rs, kb, kf, hi);
-    load_rowfrags<T, D>(Vp, kvc, d.v_rs, vb, vf, hi);
+    load_rowfrags<T, D>(Kp, kvc, d.k_rs, kb, kl, kf, hi);
+    load_rowfrags<T, D>(Vp, kvc, d.v_rs, vb, vl, vf, hi);
     const float bias2 = (d.key_bias ? d.key_bias[(int64_t)b * d.Lk + kvc] : 0.f) * 1.4426950408889634f;
     const float c2 = d.scale * 1.4426950408889634f;
     f32x16 dk[D / 32], dv[D / 32];
@@ -368,8 +422,8 @@ __global__ __launch_bounds__(256, (D == 32 ? P3_DKV32_WAVES : 2)) void attn_bwd_
         for (int sub = 0; sub < QT / 32; ++sub) {
             // 32-query half beyond Lq, or (causal) entirely before this wave's first key: P == dS == 0
             if (q0 + sub * 32 >= d.Lq || (d.causal && q0 + sub * 32 + 31 < kblk + wave * 32)) continue;
-            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kf, fa, l31, hi);   // S[q, kv]
-            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vf, fa, l31, hi);  // dP[q, kv]
+            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kl, kf, fa, l31, hi);   // S[q, kv]
+            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vl, vf, fa, l31, hi);  // dP[q, kv]
             f32x16 ds;
             // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
             const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
@@ -446,5 +500,6 @@ extern "C" int p3_attention_bwd(const void* Q, const void* K, const void* V, con
     BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d; a.order = p3_attn_order();
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == P3_BF16) return d->head_dim == 64 ? launch_bwd<bf16_t, 64>(a, s) : launch_bwd<bf16_t, 32>(a, s);
+    if (p3_get_gemm_split()) return d->head_dim == 64 ? launch_bwd<f32s, 64>(a, s) : launch_bwd<f32s, 32>(a, s);      // fp32x3 mode: bf16 x 3 products (attn_tile.h)
     return d->head_dim == 64 ? launch_bwd<float, 64>(a, s) : launch_bwd<float, 32>(a, s);
 }

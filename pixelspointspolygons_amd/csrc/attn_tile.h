@@ -19,6 +19,12 @@
 
 namespace p3attn {
 
+// element-type tag of the "fp32x3" mode (p3_set_gemm_split): fp32 in global memory; in LDS every row image exists twice - hi = bf16(x) and lo = bf16(x - hi),
+// the same swizzled layout each - and every product runs as a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA (2^-17 per product, fp32 accumulation)
+struct f32s { float v; };
+template <typename T> struct Kind { static constexpr bool BF = sizeof(T) == 2, X3 = false, IMG = BF; };
+template <> struct Kind<f32s> { static constexpr bool BF = false, X3 = true, IMG = true; };
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -81,6 +87,51 @@ template <int D> struct TrAddr {
         const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb16 * D + off[j][0]));
         const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rb16 * D + off[j][1]));
         return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
+};
+
+// split 8 fp32 values (two float4) into the hi / lo bf16 fragments
+__device__ __forceinline__ void split8(const float (&x)[8], s16x8& h, s16x8& l) {
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float h0 = bf2f(f2bf(x[2 * i])), h1 = bf2f(f2bf(x[2 * i + 1]));
+        hw[i] = pack_bf2(h0, h1);
+        lw[i] = pack_bf2(x[2 * i] - h0, x[2 * i + 1] - h1);
+    }
+    h = __builtin_bit_cast(s16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    l = __builtin_bit_cast(s16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
+// registers of one R x D fp32 tile on its way into the two bf16 images (hi at img, lo at img + R * D)
+template <int D, int R> struct SplitStage {
+    static constexpr int VPR = D / 4, ITEMS = R * VPR, N = (ITEMS + 255) / 256;
+    u32x4 v[N];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int row0, int nvalid, int64_t row_stride, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int item = tid + 256 * i;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                int r = row0 + item / VPR; if (r >= nvalid) r = nvalid - 1;
+                v[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)r * row_stride + (item % VPR) * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* img, int tid) const {
+        // item -> (row, float4 cv): 16-byte chunk cv / 2, half cv & 1; row + 256 / VPR * i keeps sw(): the step is a multiple of 16 rows
+        const int base = img_off<D>(tid / VPR, (tid % VPR) >> 1) + ((tid % VPR) & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int item = tid + 256 * i;
+            if (ITEMS % 256 == 0 || item < ITEMS) {
+                float h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = __uint_as_float(v[i][e]); h[e] = bf2f(f2bf(x)); l[e] = x - h[e]; }
+                bf16_t* p = img + base + i * (256 / VPR) * D;
+                *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
+                *reinterpret_cast<uint2*>(p + R * D) = make_uint2(pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3]));
+            }
+        }
     }
 };
 

@@ -160,6 +160,33 @@ def test_attention_backward(dtype, tol, B, H, Lq, Lk, hd, causal, bias):
         assert rel_err(got.float().cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,bias", [
+    (2, 6, 785, 785, 64, False, False), (2, 8, 385, 385, 32, True, True), (2, 8, 385, 784, 32, False, False), (1, 2, 37, 50, 64, False, True)])
+def test_attention_fp32x3_forward_backward(B, H, Lq, Lk, hd, causal, bias):
+    """fp32 attention under p3_set_gemm_split (precision 'fp32x3'): K / V / Q / dO tiles as bf16 hi + lo images, every product of the three kernels as
+    a_lo b_hi + a_hi b_lo + a_hi b_hi, P and dS split in registers; against float64 math 1e-4 (the exact fp32 kernels: 2e-5, bf16: 3e-2)."""
+    h = _h()
+    Dm = H * hd
+    q, k, v = (_rand(B, L, Dm, seed=sd).double().requires_grad_(True) for L, sd in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk)
+        kb[:, Lk // 2:] = 1.0
+    scale = 1 / math.sqrt(hd)
+    o = _attn_ref(q, k, v, H, scale, causal, kb.double() if kb is not None else None)
+    do = _rand(B, Lq, Dm, seed=4)
+    o.backward(do.double())
+    qd, kd, vd = (t.detach().float().to(DEV) for t in (q, k, v))
+    kbd = kb.to(DEV) if kb is not None else None
+    with h.gemm_split(True):
+        od, lse = h.attention(qd, kd, vd, H, scale, causal=causal, key_bias=kbd, need_lse=True)
+        dq, dk, dv = h.attention_bwd(qd, kd, vd, od, lse, do.to(DEV), H, scale, causal=causal, key_bias=kbd)
+    exact, _ = h.attention(qd, kd, vd, H, scale, causal=causal, key_bias=kbd, need_lse=True)
+    assert rel_err(od.cpu(), o.detach().float()) < 1e-4 and not torch.equal(od, exact)
+    for got, ref in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
+        assert rel_err(got.cpu(), ref.float()) < 1e-4
+
+
 def test_sinkhorn_backward_vs_autograd():
     from pixelspointspolygons_amd import ops
     for (B, m, iters, seed) in ((2, 12, 100, 1), (1, 192, 100, 2), (2, 30, 7, 3)):
@@ -492,10 +519,13 @@ def _oracle_grads(sd, inp, kind="fusion", sn_decisions=None, kink=(1e-4, 1024)):
 
 # fp32 path vs FLOAT64 ground truth: L2-relative error per parameter.  Until r03 the bound was 6e-3 ("deep fp32 forward + isolated ReLU
 # flips"); with float64 evaluated at the product's ScoreNet ReLU decisions the flips are gone and the worst parameter measures 2.5e-4 .. 4.4e-4 (two runs): 1.5e-3.
-@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-3), ("fp32x3", 1.5e-3), ("bf16", 5e-2)])
+# fp32x3 (r04): 4e-3.  Arithmetic is not what these bounds measure - op by op the mode is at 1e-5 (GEMM) / 1e-4 (attention backward), the exact mode at 1e-6, yet the exact mode's
+# worst parameter sits at 4e-4 .. 1e-3 from run to run: what is left after the ScoreNet decisions are pinned are the ReLU decisions of the decoder's FFNs inside the forward
+# error band, and that band is ~10 x wider at 2^-17 per product (measured 1.5e-3 .. 2.3e-3, the deepest decoder parameters: embedding, positional embedding, layer-0 norm1)
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-3), ("fp32x3", 4e-3), ("bf16", 5e-2)])
 def test_train_step_gradients_vs_oracle_autograd(precision, tol):
     """fwd + CE + 10*BCE + backward of the whole early-fusion model: parameter gradients vs autograd of the CPU oracle.  'fp32x3' (r04): fp32 storage, every
-    GEMM / weight gradient as bf16 x 3 on the bf16 MFMA - held to the SAME bounds as the exact fp32 mode."""
+    GEMM / weight gradient / attention product as bf16 x 3 on the bf16 MFMA."""
     mode, precision = precision, ("fp32" if precision == "fp32x3" else precision)
     from pixelspointspolygons_amd.config import make_config
     from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
@@ -804,7 +834,7 @@ def test_dropout_mask_statistics():
 # fp32 tolerance: forward agrees to 1e-6 (tools/dbg_dropout.py checks every site).  Until r03 the gradient bound was 1.5e-2, set by isolated
 # ReLU flips in the batch-normalised ScoreNets (1.0e-2 with these masks, 4e-3 with another seed); with float64 evaluated at the product's own
 # ReLU decisions the bound is 2e-3 (the dropout-free whole-model test holds 1.5e-3).
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("fp32x3", 4e-3), ("bf16", 5e-2)])
 def test_train_step_with_decoder_dropout_vs_oracle_replaying_the_masks(precision, tol):
     """Training-mode decoder (attention-probability dropout 0.1, dropout1/2/3 + FFN dropout 0.1, positional dropouts 0.05, the
     reference's defaults): loss and parameter gradients vs float64 autograd of the oracle run with the SAME masks."""
@@ -816,7 +846,8 @@ def test_train_step_with_decoder_dropout_vs_oracle_replaying_the_masks(precision
     inp = O.make_inputs(2, seed=55)
     probs = lambda site: 0.05 if site >= 250 else 0.1
     SEED = 20260101
-    cfg = make_config("vit", precision=precision, device=DEV)
+    mode, precision = precision, ("fp32" if precision == "fp32x3" else precision)        # fp32x3: fp32 storage, every product as bf16 x 3 (bound: see the dropout-free test)
+    cfg = make_config("vit", precision=mode, device=DEV)
     m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
     m.load_state_dict(sd, strict=True)
     m.train()
@@ -834,7 +865,7 @@ def test_train_step_with_decoder_dropout_vs_oracle_replaying_the_masks(precision
     logits_r, perm_r = O.pix2poly_forward(pr, inp["y"][:, :-1], inp["image"].double(), None, training=True, dec_masks=_mask_provider(SEED, probs),
                                           sn_decisions=dec, sn_zs=zs)
     if dec is not None:
-        _assert_kink_only(dec, zs, limit=1e-4, count=1024)       # whole-network fp32 forward error ~1e-5 in front of the ScoreNets
+        _assert_kink_only(dec, zs, limit=1e-3 if mode == "fp32x3" else 1e-4, count=4096 if mode == "fp32x3" else 1024)   # whole-network forward error ~1e-5 (fp32x3: ~1e-4) in front of the ScoreNets
     loss_r, _, _ = O.pix2poly_loss(logits_r, perm_r, inp["y"][:, 1:], inp["y_perm"].double())
     loss_r.backward()
     assert abs(float(loss) - float(loss_r)) < (2e-3 if precision == "fp32" else 5e-2) * abs(float(loss_r))
