@@ -16,9 +16,12 @@ Default workload = the configuration the metric is quoted on ("224px img + 3k-pt
 `--workload ffl_fusion` = BASELINE configs[4]: FFL early_fusion_vit_cnn, step = forward + FFL criterion + backward + AdamW.
 
 Extra objects in the JSON line (N = 1): `roofline` (dominant kernel, HIP events on the launch stream; step-level traffic from the
-committed PMC passes), `fp32_parity_mode` (the same step in the precision all 1e-3 parity claims are made in), `predict` (BASELINE
-configs[0]: image-only model, batch 1, 385-step greedy decode of the demo tile), `pcie_inclusive` (host-fed step, never `value`),
-`cpu_baseline` (the oracle on this box's host cores).
+committed PMC passes), `encoder_fwd` (the fused ViT + LiDAR encoder forward alone: the quantity the north star's MFMA fraction is defined on),
+`fp32_parity_mode` (the same step on the exact fp32 MFMA path) and `fp32x3_parity_mode` (fp32 storage, every product as bf16 x 3: the two modes the
+tests hold to the north star's 1e-3), `bf16_vs_oracle` / `fp32_vs_oracle` / `fp32x3_vs_oracle` (MEASURED error of each bench model on two tiles of the
+bench batch against the oracle on the host), `dense_lidar` (the LiDAR stem at 3 k and 40 k points per tile), `ffl` (BASELINE configs[4], 5 captured steps),
+`predict` (BASELINE configs[0]: image-only model, batch 1, 385-step greedy decode of the demo tile), `pcie_inclusive` (host-fed step, never `value`),
+`cpu_baseline` (the oracle on this box's host cores), `rank_ms_per_step` (min / max over the ranks).
 """
 import argparse
 import json

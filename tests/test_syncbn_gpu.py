@@ -23,15 +23,35 @@ def _free_port():
 
 
 def _init(rank, world, port):
+    import datetime
+    import faulthandler
     import torch.distributed as dist
+    # a rank that dies (or waits for one that died) must not hold the suite for the process group's default 30 minutes: collectives time out after 4 minutes and a
+    # rank still alive after 6 prints every thread's stack and exits (r04: one full-suite run sat in exactly this state until the box's time limit)
+    faulthandler.dump_traceback_later(360, exit=True)
+    tmo = datetime.timedelta(seconds=240)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if torch.cuda.device_count() >= world:
         torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"), timeout=tmo)
         return f"cuda:{rank}"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
     torch.cuda.set_device(0)
     return "cuda:0"
+
+
+def _spawn(fn, world, outdir, *extra):
+    """two ranks on this box; a rendezvous / transport failure (one rank never connects: the collectives' 4-minute timeout or the 6-minute watchdog of _init
+    fires) is retried ONCE on a fresh port - a second failure is the test's failure"""
+    import torch.multiprocessing as mp
+    for attempt in (0, 1):
+        try:
+            mp.spawn(fn, args=(world, _free_port(), outdir, *extra), nprocs=world, join=True)
+            return
+        except Exception as e:                      # noqa: BLE001 - reported below
+            if attempt == 1:
+                raise
+            print(f"[test_syncbn_gpu] first two-rank launch failed ({type(e).__name__}: {str(e)[:300]}); retrying once", flush=True)
 
 
 def _worker(rank, world, port, outdir, precision):
@@ -78,7 +98,7 @@ def test_two_ranks_with_sync_batchnorm_equal_the_oracle_on_the_whole_batch(preci
     from tests.helpers import l2_err, rel_err
     world = 2
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(world, _free_port(), outdir, precision), nprocs=world, join=True)
+        _spawn(_worker, world, outdir, precision)
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     sd = O.make_state_dict("fusion", seed=42)
     inp = O.make_inputs(2 * world, seed=99)
@@ -157,7 +177,7 @@ def test_bucketed_reducer_overlaps_backward_under_sync_batchnorm():
     from tests.helpers import l2_err
     world = 2
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker_reducer, args=(world, _free_port(), outdir), nprocs=world, join=True)
+        _spawn(_worker_reducer, world, outdir)
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     info = res[0]["info"]
     assert res[0]["nb"] >= 3
@@ -232,7 +252,7 @@ def test_ffl_two_ranks_with_sync_batchnorm_equal_the_oracle_on_the_whole_batch()
     from tests.helpers import l2_err, rel_err
     world = 2
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker_ffl, args=(world, _free_port(), outdir), nprocs=world, join=True)
+        _spawn(_worker_ffl, world, outdir)
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     sd = O.make_ffl_state_dict("fusion", SMALL, seed=11)
     p = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
