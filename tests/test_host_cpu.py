@@ -112,7 +112,10 @@ def test_flat_arena_views_and_buckets():
 
 def _ddp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)         # a rank that waits for a dead peer must not hold the suite for gloo's default 30 minutes
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer, sync_bn_sums
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))

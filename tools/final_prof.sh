@@ -19,6 +19,10 @@ python tools/pmc_kernels.py /tmp/pf_sq > gpurun_out/final/${R}_sq_counters_summa
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_fp32 -o st32 -- python bench.py --lean --precision fp32 --steps 6 --warmup 2 > gpurun_out/final/fp32_run.log 2>&1
 find /tmp/pf_fp32 -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/${R}_fp32_step_kernel_stats.csv \;
 python tools/kstats.py gpurun_out/final/${R}_fp32_step_kernel_stats.csv 9 40 > gpurun_out/final/${R}_fp32_step_summary.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_x3 -o stx3 -- python bench.py --lean --precision fp32x3 --steps 6 --warmup 2 > gpurun_out/final/fp32x3_run.log 2>&1
+find /tmp/pf_x3 -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/${R}_fp32x3_step_kernel_stats.csv \;
+python tools/kstats.py gpurun_out/final/${R}_fp32x3_step_kernel_stats.csv 9 40 > gpurun_out/final/${R}_fp32x3_step_summary.txt
+P3_FORCE_COLLECTIVES=1 python bench.py --no-cpu-baseline --no-fp32-leg --no-predict --no-host-feed --no-ffl --no-fwd 2>&1 | tail -1 > gpurun_out/final/${R}_bench_rccl_single_rank.json
 tail -3 gpurun_out/final/${R}_pmc_summary.txt
 cut -c1-900 gpurun_out/final/${R}_bench.json
 cut -c1-300 gpurun_out/final/${R}_bench_ffl.json
