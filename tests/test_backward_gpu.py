@@ -679,6 +679,28 @@ def test_bn_sums_from_the_dual_operand_weight_gradient(dtype, tol):
         assert l2_err(acc.cpu(), acc_old.cpu()) < 5e-3
 
 
+@pytest.mark.parametrize("R", [128 * 256, 128 * 601])
+def test_dual_operand_weight_gradient_streaming_kernel(R):
+    """csrc/mask2_dw_mma.hip (p3_gemm_tn_ex P3_A_AFFINE_MASK2 at the ScoreNet conv3 shape, bf16, R % 128 == 0, R >= 32768): G = dH3^T [y > 0] and G2 = dH3^T ([y > 0] H2)
+    from transposing reads of the two row tiles, the masks built in registers - against float64 with the kernel's own decisions (y = fma(H2, scale, shift) in fp32),
+    accumulating into a non-zero matrix; 601 steps over 256 workgroups: ragged walk."""
+    h = _h()
+    g = torch.Generator().manual_seed(17)
+    dH3 = (torch.randn(R, 64, generator=g) * 0.3).bfloat16()
+    H2 = torch.randn(R, 128, generator=g).bfloat16()
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    on = torch.addcmul(sh, H2.float(), sc) > 0
+    ref = torch.cat([dH3.double().t() @ on.double(), dH3.double().t() @ (on * H2.float()).double()], 1)
+    h.lib().p3_trace_kernels(1)
+    G = torch.full((64, 256), 0.5, device=DEV)
+    h.gemm_tn_ex(dH3.to(DEV), H2.to(DEV), G, h.A_AFFINE_MASK2, sc.to(DEV), sh.to(DEV))
+    picked = h.lib().p3_last_kernel().decode()
+    h.lib().p3_trace_kernels(0)
+    assert picked == "mask2_dw_mma_kernel", picked
+    # a decision may differ from this host expression's where y rounds to +-0 (fma vs mul + add): 1e-4 instead of the 2e-5 of a plain product
+    assert rel_err(G.cpu() - 0.5, ref.float()) < 1e-4
+
+
 @pytest.mark.parametrize("B,N", [(2, 192), (3, 60), (2, 24), (1, 13), (1, 16)])
 def test_pair_bwd_fused_vs_float64_and_the_two_launch_form(B, N):
     """csrc/pair_bwd_mma.hip: conv2's input gradient dA2 = dH2 W2 formed in the MFMA accumulators of the pair kernel (never stored) - dU, dV and the
