@@ -1,3 +1,4 @@
+# (historical: the knobs this sweep drove - P3_TN_BLOCKS, P3_GEMM_BK, P3_LN_RPB - were removed in r04 once their A/Bs were decided)
 run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fwd 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
 for r in 1 2; do
 echo -n "base: "; run
