@@ -508,11 +508,11 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     // N x K fp32 atomics whose lines migrate between the XCDs' L2s - 15 us of the 70 us mean launch, P3_DETERMINISTIC=2 A/B): 512 -> 39.59 ms,
     // 576 -> 39.47, 640 -> 39.05, 704 -> 39.00, 768 -> 39.39, 896 -> 39.34, 1024 -> 39.91
     // r03, second sweep (the first never went below 512): the best grids are the ones that fit ONE resident wave of workgroups (2 per CU = 512) -
-    // 320 -> 40.48 ms, 352 -> 40.11, 384 -> 39.89, 416 -> 39.59, 448 -> 39.41, 480 -> 39.55, 704 -> 40.33 (same box); per shape (tools/mb_tn_sweep.py)
+    // 320 -> 40.48 ms, 352 -> 40.11, 384 -> 39.89, 416 -> 39.59, 448 -> 39.41, 480 -> 39.55, 704 -> 40.33 (same box); per shape (tools/probe/mb_tn_sweep_r03.py)
     // qkv 82 us at 405 workgroups, 105 at 513 (one past the wave), 93 at 704
     const int tgt = 448;
     // (measured and dropped: outputs of <= 8 tiles - the decoder's 256 x 256 projections, the head - run 18.5 instead of 27.7 us ALONE with ~192
-    // instead of 512 workgroups, tools/mb_tn_sweep.py, but the captured step got 0.2 ms slower with that rule: 39.93 vs 39.72 ms, same box)
+    // instead of 512 workgroups, tools/probe/mb_tn_sweep_r03.py, but the captured step got 0.2 ms slower with that rule: 39.93 vs 39.72 ms, same box)
     int splits = (512 % tiles == 0) ? 512 / tiles : p3_ceil_div(tgt, tiles);
     if (tgt <= 512 && splits > 1 && splits * tiles > 512) --splits;              // never one workgroup past the resident wave
     if (slabs && splits > max_slabs) splits = max_slabs;
