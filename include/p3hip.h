@@ -74,6 +74,17 @@ int p3_get_deterministic(void);
  * launches take their atomics path).  Single-threaded like the rest of the library. */
 int p3_scratch_regions(int n);
 int p3_scratch_side_stream(void* stream);
+/* Deferred parameter-gradient reduces (r04).  p3_reduce_defer(arena, floats): from now on a launch whose workgroup partials only feed parameter gradients (the
+ * LayerNorm backward's dgamma / dbeta: 42 launches per Pix2Poly train step) parks them in `arena` while p3_reduce_defer_enable(1) is in force (device memory, caller-owned; NULL switches the mode off) instead
+ * of launching its own reduce; p3_reduce_flush(stream) adds every parked set to its outputs in ONE launch, in the same fixed float64 order (bit-identical
+ * gradients) - call it after the backward pass, before anything reads the gradients.  p3_reduce_pending(): sets parked since the last flush.  A full arena or
+ * table (48 sets) falls back to the immediate reduce. */
+int p3_reduce_defer(float* arena, int64_t floats);
+int p3_reduce_defer_enable(int on);    /* parking happens only between enable(1) and enable(0): the host brackets exactly the launches whose outputs are
+                                         * accumulation targets that stay valid until the flush (gradient arena views), returns the previous setting */
+int p3_reduce_flush(void* stream);
+int p3_reduce_pending(void);
+int p3_reduce_drop(void);              /* forget the parked sets without adding them (after a backward pass that raised); returns how many */
 int p3_scratch_stream(void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -129,6 +129,78 @@ __global__ __launch_bounds__(64 * NQ) void det_reduce_kernel(const float* __rest
 }
 }  // namespace
 
+// ---- deferred reduces (r04): a launch whose partials only feed PARAMETER gradients (LayerNorm dgamma / dbeta: 42 launches of 7 us per train step) may park its
+// partials in a caller-provided arena instead of reducing them at once; p3_reduce_flush adds all parked sets in ONE launch (grid.y = set), the same
+// 16-lane fixed-order float64 sum per value as det_reduce_kernel<16>: bit-identical results.
+namespace {
+constexpr int DEF_MAX = 48;
+struct DefTable { const float* parts[DEF_MAX]; float* out[DEF_MAX]; float* out2[DEF_MAX]; int nparts[DEF_MAX]; int nvals[DEF_MAX]; int split[DEF_MAX]; };
+DefTable g_def;
+float* g_def_arena = nullptr;
+int64_t g_def_cap = 0, g_def_used = 0;
+int g_def_n = 0, g_def_maxvals = 0, g_def_on = 0;
+
+__global__ __launch_bounds__(1024) void det_reduce_many_kernel(DefTable t) {
+    constexpr int NQ = 16;
+    __shared__ double red[NQ][64];
+    const int e = blockIdx.y, nvals = t.nvals[e], nparts = t.nparts[e];
+    if ((int)blockIdx.x * 64 >= nvals) return;
+    const float* parts = t.parts[e];
+    const int64_t stride = nvals;
+    const int v = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (nparts + NQ - 1) / NQ, p0 = q * per, p1 = min(nparts, p0 + per);
+    double a = 0.0;
+    if (v < nvals) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = parts[(int64_t)(p + u) * stride + v];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)x[u];
+        }
+        for (; p < p1; ++p) a += (double)parts[(int64_t)p * stride + v];
+    }
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && v < nvals) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) s += red[k][threadIdx.x];
+        float* o = v >= t.split[e] ? t.out2[e] + (v - t.split[e]) : t.out[e] + v;
+        *o = (float)((double)*o + s);
+    }
+}
+}  // namespace
+
+extern "C" int p3_reduce_defer(float* arena, int64_t floats) {
+    if (g_def_n != 0) { p3_set_error("p3_reduce_defer: parked reduces pending - call p3_reduce_flush first"); return P3_EINVAL; }
+    g_def_arena = arena; g_def_cap = arena ? floats : 0; g_def_used = 0; g_def_maxvals = 0;
+    return P3_OK;
+}
+extern "C" int p3_reduce_pending(void) { return g_def_n; }
+extern "C" int p3_reduce_drop(void) { const int n = g_def_n; g_def_n = 0; g_def_used = 0; g_def_maxvals = 0; return n; }     // forget parked sets (a backward pass that raised)
+extern "C" int p3_reduce_defer_enable(int on) { const int was = g_def_on; g_def_on = on ? 1 : 0; return was; }
+
+// a slot of `floats` for the partials of one set (nparts x nvals, stride nvals; values [0, split) += out, the rest += out2), or NULL: the caller reduces now
+float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* out, float* out2) {
+    if (!g_def_on || !g_def_arena || g_def_n >= DEF_MAX || g_def_used + floats > g_def_cap || nparts > 16 * 128) return nullptr;
+    float* slot = g_def_arena + g_def_used;
+    g_def_used += (floats + 63) / 64 * 64;
+    const int e = g_def_n++;
+    g_def.parts[e] = slot; g_def.out[e] = out; g_def.out2[e] = out2; g_def.nparts[e] = nparts; g_def.nvals[e] = nvals; g_def.split[e] = split;
+    if (nvals > g_def_maxvals) g_def_maxvals = nvals;
+    return slot;
+}
+
+extern "C" int p3_reduce_flush(void* stream) {
+    if (g_def_n == 0) return P3_OK;
+    hipLaunchKernelGGL(det_reduce_many_kernel, dim3((g_def_maxvals + 63) / 64, g_def_n), dim3(1024), 0, (hipStream_t)stream, g_def);
+    g_def_n = 0; g_def_used = 0; g_def_maxvals = 0;
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
 int p3_det_reduce(const float* parts, int nparts, int64_t stride, float* out, int nvals, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(det_reduce_kernel<4>, dim3((nvals + 63) / 64), dim3(256), 0, s, parts, nparts, stride, out, nvals, accumulate, (float*)nullptr, 0);
     P3_LAUNCH_CHECK();

@@ -321,8 +321,10 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     const bool halfk = half_cols;
     const int nblk = (int)grid.x;
     const int64_t slab_floats = (int64_t)nblk * 2 * cols, tmp_floats = (int64_t)p3_ceil_div(nblk, 128) * 2 * cols;
-    float* slab = (halfk && dgamma && nblk > 8) ? p3_reduce_scratch(slab_floats + tmp_floats) : nullptr;
-    auto finish = [&]() { return slab ? p3_det_reduce2(slab, nblk, 2 * cols, slab + slab_floats, dgamma, dbeta, cols, 2 * cols, 1, s) : P3_OK; };
+    // p3_reduce_defer active: the partials are parked and added with every other parked set by ONE p3_reduce_flush launch (42 reduce launches less per train step)
+    float* parked = (halfk && dgamma && nblk > 8 && p3_reduce_scratch(1)) ? p3_reduce_park(slab_floats, nblk, 2 * cols, cols, dgamma, dbeta) : nullptr;
+    float* slab = parked ? parked : ((halfk && dgamma && nblk > 8) ? p3_reduce_scratch(slab_floats + tmp_floats) : nullptr);
+    auto finish = [&]() { return (slab && !parked) ? p3_det_reduce2(slab, nblk, 2 * cols, slab + slab_floats, dgamma, dbeta, cols, 2 * cols, 1, s) : P3_OK; };
     if (lod) {
 #define LNH_D(CPL) hipLaunchKernelGGL((ln_bwd_half_kernel<bf16_t, float, float, CPL, false, true>), grid, block, 0, s, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (const float*)nullptr, (float*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab, *lo_drop)
         if (cols == 256) LNH_D(2); else if (cols == 384) LNH_D(3); else LNH_D(6);

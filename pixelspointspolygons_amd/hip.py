@@ -259,10 +259,34 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, save_stats=False, out=None):
 LN_TWIN_COLS = (256, 384, 768)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None):
+_park = {"buf": None}
+
+
+def param_reduce_arena(mb=None):
+    """register (once per process) the arena deferred parameter-gradient reduces park their partials in (p3_reduce_defer); P3_DEFER_MB, default 192"""
+    if _park["buf"] is None:
+        mb = int(_os0.environ.get("P3_DEFER_MB", "192")) if mb is None else mb
+        if mb <= 0:
+            return False
+        _park["buf"] = torch.empty(mb * (1 << 20) // 4, dtype=torch.float32, device="cuda")
+        check(lib().p3_reduce_defer(ptr(_park["buf"]), c_int64(_park["buf"].numel())), "p3_reduce_defer")
+    return True
+
+
+def reduce_pending():
+    return int(lib().p3_reduce_pending())
+
+
+def reduce_flush():
+    check(lib().p3_reduce_flush(stream()), "p3_reduce_flush")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None, park=False):
     """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass.
     want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo).
-    lo_drop = (seed, site, p): the bf16 copy carries that dropout site's mask and 1/(1-p) (see p3_layernorm_bwd_lo_drop)."""
+    lo_drop = (seed, site, p): the bf16 copy carries that dropout site's mask and 1/(1-p) (see p3_layernorm_bwd_lo_drop).
+    park: dgamma / dbeta are accumulation targets that stay valid until reduce_flush() (gradient arena views): the kernel's partials may be parked
+    and added by ONE launch at the end of the backward pass (p3_reduce_defer) instead of by a reduce launch of their own."""
     cols = x.shape[-1]
     dy2, x2 = dy.reshape(-1, cols).contiguous(), x.reshape(-1, cols).contiguous()
     rows = x2.shape[0]
@@ -277,10 +301,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=No
     if lo_drop is not None and lo is None:
         raise P3Error("layernorm_bwd: lo_drop needs the bf16 copy (want_lo, fp32 dx, 256 / 384 / 768 columns)")
     dspec = _drop(lo_drop)
-    check(lib().p3_layernorm_bwd_lo_drop(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo),
-                                         byref(dspec) if lo_drop is not None else None, ptr(dgamma), ptr(dbeta),
-                                         c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
-          "p3_layernorm_bwd")
+    park = park and dgamma is not None and param_reduce_arena()
+    if park:
+        lib().p3_reduce_defer_enable(c_int(1))
+    try:
+        check(lib().p3_layernorm_bwd_lo_drop(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(lo),
+                                             byref(dspec) if lo_drop is not None else None, ptr(dgamma), ptr(dbeta),
+                                             c_int64(rows), c_int(cols), c_int(dt(dy2)), c_int(dt(x2)), c_int(dt(dx)), stream()),
+              "p3_layernorm_bwd")
+    finally:
+        if park:
+            lib().p3_reduce_defer_enable(c_int(0))
     return (dx, lo) if want_lo else dx
 
 

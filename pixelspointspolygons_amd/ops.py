@@ -22,6 +22,34 @@ DIRECT_GRAD = [False]   # set by FlatAdamW: weight / bias / LayerNorm gradients 
 GRAD_READY = [None]     # callable(param) installed by GradBucketReducer: the kernels that accumulate into param.grad are enqueued
 
 
+# Deferred parameter-gradient reduces (r04): the LayerNorm backward launches that accumulate straight into the gradient arena park their workgroup partials and ONE
+# launch at the end of the backward pass adds them all (p3_reduce_defer / p3_reduce_flush: 42 reduce launches of ~7 us less per Pix2Poly train step, bit-identical
+# gradients).  Only without a reducer (its bucket triggers need a parameter's gradient complete when the operator reports it); the flush is queued on the autograd
+# engine the first time a launch parks, so whoever reads a gradient after backward() sees it complete.  P3_DEFER_REDUCE=0: off.
+DEFER_PARAM_REDUCE = [os.environ.get("P3_DEFER_REDUCE", "1") == "1"]
+_flush_queued = [False]
+
+
+def _park_ok():
+    return DEFER_PARAM_REDUCE[0] and GRAD_READY[0] is None
+
+
+def _flush_parked():
+    _flush_queued[0] = False
+    if hip.reduce_pending():
+        hip.reduce_flush()
+
+
+def _after_parking_launch():
+    if _flush_queued[0] or not hip.reduce_pending():
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_parked)
+        _flush_queued[0] = True
+    except RuntimeError:            # not inside a backward pass of the engine (a direct call): nothing to wait for
+        _flush_parked()
+
+
 def _grad_ready(*params):
     cb = GRAD_READY[0]
     if cb is not None:
@@ -291,6 +319,12 @@ def reset_process_state():
     DIRECT_GRAD[0] = False
     GRAD_READY[0] = None
     SYNC_BN[0] = False
+    _flush_queued[0] = False
+    try:
+        from ._lib import lib as _lib
+        _lib().p3_reduce_drop()          # partials a failed backward pass left parked must not reach the next model's gradients
+    except Exception:                    # noqa: BLE001 - no library in this process: nothing parked
+        pass
     _BUMPS[0] = None
     _epoch[0] += 1
 
@@ -730,7 +764,8 @@ class _LayerNorm(torch.autograd.Function):
             return _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, None, loose=True) + (None, None, None)
         td = ctx.twin_drop if (lo and not stream) else None                                       # masked twin for the sublayer below
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo, lo_drop=td)
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, want_lo=lo, lo_drop=td, park=_park_ok())
+            _after_parking_launch()
             _grad_ready(gamma, beta)
             if lo:
                 _register_twin(*dx, drop=td)
@@ -757,8 +792,9 @@ def _ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dres, loose=False):
         dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
     else:
         dg, db = gamma.grad, beta.grad
-    dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=torch.bfloat16, dgamma=dg, dbeta=db, dres=dres_bf)
+    dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=torch.bfloat16, dgamma=dg, dbeta=db, dres=dres_bf, park=(not loose) and _park_ok())
     if not loose:
+        _after_parking_launch()
         _grad_ready(gamma, beta)
     car = _stream_carrier(dx, x.shape)
     return (car, dg, db) if loose else car
@@ -801,7 +837,8 @@ class _LayerNormFork(torch.autograd.Function):
         if dres is not None and dres.dtype != x.dtype:
             dres = dres.to(x.dtype)
         if DIRECT_GRAD[0] and gamma.grad is not None and beta.grad is not None:
-            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres, want_lo=lo)
+            dx = hip.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dx_dtype=x.dtype, dgamma=gamma.grad, dbeta=beta.grad, dres=dres, want_lo=lo, park=_park_ok())
+            _after_parking_launch()
             _grad_ready(gamma, beta)
             if lo:
                 _register_twin(*dx)

@@ -47,3 +47,45 @@ def test_overfit_fixed_batch_bf16_tracks_fp32():
 def test_overfit_with_decoder_dropout():
     l = _run("bf16", 60, dropout=True)
     assert all(x == x for x in l) and min(l[-10:]) < 0.92 * l[0], (l[0], l[-10:])
+
+
+def test_deferred_layernorm_parameter_reduces_are_bit_identical():
+    """ops.DEFER_PARAM_REDUCE (p3_reduce_defer / p3_reduce_flush): the LayerNorm backward launches park their dgamma / dbeta partials and ONE launch at the end of
+    the backward pass adds them - the same fixed-order float64 sums: in the fp32 mode (every reduction of the step deterministic) every gradient of the train step (but the two that are summed with atomics in every mode) equals
+    the immediate-reduce form bit for bit; nothing stays parked after backward()."""
+    from oracle import p3_oracle as O
+    from pixelspointspolygons_amd import hip, ops
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import FlatAdamW, pix2poly_loss
+    sd = O.make_state_dict("image", seed=42)
+    inp = {k: v.to("cuda") for k, v in O.make_inputs(2, seed=11).items()}
+
+    def run(defer):
+        ops.reset_process_state()
+        was, ops.DEFER_PARAM_REDUCE[0] = ops.DEFER_PARAM_REDUCE[0], defer
+        try:
+            cfg = make_config("vit", precision="fp32", device="cuda")
+            m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+            m.load_state_dict(sd, strict=True)
+            m.train()
+            m.decoder.set_dropout(0.0)
+            opt = FlatAdamW(m, compute_dtype=torch.float32)
+            opt.zero_grad()
+            logits, perm = m(inp["image"], None, inp["y"][:, :-1])
+            pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])[0].backward()
+            assert hip.reduce_pending() == 0
+            grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}
+            opt.close()
+            return grads
+        finally:
+            ops.DEFER_PARAM_REDUCE[0] = was
+    g1, g0 = run(True), run(False)
+    ln = [k for k in g1 if ".norm" in k or k.endswith("norm.weight") or k.endswith("norm.bias")]
+    assert len(ln) >= 2 * (2 * 12 + 1 + 3 * 6)
+    assert all(float(g1[k].abs().max()) > 0 for k in ln)
+    # the embedding gradient and the Sinkhorn bin score are summed with fp32 atomics in every mode (DESIGN section 8): they differ at 1e-7 between ANY two runs
+    atomic = {"bin_score", "decoder.embedding.weight"}
+    diff = {k: float((g1[k] - g0[k]).abs().max() / g0[k].abs().max().clamp_min(1e-30)) for k in g1 if k not in atomic and not torch.equal(g1[k], g0[k])}
+    assert not diff, (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:8])
+    assert all(torch.allclose(g1[k], g0[k], rtol=1e-5, atol=1e-6 * float(g0[k].abs().max())) for k in atomic)
