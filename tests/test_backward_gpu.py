@@ -521,8 +521,9 @@ def _oracle_grads(sd, inp, kind="fusion", sn_decisions=None, kink=(1e-4, 1024)):
 # flips"); with float64 evaluated at the product's ScoreNet ReLU decisions the flips are gone and the worst parameter measures 2.5e-4 .. 4.4e-4 (two runs): 1.5e-3.
 # fp32x3 (r04): 4e-3.  Arithmetic is not what these bounds measure - op by op the mode is at 1e-5 (GEMM) / 1e-4 (attention backward), the exact mode at 1e-6, yet the exact mode's
 # worst parameter sits at 4e-4 .. 1e-3 from run to run: what is left after the ScoreNet decisions are pinned are the ReLU decisions of the decoder's FFNs inside the forward
-# error band, and that band is ~10 x wider at 2^-17 per product (measured 1.5e-3 .. 2.3e-3, the deepest decoder parameters: embedding, positional embedding, layer-0 norm1)
-@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-3), ("fp32x3", 4e-3), ("bf16", 5e-2)])
+# error band, and that band is ~10 x wider at 2^-17 per product (measured 1.5e-3 .. 2.3e-3 over four runs, the deepest decoder parameters: embedding, positional embedding,
+# layer-0 norm1; the bound leaves the same 2.5 x run-to-run spread the exact mode shows)
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-3), ("fp32x3", 6e-3), ("bf16", 5e-2)])
 def test_train_step_gradients_vs_oracle_autograd(precision, tol):
     """fwd + CE + 10*BCE + backward of the whole early-fusion model: parameter gradients vs autograd of the CPU oracle.  'fp32x3' (r04): fp32 storage, every
     GEMM / weight gradient / attention product as bf16 x 3 on the bf16 MFMA."""
@@ -856,7 +857,7 @@ def test_dropout_mask_statistics():
 # fp32 tolerance: forward agrees to 1e-6 (tools/dbg_dropout.py checks every site).  Until r03 the gradient bound was 1.5e-2, set by isolated
 # ReLU flips in the batch-normalised ScoreNets (1.0e-2 with these masks, 4e-3 with another seed); with float64 evaluated at the product's own
 # ReLU decisions the bound is 2e-3 (the dropout-free whole-model test holds 1.5e-3).
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("fp32x3", 4e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("fp32x3", 6e-3), ("bf16", 5e-2)])
 def test_train_step_with_decoder_dropout_vs_oracle_replaying_the_masks(precision, tol):
     """Training-mode decoder (attention-probability dropout 0.1, dropout1/2/3 + FFN dropout 0.1, positional dropouts 0.05, the
     reference's defaults): loss and parameter gradients vs float64 autograd of the oracle run with the SAME masks."""
