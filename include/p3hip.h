@@ -14,7 +14,9 @@
  *     never synchronise, and are safe to capture into a hipGraph.
  *   - return 0 on success; negative P3_E* for argument errors (p3_last_error_string() has text);
  *     positive values are hipError_t codes from a failed launch.
- *   - dtype codes: P3_F32 = 0 (exact fp32 path, fp32 MFMA), P3_BF16 = 1 (bf16 storage, fp32 accumulate).
+ *   - dtype codes: P3_F32 = 0 (exact fp32 path, fp32 MFMA), P3_BF16 = 1 (bf16 storage, fp32 accumulate), P3_F32X3 = 2 (fp32 storage, products as
+ *     bf16 x 3 on the bf16 MFMA: accepted wherever a descriptor's dtype names the operands of a PRODUCT - p3_gemm_desc.dtype_in, p3_gemm_tn's dtype,
+ *     p3_attn_desc.dtype, p3_pillar_desc.dtype - and chosen per call, so two models of different precision share one process).
  *   - matrices are row-major with explicit element strides.
  */
 #ifndef P3HIP_H
@@ -33,6 +35,9 @@ extern "C" {
 
 #define P3_F32 0
 #define P3_BF16 1
+#define P3_F32X3 2 /* operands stored as fp32 exactly like P3_F32; every value is split into hi = bf16(x) and lo = bf16(x - hi) while it is staged and the product
+                    * accumulates a_lo b_hi + a_hi b_lo + a_hi b_hi in fp32 on the bf16 MFMA (2^-17 relative per product instead of the exact fp32 MFMA's 2^-24;
+                    * outputs, epilogues and every non-product kernel stay fp32).  The "fp32x3" precision of the Python host; tests hold it to the north star's 1e-3. */
 
 #define P3_ACT_NONE 0
 #define P3_ACT_GELU 1 /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
@@ -152,12 +157,6 @@ int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* 
  * and K >= 1024: 9; other K >= 1024: 4; K <= 512 and N >= 1024: 6; P3_GEMM_DMA=0 switches that off).  All of them add the same 16-deep MFMA blocks in
  * ascending k order as the register-staged kernel: bit-identical outputs. */
 int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream);
-/* fp32 products as bf16 x 3 (r04): with the switch on, every p3_gemm / p3_gemm_tn / p3_attention / p3_attention_bwd launch whose operands are fp32 splits each value into hi = bf16(x) and
- * lo = bf16(x - hi) while staging it and accumulates a_lo b_hi + a_hi b_lo + a_hi b_hi in fp32 on the bf16 MFMA (error 2^-17 relative per product instead of the
- * exact fp32 MFMA's 2^-24; storage, epilogues and every non-GEMM kernel stay fp32).  Process-global (one model per process sets it before its first launch and
- * before a hipGraph capture); returns the previous setting.  The precision mode "fp32x3" of the Python host: tests hold it to the north star's 1e-3. */
-int p3_set_gemm_split(int on);
-int p3_get_gemm_split(void);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim:  y = (x - mean) / sqrt(var + eps) * gamma + beta

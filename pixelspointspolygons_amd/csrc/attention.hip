@@ -489,7 +489,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     P3_CHECK(Q && K && V && O && d, P3_EINVAL, "p3_attention: null pointer");
     P3_CHECK(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0, P3_ESHAPE, "p3_attention: empty problem");
     P3_CHECK(d->head_dim == 32 || d->head_dim == 64, P3_EUNSUP, "p3_attention: head_dim must be 32 or 64");
-    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention: dtype");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16 || d->dtype == P3_F32X3, P3_EUNSUP, "p3_attention: dtype");
     const int al = d->dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
     P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
@@ -515,7 +515,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     } while (0)
     if (d->dtype == P3_BF16) {
         if (d->head_dim == 64) P3_ATTN_FWD(bf16_t, 64); else P3_ATTN_FWD(bf16_t, 32);
-    } else if (p3_get_gemm_split()) {                    // fp32x3 mode: bf16 x 3 products on split images (attn_tile.h)
+    } else if (d->dtype == P3_F32X3) {                   // fp32x3 mode: bf16 x 3 products on split images (attn_tile.h)
         if (d->head_dim == 64) P3_ATTN_FWD(f32s, 64); else P3_ATTN_FWD(f32s, 32);
     } else {
         if (d->head_dim == 64) P3_ATTN_FWD(float, 64); else P3_ATTN_FWD(float, 32);

@@ -494,12 +494,12 @@ extern "C" int p3_attention_bwd(const void* Q, const void* K, const void* V, con
                                 void* dK, void* dV, float* delta_ws, const p3_attn_desc* d, void* stream) {
     P3_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws && d, P3_EINVAL, "p3_attention_bwd: null pointer");
     P3_CHECK(d->head_dim == 32 || d->head_dim == 64, P3_EUNSUP, "p3_attention_bwd: head_dim must be 32 or 64");
-    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_attention_bwd: dtype");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16 || d->dtype == P3_F32X3, P3_EUNSUP, "p3_attention_bwd: dtype");
     const int al = d->dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % al == 0, P3_EALIGN, "p3_attention_bwd: row strides");
     BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d; a.order = p3_attn_order();
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == P3_BF16) return d->head_dim == 64 ? launch_bwd<bf16_t, 64>(a, s) : launch_bwd<bf16_t, 32>(a, s);
-    if (p3_get_gemm_split()) return d->head_dim == 64 ? launch_bwd<f32s, 64>(a, s) : launch_bwd<f32s, 32>(a, s);      // fp32x3 mode: bf16 x 3 products (attn_tile.h)
+    if (d->dtype == P3_F32X3) return d->head_dim == 64 ? launch_bwd<f32s, 64>(a, s) : launch_bwd<f32s, 32>(a, s);      // fp32x3 mode: bf16 x 3 products (attn_tile.h)
     return d->head_dim == 64 ? launch_bwd<float, 64>(a, s) : launch_bwd<float, 32>(a, s);
 }

@@ -185,6 +185,11 @@ extern "C" int p3_reduce_defer_enable(int on) { const int was = g_def_on; g_def_
 // a slot of `floats` for the partials of one set (nparts x nvals, stride nvals; values [0, split) += out, the rest += out2), or NULL: the caller reduces now
 float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* out, float* out2) {
     if (!g_def_on || !g_def_arena || g_def_n >= DEF_MAX || g_def_used + floats > g_def_cap || nparts > 16 * 128) return nullptr;
+    // the flush adds every parked set from its own block row without atomics: two sets with a common target (a LayerNorm module applied twice in one forward,
+    // a second backward before the flush) would race there - the later one reduces immediately instead (stream order serialises it behind... the flush adds
+    // to whatever it finds, so the order of the two additions does not matter, only that they are not concurrent)
+    for (int e = 0; e < g_def_n; ++e)
+        if (g_def.out[e] == out || g_def.out2[e] == out || (out2 && (g_def.out[e] == out2 || g_def.out2[e] == out2))) return nullptr;
     float* slot = g_def_arena + g_def_used;
     g_def_used += (floats + 63) / 64 * 64;
     const int e = g_def_n++;

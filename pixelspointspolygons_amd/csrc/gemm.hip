@@ -24,6 +24,7 @@ struct GemmArgs {
     int vec_epi;   // 16-byte epilogue accesses are legal (strides / base pointers aligned)
     float* stat_slab;   // deterministic mode: [gridDim.x / tiles_n][2 row halves][2][N] partials of (colsum, colsumsq) instead of atomics
     float* tile_stats;  // non-STATS launch that still owes BatchNorm column sums: [tiles_m][2 row halves][2][N] per-tile partials (see launch_bk)
+    int split;          // the caller's dtype_in was P3_F32X3: fp32 operands, products as bf16 x 3
 };
 
 constexpr int BM = 128, BN = 128;
@@ -746,8 +747,6 @@ int launch_bk(const GemmArgs& g, hipStream_t s) {
     return p3_det_reduce2(scratch, nparts, 2 * (int64_t)g.d.N, scratch + slab_f, g.d.colsum, g.d.colsumsq, g.d.N, 2 * g.d.N, 1, s);   // (sum | sum of squares) in one go
 }
 
-int g_gemm_split = 0;      // p3_set_gemm_split: fp32 products on the bf16 x 3 path
-
 template <typename T, typename TO>
 int launch_mode(const GemmArgs& g, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
@@ -758,7 +757,7 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
     } else {
         // the split form walks K in 32-deep slices; a K (or conv channel count) that is only a multiple of 16 stays on the exact kernel
         const bool conv = g.d.a_mode == P3_A_CONV3X3 || g.d.a_mode == P3_A_CONV3X3_AFFINE_RELU;
-        const bool can_split = g_gemm_split && g.d.K % SPLIT_BK == 0 && (!conv || g.d.conv_C % SPLIT_BK == 0);
+        const bool can_split = g.split && g.d.K % SPLIT_BK == 0 && (!conv || g.d.conv_C % SPLIT_BK == 0);
         return can_split ? launch_bk<T, TO, BK_SPLIT>(g, s) : launch_bk<T, TO, 16>(g, s);
     }
 }
@@ -773,9 +772,6 @@ int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, co
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
 static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
 
-extern "C" int p3_set_gemm_split(int on) { const int was = g_gemm_split; g_gemm_split = on ? 1 : 0; return was; }
-extern "C" int p3_get_gemm_split(void) { return g_gemm_split; }
-
 extern "C" int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream) {
     P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm_dma: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm_dma: empty problem");
@@ -784,8 +780,12 @@ extern "C" int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_
     return p3_gemm_dma_launch(A, W, C, d, variant, (hipStream_t)stream);
 }
 
-extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* stream) {
-    P3_CHECK(A && W && C && d, P3_EINVAL, "p3_gemm: null pointer");
+extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d_in, void* stream) {
+    P3_CHECK(A && W && C && d_in, P3_EINVAL, "p3_gemm: null pointer");
+    p3_gemm_desc dn = *d_in;                      // P3_F32X3 = fp32 operands + the split flag: everything below sees P3_F32
+    const int split = dn.dtype_in == P3_F32X3;
+    if (split) dn.dtype_in = P3_F32;
+    const p3_gemm_desc* d = &dn;
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm: empty problem");
     const int bk = d->dtype_in == P3_BF16 ? 32 : 16;
     const int vec = d->dtype_in == P3_BF16 ? 8 : 4;
@@ -810,7 +810,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
              "p3_gemm: bwd_saved needs bwd_act = GELU, RELU, MUL or BN_RELU");
     P3_CHECK(!(d->bwd_saved && d->bwd_act == P3_ACT_BN_RELU) || d->bwd_bn, P3_EINVAL, "p3_gemm: P3_ACT_BN_RELU needs bwd_bn");
     GemmArgs g;
-    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.tile_stats = nullptr;
+    g.A = A; g.W = W; g.C = C; g.d = *d; g.stat_slab = nullptr; g.tile_stats = nullptr; g.split = split;
     g.tiles_m = p3_ceil_div(d->M, BM);
     g.tiles_n = p3_ceil_div(d->N, BN);
     {

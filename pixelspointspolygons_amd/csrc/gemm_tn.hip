@@ -470,11 +470,14 @@ int p3_pair_dw_try(const void* A, const void* U, float* C, int M, int N, int K, 
 int p3_mask2_dw_try(const void* A, const void* B, float* C, int M, int N, int Kb, int lda, int ldb, int ldc, const float* scale, const float* shift,
                     float* slabs, int max_slabs, hipStream_t s);      // mask2_dw_mma.hip
 
-extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype, int b_mode,
+extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype_in, int b_mode,
                              const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, float* slabs, int max_slabs, void* stream) {
+    const bool split = dtype_in == P3_F32X3;       // fp32 operands, products as bf16 x 3
+    const int dtype = split ? P3_F32 : dtype_in;
     P3_CHECK(A && B && C && M > 0 && N > 0 && K > 0, P3_EINVAL, "p3_gemm_tn: bad arguments");
     P3_CHECK(b_mode == 0 || b_mode == P3_A_AFFINE_RELU || b_mode == P3_A_PAIR_AFFINE_RELU || b_mode == P3_A_AFFINE_MASK2, P3_EINVAL, "p3_gemm_tn: b_mode");
     P3_CHECK(b_mode != P3_A_AFFINE_MASK2 || ldc >= 2 * K, P3_ESHAPE, "p3_gemm_tn: P3_A_AFFINE_MASK2 writes [N, 2K]");
+    P3_CHECK(b_mode != P3_A_AFFINE_MASK2 || K % 8 == 0, P3_ESHAPE, "p3_gemm_tn: P3_A_AFFINE_MASK2 needs K % 8 == 0 (a staged vector must not straddle the two generated operands)");
     P3_CHECK(b_mode == 0 || (b_scale && b_shift), P3_EINVAL, "p3_gemm_tn: generated B operand needs b_scale / b_shift");
     P3_CHECK(b_mode != P3_A_PAIR_AFFINE_RELU || (pair_V && pair_n > 0 && M % (pair_n * pair_n) == 0), P3_ESHAPE, "p3_gemm_tn: pair mode needs V and M == B*n*n");
     P3_CHECK(dtype == P3_F32 || dtype == P3_BF16, P3_EUNSUP, "p3_gemm_tn: dtype");
@@ -529,7 +532,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
 #define P3_TN_LAUNCH(MODE)                                                                            \
     do {                                                                                              \
         if (dtype == P3_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, MODE>), grid, block, 0, s, g); \
-        else if (p3_get_gemm_split()) hipLaunchKernelGGL((gemm_tn_kernel<float, MODE, true>), grid, block, 0, s, g); \
+        else if (split) hipLaunchKernelGGL((gemm_tn_kernel<float, MODE, true>), grid, block, 0, s, g); \
         else hipLaunchKernelGGL((gemm_tn_kernel<float, MODE>), grid, block, 0, s, g);                  \
     } while (0)
     if (g.b_mode == 0) P3_TN_LAUNCH(0);

@@ -912,7 +912,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     P3_CHECK(values && offsets && w1 && w2 && out && workspace && d, P3_EINVAL, "p3_pillar_stem: null pointer");
     P3_CHECK(d->B > 0 && d->nx > 0 && d->ny > 0 && d->max_points > 0 && d->max_points <= 4096, P3_ESHAPE, "p3_pillar_stem: max_points must be 1..4096");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768, P3_ESHAPE, "p3_pillar_stem: C must be a multiple of 64, <= 768");
-    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16, P3_EUNSUP, "p3_pillar_stem: dtype");
+    P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16 || d->dtype == P3_F32X3, P3_EUNSUP, "p3_pillar_stem: dtype");
     P3_CHECK(d->vz >= d->zmax, P3_EUNSUP, "p3_pillar_stem: only one z cell (voxel z size == z range) is supported");
     PillarGeom g;
     g.nx = d->nx; g.ny = d->ny; g.ncx = d->nx + 1; g.ncy = d->ny + 1; g.nc = g.ncx * g.ncy * 2;
@@ -977,7 +977,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
     gd.M = (int)rows; gd.N = d->C; gd.K = K2; gd.lda = K2; gd.ldb = K2; gd.ldc = d->C;
-    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32 gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
     int rc = p3_gemm(w.X2, w2, w.H2, &gd, stream);
     if (rc != P3_OK) return rc;
     float* sums2 = d->training ? w.sums2 : nullptr;
@@ -1067,7 +1067,7 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
     gd.M = (int)rows; gd.N = K2; gd.K = C; gd.lda = C; gd.ldb = C; gd.ldc = K2;
-    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32 gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
     rc = p3_gemm(w.H2, w2t, w.X2, &gd, stream);
     if (rc != P3_OK) return rc;
     if (bf)

@@ -16,7 +16,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 from . import hip, ops
 from .fusion_layers import EarlyFusionViT
 from .pointpillars import PointPillarsViT
-from .vision_transformer import ViT, compute_dtype
+from .vision_transformer import ViT, model_precision
 
 import os
 LDF = 320   # row stride of the padded conv-input image: 256 features + 1 seg channel, padded to a multiple of the GEMM's K slice (288 measured slower)
@@ -150,6 +150,7 @@ def _conv3x3_bwd(dY, Xpad, ldx, cin, w, cd, B, H, ci_dx, key, residual=None):
     return dW2.view(Co, 3, 3, cin), dX
 
 
+@hip.precision_scoped
 class _CNNFeatures(torch.autograd.Function):
     """Stand-alone `*CNN` encoder tail (early_fusion_vit_cnn.py:96-104): LN'd tokens -> NCHW fp32 relu(bn(conv3x3(upsample(tokens)))),
     backward through BatchNorm + ReLU, the 3x3 convolution (weight / input gradients on the MFMA GEMMs) and the bilinear upsample."""
@@ -184,6 +185,7 @@ class _CNNFeatures(torch.autograd.Function):
         return dtok, None, dW.permute(0, 3, 1, 2).contiguous(), g_conv_b, g_bn_w, g_bn_b
 
 
+@hip.precision_scoped
 class _FFLTail(torch.autograd.Function):
     """tokens -> (seg, crossfield) with a hand-written backward (see module docstring)."""
 
@@ -258,6 +260,7 @@ class EncoderDecoder(nn.Module):
         assert mc.compute_seg or mc.compute_crossfield, "Model has to compute at least one of those:\n\t- segmentation\n\t- cross-field"
         self.cfg = cfg
         self.encoder = encoder
+        model_precision(self, cfg, ("inference", "_tail"))
         c = int(cfg.experiment.encoder.out_feature_dim)
         seg_channels = 0
         if mc.compute_seg:

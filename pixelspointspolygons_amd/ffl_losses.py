@@ -21,6 +21,7 @@ from . import hip
 LOSS_NAMES = ("seg", "crossfield_align", "crossfield_align90", "crossfield_smooth", "seg_interior_crossfield")
 
 
+@hip.precision_scoped
 class _FFLLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seg, crossfield, gt, angle, coef, bce_coef, dice_coef, seg_weights):

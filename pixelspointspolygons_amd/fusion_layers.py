@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import hip, ops
 from .pointpillars import PointPillarsEncoder, jagged_parts
-from .vision_transformer import VisionTransformer, compute_dtype, parse_timm_name, pool
+from .vision_transformer import VisionTransformer, model_precision, parse_timm_name, pool
 
 
 class EarlyFusionViT(nn.Module):
@@ -20,7 +20,7 @@ class EarlyFusionViT(nn.Module):
         self.cfg = cfg
         enc = cfg.experiment.encoder
         D = enc.patch_feature_dim
-        self.cd = compute_dtype(cfg)
+        self.cd = model_precision(self, cfg, ("fused_tokens",))
         self.lidar_embed = PointPillarsEncoder(cfg, voxel_encoder={"in_channels": 3, "feat_channels": [64, D]},
                                                scatter={"in_channels": D, "output_shape": [enc.patch_feature_width, enc.patch_feature_height]},
                                                local_rank=local_rank)
@@ -69,6 +69,7 @@ def _zero_lidar(canvas, D):
     return canvas
 
 
+@hip.precision_scoped
 class _FusionConvBN(torch.autograd.Function):
     """Conv3x3 (implicit GEMM, stats in the epilogue) + BatchNorm2d scale/shift (applied later by tokens_assemble)."""
 

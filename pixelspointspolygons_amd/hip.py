@@ -7,7 +7,7 @@ import torch
 
 from ._lib import P3Error, check, lib
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL, ACT_BN_RELU = 0, 1, 2, 3, 4
 A_PLAIN, A_CONV3X3, A_AFFINE_RELU, A_PAIR_AFFINE_RELU = 0, 1, 2, 3
 
@@ -62,6 +62,85 @@ def dt(t):
     if t.dtype == torch.bfloat16:
         return BF16
     raise P3Error(f"unsupported dtype {t.dtype}")
+
+
+# ---- precision scope of the products ('fp32x3', include/p3hip.h P3_F32X3) --------------------------------------------------------------------------
+# The library takes the precision of a product PER CALL (the dtype code of the descriptor); here it is a scope that the modules of an 'fp32x3' model open around
+# their forward (scope_module) and that every autograd Function of the package re-opens around its backward with the value its forward saw (@precision_scoped),
+# so that two models of different precision in one process - and a bf16 model's fp32 side products - never see each other's setting.
+_SPLIT = [False]
+
+
+def split_now():
+    return _SPLIT[0]
+
+
+def dt_mm(t):
+    """dtype code of a PRODUCT operand: fp32 tensors inside an 'fp32x3' scope are multiplied as bf16 x 3"""
+    c = dt(t)
+    return F32X3 if (c == F32 and _SPLIT[0]) else c
+
+
+class gemm_split:
+    """`with hip.gemm_split(True):` fp32 products launched inside the block run as bf16 x 3 (P3_F32X3); the previous setting comes back after it."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.was, _SPLIT[0] = _SPLIT[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SPLIT[0] = self.was
+        return False
+
+
+def precision_scoped(cls):
+    """class decorator for torch.autograd.Function: the backward runs under the product precision the forward ran under (the autograd engine calls it later,
+    from its own thread, possibly between the passes of another model)"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a):
+        ctx._p3_split = _SPLIT[0]
+        return fwd(ctx, *a)
+
+    def backward(ctx, *g):
+        was, _SPLIT[0] = _SPLIT[0], ctx._p3_split
+        try:
+            return bwd(ctx, *g)
+        finally:
+            _SPLIT[0] = was
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+def scope_module(module, split, methods=()):
+    """every forward of `module` (and whatever it calls) - and every call of the named methods - runs with the product precision `split`; scopes nest"""
+    stack = []
+    import functools
+
+    for name in methods:
+        fn = getattr(module, name)
+
+        def wrapped(*a, __fn=fn, **k):
+            with gemm_split(split):
+                return __fn(*a, **k)
+
+        setattr(module, name, functools.wraps(fn)(wrapped))
+
+    def pre(_m, _a):
+        stack.append(_SPLIT[0])
+        _SPLIT[0] = bool(split)
+
+    def post(_m, _a, _o):
+        _SPLIT[0] = stack.pop()
+
+    module.register_forward_pre_hook(pre)
+    module.register_forward_hook(post, always_call=True)
+    module.p3_split = bool(split)
+    return module
 
 
 def tdtype(code):
@@ -179,7 +258,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     d = GemmDesc()
     d.M, d.N, d.K = M_, N, K
     d.lda, d.ldb, d.ldc = lda_, w.stride(0), (out.stride(-2) if ldc is None else ldc)
-    d.dtype_in, d.dtype_out, d.act, d.a_mode = dt(a), dt(out), act, a_mode
+    d.dtype_in, d.dtype_out, d.act, d.a_mode = dt_mm(a), dt(out), act, a_mode
     if w.dtype != a.dtype:
         raise P3Error("gemm: A and W dtypes differ")
     d.bias = bias.data_ptr() if bias is not None else None
@@ -281,6 +360,10 @@ def reduce_flush():
     check(lib().p3_reduce_flush(stream()), "p3_reduce_flush")
 
 
+def reduce_drop():
+    return int(lib().p3_reduce_drop())
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None, park=False):
     """dres: gradient that reaches x through a residual connection (same dtype as dx); summed into dx in the same pass.
     want_lo: also return a bf16 copy of an fp32 dx written by the same kernel -> (dx, dx_lo).
@@ -330,7 +413,7 @@ def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None, drop_
     d.B, d.H, d.Lq, d.Lk, d.head_dim = B, heads, Lq, Lk, Dm // heads
     d.q_bs, d.k_bs, d.v_bs, d.o_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
-    d.scale, d.causal, d.dtype = scale, int(causal), dt(q)
+    d.scale, d.causal, d.dtype = scale, int(causal), dt_mm(q)
     d.key_bias = key_bias.data_ptr() if key_bias is not None else None
     d.lse = lse.data_ptr() if lse is not None else None
     d.drop = _drop(drop)
@@ -399,7 +482,7 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     d.zmax = zmax
     d.max_points, d.max_voxels, d.C = max_points, max_voxels, w2.shape[0]
     d.training, d.bn_eps, d.bn_momentum = int(training), 1e-3, 0.01
-    d.dtype, d.out_ld, d.out_col_off = dt(out), out.stride(-2), col_off
+    d.dtype, d.out_ld, d.out_col_off = dt_mm(out), out.stride(-2), col_off
     if w2.dtype != out.dtype:
         raise P3Error("pillar_stem: w2 dtype must equal the canvas dtype")
     L = lib()
@@ -449,7 +532,7 @@ def pillar_stem_bwd(dcanvas, w1, g1, w2t, g2, ws, d, sync=None):
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     dw1, dg1, db1, dw2, dgb2 = f(32, 8), f(32), f(32), f(C, 64), f(2 * C)
     db2, dg2 = dgb2[:C], dgb2[C:]
-    if dt(dcanvas) != d.dtype:
+    if dt(dcanvas) != (F32 if d.dtype == F32X3 else d.dtype):
         raise P3Error("pillar_stem_bwd: canvas gradient dtype differs from the forward's")
     args = (ptr(dcanvas), c_int(dcanvas.stride(-2)), ptr(w1), ptr(g1), ptr(w2t), ptr(g2), ptr(ws), byref(d), ptr(dw1),
             ptr(dg1), ptr(db1), ptr(dw2), ptr(dg2), ptr(db2))
@@ -768,7 +851,7 @@ def gemm_tn(a, b, out=None, colsum_out=None):
     if ev is not None:
         lib().p3_trace_kernels(c_int(1))                        # forget the previous launch's name: an untraced kernel must not inherit it
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
-                              c_int(out.stride(0)), c_int(dt(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
+                              c_int(out.stride(0)), c_int(dt_mm(a)), c_int(0), ptr(None), ptr(None), ptr(None), c_int(0), ptr(colsum_out),
                               ptr(slabs), c_int(ns), stream()), "p3_gemm_tn")
     if ev is not None:                                          # operands once, the fp32 output tile once (split-M partials are not algorithmic)
         kname = lib().p3_last_kernel().decode() or f"gemm_tn_kernel<{'bf16' if dt(a) == BF16 else 'float'}, 0>"
@@ -899,31 +982,14 @@ def bn_sums_from_g(G, W, scale, shift, mean, dW, acc):
           "p3_bn_sums_from_g")
 
 
-class gemm_split:
-    """`with hip.gemm_split(True):` fp32 products on the bf16 x 3 MFMA path (p3_set_gemm_split) inside the block; the previous setting comes back after it."""
-
-    def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        self.was = lib().p3_set_gemm_split(c_int(int(self.on)))
-        return self
-
-    def __exit__(self, *exc):
-        lib().p3_set_gemm_split(c_int(self.was))
-        return False
-
-
-def set_gemm_split(on):
-    return bool(lib().p3_set_gemm_split(c_int(int(bool(on)))))
-
-
 def gemm_tn_ex(a, b, out, b_mode, b_scale, b_shift, pair_v=None, pair_n=0, M=None):
     M_ = a.shape[0] if M is None else M
     N, K = a.shape[1], b.shape[1]
+    if tuple(out.shape) != (N, K * (2 if b_mode == A_AFFINE_MASK2 else 1)) or out.dtype != torch.float32:
+        raise P3Error(f"gemm_tn_ex: out must be float32 [{N}, {K * (2 if b_mode == A_AFFINE_MASK2 else 1)}], got {out.dtype} {tuple(out.shape)}")
     slabs, ns = _tn_slabs(N, K * (2 if b_mode == A_AFFINE_MASK2 else 1), a)
     check(lib().p3_gemm_tn_ex(ptr(a), ptr(b), ptr(out), c_int(M_), c_int(N), c_int(K), c_int(a.stride(0)), c_int(b.stride(0)),
-                              c_int(out.stride(0)), c_int(dt(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
+                              c_int(out.stride(0)), c_int(dt_mm(a)), c_int(b_mode), ptr(b_scale), ptr(b_shift), ptr(pair_v), c_int(pair_n),
                               ptr(None), ptr(slabs), c_int(ns), stream()), "p3_gemm_tn_ex")
     return out
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import hip, ops
 from .ffl import _khwc
-from .vision_transformer import compute_dtype
+from .vision_transformer import compute_dtype, is_split
 
 
 def _up32(c):
@@ -59,7 +59,8 @@ class HiSupHeads(nn.Module):
         if dim_in is None:
             dim_in = int(cfg.experiment.model.decoder.in_feature_dim)
         self.dim_in = dim_in
-        self.cd = compute_dtype(cfg) if precision is None and cfg is not None else (torch.float32 if precision in ("fp32", "float32") else torch.bfloat16)
+        self.cd = compute_dtype(cfg) if precision is None and cfg is not None else (torch.float32 if precision in ("fp32", "float32", "fp32x3") else torch.bfloat16)
+        hip.scope_module(self, is_split(cfg) if precision is None and cfg is not None else precision == "fp32x3")
         self.mask_head = self._make_conv(dim_in, dim_in, dim_in)
         self.jloc_head = self._make_conv(dim_in, dim_in, dim_in)
         self.afm_head = self._make_conv(dim_in, dim_in, dim_in)

@@ -50,6 +50,20 @@ def _after_parking_launch():
         _flush_parked()
 
 
+def settle_parked():
+    """Backstop for a backward pass that RAISED after a launch had parked (the engine drops its final callbacks then): the latch is re-armed, and partials still
+    parked are flushed - what FlatAdamW.apply() calls before it reads the gradients - or dropped (`zero_grad`: they belong to the gradients being discarded)."""
+    _flush_queued[0] = False
+    if hip.reduce_pending():
+        hip.reduce_flush()
+
+
+def drop_parked():
+    _flush_queued[0] = False
+    if hip.reduce_pending():
+        hip.reduce_drop()
+
+
 def _grad_ready(*params):
     cb = GRAD_READY[0]
     if cb is not None:
@@ -555,6 +569,7 @@ class GradSlot:
         return g
 
 
+@hip.precision_scoped
 class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ residual).  x [.., K] compute dtype; W [N, K] fp32 parameter."""
 
@@ -681,6 +696,7 @@ def _weight_grads(dpre, x2, weight, bias, need_w, need_b):
     return dw, db
 
 
+@hip.precision_scoped
 class _Mlp(torch.autograd.Function):
     """y = drop2(W2 drop1(act(W1 x + b1)) + b2) (+ residual): timm Mlp (GELU) and the FFN of nn.TransformerDecoderLayer (ReLU).
     Backward fuses act' (and the 1/(1-p) of drop1) into the epilogue of the dH = dY W2 GEMM: no separate act_bwd pass, dH never
@@ -739,6 +755,7 @@ def mlp(x, w1, b1, w2, b2, *, act, residual=None, out_dtype=None, cd=torch.float
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
+@hip.precision_scoped
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, out_dtype, twin_drop):
@@ -807,6 +824,7 @@ def layernorm(x, gamma, beta, eps, out_dtype=None, twin_drop=None, stream_grad=F
     return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype, ("stream",) if (stream_grad and twin_drop is None) else twin_drop)
 
 
+@hip.precision_scoped
 class _LayerNormFork(torch.autograd.Function):
     """(x, LN(x)) for a pre-norm residual block  x + f(LN(x)):  the gradient of the residual path comes back as the gradient of
     the first output and is added to the LayerNorm input gradient inside the ln_bwd kernel (no separate accumulate pass)."""
@@ -861,6 +879,7 @@ def layernorm_fork(x, gamma, beta, eps, out_dtype=None, stream_grad=False):
 
 
 # ---------------------------------------------------------------------------------------------- attention
+@hip.precision_scoped
 class _SelfAttention(torch.autograd.Function):
     """qkv [B, L, 3D] packed (output of the qkv / in_proj GEMM) -> o [B, L, D]; the gradient comes back packed."""
 
@@ -889,6 +908,7 @@ class _SelfAttention(torch.autograd.Function):
         return dqkv, None, None, None, None, None
 
 
+@hip.precision_scoped
 class _CrossAttention(torch.autograd.Function):
     """q [B, Lq, D], kv [B, Lk, 2D] packed -> o [B, Lq, D]."""
 
@@ -926,6 +946,7 @@ def cross_attention(q, kv, heads, drop=None):
     return _CrossAttention.apply(q, kv, heads, 1.0 / math.sqrt(q.shape[-1] // heads), drop)
 
 
+@hip.precision_scoped
 class _Dropout(torch.autograd.Function):
     """Standalone elementwise dropout (decoder_pos_drop / encoder_pos_drop): same counter-based mask forward and backward."""
 
@@ -944,6 +965,7 @@ def dropout(x, drop):
 
 
 # ---------------------------------------------------------------------------------------------- glue with autograd
+@hip.precision_scoped
 class _Cast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):
@@ -959,6 +981,7 @@ def cast(x, dtype):
     return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
 
+@hip.precision_scoped
 class _EmbedTokens(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, emb, pos, pad_idx, cd):
@@ -984,6 +1007,7 @@ def embed_tokens(tokens, emb, pos, pad_idx, cd):
     return _EmbedTokens.apply(tokens, emb, pos, pad_idx, cd)
 
 
+@hip.precision_scoped
 class _AddPos(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos):
@@ -1000,6 +1024,7 @@ def add_pos(x, pos):
     return _AddPos.apply(x, pos)
 
 
+@hip.precision_scoped
 class _SinkhornSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, alpha, iters):

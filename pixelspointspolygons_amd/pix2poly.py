@@ -15,7 +15,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 from . import hip, ops
 from .fusion_layers import EarlyFusionViT
 from .pointpillars import PointPillarsViT
-from .vision_transformer import ViT, compute_dtype
+from .vision_transformer import ViT, is_split, model_precision
 
 
 # ------------------------------------------------------------------------------------------------ Tokenizer
@@ -177,6 +177,7 @@ def scorenet_forward_steps(net, feats, out, transpose_acc, keep=None):
     return out
 
 
+@hip.precision_scoped
 class _ScoreNetPairFn(torch.autograd.Function):
     """scorenet1(f) + scorenet2(f)^T (model_pix2poly.py:257-259) as ONE autograd node: forward and backward of the two nets advance in lockstep,
     so that under SyncBatchNorm (convert_sync_batchnorm, model_pix2poly.py:326) the statistic exchanges of equal depth share one message."""
@@ -204,6 +205,7 @@ class _ScoreNetPairFn(torch.autograd.Function):
         return (dfeats, None, None, None, None, *dp1, *dp2)
 
 
+@hip.precision_scoped
 class _ScoreNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, net, out, transpose_acc, *params):
@@ -461,9 +463,10 @@ class EncoderDecoder(nn.Module):
         self.scorenet2 = ScoreNet(self.max_num_vertices, in_channels=2 * decoder.dim, token_mode=self.token_mode)
         self.bin_score = torch.nn.Parameter(torch.tensor(1.0))
         self.bottleneck = nn.AdaptiveAvgPool1d(cfg.experiment.encoder.out_feature_dim)
-        cd = compute_dtype(cfg)
-        for m in (self.decoder, self.scorenet1, self.scorenet2):
+        cd = model_precision(self, cfg, ("perm_scores", "predict", "permutations", "generate"))
+        for m, methods in ((self.decoder, ("predict", "generate_cached")), (self.scorenet1, ("scores_into",)), (self.scorenet2, ("scores_into",))):
             m.cd = cd
+            hip.scope_module(m, is_split(cfg), methods)
 
     def perm_scores(self, features):
         """scorenet1(f) + scorenet2(f)^T (model_pix2poly.py:257-259), accumulated in place by the second ScoreNet's tail kernel."""

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import hip, ops
-from .vision_transformer import VisionTransformer, compute_dtype, parse_timm_name, pool
+from .vision_transformer import VisionTransformer, model_precision, parse_timm_name, pool
 
 
 class PFNLayer(nn.Module):
@@ -60,7 +60,7 @@ class PointPillarsEncoder(nn.Module):
         self.max_points = int(enc.max_num_points_per_voxel)
         self.max_voxels = (int(enc.max_num_voxels.train), int(enc.max_num_voxels.test))
         self.C = voxel_encoder["feat_channels"][-1]
-        self.cd = compute_dtype(cfg)
+        self.cd = model_precision(self, cfg, ("scatter_into", "voxelize"))
 
     def scatter_into(self, x_lidar, canvas, col_off):
         """Run the stem and write the [B, ny*nx, C] features into canvas[..., col_off:col_off+C] (token-major)."""
@@ -119,6 +119,7 @@ class PointPillarsEncoder(nn.Module):
         return out.transpose(1, 2).reshape(B, self.C, self.ny, self.nx)
 
 
+@hip.precision_scoped
 class _PillarStem(torch.autograd.Function):
     @staticmethod
     def forward(ctx, values, offsets, w1, g1, b1, w2, g2, b2, canvas, mod, B, col_off):
@@ -162,7 +163,7 @@ class PointPillarsViT(nn.Module):
         self.cfg = cfg
         enc = cfg.experiment.encoder
         shp = parse_timm_name(enc.vit.type)
-        cd = compute_dtype(cfg)
+        cd = model_precision(self, cfg)
         self.vit = VisionTransformer(enc.in_size, enc.patch_size, enc.patch_feature_dim, getattr(enc.vit, "depth", shp["depth"]),
                                      getattr(enc.vit, "num_heads", shp["heads"]), getattr(enc.vit, "mlp_dim", None), cd=cd)
         if getattr(enc.vit, "pretrained", False):

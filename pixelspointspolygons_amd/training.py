@@ -18,6 +18,7 @@ from . import hip, ops
 
 
 # ------------------------------------------------------------------------------------------------ loss
+@hip.precision_scoped
 class _Pix2PolyLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, perm, y_expected, y_perm, w_vertex, w_perm, pad_idx):
@@ -174,6 +175,7 @@ class FlatAdamW:
         self._lr_lambda, self._host_fed = fn, True
 
     def zero_grad(self):
+        ops.drop_parked()                        # partials a failed backward left parked belong to the gradients discarded here
         self.grad.zero_()
         ops.clear_twins()
 
@@ -205,6 +207,7 @@ class FlatAdamW:
     def apply(self, grad_scale=1.0):
         """device side (capturable): schedule kernel + one fused update kernel over the arena (which also refreshes the bf16 shadow),
         then the transposed / re-laid-out weight copies are rewritten in place."""
+        ops.settle_parked()                      # normally a no-op (the engine's final callback flushed); after a backward that raised: flush + re-arm the latch
         ops.side_join()                          # side-stream branches (ops.SIDE) write into the gradient arena too
         if not self._host_fed:
             if self._sched_sent is None:         # apply() without prepare_step() (tests): upload once, outside any capture

@@ -15,14 +15,20 @@ from . import hip, ops
 
 
 def compute_dtype(cfg):
-    """precision -> storage dtype.  'fp32x3' (r04) = fp32 storage with every GEMM on the bf16 x 3 MFMA path (hip.set_gemm_split): the switch is process-global,
-    so the fp32-family model constructed LAST decides it ('fp32' switches it off again); bf16 models do not touch it."""
+    """precision -> storage dtype: 'bf16' -> bfloat16; 'fp32' and 'fp32x3' (fp32 storage, every product as bf16 x 3 on the bf16 MFMA) -> float32"""
     p = getattr(cfg, "precision", "bf16")
-    if p in ("fp32", "float32", "exact", "fp32x3"):
-        if str(getattr(cfg, "device", "cuda")).startswith("cuda") and torch.cuda.is_available():
-            hip.set_gemm_split(p == "fp32x3")
-        return torch.float32
-    return torch.bfloat16
+    return torch.float32 if p in ("fp32", "float32", "exact", "fp32x3") else torch.bfloat16
+
+
+def is_split(cfg):
+    return getattr(cfg, "precision", "bf16") == "fp32x3"
+
+
+def model_precision(module, cfg, methods=()):
+    """storage dtype of a model built from `cfg`; the module's forward (and the named methods) run inside the product-precision scope of that model
+    (hip.scope_module): the precision is a property of the MODEL, handed to the library per call - not a process setting"""
+    hip.scope_module(module, is_split(cfg), methods)
+    return compute_dtype(cfg)
 
 
 class PatchEmbed(nn.Module):
@@ -51,6 +57,7 @@ class PatchEmbed(nn.Module):
         return t.transpose(1, 2).reshape(B, -1, self.grid, self.grid)
 
 
+@hip.precision_scoped
 class _PatchGemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, patches, weight, bias, w2, canvas, cd):
@@ -177,6 +184,7 @@ class VisionTransformer(nn.Module):
         return self.forward_tokens(tok, B)
 
 
+@hip.precision_scoped
 class _Assemble(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tok, cls, pos, scale, shift, B, np_, D, src_ld, mean):
@@ -215,7 +223,7 @@ class ViT(nn.Module):
                 raise FileNotFoundError(f"Checkpoint file {ckpt} not found.")
             ckpt = ckpt2
         shp = parse_timm_name(getattr(enc, "type", None) or enc.vit.type)
-        cd = compute_dtype(cfg)
+        cd = model_precision(self, cfg)
         self.cd = cd
         depth = getattr(vitc, "depth", shp["depth"]) if vitc is not None else shp["depth"]
         heads = getattr(vitc, "num_heads", shp["heads"]) if vitc is not None else shp["heads"]
@@ -231,6 +239,7 @@ class ViT(nn.Module):
         return pool(y, self.out_dim)
 
 
+@hip.precision_scoped
 class _Pool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, pos, Dout, out_dtype):

@@ -88,7 +88,7 @@ def test_pair_weight_gradient_kernel_of_the_scorenet_conv2(Bn, n):
 
 @pytest.mark.parametrize("M,N,K", [(3000, 384, 384), (50 * 385, 256, 1024), (777, 132, 64)])
 def test_gemm_tn_fp32_operands_as_bf16x3(M, N, K):
-    """p3_gemm_tn under p3_set_gemm_split: the fp32 weight gradient as a_lo b_hi + a_hi b_lo + a_hi b_hi from transposing reads of the split images; 1e-5 against
+    """p3_gemm_tn with dtype P3_F32X3 (hip.gemm_split scope): the fp32 weight gradient as a_lo b_hi + a_hi b_lo + a_hi b_hi from transposing reads of the split images; 1e-5 against
     float64 (exact fp32 path: 2e-6), bias column sums untouched, ragged M / N."""
     h = _h()
     a, b = _rand(M, N, seed=21), _rand(M, K, seed=22)
@@ -163,7 +163,7 @@ def test_attention_backward(dtype, tol, B, H, Lq, Lk, hd, causal, bias):
 @pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,bias", [
     (2, 6, 785, 785, 64, False, False), (2, 8, 385, 385, 32, True, True), (2, 8, 385, 784, 32, False, False), (1, 2, 37, 50, 64, False, True)])
 def test_attention_fp32x3_forward_backward(B, H, Lq, Lk, hd, causal, bias):
-    """fp32 attention under p3_set_gemm_split (precision 'fp32x3'): K / V / Q / dO tiles as bf16 hi + lo images, every product of the three kernels as
+    """fp32 attention with dtype P3_F32X3 (precision 'fp32x3'): K / V / Q / dO tiles as bf16 hi + lo images, every product of the three kernels as
     a_lo b_hi + a_hi b_lo + a_hi b_hi, P and dS split in registers; against float64 math 1e-4 (the exact fp32 kernels: 2e-5, bf16: 3e-2)."""
     h = _h()
     Dm = H * hd
@@ -490,12 +490,12 @@ def test_a_derived_layout_first_created_after_capture_does_not_go_stale():
 
 
 @pytest.fixture(autouse=True)
-def _exact_fp32_gemms_unless_a_test_asks():
-    """the bf16 x 3 GEMM switch is process-global (precision='fp32x3' sets it at model construction): every test starts and ends with it off"""
+def _no_precision_scope_leaks():
+    """the product precision is a scope of the model that launches (hip.scope_module / @precision_scoped), not a process setting: no test may leave one open"""
     import pixelspointspolygons_amd.hip as hip
-    hip.set_gemm_split(False)
+    assert not hip.split_now()
     yield
-    hip.set_gemm_split(False)
+    assert not hip.split_now()
 
 
 def _oracle_grads(sd, inp, kind="fusion", sn_decisions=None, kink=(1e-4, 1024)):
@@ -533,10 +533,10 @@ def test_train_step_gradients_vs_oracle_autograd(precision, tol):
     from pixelspointspolygons_amd.training import pix2poly_loss
     sd = O.make_state_dict("fusion", seed=42)
     inp = O.make_inputs(2, seed=321)
-    cfg = make_config("early_fusion_vit", precision=mode, device=DEV)          # 'fp32x3' switches the library's split path on, 'fp32' off
+    cfg = make_config("early_fusion_vit", precision=mode, device=DEV)          # 'fp32x3': the model's modules launch their products with P3_F32X3
     m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
     from pixelspointspolygons_amd import hip as _hip
-    assert precision == "bf16" or bool(_hip.lib().p3_get_gemm_split()) == (mode == "fp32x3")
+    assert m.p3_split == (mode == "fp32x3") and not _hip.split_now()
     m.load_state_dict(sd, strict=True)
     m.train()
     m.decoder.set_dropout(0.0)
@@ -578,7 +578,6 @@ def test_train_step_gradients_vs_oracle_autograd(precision, tol):
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_err_{mode}.json", "w") as f:
         json.dump(sorted(worst.items(), key=lambda kv: -kv[1]), f, indent=0)
-    _hip.set_gemm_split(False)
     print(f"[{mode}] loss error {abs(float(loss) - ref_loss) / abs(ref_loss):.2e}, worst parameter gradient error {max(worst.values()):.3e}")
     bad = {k: v for k, v in worst.items() if not v < tol}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

@@ -26,7 +26,7 @@ def _line(name="r04_bench.json"):
 def test_defaults_are_one_gpu_and_a_run_of_minutes():
     bench, a = _bench()
     assert a.gpus == 1 and a.steps == 20 and a.warmup == 5 and a.batch == 64 and a.points == 3000
-    assert a.workload == "fusion_s8" and a.precision == "bf16" and a.graph == 1 and a.sync_bn == 1
+    assert a.workload == "fusion_s8" and a.precision == "fp32x3" and a.graph == 1 and a.sync_bn == 1      # the headline precision meets north_star's tolerance
     assert not (a.no_cpu_baseline or a.no_fp32_leg or a.no_predict or a.no_host_feed)      # the default run reports every leg
 
 

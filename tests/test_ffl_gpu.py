@@ -21,7 +21,7 @@ def _model(encoder, precision, kind, cfg_o, **kw):
 SMALL = dict(dim=384, depth=2, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("fp32x3", 1e-3), ("bf16", 4e-2)])
 @pytest.mark.parametrize("training", [False, True])
 def test_ffl_early_fusion_forward(precision, tol, training):
     from oracle import p3_oracle as O
@@ -52,10 +52,11 @@ def test_ffl_early_fusion_forward(precision, tol, training):
         assert rel_err(f.cpu(), feats) < tol
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("encoder,kind", [("vit_cnn", "image"), ("pointpillars_vit_cnn", "lidar")])
-def test_ffl_single_modality(encoder, kind):
+def test_ffl_single_modality(encoder, kind, precision):
     from oracle import p3_oracle as O
-    m, sd, cfg = _model(encoder, "fp32", kind, SMALL, vit_depth=2)
+    m, sd, cfg = _model(encoder, precision, kind, SMALL, vit_depth=2)
     d = O.make_inputs(1, seed=6)
     img, lidar_vals, lidar_offs = d["image"], d["lidar_values"], d["lidar_offsets"]
     nt = torch.nested.nested_tensor_from_jagged(lidar_vals.cuda(), lidar_offs.cuda())
@@ -71,13 +72,14 @@ def test_ffl_single_modality(encoder, kind):
     assert rel_err(out["crossfield"].cpu(), ref["crossfield"]) < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("training", [True, False])
-def test_cnn_encoder_standalone_forward_is_differentiable(training):
+def test_cnn_encoder_standalone_forward_is_differentiable(training, precision):
     """ViTCNN.forward (vit_cnn.py:45-57) on its own: NCHW features and the gradients of every encoder parameter + the input image
     for a random linear functional, vs float64 autograd of the oracle (encoder tokens -> vitcnn_tail)."""
     from oracle import p3_oracle as O
     from helpers import l2_err
-    m, sd, cfg = _model("vit_cnn", "fp32", "image", SMALL, vit_depth=2)
+    m, sd, cfg = _model("vit_cnn", precision, "image", SMALL, vit_depth=2)
     enc = m.encoder.train(training)
     img = O.make_inputs(1, seed=12)["image"]
     gen = torch.Generator().manual_seed(5)
@@ -106,13 +108,14 @@ def test_cnn_encoder_standalone_forward_is_differentiable(training):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("training", [True, False])
-def test_ffl_backward_vs_oracle_autograd(training):
+def test_ffl_backward_vs_oracle_autograd(training, precision):
     """FFL training path (a-14): gradients of every parameter (heads, BatchNorms, 3x3 convs, proj, fusion stem, ViT) for a random
     linear functional of (seg, crossfield) vs float64 autograd of the oracle; train- and eval-mode BatchNorm."""
     from oracle import p3_oracle as O
     from helpers import l2_err
-    m, sd, cfg = _model("early_fusion_vit_cnn", "fp32", "fusion", SMALL, vit_depth=2)
+    m, sd, cfg = _model("early_fusion_vit_cnn", precision, "fusion", SMALL, vit_depth=2)
     B = 1
     d = O.make_inputs(B, seed=9)
     img, lv, lo = d["image"], d["lidar_values"], d["lidar_offsets"]
@@ -143,7 +146,7 @@ def test_ffl_backward_vs_oracle_autograd(training):
 FULL = dict(dim=384, depth=12, heads=6, mlp=1536, patch=8, img=224, eps=1e-6)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
 def test_ffl_full_batch_is_batch_independent_and_matches_the_oracle(precision):
     """BASELINE configs[4] at its REAL size (model_ffl.py:28-104 over early_fusion_vit_cnn.py:87-104): ViT depth 12, 64 tiles of 224 x 224 +
     3 k points.  Eval mode: tile b of the batch of 64 == the same tile run alone, bit for bit (row-independent implicit-GEMM convs, per-tile
@@ -170,7 +173,7 @@ def test_ffl_full_batch_is_batch_independent_and_matches_the_oracle(precision):
             l0, l1 = int(off[b]), int(off[b + 1])
             ref, _ = O.ffl_forward({k: v.clone() for k, v in sd.items()}, inp["image"][b:b + 1],
                                    (inp["lidar_values"][l0:l1], torch.tensor([0, l1 - l0])), FULL, 224, False)
-            if precision == "fp32":
+            if precision != "bf16":
                 assert rel_err(seg[b:b + 1].float().cpu(), ref["seg"]) < 1e-3
                 assert rel_err(cf[b:b + 1].float().cpu(), ref["crossfield"]) < 1e-3
             else:

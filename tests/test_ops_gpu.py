@@ -306,7 +306,7 @@ def test_gemm_batchnorm_relu_backward_epilogue(dtype, tol, N):
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (4200, 1536, 384), (512, 227, 256), (777, 256, 2048)])
 def test_gemm_fp32_operands_as_bf16x3(M, N, K):
-    """p3_set_gemm_split (include/p3hip.h): fp32 operands split into bf16 hi + lo while staged, a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA.  Against float64:
+    """P3_F32X3 (include/p3hip.h; host scope hip.gemm_split): fp32 operands split into bf16 hi + lo while staged, a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA.  Against float64:
     1e-5 (2^-17 per product, fp32 accumulation) - two orders tighter than a plain bf16 product, one looser than the exact fp32 MFMA path (checked in the same test);
     epilogues (bias + GELU + aux + residual, ReLU gradient) ride on the unchanged fp32 code."""
     hip = _h()
@@ -318,7 +318,7 @@ def test_gemm_fp32_operands_as_bf16x3(M, N, K):
         split = hip.gemm(a.to(DEV), w.to(DEV)).cpu()
         aux = torch.empty(M, N, device=DEV)
         full = hip.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=hip.ACT_GELU, aux=aux, residual=res.to(DEV)).cpu()
-    assert not hip.lib().p3_get_gemm_split()
+    assert not hip.split_now()
     e_exact, e_split = rel_err(exact, ref.float()), rel_err(split, ref.float())
     assert e_exact < 2e-6 and e_split < 1e-5, (e_exact, e_split)
     pre = ref + bias.double()

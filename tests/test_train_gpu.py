@@ -89,3 +89,54 @@ def test_deferred_layernorm_parameter_reduces_are_bit_identical():
     diff = {k: float((g1[k] - g0[k]).abs().max() / g0[k].abs().max().clamp_min(1e-30)) for k in g1 if k not in atomic and not torch.equal(g1[k], g0[k])}
     assert not diff, (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:8])
     assert all(torch.allclose(g1[k], g0[k], rtol=1e-5, atol=1e-6 * float(g0[k].abs().max())) for k in atomic)
+
+
+def test_a_backward_pass_that_raises_does_not_poison_the_next_step():
+    """the deferred LayerNorm reduces are flushed by a final callback of the autograd engine, which a backward pass that RAISES never runs - the
+    partials stay parked and the latch stays set.  FlatAdamW.zero_grad() drops them (they belong to the discarded gradients) and apply() settles whatever is
+    left: the step after the failure gives bit for bit the gradients of a process that never failed."""
+    from oracle import p3_oracle as O
+    from pixelspointspolygons_amd import hip, ops
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import FlatAdamW, pix2poly_loss
+    sd = O.make_state_dict("image", seed=42)
+    inp = {k: v.to("cuda") for k, v in O.make_inputs(2, seed=11).items()}
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def run(fail_first):
+        ops.reset_process_state()
+        cfg = make_config("vit", precision="fp32", device="cuda")
+        m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        m.decoder.set_dropout(0.0)
+        opt = FlatAdamW(m, compute_dtype=torch.float32)
+        if fail_first:
+            opt.zero_grad()
+            enc = m.encoder(inp["image"])
+            logits, _ = m.decoder(_Boom.apply(enc), inp["y"][:, :-1])      # the decoder's LayerNorm launches park, then the node in front of the encoder raises
+            with pytest.raises(RuntimeError, match="boom"):
+                logits.sum().backward()
+            assert hip.reduce_pending() > 0 and ops._flush_queued[0]       # the state ADVICE r04 describes: partials parked, latch set, no callback alive ...
+        opt.zero_grad()                                          # ... is gone after zero_grad
+        assert hip.reduce_pending() == 0 and not ops._flush_queued[0]
+        logits, perm = m(inp["image"], None, inp["y"][:, :-1])
+        pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])[0].backward()
+        assert hip.reduce_pending() == 0
+        grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}
+        opt.apply()
+        opt.close()
+        return grads
+    g_fail, g_ok = run(True), run(False)
+    atomic = {"bin_score", "decoder.embedding.weight"}
+    bad = [k for k in g_ok if k not in atomic and not torch.equal(g_fail[k], g_ok[k])]
+    assert not bad, bad[:8]
