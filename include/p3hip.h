@@ -159,6 +159,44 @@ int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc* d, void* 
 int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * "Planes" - the operand format of the fp32x3 ViT block (r05).  A value x of an fp32 tensor travels between the kernels of one timm Block
+ * (models/vision_transformer/vit.py:48) as TWO bf16 numbers, hi = bf16(x) and lo = bf16(x - hi) (16 significant bits, the same 4 bytes as the fp32 value), stored
+ * as two row-major bf16 matrices with one leading dimension (typically the two halves [:, :K] and [:, K:] of one [M, 2K] buffer).  The PRODUCER writes the
+ * split (LayerNorm output, GELU output, attention output, the gradients between the backward GEMMs), so that the consuming GEMM stages all four operand
+ * images global -> LDS by LDS-DMA with no conversion pass and multiplies a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA - the arithmetic of P3_F32X3
+ * (2^-17 per product) at the memory path of the bf16 kernels.  Weights: the optimizer keeps hi / lo bf16 arenas beside the fp32 master (p3_adamw, shadow_lo).
+ *
+ * p3_gemm_x3:  C = epilogue(A W^T),  A = a_hi + a_lo [M, K], W = w_hi + w_lo [N, K]
+ *   v = A W^T + bias;  act == P3_ACT_GELU: aux <- GELU'(v) (fp32 [M, N], ldaux), v <- GELU(v);  mul != NULL: v *= mul[m, n] (fp32, ldmul: the backward of
+ *   that GELU);  residual != NULL: v += residual[m, n] (fp32, ldr);  then C <- v as fp32 (c, ldc; c_lo == NULL) or as planes (c = hi, c_lo = lo, ldc).
+ *   Fused LayerNorm of the OUTPUT row (ln_gamma != NULL; needs N == 384 == the tile width, fp32 C): besides C the kernel writes LN(C) as planes (ln_hi, ln_lo,
+ *   ldln) and the row statistics (ln_mean, ln_rstd) - the norm2 / next block's norm1 of timm's Block, whose separate pass re-read the 77 MB stream.
+ * Shapes: K % 32 == 0, N % 8 == 0, 16-byte aligned rows.  Tiles: 128 x 128 (4 waves) or, for N == 384, 128 x 384 (8 waves).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    const void* a_hi; const void* a_lo; int lda;
+    const void* w_hi; const void* w_lo; int ldb;
+    void* c; void* c_lo; int ldc;
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    float* aux; int ldaux;
+    const float* mul; int ldmul;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    void* ln_hi; void* ln_lo; int ldln;
+    float* ln_mean; float* ln_rstd;
+} p3_gemm_x3_desc;
+int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream);
+/* weight gradient from planes:  C[N, K] (+)= (a_hi + a_lo)[M, N]^T (b_hi + b_lo)[M, K]  (fp32 C, split over M: fp32 atomics, or - `slabs` given - partial
+ * tiles + a fixed-order reduce like p3_gemm_tn_ex); colsum (optional, [N]) += column sums of A (the bias gradient).  M % 64 == 0, N % 128 == 0, K % 128 == 0. */
+int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, float* C, int ldc, int M, int N, int K,
+                  float* colsum, float* slabs, int max_slabs, void* stream);
+/* fp32 [rows, cols] (ld_src) -> planes (hi, lo; ld_dst), and back (x = hi + lo): the seams of the planes region (attention outputs, tests) */
+int p3_to_planes(const float* src, int ld_src, void* hi, void* lo, int ld_dst, int64_t rows, int cols, void* stream);
+int p3_from_planes(const void* hi, const void* lo, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim:  y = (x - mean) / sqrt(var + eps) * gamma + beta
  * timm Block.norm1/norm2/VisionTransformer.norm (eps 1e-6); nn.TransformerDecoderLayer.norm1..3
  * (eps 1e-5, models/pix2poly/model_pix2poly.py:138).  x dtype_in, y dtype_out; optional save of
@@ -182,6 +220,13 @@ int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* gamma, const
 int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                              void* dx, void* dx_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
                              int dtype_dy, int dtype_x, int dtype_dx, void* stream);
+/* planes forms (fp32x3 ViT block, see p3_gemm_x3): LayerNorm of the fp32 stream written as planes (y_hi, y_lo, row stride ldy) - the qkv / fc1 operand;
+ * and the backward whose fp32 dx (the residual-gradient stream, + dres) is ALSO written as planes from the same registers (dx_hi, dx_lo, ld_planes): the
+ * operand of the dX / dW GEMMs of the sublayer below. */
+int p3_layernorm_planes(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int64_t rows, int cols, int ldx, int ldy, float eps,
+                        float* save_mean, float* save_rstd, void* stream);
+int p3_layernorm_bwd_planes(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                            void* dx_hi, void* dx_lo, int ld_planes, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream);
 int p3_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, int64_t rows, int cols, int dtype_dy, int dtype_x, int dtype_dx,
                      void* stream);
@@ -210,6 +255,11 @@ typedef struct {
     unsigned int* drop_rows; /* optional keep-bit words, B*H*ceil(Lk/32)*Lq of them laid out [B*H][ceil(Lk/32)][Lq] (bit k%32 of word k/32
                               * of query q = element kept; q innermost so that a wave's 32 queries touch 128 contiguous bytes): WRITTEN
                               * by p3_attention when given, READ by p3_attention_bwd instead of re-hashing (NULL: hash again) */
+    int grad_planes;        /* p3_attention_bwd with dtype P3_F32X3 only: 1 = dQ / dK / dV are written as PLANES (see p3_gemm_x3): the pointers address the bf16 hi
+                             * plane with batch stride g_bs and row stride g_rs (bf16 elements), the lo plane lies g_lo elements behind - the packed qkv gradient
+                             * leaves as the operand of the projection's dX / dW GEMMs, no fp32 tensor and no conversion pass.  0: dtype / strides of Q, K, V */
+    int g_rs;
+    int64_t g_bs, g_lo;
 } p3_attn_desc;
 int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream);
 

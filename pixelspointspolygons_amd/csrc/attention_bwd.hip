@@ -201,8 +201,10 @@ __device__ __forceinline__ void load_rowfrags(const T* base, int64_t row, int ro
 }
 
 template <typename T, int D>
-__device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 32], float mul, int hi) {
+__device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 32], float mul, int hi, int64_t planes_lo = 0) {
     // acc[j][r] holds element d = j*32 + crow32(r, hi) of this lane's row
+    // planes_lo != 0 (p3_attn_desc.grad_planes): dst_row is a bf16 hi-plane row and the lo plane lies planes_lo elements behind it - the gradient leaves as the
+    // operand of the qkv projection's dX / dW GEMMs on planes (p3_gemm_x3 / p3_gemm_tn_x3), no fp32 tensor and no conversion pass in between
 #pragma unroll
     for (int j = 0; j < D / 32; ++j)
 #pragma unroll
@@ -211,6 +213,16 @@ __device__ __forceinline__ void store_T_acc(T* dst_row, const f32x16 (&acc)[D / 
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = acc[j][4 * rg + i] * mul;
+            if (planes_lo != 0) {
+                bf16_t* ph = reinterpret_cast<bf16_t*>(dst_row) + dd;
+                uint2 h, l;
+                h.x = pack_bf2(o[0], o[1]); h.y = pack_bf2(o[2], o[3]);
+                l.x = pack_bf2(o[0] - __uint_as_float(h.x << 16), o[1] - __uint_as_float(h.x & 0xffff0000u));
+                l.y = pack_bf2(o[2] - __uint_as_float(h.y << 16), o[3] - __uint_as_float(h.y & 0xffff0000u));
+                *reinterpret_cast<uint2*>(ph) = h;
+                *reinterpret_cast<uint2*>(ph + planes_lo) = l;
+                continue;
+            }
             if constexpr (Kind<T>::BF) {
                 uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
                 *reinterpret_cast<uint2*>(dst_row + dd) = pk;
@@ -240,7 +252,8 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? 3 : 2)) void attn_b
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
     const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
     const T* dOp = reinterpret_cast<const T*>(a.dO) + (int64_t)b * d.o_bs + h * D;
-    T* dQp = reinterpret_cast<T*>(a.dQ) + (int64_t)b * d.q_bs + h * D;
+    const bool gpl = d.grad_planes != 0;          // gradients as bf16 planes with their own strides (g_bs, g_rs) and lo-plane offset g_lo
+    T* dQp = gpl ? reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(a.dQ) + (int64_t)b * d.g_bs + h * D) : reinterpret_cast<T*>(a.dQ) + (int64_t)b * d.q_bs + h * D;
     const int q = qblk + wave * 32 + l31;
     const int qc = q < d.Lq ? q : d.Lq - 1;
     s16x8 qb[D / 16], gb[D / 16], ql[D / 16], gl[D / 16];       // ql / gl: the lo fragments of the fp32x3 mode
@@ -351,7 +364,10 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? 3 : 2)) void attn_b
             accum_mma<T, D, KT>(Krow, sub, s, dq, fa, l31, hi);               // dQ^T[d, q] += K^T . dS^T
         }
     }
-    if (q < d.Lq) store_T_acc<T, D>(dQp + (int64_t)q * d.q_rs, dq, d.scale, hi);
+    if (q < d.Lq) {
+        if (gpl) store_T_acc<T, D>(reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(dQp) + (int64_t)q * d.g_rs), dq, d.scale, hi, d.g_lo);
+        else store_T_acc<T, D>(dQp + (int64_t)q * d.q_rs, dq, d.scale, hi);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -373,8 +389,9 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)
     const T* Kp = reinterpret_cast<const T*>(a.K) + (int64_t)b * d.k_bs + h * D;
     const T* Vp = reinterpret_cast<const T*>(a.V) + (int64_t)b * d.v_bs + h * D;
     const T* dOp = reinterpret_cast<const T*>(a.dO) + (int64_t)b * d.o_bs + h * D;
-    T* dKp = reinterpret_cast<T*>(a.dK) + (int64_t)b * d.k_bs + h * D;
-    T* dVp = reinterpret_cast<T*>(a.dV) + (int64_t)b * d.v_bs + h * D;
+    const bool gpl = d.grad_planes != 0;
+    T* dKp = gpl ? reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(a.dK) + (int64_t)b * d.g_bs + h * D) : reinterpret_cast<T*>(a.dK) + (int64_t)b * d.k_bs + h * D;
+    T* dVp = gpl ? reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(a.dV) + (int64_t)b * d.g_bs + h * D) : reinterpret_cast<T*>(a.dV) + (int64_t)b * d.v_bs + h * D;
     const int kv = kblk + wave * 32 + l31;
     const int kvc = kv < d.Lk ? kv : d.Lk - 1;
     s16x8 kb[D / 16], vb[D / 16], kl[D / 16], vl[D / 16];
@@ -460,8 +477,13 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)
         }
     }
     if (kv < d.Lk) {
-        store_T_acc<T, D>(dKp + (int64_t)kv * d.k_rs, dk, d.scale, hi);
-        store_T_acc<T, D>(dVp + (int64_t)kv * d.v_rs, dv, 1.f, hi);
+        if (gpl) {
+            store_T_acc<T, D>(reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(dKp) + (int64_t)kv * d.g_rs), dk, d.scale, hi, d.g_lo);
+            store_T_acc<T, D>(reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(dVp) + (int64_t)kv * d.g_rs), dv, 1.f, hi, d.g_lo);
+        } else {
+            store_T_acc<T, D>(dKp + (int64_t)kv * d.k_rs, dk, d.scale, hi);
+            store_T_acc<T, D>(dVp + (int64_t)kv * d.v_rs, dv, 1.f, hi);
+        }
     }
 }
 
@@ -497,6 +519,8 @@ extern "C" int p3_attention_bwd(const void* Q, const void* K, const void* V, con
     P3_CHECK(d->dtype == P3_F32 || d->dtype == P3_BF16 || d->dtype == P3_F32X3, P3_EUNSUP, "p3_attention_bwd: dtype");
     const int al = d->dtype == P3_BF16 ? 8 : 4;
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % al == 0, P3_EALIGN, "p3_attention_bwd: row strides");
+    P3_CHECK(!d->grad_planes || (d->dtype == P3_F32X3 && d->g_lo != 0 && d->g_rs % 4 == 0 && d->g_bs % 4 == 0 && d->g_lo % 4 == 0 && ((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) % 8 == 0),
+             P3_EINVAL, "p3_attention_bwd: grad_planes goes with P3_F32X3 and needs g_bs / g_rs / g_lo (multiples of 4 bf16 elements)");
     BwdArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.lse = lse; a.delta = delta_ws; a.d = *d; a.order = p3_attn_order();
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == P3_BF16) return d->head_dim == 64 ? launch_bwd<bf16_t, 64>(a, s) : launch_bwd<bf16_t, 32>(a, s);

@@ -40,11 +40,21 @@ __device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
     }
 }
 
+// planes (include/p3hip.h): hi = bf16(x), lo = bf16(x - hi) of four values
+__device__ __forceinline__ void store4_planes(bf16_t* ph, bf16_t* pl, const float (&v)[4]) {
+    uint2 h, l;
+    h.x = pack_bf2(v[0], v[1]); h.y = pack_bf2(v[2], v[3]);
+    l.x = pack_bf2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack_bf2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(ph) = h;
+    *reinterpret_cast<uint2*>(pl) = l;
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TO* __restrict__ y, int64_t rows,
                                                      int cols, int ldx, int ldy, float eps, float* __restrict__ smean,
-                                                     float* __restrict__ srstd) {
+                                                     float* __restrict__ srstd, bf16_t* __restrict__ y_lo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -79,6 +89,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, c
             load4<float>(beta + ci * 4, b);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+            if constexpr (sizeof(TO) == 2) {
+                if (y_lo) { store4_planes(reinterpret_cast<bf16_t*>(y) + row * ldy + ci * 4, y_lo + row * ldy + ci * 4, o); continue; }
+            }
             store4<TO>(y + row * ldy + ci * 4, o);
         }
     }
@@ -176,7 +189,8 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const TDX* __restrict__ dres, TDX* __restrict__ dx, bf16_t* __restrict__ dx_lo,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int rows_per_block,
-                                                             float* __restrict__ slab, p3_dropout lo_drop = p3_dropout{nullptr, 0u, 0.f}) {
+                                                             float* __restrict__ slab, p3_dropout lo_drop = p3_dropout{nullptr, 0u, 0.f},
+                                                             bf16_t* __restrict__ dx_lo2 = nullptr, int ld_lo = CPL * 128) {
     constexpr int cols = CPL * 128;
     DropKey dk;
     if constexpr (LODROP) dk = drop_key(lo_drop);
@@ -236,7 +250,9 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
                     lv[2] = drop_keep_lo(dk, b1) ? ov[2] * dk.inv_keep : 0.f; lv[3] = drop_keep_hi(dk, b1) ? ov[3] * dk.inv_keep : 0.f;
                     store4<bf16_t>(dx_lo + o, lv);
                 } else {
-                    if (dx_lo) store4<bf16_t>(dx_lo + o, ov);
+                    // dx_lo2: the copy is PLANES (hi -> dx_lo, lo -> dx_lo2, row stride ld_lo): the operand of the fp32x3 block's backward GEMMs
+                    if (dx_lo2) store4_planes(dx_lo + row * ld_lo + (l31 + 32 * c) * 4, dx_lo2 + row * ld_lo + (l31 + 32 * c) * 4, ov);
+                    else if (dx_lo) store4<bf16_t>(dx_lo + row * ld_lo + (l31 + 32 * c) * 4, ov);
                 }
             }
         }
@@ -298,9 +314,38 @@ extern "C" int p3_layernorm_bwd_lo(const void* dy, const void* x, const float* g
     return p3_layernorm_bwd_lo_drop(dy, x, gamma, mean, rstd, dres, dx, dx_lo, nullptr, dgamma, dbeta, rows, cols, dtype_dy, dtype_x, dtype_dx, stream);
 }
 
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                       void* dx, void* dx_lo, void* dx_lo2, int ld_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
+                       int dtype_dy, int dtype_x, int dtype_dx, void* stream);
+
 extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
                                         void* dx, void* dx_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
                                         int dtype_dy, int dtype_x, int dtype_dx, void* stream) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dx_lo, nullptr, cols, lo_drop, dgamma, dbeta, rows, cols, dtype_dy, dtype_x, dtype_dx, stream);
+}
+
+extern "C" int p3_layernorm_bwd_planes(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                                       void* dx_hi, void* dx_lo, int ld_planes, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream) {
+    P3_CHECK(dx_hi && dx_lo && ld_planes % 4 == 0 && ((uintptr_t)dx_hi | (uintptr_t)dx_lo) % 8 == 0, P3_EINVAL, "p3_layernorm_bwd_planes: planes arguments");
+    P3_CHECK(cols == 256 || cols == 384 || cols == 768, P3_EUNSUP, "p3_layernorm_bwd_planes: 256 / 384 / 768 columns");
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dx_hi, dx_lo, ld_planes, nullptr, dgamma, dbeta, rows, cols, P3_F32, P3_F32, P3_F32, stream);
+}
+
+extern "C" int p3_layernorm_planes(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int64_t rows, int cols, int ldx, int ldy, float eps,
+                                   float* save_mean, float* save_rstd, void* stream) {
+    P3_CHECK(x && gamma && beta && y_hi && y_lo, P3_EINVAL, "p3_layernorm_planes: null pointer");
+    P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, P3_ESHAPE, "p3_layernorm_planes: cols must be <=1024 and %4");
+    P3_CHECK((save_mean == nullptr) == (save_rstd == nullptr), P3_EINVAL, "p3_layernorm_planes: save_mean / save_rstd go together");
+    if (rows <= 0) return P3_OK;
+    hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t>), dim3(p3_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_hi, rows, cols, ldx, ldy, eps,
+                       save_mean, save_rstd, (bf16_t*)y_lo);
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
+
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                       void* dx, void* dx_lo, void* dx_lo2, int ld_lo, const p3_dropout* lo_drop, float* dgamma, float* dbeta, int64_t rows, int cols,
+                       int dtype_dy, int dtype_x, int dtype_dx, void* stream) {
     P3_CHECK(dy && x && gamma && mean && rstd && dx, P3_EINVAL, "p3_layernorm_bwd: null pointer");
     const bool lod = lo_drop && lo_drop->seed && lo_drop->p > 0.f;
     P3_CHECK(!lod || (dx_lo && !dres && dtype_dy == P3_BF16 && dtype_x == P3_F32 && dtype_dx == P3_F32 && (cols == 256 || cols == 384 || cols == 768)),
@@ -334,7 +379,7 @@ extern "C" int p3_layernorm_bwd_lo_drop(const void* dy, const void* x, const flo
     }
     if (half_cols) {
 #define LNH_R(TDY, TX, TDX, CPL, RES) \
-    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab)
+    hipLaunchKernelGGL((ln_bwd_half_kernel<TDY, TX, TDX, CPL, RES>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (const TDX*)dres, (TDX*)dx, (bf16_t*)dx_lo, dgamma, dbeta, rows, rpb, slab, p3_dropout{nullptr, 0u, 0.f}, (bf16_t*)dx_lo2, ld_lo)
 #define LNH_C(TDY, TX, TDX, CPL) \
     do { if (dres) LNH_R(TDY, TX, TDX, CPL, true); else LNH_R(TDY, TX, TDX, CPL, false); } while (0)
 #define LNH(TDY, TX, TDX) \

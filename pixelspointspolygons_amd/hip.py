@@ -403,7 +403,7 @@ class AttnDesc(Structure):
                 ("q_bs", c_int64), ("k_bs", c_int64), ("v_bs", c_int64), ("o_bs", c_int64),
                 ("q_rs", c_int), ("k_rs", c_int), ("v_rs", c_int), ("o_rs", c_int),
                 ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p),
-                ("drop", Dropout), ("drop_rows", c_void_p)]
+                ("drop", Dropout), ("drop_rows", c_void_p), ("grad_planes", c_int), ("g_rs", c_int), ("g_bs", c_int64), ("g_lo", c_int64)]
 
 
 def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None, drop_rows=None):
@@ -809,8 +809,24 @@ def add_pos(x, pos):
 
 
 # ------------------------------------------------------------------------------------------ backward / training ops
-def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None, drop=None, drop_rows=None):
-    """dq/dk/dv get the same batch/row strides as q/k/v (pass views of a packed buffer to get a packed gradient)."""
+def attention_bwd(q, k, v, o, lse, do, heads, scale, causal=False, key_bias=None, dq=None, dk=None, dv=None, drop=None, drop_rows=None, grad_planes=None):
+    """dq/dk/dv get the same batch/row strides as q/k/v (pass views of a packed buffer to get a packed gradient).
+    grad_planes (fp32x3 self-attention on a packed qkv [B, L, 3D]): a Planes [B * L, 3D] that receives the packed gradient (dq | dk | dv) as planes - the operand
+    of the qkv projection's backward GEMMs - instead of fp32 tensors; returns it."""
+    if grad_planes is not None:
+        B, L, D = q.shape
+        gp = grad_planes
+        if gp.cols != 3 * D or gp.rows != B * L or not split_now():
+            raise P3Error("attention_bwd: grad_planes must be [B * L, 3D] and the call must run in an fp32x3 scope")
+        if do.stride() != o.stride():
+            raise P3Error("attention_bwd: dO strides must equal O strides")
+        d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, None, drop, drop_rows)
+        d.grad_planes, d.g_rs, d.g_bs, d.g_lo = 1, gp.ld, L * gp.ld, gp.cols
+        delta = torch.empty((B, heads, L), dtype=torch.float32, device=q.device)
+        base, es = gp.hi.data_ptr(), 2
+        check(lib().p3_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), c_void_p(base), c_void_p(base + D * es), c_void_p(base + 2 * D * es),
+                                     ptr(delta), byref(d), stream()), "p3_attention_bwd")
+        return gp
     dq = torch.empty_like(q) if dq is None else dq
     dk = torch.empty_like(k) if dk is None else dk
     dv = torch.empty_like(v) if dv is None else dv
@@ -1183,3 +1199,153 @@ def transpose_many(src, dst, table, n_entries, total_tiles):
 def attention_mask_words(B, heads, Lq, Lk, device):
     """keep-bit words the attention forward publishes for its backward (p3_attn_desc.drop_rows)."""
     return torch.empty((B * heads, (Lk + 31) // 32, Lq), dtype=torch.int32, device=device)     # [b*H + h][key word][q]
+
+
+# ------------------------------------------------------------------------------------------ planes (fp32x3 ViT block; include/p3hip.h p3_gemm_x3)
+class Planes:
+    """An fp32-valued [rows, cols] matrix stored as hi = bf16(x) and lo = bf16(x - hi): two bf16 views with one row stride (the two halves of one
+    [rows_alloc, 2 * cols] buffer).  rows_alloc rounds the row count up (64: the weight-gradient kernel walks whole 64-row steps); the tail rows are zero."""
+    __slots__ = ("buf", "hi", "lo", "rows", "cols")
+
+    def __init__(self, buf, rows, cols):
+        self.buf, self.rows, self.cols = buf, rows, cols
+        self.hi, self.lo = buf[:, :cols], buf[:, cols:]
+
+    @staticmethod
+    def empty(rows, cols, device, pad=64):
+        ra = (rows + pad - 1) // pad * pad
+        buf = torch.empty((ra, 2 * cols), dtype=torch.bfloat16, device=device)
+        if ra > rows:
+            buf[rows:].zero_()
+        return Planes(buf, rows, cols)
+
+    @property
+    def ld(self):
+        return self.buf.stride(0)
+
+    @property
+    def rows_alloc(self):
+        return self.buf.shape[0]
+
+
+def to_planes(x, out=None, pad=64):
+    """fp32 [rows, cols] (row stride free) -> Planes"""
+    _dev(x)
+    rows, cols = x.shape
+    if out is None:
+        out = Planes.empty(rows, cols, x.device, pad)
+    check(lib().p3_to_planes(ptr(x), c_int(x.stride(0)), ptr(out.hi), ptr(out.lo), c_int(out.ld), c_int64(rows), c_int(cols), stream()), "p3_to_planes")
+    return out
+
+
+def to_planes_into(x, hi, lo):
+    """fp32 [rows, cols] -> the given bf16 hi / lo matrices (same shape, one row stride)"""
+    rows, cols = x.shape
+    check(lib().p3_to_planes(ptr(x), c_int(x.stride(0)), ptr(hi), ptr(lo), c_int(hi.stride(0)), c_int64(rows), c_int(cols), stream()), "p3_to_planes")
+
+
+def from_planes(p, out=None):
+    if out is None:
+        out = torch.empty((p.rows, p.cols), dtype=torch.float32, device=p.buf.device)
+    check(lib().p3_from_planes(ptr(p.hi), ptr(p.lo), c_int(p.ld), ptr(out), c_int(out.stride(0)), c_int64(p.rows), c_int(p.cols), stream()), "p3_from_planes")
+    return out
+
+
+class GemmX3Desc(Structure):
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int),
+                ("a_hi", c_void_p), ("a_lo", c_void_p), ("lda", c_int),
+                ("w_hi", c_void_p), ("w_lo", c_void_p), ("ldb", c_int),
+                ("c", c_void_p), ("c_lo", c_void_p), ("ldc", c_int),
+                ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
+                ("aux", c_void_p), ("ldaux", c_int), ("mul", c_void_p), ("ldmul", c_int),
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+                ("ln_hi", c_void_p), ("ln_lo", c_void_p), ("ldln", c_int), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
+
+
+def gemm_x3(a, w, *, bias=None, act=ACT_NONE, residual=None, aux=None, mul=None, out=None, out_planes=False, ln=None):
+    """C = epilogue((a_hi + a_lo) (w_hi + w_lo)^T).  a: Planes [M, K]; w: (hi, lo) bf16 [N, K] tensors (or Planes); out: fp32 [M, N] tensor or Planes
+    (out_planes=True allocates one).  ln = (gamma, beta, eps, Planes out, mean, rstd): LayerNorm of the output row fused into the epilogue (N == 384)."""
+    M, K = a.rows, a.cols
+    w_hi, w_lo = (w.hi, w.lo) if isinstance(w, Planes) else w
+    N = w_hi.shape[0]
+    if w_hi.shape[1] != K or w_hi.stride(0) != w_lo.stride(0):
+        raise P3Error("gemm_x3: weight planes must be [N, K] with one row stride")
+    d = GemmX3Desc()
+    d.M, d.N, d.K = M, N, K
+    d.a_hi, d.a_lo, d.lda = a.hi.data_ptr(), a.lo.data_ptr(), a.ld
+    d.w_hi, d.w_lo, d.ldb = w_hi.data_ptr(), w_lo.data_ptr(), w_hi.stride(0)
+    if out is None:
+        out = Planes.empty(M, N, a.buf.device) if out_planes else torch.empty((M, N), dtype=torch.float32, device=a.buf.device)
+    if isinstance(out, Planes):
+        d.c, d.c_lo, d.ldc = out.hi.data_ptr(), out.lo.data_ptr(), out.ld
+    else:
+        if out.dtype != torch.float32:
+            raise P3Error("gemm_x3: out must be float32 or Planes")
+        d.c, d.c_lo, d.ldc = out.data_ptr(), None, out.stride(-2)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(-2)
+    d.act = act
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(-2)
+    if mul is not None:
+        d.mul, d.ldmul = mul.data_ptr(), mul.stride(-2)
+    if ln is not None:
+        gamma, beta, eps, lnout, mean, rstd = ln
+        d.ln_gamma, d.ln_beta, d.ln_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+        d.ln_hi, d.ln_lo, d.ldln = lnout.hi.data_ptr(), lnout.lo.data_ptr(), lnout.ld
+        d.ln_mean, d.ln_rstd = (mean.data_ptr() if mean is not None else None), (rstd.data_ptr() if rstd is not None else None)
+    ev = KTIMER.begin()
+    check(lib().p3_gemm_x3(byref(d), stream()), "p3_gemm_x3")
+    if ev is not None:
+        nbytes = 4.0 * (M * K + N * K + M * N) + (4.0 * M * N if residual is not None else 0) + (4.0 * M * N if aux is not None else 0) + (4.0 * M * N if mul is not None else 0) \
+            + (4.0 * M * N if ln is not None else 0)
+        KTIMER.end(ev, lib().p3_last_kernel().decode() or "gemm_x3_kernel", 2.0 * M * N * K, nbytes)
+    return out
+
+
+def gemm_tn_x3(a, b, out=None, colsum_out=None):
+    """out[N, K] (+)= (a_hi + a_lo)[M, N]^T (b_hi + b_lo)[M, K]; a, b: Planes with the same (64-padded, zero-tailed) row count; fp32 out, zero-filled when not given"""
+    if a.rows_alloc != b.rows_alloc:
+        raise P3Error("gemm_tn_x3: operands must share the padded row count")
+    M, N, K = a.rows_alloc, a.cols, b.cols
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=a.buf.device)
+    slabs, ns = _tn_slabs(N, K, out)
+    ev = KTIMER.begin()
+    check(lib().p3_gemm_tn_x3(ptr(a.hi), ptr(a.lo), c_int(a.ld), ptr(b.hi), ptr(b.lo), c_int(b.ld), ptr(out), c_int(out.stride(0)), c_int(M), c_int(N), c_int(K),
+                              ptr(colsum_out), ptr(slabs), c_int(ns), stream()), "p3_gemm_tn_x3")
+    if ev is not None:
+        KTIMER.end(ev, "gemm_tn_x3_kernel<2>", 2.0 * a.rows * N * K, float(4 * a.rows * (N + K) + N * K * 4))
+    return out
+
+
+def layernorm_planes(x, gamma, beta, eps, out=None, save_stats=True):
+    """LayerNorm of the fp32 rows of x [rows, cols] written as Planes (+ mean, rstd)"""
+    rows, cols = x.shape
+    if out is None:
+        out = Planes.empty(rows, cols, x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib().p3_layernorm_planes(ptr(x), ptr(gamma), ptr(beta), ptr(out.hi), ptr(out.lo), c_int64(rows), c_int(cols), c_int(x.stride(0)), c_int(out.ld), c_float(eps),
+                                    ptr(mean), ptr(rstd), stream()), "p3_layernorm_planes")
+    return out, mean, rstd
+
+
+def layernorm_bwd_planes(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, out=None, park=False):
+    """dx (fp32) = LayerNorm backward (+ dres); the same values also as Planes; dgamma / dbeta are accumulated into"""
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    if out is None:
+        out = Planes.empty(rows, cols, x.device)
+    L = lib()
+    park = park and dgamma is not None and param_reduce_arena()
+    if park:
+        L.p3_reduce_defer_enable(c_int(1))
+    try:
+        check(L.p3_layernorm_bwd_planes(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(out.hi), ptr(out.lo), c_int(out.ld),
+                                        ptr(dgamma), ptr(dbeta), c_int64(rows), c_int(cols), stream()), "p3_layernorm_bwd_planes")
+    finally:
+        if park:
+            L.p3_reduce_defer_enable(c_int(0))
+    return dx, out

@@ -311,12 +311,47 @@ def register_shadow_T(p, view_t):
     _registered_T[id(p)] = (p, view_t)
 
 
+# ---- weight planes (fp32x3 on planes, ops_x3.py): hi / lo bf16 images of a 2-D fp32 weight, plain [N, K] and transposed [K, N] --------------------------------
+_registered_planes = {}    # id(param) -> (param, (hi, lo), (hi_T, lo_T), owner): views of FlatAdamW's plane arenas, rewritten after every update (in the captured graph too)
+_planes_cache = {}         # (id(param), transposed) -> (param, version, hi, lo): optimizer-less use (eval, tests), re-derived when the parameter changes
+
+
+def register_planes(p, plain, transposed, owner=None):
+    _registered_planes[id(p)] = (p, plain, transposed, owner)
+
+
+def weight_planes(p, transpose=False):
+    """(hi, lo) bf16 tensors of weight p [N, K] (transpose: of p^T [K, N]) with hi + lo = p to 16 significant bits"""
+    reg = _registered_planes.get(id(p))
+    if reg is not None and reg[0] is p:
+        if reg[3] is not None:
+            reg[3].check_fresh(p)
+        pl = reg[2] if transpose else reg[1]
+        if pl is not None:
+            return pl
+    k = (id(p), bool(transpose))
+    ver = (p._version, _epoch[0])
+    ent = _planes_cache.get(k)
+    if ent is not None and ent[0] is p and ent[1] == ver:
+        return ent[2], ent[3]
+    src = p.detach()
+    src = src.t().contiguous() if transpose else src.contiguous()
+    pl = hip.to_planes(src, pad=1)
+    if len(_planes_cache) > 512:
+        _planes_cache.clear()
+    _planes_cache[k] = (p, ver, pl.hi, pl.lo)
+    return pl.hi, pl.lo
+
+
 def unregister(params):
     """optimizer teardown: forget the arena views (and the cached copies derived from them) of these parameters."""
     ids = {id(p) for p in params}
     for i in ids:
         _registered.pop(i, None)
         _registered_T.pop(i, None)
+        _registered_planes.pop(i, None)
+    for k in [k for k in _planes_cache if k[0] in ids]:
+        del _planes_cache[k]
     for k in [k for k in _shadow_cache if k[0] in ids]:
         del _shadow_cache[k]
 
@@ -327,6 +362,8 @@ def reset_process_state():
     an optimizer that was never close()d otherwise keeps its arenas alive and leaves DIRECT_GRAD / GRAD_READY set for the next model."""
     _registered.clear()
     _registered_T.clear()
+    _registered_planes.clear()
+    _planes_cache.clear()
     _shadow_cache.clear()
     _twins.clear()
     _stream.clear()

@@ -53,8 +53,12 @@ def pix2poly_loss(logits, perm, y_expected, y_perm, w_vertex=1.0, w_perm=10.0, p
 class FlatAdamW:
     """torch.optim.AdamW semantics over one flat arena; `model.parameters()` become views (state_dict unchanged)."""
 
-    def __init__(self, model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), eps=1e-8, compute_dtype=torch.bfloat16, bucket_mb=32, direct_grad=True):
+    def __init__(self, model, lr=3e-4, weight_decay=1e-4, betas=(0.9, 0.95), eps=1e-8, compute_dtype=torch.bfloat16, bucket_mb=32, direct_grad=True, planes=None):
+        """planes (default: the model's own precision scope, 'fp32x3' -> True): keep hi = bf16(w) / lo = bf16(w - hi) arenas of the fp32 master (and their
+        transposes) fresh after every update - the weight operands of the planes GEMMs (ops_x3.py)"""
         params = [p for p in model.parameters() if p.requires_grad]
+        if planes is None:
+            planes = bool(getattr(model, "p3_split", False)) and compute_dtype == torch.float32
         dev = params[0].device
         offs, total = [], 0
         for p in params:
@@ -78,7 +82,11 @@ class FlatAdamW:
                 ops.register_shadow(p, self.shadow[o:o + n].view(p.shape), self)
         if self.shadow is not None:
             self.shadow.copy_(self.flat)
+        self.hi = torch.zeros(total, dtype=torch.bfloat16, device=dev) if planes else None
+        self.lo = torch.zeros(total, dtype=torch.bfloat16, device=dev) if planes else None
         self._build_transposes(params, offs, dev)
+        if planes:
+            self._refresh_planes()
         self._versions = [p._version for p in params]
         self._index = {id(p): i for i, p in enumerate(params)}
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -119,7 +127,16 @@ class FlatAdamW:
             if self.shadow_T is not None:
                 hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
             ops.refresh_derived(self.params)
+        if self.hi is not None:
+            self._refresh_planes()
         self._versions = [p._version for p in self.params]
+
+    def _refresh_planes(self):
+        """hi / lo arenas <- the fp32 master, one pass; their transposed arenas by the batched transpose (capturable: runs inside apply())"""
+        hip.to_planes_into(self.flat.view(1, -1), self.hi.view(1, -1), self.lo.view(1, -1))
+        if self.hi_T is not None:
+            hip.transpose_many(self.hi, self.hi_T, self.t_table, self.t_entries, self.t_tiles)
+            hip.transpose_many(self.lo, self.lo_T, self.t_table, self.t_entries, self.t_tiles)
 
     def close(self):
         """teardown: drop this optimizer's entries from the process-wide registries (they hold strong references to the arenas)."""
@@ -130,7 +147,8 @@ class FlatAdamW:
         """bf16 W^T copies ([in, out]) of every 2-D weight whose dX GEMM reads the plain transpose (out % 64 == 0): one arena, one
         table, refreshed by ONE kernel after each AdamW step instead of one strided copy per weight per step."""
         self.shadow_T, self.t_table, self.t_entries, self.t_tiles = None, None, 0, 0
-        if self.shadow is None:
+        self.hi_T = self.lo_T = None
+        if self.shadow is None and self.hi is None:
             return
         import struct
         recs, total, tiles = [], 0, 0
@@ -146,9 +164,20 @@ class FlatAdamW:
             total += (rows * cols + 63) // 64 * 64
         if not recs:
             return
-        self.shadow_T = torch.zeros(total, dtype=torch.bfloat16, device=dev)
         self.t_table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
         self.t_entries, self.t_tiles = len(recs), tiles
+        if self.hi is not None:            # planes arenas: plain views + transposed views of every such weight
+            self.hi_T = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+            self.lo_T = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+            offs_of = {id(p): o for p, o in zip(params, offs)}
+            for p, t0, rows, cols in views:
+                o = offs_of[id(p)]
+                n = rows * cols
+                ops.register_planes(p, (self.hi[o:o + n].view(rows, cols), self.lo[o:o + n].view(rows, cols)),
+                                    (self.hi_T[t0:t0 + n].view(cols, rows), self.lo_T[t0:t0 + n].view(cols, rows)), self)
+        if self.shadow is None:
+            return
+        self.shadow_T = torch.zeros(total, dtype=torch.bfloat16, device=dev)
         for p, t0, rows, cols in views:
             ops.register_shadow_T(p, self.shadow_T[t0:t0 + rows * cols].view(cols, rows))
         hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
@@ -218,6 +247,8 @@ class FlatAdamW:
                   grad_scale=grad_scale, shadow=self.shadow)
         if self.shadow_T is not None:
             hip.transpose_many(self.shadow, self.shadow_T, self.t_table, self.t_entries, self.t_tiles)
+        if self.hi is not None:
+            self._refresh_planes()
         ops.refresh_derived(self.params)
         ops.invalidate_derived()
         ops.clear_twins()

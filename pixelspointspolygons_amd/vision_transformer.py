@@ -11,7 +11,9 @@ import os
 import torch
 import torch.nn as nn
 
-from . import hip, ops
+from . import hip, ops, ops_x3
+
+X3_STACK = [os.environ.get("P3_X3_STACK", "1") == "1"]      # 0: 'fp32x3' blocks on the per-operator path (fp32 operands split while staged, gemm.hip SPLIT): the A/B and cross-check arm
 
 
 def compute_dtype(cfg):
@@ -165,8 +167,14 @@ class VisionTransformer(nn.Module):
         timm `_pos_embed` (cat CLS, + pos_embed) is fused with the optional BN+ReLU affine of the fusion layer."""
         np_ = self.pos_embed.shape[1] - 1
         x = _Assemble.apply(tok, self.cls_token, self.pos_embed, scale, shift, B, np_, self.embed_dim, src_ld, mean)
-        for blk in self.blocks:
-            x = blk.run(x, self.cd)
+        b0 = self.blocks[0] if len(self.blocks) else None
+        if (b0 is not None and hip.split_now() and self.cd == torch.float32 and X3_STACK[0]
+                and ops_x3.eligible(self.embed_dim, b0.mlp.fc1.weight.shape[0], b0.attn.num_heads)):
+            # 'fp32x3': the whole block stack as one node on planes (ops_x3.py) - the same bf16 x 3 arithmetic, operands split by their producers
+            x = ops_x3.vit_stack(x, self.blocks, b0.attn.num_heads, b0.norm1.eps)
+        else:
+            for blk in self.blocks:
+                x = blk.run(x, self.cd)
         return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=self.cd, stream_grad=True)
 
     def forward(self, x):

@@ -80,7 +80,7 @@ def test_descriptor_structs_have_the_layout_the_header_declares(tmp_path):
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     mirrors = {"p3_dropout": h.Dropout, "p3_gemm_desc": h.GemmDesc, "p3_attn_desc": h.AttnDesc, "p3_pillar_desc": h.PillarDesc,
-               "p3_decode_layer_desc": h.DecodeLayerDesc}
+               "p3_decode_layer_desc": h.DecodeLayerDesc, "p3_gemm_x3_desc": h.GemmX3Desc}
     structs = {}
     for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(p3_\w+)\s*;", text, flags=re.S):
         fields = []

@@ -451,7 +451,11 @@ def test_two_models_of_different_precision_share_one_process():
     loss1.backward()                                                # the exact model's backward runs between the fp32x3 model's forward and backward
     loss2.backward()
     assert torch.equal(l1.detach(), la) and torch.equal(l2.detach(), lb)
+    atomic = {"bin_score", "decoder.embedding.weight"}              # summed with fp32 atomics in every mode: equal to rounding, not bit for bit
     for m, g in ((ma, ga), (mb, gb)):
         for k, p in m.named_parameters():
             if p.grad is not None:
-                assert torch.equal(p.grad, g[k]), k
+                if k in atomic:
+                    assert torch.allclose(p.grad, g[k], rtol=1e-5, atol=1e-6 * float(g[k].abs().max())), k
+                else:
+                    assert torch.equal(p.grad, g[k]), k

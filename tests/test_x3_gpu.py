@@ -1,0 +1,179 @@
+"""The planes kernels of the fp32x3 ViT block (include/p3hip.h p3_gemm_x3 / p3_gemm_tn_x3 / p3_layernorm*_planes; host: ops_x3.py) against float64 math:
+every product is a_lo b_hi + a_hi b_lo + a_hi b_hi on operands split by their PRODUCER - 2^-17 per product, held to 1e-5 here (the exact fp32 MFMA path: 2e-6,
+a plain bf16 product: 4e-3) - and the block stack built from them against the per-operator fp32x3 path and float64 autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _h():
+    import pixelspointspolygons_amd.hip as hip
+    return hip
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def test_planes_round_trip_carries_16_significant_bits():
+    hip = _h()
+    x = _rand(777, 384, seed=1) * torch.logspace(-6, 6, 384)
+    p = hip.to_planes(x.to(DEV))
+    assert p.buf.shape == (832, 768) and float(p.buf[777:].float().abs().max()) == 0.0           # 64-row padding, zero tail
+    back = hip.from_planes(p).cpu()
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15.9
+    assert torch.equal(p.hi[:777].float().cpu(), x.bfloat16().float())                              # hi = the bf16 rounding of x, lo = the bf16 rounding of the rest
+    assert torch.equal(p.lo[:777].float().cpu(), (x - x.bfloat16().float()).bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (1570, 1536, 384), (1570, 384, 1536), (640, 1152, 384), (300, 256, 256), (1570, 768, 768), (129, 360, 64)])
+def test_gemm_x3_plain_and_epilogues(M, N, K):
+    hip = _h()
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1)
+    bias, res, mul = _rand(N, seed=3), _rand(M, N, seed=4), _rand(M, N, seed=5)
+    ap, wp = hip.to_planes(a.to(DEV)), hip.to_planes(w.to(DEV), pad=1)
+    ref = a.double() @ w.double().t()
+    out = hip.gemm_x3(ap, wp).cpu()
+    assert rel_err(out, ref.float()) < 1e-5
+    # bias + GELU (+ aux = GELU') as planes: what fc1 writes
+    aux = torch.empty(M, N, device=DEV)
+    hp = hip.gemm_x3(ap, (wp.hi, wp.lo), bias=bias.to(DEV), act=hip.ACT_GELU, aux=aux, out_planes=True)
+    pre = (ref + bias.double()).requires_grad_(True)
+    g = F.gelu(pre)
+    g.sum().backward()
+    assert rel_err(hip.from_planes(hp).cpu(), g.detach().float()) < 2e-5
+    assert rel_err(aux.cpu(), pre.grad.float()) < 1e-4            # GELU' of a pre-activation that carries the product's own 1e-5
+    # bias + residual, fp32 out: proj / fc2;  mul: the hidden gradient
+    out = hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV)).cpu()
+    assert rel_err(out, (ref + bias.double() + res.double()).float()) < 1e-5
+    dp = hip.gemm_x3(ap, wp, mul=mul.to(DEV), out_planes=True)
+    assert rel_err(hip.from_planes(dp).cpu(), (ref * mul.double()).float()) < 2e-5
+
+
+@pytest.mark.parametrize("M,K", [(1570, 384), (1000, 1536), (128, 384)])
+def test_gemm_x3_fused_layernorm_of_the_output_row(M, K):
+    """proj / fc2 of timm's Block with the following LayerNorm in the epilogue (N == 384): C, LN(C) as planes, mean and rstd"""
+    hip = _h()
+    N = 384
+    a, w = _rand(M, K, seed=11), _rand(N, K, seed=12, scale=0.05)
+    bias, res = _rand(N, seed=13), _rand(M, N, seed=14) * 3.0 + 0.5
+    gamma, beta = _rand(N, seed=15) * 0.2 + 1.0, _rand(N, seed=16) * 0.1
+    ap, wp = hip.to_planes(a.to(DEV)), hip.to_planes(w.to(DEV), pad=1)
+    c = torch.empty(M, N, device=DEV)
+    h = hip.Planes.empty(M, N, DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV), out=c, ln=(gamma.to(DEV), beta.to(DEV), 1e-6, h, mean, rstd))
+    ref = a.double() @ w.double().t() + bias.double() + res.double()
+    assert rel_err(c.cpu(), ref.float()) < 1e-5
+    lref = F.layer_norm(ref, (N,), gamma.double(), beta.double(), 1e-6)
+    assert rel_err(hip.from_planes(h).cpu(), lref.float()) < 3e-5
+    assert rel_err(mean.cpu(), ref.mean(-1).float()) < 1e-5
+    assert rel_err(rstd.cpu(), (ref.var(-1, unbiased=False) + 1e-6).rsqrt().float()) < 1e-5
+    # the separate kernel gives the same planes from the same C (statistics over the fp32 values either way)
+    h2, m2, r2 = hip.layernorm_planes(c, gamma.to(DEV), beta.to(DEV), 1e-6)
+    assert rel_err(hip.from_planes(h2).cpu(), hip.from_planes(h).cpu()) < 1e-5 and rel_err(m2.cpu(), mean.cpu()) < 1e-5 and rel_err(r2.cpu(), rstd.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1570, 384, 384), (1570, 1536, 384), (1570, 384, 1536), (3200, 1152, 384), (130, 768, 768)])
+def test_gemm_tn_x3_weight_gradient(M, N, K):
+    hip = _h()
+    dy, x = _rand(M, N, seed=21), _rand(M, K, seed=22)
+    dyp, xp = hip.to_planes(dy.to(DEV)), hip.to_planes(x.to(DEV))
+    ref = dy.double().t() @ x.double()
+    cs = torch.zeros(N, device=DEV)
+    out = hip.gemm_tn_x3(dyp, xp, colsum_out=cs)
+    assert rel_err(out.cpu(), ref.float()) < 1e-5
+    assert rel_err(cs.cpu(), dy.double().sum(0).float()) < 1e-5
+    hip.gemm_tn_x3(dyp, xp, out=out, colsum_out=cs)                 # accumulates (gradient arena semantics)
+    assert rel_err(out.cpu(), (2 * ref).float()) < 1e-5 and rel_err(cs.cpu(), (2 * dy.double().sum(0)).float()) < 1e-5
+
+
+def test_layernorm_planes_forward_backward():
+    hip = _h()
+    rows, cols = 1570, 384
+    x = (_rand(rows, cols, seed=31) * 2.0 + 0.3).double().requires_grad_(True)
+    gamma, beta = (_rand(cols, seed=32) * 0.2 + 1.0).double().requires_grad_(True), (_rand(cols, seed=33) * 0.1).double().requires_grad_(True)
+    dy, dres = _rand(rows, cols, seed=34), _rand(rows, cols, seed=35)
+    y = F.layer_norm(x, (cols,), gamma, beta, 1e-6)
+    (y * dy.double()).sum().backward()
+    xd, gd, bd = x.detach().float().to(DEV), gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    yp, mean, rstd = hip.layernorm_planes(xd, gd, bd, 1e-6)
+    assert rel_err(hip.from_planes(yp).cpu(), y.detach().float()) < 3e-5
+    dg, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    dx, dxp = hip.layernorm_bwd_planes(dy.to(DEV), xd, gd, mean, rstd, dres.to(DEV), dg, db)
+    want = (x.grad + dres.double()).float()
+    assert rel_err(dx.cpu(), want) < 1e-5 and rel_err(hip.from_planes(dxp).cpu(), want) < 3e-5
+    assert torch.equal(dxp.hi[:rows].float().cpu(), dx.cpu().bfloat16().float())                           # the planes are the split of the fp32 dx, bit for bit
+    assert rel_err(dg.cpu(), gamma.grad.float()) < 1e-5 and rel_err(db.cpu(), beta.grad.float()) < 1e-5
+
+
+def _vit(precision, depth=2):
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.vision_transformer import ViT
+    cfg = make_config("vit", precision=precision, device=DEV, vit_depth=depth)
+    torch.manual_seed(7)
+    return ViT(cfg, bottleneck=True).to(DEV)
+
+
+@pytest.mark.parametrize("fuse_ln", [True, False])
+def test_block_stack_on_planes_equals_the_per_operator_fp32x3_path_and_float64_autograd(fuse_ln):
+    """ViT encoder (2 blocks, 785 tokens) forward + backward in 'fp32x3': the planes stack (ops_x3.py) against (a) the per-operator path - the same products with
+    the operands split while they are staged (vision_transformer.X3_STACK off) - and (b) the exact fp32 path: outputs 1e-4, every parameter gradient 2e-3 of the
+    largest one.  fuse_ln: LayerNorm inside the proj / fc2 epilogue or as its own launch."""
+    from pixelspointspolygons_amd import ops_x3
+    import pixelspointspolygons_amd.vision_transformer as vt
+    img = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(3)).to(DEV)
+    w = torch.randn(2, 784, 256, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def run(precision, stack):
+        was, vt.X3_STACK[0] = vt.X3_STACK[0], stack
+        wasf, ops_x3.FUSE_LN[0] = ops_x3.FUSE_LN[0], fuse_ln
+        try:
+            m = _vit(precision).train()
+            y = m(img)
+            (y.float() * w).sum().backward()
+            return y.detach().float().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters()}
+        finally:
+            vt.X3_STACK[0], ops_x3.FUSE_LN[0] = was, wasf
+    y_st, g_st = run("fp32x3", True)
+    y_op, g_op = run("fp32x3", False)
+    y_ex, g_ex = run("fp32", False)
+    assert rel_err(y_st, y_ex) < 1e-4 and rel_err(y_op, y_ex) < 1e-4 and rel_err(y_st, y_op) < 1e-4
+    gmax = max(float(v.abs().max()) for v in g_ex.values())
+    for other in (g_op, g_ex):
+        bad = {k: float((g_st[k] - other[k]).abs().max()) / gmax for k in g_ex if float((g_st[k] - other[k]).abs().max()) > 2e-3 * gmax}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+def test_flat_adamw_keeps_the_weight_planes_fresh():
+    """FlatAdamW on an 'fp32x3' model: the hi / lo arenas (and their transposes) are rewritten after every update, inside apply(); a parameter written from outside
+    (load_state_dict) is noticed; the planes always split the CURRENT fp32 master"""
+    from pixelspointspolygons_amd import ops
+    from pixelspointspolygons_amd.training import FlatAdamW
+    hip = _h()
+    ops.reset_process_state()
+    m = _vit("fp32x3", depth=1)
+    opt = FlatAdamW(m, lr=1e-2, compute_dtype=torch.float32)
+    assert opt.hi is not None and opt.hi_T is not None
+    wq = m.vit.blocks[0].attn.qkv.weight
+
+    def check():
+        hi, lo = ops.weight_planes(wq)
+        hit, lot = ops.weight_planes(wq, transpose=True)
+        assert hi.data_ptr() >= opt.hi.data_ptr() and hi.data_ptr() < opt.hi.data_ptr() + opt.hi.numel() * 2          # arena views, not cached copies
+        assert torch.equal(hi.float(), wq.detach().bfloat16().float()) and torch.equal(lo.float(), (wq.detach() - hi.float()).bfloat16().float())
+        assert torch.equal(hit, hi.t()) and torch.equal(lot, lo.t())
+    check()
+    opt.grad.normal_()
+    opt.step()
+    check()
+    with torch.no_grad():
+        wq.mul_(1.5)                    # written behind the optimizer's back (what load_state_dict does)
+    check()
+    opt.close()
+    ops.reset_process_state()
