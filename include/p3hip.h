@@ -188,6 +188,8 @@ typedef struct {
     float* ln_mean; float* ln_rstd;
 } p3_gemm_x3_desc;
 int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream);
+/* measurement hook (tools/mb_x3.py): 0 = the library's tile rule, 1 = every product on the 128 x 128 tile, 2 = on the 128 x 384 tile; returns the previous mode */
+int p3_gemm_x3_tile(int mode);
 /* weight gradient from planes:  C[N, K] (+)= (a_hi + a_lo)[M, N]^T (b_hi + b_lo)[M, K]  (fp32 C, split over M: fp32 atomics, or - `slabs` given - partial
  * tiles + a fixed-order reduce like p3_gemm_tn_ex); colsum (optional, [N]) += column sums of A (the bias gradient).  M % 64 == 0, N % 128 == 0, K % 128 == 0. */
 int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, float* C, int ldc, int M, int N, int K,

@@ -479,11 +479,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
 }
 
-int p3_attn_order(void) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("P3_ATTN_TAIL_FIRST"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
+int p3_attn_order(void) { return 1; }      // tail blocks first (attn_block_of mode 1; r04 A/B: profiles/r04_mb_attn_ab.txt - the pair-major order is gone)
 
 extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream) {
     P3_CHECK(Q && K && V && O && d, P3_EINVAL, "p3_attention: null pointer");
@@ -499,8 +495,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     hipStream_t s = (hipStream_t)stream;
     const bool drop = d->drop.seed != nullptr && d->drop.p > 0.f;
     P3_CHECK(!drop || d->drop.p < 1.f, P3_EINVAL, "p3_attention: dropout p must be < 1");
-    static int no_decode = -1;                        // P3_NO_SKINNY=1: A/B switch (tiled kernel for the 1-query problem too)
-    if (no_decode < 0) { const char* e = getenv("P3_NO_SKINNY"); no_decode = (e && e[0] == '1') ? 1 : 0; }
+    constexpr int no_decode = 0;
     if (!no_decode && d->dtype == P3_BF16 && d->Lq == 1 && !d->causal && !drop && !d->lse && d->Lk <= 8192 && d->v_rs % 8 == 0 && d->v_bs % 8 == 0) {
         const size_t lds = (size_t)(((d->Lk + 3) & ~3) + (256 / (d->head_dim / 8)) * d->head_dim) * sizeof(float);
         if (d->head_dim == 64) hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(d->B * d->H), dim3(256), lds, s, a);

@@ -33,7 +33,7 @@ constexpr int BM = 128, BN = 128;
 // two-pass 34 KB epilogue staging -> more workgroups per CU) is the default: the GEMMs of this path are short-K and HBM / latency
 // bound.  BK = 64 (74 KB, 2 workgroups / CU, half the barriers per FLOP, one-pass epilogue) takes over from K = 2048 (decoder linear2,
 // the 3x3 convolutions).  Same-box A/B of the whole train step (tools/ab.sh, r01): all-64 61.4 ms, all-32 60.1, 64 above K = 512
-// 61.1, 64 from K = 2048 60.0.  P3_GEMM_BK=32 | 64 | <K threshold> overrides for such sweeps.
+// 61.1, 64 from K = 2048 60.0.
 template <typename T, int BKSEL> struct Tr;
 template <int BKSEL> struct Tr<bf16_t, BKSEL> { static constexpr int BK = BKSEL, PITCH = BKSEL + 8, VEC = 8, LDS_ELEMS = BM * (BKSEL + 8); };
 template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PITCH = 132, VEC = 4, LDS_ELEMS = 16 * 132; };
@@ -838,8 +838,7 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         if (d->N == 384 && d->K >= 1024) v = 9;
         if (v) return p3_gemm_dma_launch(A, W, C, d, v, s);
     }
-    static int no_skinny = -1;                        // P3_NO_SKINNY=1: A/B switch
-    if (no_skinny < 0) { const char* e = getenv("P3_NO_SKINNY"); no_skinny = (e && e[0] == '1') ? 1 : 0; }
+    constexpr int no_skinny = 0;
     if (!no_skinny && d->dtype_in == P3_BF16 && d->M <= 128 && d->a_mode == P3_A_PLAIN && !d->colsum && !d->aux && !d->bwd_saved &&
         !(d->drop.seed && d->drop.p > 0.f)) {
         dim3 grid(p3_ceil_div(d->N, 32), p3_ceil_div(d->M, 32));

@@ -97,7 +97,14 @@ __device__ __forceinline__ void x3_epi8(const p3_gemm_x3_desc& d, int row, int c
     }
 }
 
-// ---- 128 x 128 tile, 4 waves -------------------------------------------------------------------------------------------------------------
+// ---- 128 x 128 tile, 4 waves, 64 KB of LDS -> TWO workgroups per CU ---------------------------------------------------------------------------
+// Same software-pipelined loop as the 128 x 384 kernel below (fragments double-buffered per 16-deep block, the next slice's DMA pieces and the next block's
+// fragment reads issued in the gaps between the MFMAs, one barrier in the middle of the iteration).  What the smaller tile buys: two INDEPENDENT workgroups
+// share a CU - their barriers are not coupled, so while one sits in its epilogue (for the K = 384 products with 1152 / 1536-wide outputs the epilogue moves
+// more bytes than the main loop stages) or in a barrier the other one's MFMAs fill the pipe; and 393 x N / 128 tiles quantise better over 256 CUs than 393 x
+// N / 384 (N = 384: 1179 tiles = 4.6 rounds against 393 = 1.54 rounds of the big tile).  What it costs: 98 MFMA-flop per staged byte against 147.
+struct X3Frag2 { uint4 ah[2], al[2], bh[2], bl[2]; };
+
 template <bool PLANES>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
     constexpr int CPR = 4, TILE_U4 = 128 * CPR, STAGE_U4 = 4 * TILE_U4;      // a_hi | a_lo | w_hi | w_lo
@@ -126,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
         voffB[q] = (uint32_t)(((int64_t)rb * d.ldb + c * 8) * 2);
     }
     const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(&lds[0]));
-    auto stage = [&](int kt) __attribute__((always_inline)) {
-        const uint32_t base = lds_addr + (uint32_t)(((kt & 1) * STAGE_U4 + wave * 2 * 64) * 16);
+    auto dma_part = [&](int kt, int n) __attribute__((always_inline)) {      // n = 0 a_hi, 1 a_lo, 2 w_hi, 3 w_lo: two pieces each
+        const uint32_t base = lds_addr + (uint32_t)(((kt & 1) * STAGE_U4 + n * TILE_U4 + wave * 2 * 64) * 16);
         const int64_t ko = (int64_t)kt * 32;
-        x3_dma2(Ah + ko, base, voffA[0], voffA[1]);
-        x3_dma2(Al + ko, base + TILE_U4 * 16, voffA[0], voffA[1]);
-        x3_dma2(Wh + ko, base + 2 * TILE_U4 * 16, voffB[0], voffB[1]);
-        x3_dma2(Wl + ko, base + 3 * TILE_U4 * 16, voffB[0], voffB[1]);
+        if (n == 0) x3_dma2(Ah + ko, base, voffA[0], voffA[1]);
+        else if (n == 1) x3_dma2(Al + ko, base, voffA[0], voffA[1]);
+        else if (n == 2) x3_dma2(Wh + ko, base, voffB[0], voffB[1]);
+        else x3_dma2(Wl + ko, base, voffB[0], voffB[1]);
     };
 
     f32x16 acc[2][2];
@@ -144,43 +151,64 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sw = (l31 >> 2) & 3;
-    const int arow = (wr * 64 + l31) * CPR, brow = (wc * 64 + l31) * CPR;
-    stage(0);
+    const int arow = (wr * 64 + l31) * CPR, brow = 2 * TILE_U4 + (wc * 64 + l31) * CPR;
+    auto frag_read = [&](X3Frag2& f, const uint4* sb, int kk, int n) __attribute__((always_inline)) {       // n = 0-1 a_hi, 2-3 a_lo, 4-5 w_hi, 6-7 w_lo
+        const int ch = (2 * kk + hi) ^ sw;
+        if (n < 2) f.ah[n] = sb[arow + n * 32 * CPR + ch];
+        else if (n < 4) f.al[n - 2] = sb[TILE_U4 + arow + (n - 2) * 32 * CPR + ch];
+        else if (n < 6) f.bh[n - 4] = sb[brow + (n - 4) * 32 * CPR + ch];
+        else f.bl[n - 6] = sb[TILE_U4 + brow + (n - 6) * 32 * CPR + ch];
+    };
+    auto mfma_n = [&](const X3Frag2& f, int n) __attribute__((always_inline)) {      // n = 0 .. 11: small terms first, term-major
+        const int t = n / 4, i = (n % 4) / 2, j = n % 2;
+        const uint4& av = t == 0 ? f.al[i] : f.ah[i];
+        const uint4& bv = t == 1 ? f.bl[j] : f.bh[j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc[i][j], 0, 0, 0);
+    };
+    X3Frag2 F0, F1;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma_part(0, n);
+    if (nk > 1) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) dma_part(1, n);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // slice 0 landed (this wave's pieces); slice 1 stays in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) frag_read(F0, lds, 0, n);
     for (int kt = 0; kt < nk; ++kt) {
-        x3_wait_vm0();
-        __builtin_amdgcn_s_barrier();                  // slice kt readable; slice kt - 1 consumed by every wave: its buffer takes slice kt + 1
-        if (kt + 1 < nk) stage(kt + 1);
         const uint4* sb = lds + (kt & 1) * STAGE_U4;
+        const uint4* sn = lds + ((kt + 1) & 1) * STAGE_U4;
+        const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 ah[2], al[2], bh[2], bl[2];
-            const int ch = (2 * kk + hi) ^ sw;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = sb[arow + i * 32 * CPR + ch];
-                al[i] = sb[TILE_U4 + arow + i * 32 * CPR + ch];
-                bh[i] = sb[2 * TILE_U4 + brow + i * 32 * CPR + ch];
-                bl[i] = sb[3 * TILE_U4 + brow + i * 32 * CPR + ch];
+        for (int n = 0; n < 12; ++n) {                       // block (kt, 0) on F0; the reads of block (kt, 1) fill F1 in the gaps
+            mfma_n(F0, n);
+            if (n % 3 == 2 && n < 11) {
+                __builtin_amdgcn_sched_barrier(0);
+                frag_read(F1, sb, 1, (n / 3) * 3); frag_read(F1, sb, 1, (n / 3) * 3 + 1);
+                if ((n / 3) * 3 + 2 < 8) frag_read(F1, sb, 1, (n / 3) * 3 + 2);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_s_setprio(1);
-            // small terms first; term-major order: four independent accumulators between two MFMAs on the same one
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al[i]), __builtin_bit_cast(bf16x8_t, bh[j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[i]), __builtin_bit_cast(bf16x8_t, bl[j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah[i]), __builtin_bit_cast(bf16x8_t, bh[j]), acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // slice kt + 1 landed (this wave's pieces); this wave's reads of slice kt done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int n = 0; n < 12; ++n) {                       // block (kt, 1) on F1; DMA of slice kt + 2 and the reads of block (kt + 1, 0) in the gaps
+            mfma_n(F1, n);
+            if (n % 3 == 2 && n < 11) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int sl = n / 3;                      // 0 .. 2
+                if (more2) { dma_part(kt + 2, sl); if (sl == 2) dma_part(kt + 2, 3); }
+                if (more) { frag_read(F0, sn, 0, sl * 3); frag_read(F0, sn, 0, sl * 3 + 1); if (sl * 3 + 2 < 8) frag_read(F0, sn, 0, sl * 3 + 2); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // every wave is done with the operands: the epilogue may overwrite them
@@ -505,6 +533,15 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const bf16_t* __restri
 
 }  // namespace
 
+static int g_x3_tile = 0;
+extern "C" int p3_gemm_x3_tile(int mode) { const int was = g_x3_tile; g_x3_tile = mode; return was; }
+// the 128 x 384 tile (one workgroup per CU, 147 MFMA-flop per staged byte) pays where its quantisation over the CUs is not worse than the small tile's and
+// the epilogue is short against the main loop; see the table in DESIGN.md section 5
+static bool x3_big_tile(const p3_gemm_x3_desc* d) {
+    if (d->N <= 256) return false;
+    return d->K >= 1024;
+}
+
 extern "C" int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream) {
     P3_CHECK(d && d->a_hi && d->a_lo && d->w_hi && d->w_lo && d->c, P3_EINVAL, "p3_gemm_x3: null pointer");
     P3_CHECK(d->M > 0 && d->N > 0 && d->K > 0, P3_ESHAPE, "p3_gemm_x3: empty problem");
@@ -529,9 +566,9 @@ extern "C" int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream) {
     g.tiles_m = p3_ceil_div(d->M, 128);
     hipStream_t s = (hipStream_t)stream;
     P3_CHECK(d->K % 32 == 0, P3_ESHAPE, "p3_gemm_x3: K % 32 == 0");
-    static int small_tile = -1;                      // P3_X3_TILE128=1: every product on the 128 x 128 two-slice kernel (A/B arm)
-    if (small_tile < 0) { const char* e = getenv("P3_X3_TILE128"); small_tile = (e && e[0] == '1') ? 1 : 0; }
-    if (ln || (!small_tile && d->N > 256)) {
+    // tile choice: p3_gemm_x3_tile(1) forces the 128 x 128 kernel, (2) the 128 x 384 kernel, (0) the measured rule (tools/mb_x3.py, profiles/r05_mb_x3.txt)
+    const bool big = g_x3_tile == 2 ? d->N > 128 : (g_x3_tile == 1 ? false : x3_big_tile(d));
+    if (ln || big) {
         g.tiles_n = p3_ceil_div(d->N, 384);
         constexpr size_t LDS = 2 * (2 * 128 * 4 + 2 * 384 * 4) * 16;          // 2 slices x 64 KB
         static bool attr_set = false;

@@ -121,9 +121,7 @@ void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, in
 // p3_gemm_tn_ex's hook for P3_A_AFFINE_MASK2: 1 when the shape is not this kernel's (the caller goes on with gemm_tn.hip), else the launch status
 int p3_mask2_dw_try(const void* A, const void* B, float* C, int M, int N, int Kb, int lda, int ldb, int ldc, const float* scale, const float* shift,
                     float* slabs, int max_slabs, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("P3_MASK2_DW"); on = (e && e[0] == '0') ? 0 : 1; }       // A/B switch
-    if (!on || N != 64 || Kb != 128 || lda != 64 || ldb != 128 || M % 128 != 0 || M < 128 * 256) return 1;
+    if (N != 64 || Kb != 128 || lda != 64 || ldb != 128 || M % 128 != 0 || M < 128 * 256) return 1;
     if ((((uintptr_t)A | (uintptr_t)B) % 16) != 0) return 1;
     MdArgs g;
     g.dH = (const bf16_t*)A; g.H2 = (const bf16_t*)B; g.sc = scale; g.sh = shift; g.C = C; g.ldc = ldc; g.steps = M / 128;

@@ -152,9 +152,7 @@ void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, in
 // p3_gemm_tn_ex's hook for the pair mode: 1 when the shape is not this kernel's (the caller goes on with gemm_tn.hip), else the launch status
 int p3_pair_dw_try(const void* A, const void* U, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* scale, const float* shift,
                    const void* pair_V, int pair_n, float* slabs, int max_slabs, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("P3_PAIR_DW"); on = (e && e[0] == '0') ? 0 : 1; }        // A/B switch
-    if (!on || N != 128 || K != 256 || lda != 128 || ldb != 256 || pair_n < PD_JT || pair_n % PD_JT != 0) return 1;
+    if (N != 128 || K != 256 || lda != 128 || ldb != 256 || pair_n < PD_JT || pair_n % PD_JT != 0) return 1;
     if ((((uintptr_t)A | (uintptr_t)U | (uintptr_t)pair_V) % 16) != 0) return 1;
     const int n = pair_n;
     const int64_t B = (int64_t)M / ((int64_t)n * n);

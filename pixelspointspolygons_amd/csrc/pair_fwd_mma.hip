@@ -204,9 +204,6 @@ __global__ __launch_bounds__(512, 1) void pair_fwd_mma_kernel(QfArgs g) {
 
 // p3_gemm's hook for P3_A_PAIR_AFFINE_RELU: P3_PAIR_FWD_SKIP when the problem is not the ScoreNet conv2 shape (the caller goes on with its tile kernel)
 int p3_pair_fwd_try(const void* U, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("P3_PAIR_FWD"); on = (e && e[0] == '0') ? 0 : 1; }       // A/B switch
-    if (!on) return P3_PAIR_FWD_SKIP;
     if (d->a_mode != P3_A_PAIR_AFFINE_RELU || d->dtype_in != P3_BF16 || d->dtype_out != P3_BF16 || d->K != 256 || d->N != 128) return P3_PAIR_FWD_SKIP;
     if (d->lda != 256 || d->ldb != 256 || d->ldc != 128 || d->pair_n < 8 || d->pair_n % QF_IB != 0) return P3_PAIR_FWD_SKIP;
     if (d->act != P3_ACT_NONE || d->residual || d->aux || d->bwd_saved || (d->drop.seed && d->drop.p > 0.f)) return P3_PAIR_FWD_SKIP;

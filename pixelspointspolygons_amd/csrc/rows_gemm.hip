@@ -189,9 +189,6 @@ int rows_launch(RGArgs& g, const char* name, float* colsum, float* colsumsq, hip
 
 // p3_gemm's hook: returns P3_ROWS_SKIP when the problem is not one of the two shapes (the caller goes on with its tiled kernels), else the launch status.
 int p3_rows_gemm_try(const void* A, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("P3_ROWS_GEMM"); on = (e && e[0] == '0') ? 0 : 1; }      // A/B switch
-    if (!on) return P3_ROWS_SKIP;
     if (d->dtype_in != P3_BF16 || d->dtype_out != P3_BF16 || d->M % 32 != 0 || d->M < 4096) return P3_ROWS_SKIP;
     if (d->lda != d->K || d->ldb != d->K || d->ldc != d->N) return P3_ROWS_SKIP;
     if (d->act != P3_ACT_NONE || d->residual || d->aux || (d->drop.seed && d->drop.p > 0.f)) return P3_ROWS_SKIP;

@@ -793,7 +793,8 @@ def test_scorenet_backward_native_vs_oracle_autograd(transpose, train, N, B):
 
 
 @pytest.mark.parametrize("train,max_points,n_points", [(True, 64, 3000), (False, 64, 3000), (True, 8, 6000), (True, 64, 400),
-                                                       (True, 128, 90000), (True, 256, 120000)])   # density-ablation configs: > 64 slots
+                                                       (True, 128, 90000), (True, 256, 120000),    # density-ablation configs: > 64 slots
+                                                       (True, 4, 6000), (True, 16, 12000), (True, 32, 24000), (True, 512, 150000)])   # ... and the remaining caps of lidar_density_ablation{4..512}.yaml:13
 def test_pillar_stem_backward_native_vs_oracle_autograd(train, max_points, n_points):
     """p3_pillar_stem_bwd (PFN parameter gradients) vs float64 autograd of the oracle's dense [V, max_points] formulation:
     truncated pillars (max_points 8), mostly-padded pillars (400 points), train- and eval-mode BatchNorm."""

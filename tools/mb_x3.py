@@ -53,6 +53,19 @@ rows = [
     ("ln_planes 384", lambda: hip.layernorm_planes(out384, gam, bet, 1e-6, out=outp384), 0.0),
 ]
 hip.set_deterministic(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+from pixelspointspolygons_amd._lib import lib
+print(f"{'':42s} {'128x128 tile':>22s} {'128x384 tile':>22s}")
 for name, fn, flop in rows:
-    us = bench(fn)
-    print(f"{name:42s} {us:8.1f} us   {flop / us / 1e6:7.1f} TF (algorithmic; x3 MFMA issued)")
+    cols = []
+    for mode in (1, 2):
+        if mode == 2 and ("dW" in name or "planes " in name or "+LN" in name and False):
+            cols.append("")
+            continue
+        lib().p3_gemm_x3_tile(mode)
+        try:
+            us = bench(fn)
+            cols.append(f"{us:8.1f} us {flop / us / 1e6:6.1f} TF")
+        except Exception as e:      # the fused LayerNorm exists on the 128 x 384 tile only
+            cols.append(f"{'-':>22s}")
+    lib().p3_gemm_x3_tile(0)
+    print(f"{name:42s} {cols[0]:>22s} {cols[1]:>22s}")
