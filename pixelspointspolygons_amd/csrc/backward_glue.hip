@@ -45,25 +45,30 @@ __global__ void embed_bwd_kernel(const T* __restrict__ dx, const int64_t* __rest
 // addresses), then adds its non-zero table entries to demb once.  r02: the global-atomic form took 297 us for 6.3 M atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const T* __restrict__ dx, const int64_t* __restrict__ tok, float* __restrict__ demb,
-                                                            int64_t rows, int D, int V, int rows_per_block) {
+                                                            int64_t rows, int D, int V, int rows_per_block, float* __restrict__ slab) {
+    // slab != NULL (deterministic mode): launched with ONE wave per workgroup - every table entry has a single adder that walks its rows in order - and the
+    // whole table (zeros included) goes to slab[blockIdx.x][V][D]; p3_det_reduce adds the workgroups' tables in workgroup order.  Otherwise four waves share
+    // the table through LDS atomics and the non-zero entries are added to demb with global atomics.
     extern __shared__ float tab[];                     // [V][64]
-    const int tid = threadIdx.x, c = tid & 63, slot = tid >> 6;
+    const int tid = threadIdx.x, c = tid & 63, slot = tid >> 6, nslot = blockDim.x >> 6;
     const int c0 = blockIdx.y * 64;
-    for (int i = tid; i < V * 64; i += 256) tab[i] = 0.f;
+    for (int i = tid; i < V * 64; i += blockDim.x) tab[i] = 0.f;
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     if (c0 + c < D) {
-        for (int64_t r = r0 + slot; r < r1; r += 4) {
+        for (int64_t r = r0 + slot; r < r1; r += nslot) {
             const int64_t t = tok[r];
             if (t >= 0 && t < V) atomicAdd(&tab[(int)t * 64 + c], Cvt<T>::to_f(dx[r * D + c0 + c]));
         }
     }
     __syncthreads();
-    for (int i = tid; i < V * 64; i += 256) {
+    for (int i = tid; i < V * 64; i += blockDim.x) {
         const float v = tab[i];
         const int cc = c0 + (i & 63);
-        if (v != 0.f && cc < D) atomicAdd(demb + (int64_t)(i >> 6) * D + cc, v);
+        if (cc >= D) continue;
+        if (slab) slab[((int64_t)blockIdx.x * V + (i >> 6)) * D + cc] = v;
+        else if (v != 0.f) atomicAdd(demb + (int64_t)(i >> 6) * D + cc, v);
     }
 }
 
@@ -229,10 +234,18 @@ extern "C" int p3_embed_tokens_bwd_v(const void* dx, int dtype, const int64_t* t
     const int rpb = (int)p3_ceil_div(rows, (int64_t)64) < 32 ? 32 : (int)p3_ceil_div(rows, (int64_t)64);     // ~64 row groups x D/64 channel groups
     dim3 grid((unsigned)p3_ceil_div(rows, (int64_t)rpb), (unsigned)p3_ceil_div(D, 64)), block(256);
     const size_t lds = (size_t)V * 64 * sizeof(float);
-    if (dtype == P3_BF16) hipLaunchKernelGGL((embed_bwd_lds_kernel<bf16_t>), grid, block, lds, s, (const bf16_t*)dx, tokens, demb, rows, D, V, rpb);
-    else if (dtype == P3_F32) hipLaunchKernelGGL((embed_bwd_lds_kernel<float>), grid, block, lds, s, (const float*)dx, tokens, demb, rows, D, V, rpb);
+    // deterministic mode: one wave per workgroup, 128 row groups, the workgroups' tables through the scratch (128 x V x D floats: 30 MB at V = 227, D = 256)
+    const int det_groups = 128;
+    const int det_rpb = (int)p3_ceil_div(rows, (int64_t)det_groups);
+    const int det_grid = (int)p3_ceil_div(rows, (int64_t)det_rpb);
+    float* slab = p3_det_scratch((int64_t)det_grid * V * D, dtype);
+    if (slab) { grid = dim3((unsigned)det_grid, (unsigned)p3_ceil_div(D, 64)); block = dim3(64); }
+    const int rpb_used = slab ? det_rpb : rpb;
+    if (dtype == P3_BF16) hipLaunchKernelGGL((embed_bwd_lds_kernel<bf16_t>), grid, block, lds, s, (const bf16_t*)dx, tokens, demb, rows, D, V, rpb_used, slab);
+    else if (dtype == P3_F32) hipLaunchKernelGGL((embed_bwd_lds_kernel<float>), grid, block, lds, s, (const float*)dx, tokens, demb, rows, D, V, rpb_used, slab);
     else { p3_set_error("p3_embed_tokens_bwd_v: dtype"); return P3_EUNSUP; }
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, det_grid, (int64_t)V * D, demb, V * D, 1, s);
     return P3_OK;
 }
 

@@ -121,6 +121,13 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& h, float& g) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { float h, g; gelu_and_grad(x, h, g); return h; }
 
+// a workgroup's partial of value idx (n values per workgroup): into `slab` [gridDim.x][n] - deterministic mode, summed in workgroup order in float64 by
+// p3_det_reduce right behind the launch - or, without a slab, an fp32 atomic onto out[idx].  EVERY workgroup of the grid must commit every idx (zeros included).
+__device__ __forceinline__ void p3_commit(float* out, float* slab, int n, int idx, float v) {
+    if (slab) slab[(int64_t)blockIdx.x * n + idx] = v;
+    else atomicAdd(out + idx, v);
+}
+
 static inline int p3_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void p3_set_error(const char* msg);

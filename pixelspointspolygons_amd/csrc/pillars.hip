@@ -258,7 +258,7 @@ __device__ __forceinline__ float quad_sum16(float v) {
 
 template <bool MULTI>
 __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restrict__ pts, VoxTab t, PillarGeom g, int max_voxels,
-                                                           int nslots, const float* __restrict__ w1, float* __restrict__ sums /*[2*C1]*/) {
+                                                           int nslots, const float* __restrict__ w1, float* __restrict__ sums /*[2*C1]*/, float* __restrict__ slab) {
     __shared__ float w1s[C1 * 8];
     for (int i = threadIdx.x; i < C1 * 8; i += 256) w1s[i] = w1[i];
     __syncthreads();
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void pfn_l1_stats_kernel(const float* __restri
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * C1) atomicAdd(sums + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (threadIdx.x < 2 * C1) p3_commit(sums, slab, 2 * C1, threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // scale/shift from batch statistics (train) or running statistics (eval); updates running stats like torch BatchNorm
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void pfn_l1_apply_kernel(const float* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict__ H2, VoxTab t, int max_voxels, int max_points, int nslots,
                                                             int C, float* __restrict__ hmax, float* __restrict__ hmin,
-                                                            float* __restrict__ sums /*[2C] or null*/) {
+                                                            float* __restrict__ sums /*[2C] or null*/, float* __restrict__ slab = nullptr) {
     const int lane = threadIdx.x & 63;
     constexpr int MAXJ = 12;
     float s1[MAXJ], s2[MAXJ];
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict_
             if (j < nj) { red[wv][lane + 64 * j] = s1[j]; red[wv][64 * MAXJ + lane + 64 * j] = s2[j]; }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
-            atomicAdd(sums + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-            atomicAdd(sums + C + c, (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]));
+            p3_commit(sums, slab, 2 * C, c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+            p3_commit(sums, slab, 2 * C, C + c, (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]));
         }
     }
 }
@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max
                                                                const T* __restrict__ dcanvas, int dld, const float* __restrict__ sc2,
                                                                const float* __restrict__ sh2, const float* __restrict__ mean2,
                                                                const float* __restrict__ rstd2, float* __restrict__ hmax,
-                                                               float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                               float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                               float* __restrict__ slab = nullptr /* [gridDim.x][dbeta(C) | dgamma(C)] */) {
     const int lane = threadIdx.x & 63;
     constexpr int MAXJ = 12;
     float s1[MAXJ], s2[MAXJ];
@@ -622,8 +623,10 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max
         if (j < nj) { red[wv][lane + 64 * j] = s1[j]; red[wv][64 * MAXJ + lane + 64 * j] = s2[j]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(dbeta + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-        atomicAdd(dgamma + c, (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]));
+        const float vb = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        const float vg = (red[0][64 * MAXJ + c] + red[1][64 * MAXJ + c]) + (red[2][64 * MAXJ + c] + red[3][64 * MAXJ + c]);
+        if (slab) { slab[(int64_t)blockIdx.x * 2 * C + c] = vb; slab[(int64_t)blockIdx.x * 2 * C + C + c] = vg; }
+        else { atomicAdd(dbeta + c, vb); atomicAdd(dgamma + c, vg); }
     }
 }
 
@@ -763,7 +766,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxels, int max_points, int nslots, const float* __restrict__ F8,
                                                          const T* __restrict__ dX2, const float* __restrict__ w1, const float* __restrict__ sc1,
                                                          const float* __restrict__ sh1, const float* __restrict__ mean1,
-                                                         const float* __restrict__ rstd1, float* __restrict__ acc) {
+                                                         const float* __restrict__ rstd1, float* __restrict__ acc, float* __restrict__ slab = nullptr) {
     const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     float wr[8];
 #pragma unroll
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxel
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ACC1_FLOATS; i += 256) atomicAdd(acc + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+    for (int i = threadIdx.x; i < ACC1_FLOATS; i += 256) p3_commit(acc, slab, ACC1_FLOATS, i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
 }
 
 // step 4: dW1 = gamma*rstd * (S_dyf - dbeta/n * S_f - dgamma/n * S_xf), dgamma1, dbeta1
@@ -920,6 +923,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     g.invx = 1.0f / d->vx; g.invy = 1.0f / d->vy; g.invz = 1.0f / d->vz;
     g.xmax = d->nx * d->vx; g.ymax = d->ny * d->vy; g.zmax = d->zmax; g.vx = d->vx; g.vy = d->vy;
     hipStream_t s = (hipStream_t)stream;
+    const int kdt = d->dtype == P3_BF16 ? P3_BF16 : P3_F32;       // the dtype p3_det_scratch decides by (P3_F32X3 is fp32 storage)
     Ws w = carve(workspace, d);
     const int nslots = d->B * d->max_voxels;
     const size_t es = d->dtype == P3_BF16 ? 2 : 4;
@@ -960,9 +964,13 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
     P3_LAUNCH_CHECK();
     if (d->training) {
-        if (d->max_points > 64) hipLaunchKernelGGL(pfn_l1_stats_kernel<true>, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
-        else hipLaunchKernelGGL(pfn_l1_stats_kernel<false>, dim3(vgrid < 512 ? vgrid : 512), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1);
+        // deterministic mode (p3_set_deterministic covers this dtype): the workgroups' partial sums go to the scratch and are added in workgroup order in float64
+        const int g1 = vgrid < 512 ? vgrid : 512;
+        float* slab1 = p3_det_scratch((int64_t)g1 * 2 * C1, kdt);
+        if (d->max_points > 64) hipLaunchKernelGGL(pfn_l1_stats_kernel<true>, dim3(g1), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1, slab1);
+        else hipLaunchKernelGGL(pfn_l1_stats_kernel<false>, dim3(g1), dim3(256), 0, s, values, t, g, d->max_voxels, nslots, w1, w.sums1, slab1);
         P3_LAUNCH_CHECK();
+        if (slab1) { int rc1 = p3_det_reduce(slab1, g1, 2 * C1, w.sums1, 2 * C1, 1, s); if (rc1 != P3_OK) return rc1; }
     }
     }
     if (phases & 2) {
@@ -977,7 +985,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
     gd.M = (int)rows; gd.N = d->C; gd.K = K2; gd.lda = K2; gd.ldb = K2; gd.ldc = d->C;
-    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32 gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32
     int rc = p3_gemm(w.X2, w2, w.H2, &gd, stream);
     if (rc != P3_OK) return rc;
     float* sums2 = d->training ? w.sums2 : nullptr;
@@ -985,8 +993,13 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
         hipLaunchKernelGGL(pfn_l2_reduce8_kernel, dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     else if (d->dtype == P3_BF16)
         hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
-    else
-        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
+    else {
+        const int g2 = vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS;
+        float* slab2 = sums2 ? p3_det_scratch((int64_t)g2 * 2 * d->C, kdt) : nullptr;
+        hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2, slab2);
+        P3_LAUNCH_CHECK();
+        if (slab2) { int rc2 = p3_det_reduce(slab2, g2, 2 * d->C, sums2, 2 * d->C, 1, s); if (rc2 != P3_OK) return rc2; }
+    }
     P3_LAUNCH_CHECK();
     }
     if (phases & 4) {
@@ -1024,6 +1037,7 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
              "p3_pillar_stem_bwd: null pointer");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 4096, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
     hipStream_t s = (hipStream_t)stream;
+    const int kdt = d->dtype == P3_BF16 ? P3_BF16 : P3_F32;       // the dtype p3_det_scratch decides by (P3_F32X3 is fp32 storage)
     Ws w = carve(workspace, d);
     const int nslots = d->B * d->max_voxels;
     const size_t rows = (size_t)d->total_points + (size_t)nslots;
@@ -1048,8 +1062,17 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
             hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel, dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
         else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
-    else
-        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+    else {
+        const int g3 = vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS;
+        float* slab3 = p3_det_scratch((int64_t)g3 * 2 * C, kdt);
+        hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(g3), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2, slab3);
+        P3_LAUNCH_CHECK();
+        if (slab3) {
+            int rc3 = p3_det_reduce(slab3, g3, 2 * C, db2, C, 1, s);
+            if (rc3 == P3_OK) rc3 = p3_det_reduce(slab3 + C, g3, 2 * C, dg2, C, 1, s);
+            if (rc3 != P3_OK) return rc3;
+        }
+    }
     P3_LAUNCH_CHECK();
     }
     if (phases & 2) {
@@ -1067,13 +1090,17 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
     gd.M = (int)rows; gd.N = K2; gd.K = C; gd.lda = C; gd.ldb = C; gd.ldc = K2;
-    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32 gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;
+    gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32
     rc = p3_gemm(w.H2, w2t, w.X2, &gd, stream);
     if (rc != P3_OK) return rc;
     if (bf)
         hipLaunchKernelGGL((pfn_bwd_l1_kernel<bf16_t>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const bf16_t*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1);
-    else
-        hipLaunchKernelGGL((pfn_bwd_l1_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const float*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1);
+    else {
+        float* slab4 = p3_det_scratch((int64_t)sgrid * ACC1_FLOATS, kdt);
+        hipLaunchKernelGGL((pfn_bwd_l1_kernel<float>), dim3(sgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, w.F8, (const float*)w.X2, w1, w.sc1, w.sh1, w.m1, w.r1, w.acc1, slab4);
+        P3_LAUNCH_CHECK();
+        if (slab4) { int rc4 = p3_det_reduce(slab4, sgrid, ACC1_FLOATS, w.acc1, ACC1_FLOATS, 1, s); if (rc4 != P3_OK) return rc4; }
+    }
     P3_LAUNCH_CHECK();
     }
     if (phases & 4) {

@@ -16,7 +16,8 @@ constexpr int SK_MAXK = 13, SK_MAXC = 4;   // rows <= 16*13 = 208, cols <= 256  
 __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n,
                                                             int iters, const float* __restrict__ perm, const float* __restrict__ uv_hist,
                                                             const float* __restrict__ dperm, float* __restrict__ dscores,
-                                                            float* __restrict__ dalpha, const int* __restrict__ tile_flags) {
+                                                            float* __restrict__ dalpha, const int* __restrict__ tile_flags,
+                                                            float* __restrict__ da_slab = nullptr /* deterministic mode: this tile's dalpha share, slot blockIdx.x */) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int M1 = m + 1, N1 = n + 1;
     float* Z = sm;                   // [M1][N1]
@@ -27,7 +28,10 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
     float* dv = du + M1;             // [N1]
     float* dvn = dv + N1;            // [N1] next dv (accumulated with LDS atomics)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tile_flags[b] == 0) return;       // this tile was done by sinkhorn_bwd_fast_kernel (linear domain)
+    if (tile_flags[b] == 0) {             // this tile was done by sinkhorn_bwd_fast_kernel (linear domain)
+        if (da_slab && tid == 0) da_slab[b] = 0.f;
+        return;
+    }
     const float alpha = alpha_p[0];
     for (int i = tid; i < M1 * N1; i += 1024) {
         const int r = i / N1, c = i - r * N1;
@@ -127,7 +131,12 @@ __global__ __launch_bounds__(1024) void sinkhorn_bwd_kernel(const float* __restr
         }
     }
     da = wave_sum(da);
-    if (lane == 0 && da != 0.f) atomicAdd(dalpha, da);
+    if (da_slab) {                        // fixed order: the 16 waves fold through LDS, one plain store per tile; p3_det_reduce adds the tiles in tile order
+        __syncthreads();
+        if (lane == 0) sm[w] = da;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += sm[k]; da_slab[b] = t; }
+    } else if (lane == 0 && da != 0.f) atomicAdd(dalpha, da);
 }
 
 // ---- linear-domain backward (tiles whose row spread allows E = exp(Z - rowmax), see sinkhorn.hip) -------------------------------
@@ -303,13 +312,15 @@ template <int RA2, int CB>
 __global__ __launch_bounds__(256) void sinkhorn_bwd_dz_kernel(const float* __restrict__ scores, const float* __restrict__ alpha_p, int m, int n, int iters,
                                                               const float* __restrict__ perm, const float* __restrict__ dperm, float* __restrict__ dscores,
                                                               float* __restrict__ dalpha, const int* __restrict__ tile_flags, const float* __restrict__ vecs,
-                                                              const float* __restrict__ rmax_in) {
+                                                              const float* __restrict__ rmax_in, float* __restrict__ da_slab = nullptr /* slot blockIdx.x */) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / SK_RS, rs = blockIdx.x - b * SK_RS;
-    if (tile_flags[b] != 0) return;                       // a wide tile: the log-domain kernel computes it
     const int M1 = m + 1, N1 = n + 1, VS = 2 * (M1 + N1);
     const int RPW = (M1 + SK_RS - 1) / SK_RS, r0 = rs * RPW, nr = min(M1 - r0, RPW);
-    if (nr <= 0) return;
+    if (tile_flags[b] != 0 || nr <= 0) {                  // a wide tile (the log-domain kernel computes it) / a row block past the end
+        if (da_slab && threadIdx.x == 0) da_slab[blockIdx.x] = 0.f;
+        return;
+    }
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int W = 2 * RPW + 2 * N1;                       // floats staged per iteration: [A rows | D rows | B | C]
     const float* vt_all = vecs + (int64_t)b * iters * VS;
@@ -384,14 +395,19 @@ __global__ __launch_bounds__(256) void sinkhorn_bwd_dz_kernel(const float* __res
         }
     }
     da = wave_sum(da);
-    if ((tid & 63) == 0 && da != 0.f) atomicAdd(dalpha, da);
+    if (da_slab) {
+        __syncthreads();
+        if ((tid & 63) == 0) sm[tid >> 6] = da;
+        __syncthreads();
+        if (tid == 0) da_slab[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    } else if ((tid & 63) == 0 && da != 0.f) atomicAdd(dalpha, da);
 }
 
 // ------------------------------------------------------------------------------------------------ losses
 // CrossEntropyLoss(ignore_index) over rows: acc[0] += sum(lse - logit[target]), acc[1] += #valid rows; row_lse saved
 // grid-stride over rows (one wave per row), ONE pair of atomics per block: 24640 same-address atomics from per-row lanes cost 0.3 ms
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ tgt, int R, int V,
-                                                     int ignore, float* __restrict__ row_lse, float* __restrict__ acc) {
+                                                     int ignore, float* __restrict__ row_lse, float* __restrict__ acc, float* __restrict__ slab) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float loss = 0.f, cnt = 0.f;
     for (int row = blockIdx.x * 4 + wv; row < R; row += gridDim.x * 4) {
@@ -413,8 +429,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     if (lane == 0) { red[0][wv] = loss; red[1][wv] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(acc, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-        atomicAdd(acc + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        p3_commit(acc, slab, 2, 0, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        p3_commit(acc, slab, 2, 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
     }
 }
 
@@ -435,7 +451,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const in
 }
 
 // BCELoss (mean): acc[0] += sum -(y*max(log p,-100) + (1-y)*max(log(1-p),-100))
-__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float* __restrict__ acc, float* __restrict__ slab) {
     // four elements per thread in flight; ONE atomic per workgroup (r03: one per wave from 1024 workgroups was a 4096-deep same-address chain
     // - 58 us for 19 MB of input)
     float s = 0.f;
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) p3_commit(acc, slab, 1, 0, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, const float* __restrict__ gscale,
@@ -562,6 +578,8 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
     // two launches: the linear-domain kernel takes every tile whose row spread allows it and flags the others for the log-domain
     // kernel, which returns at once for the tiles already done (one kernel holding both loops spilled 40 more registers)
     float* rmaxs = vecs + (int64_t)B * iters * 2 * (m + n + 2);
+    // deterministic mode: dalpha (the gradient of bin_score) = the tiles' / row blocks' shares added in a fixed order instead of by fp32 atomics
+    float* da_slab = p3_det_scratch((int64_t)B * SK_RS + B, P3_F32);
 #define P3_SKB_LAUNCH(RA, CB, RA2)                                                                                                        \
     do {                                                                                                                                  \
         const size_t zf = (size_t)(m + 1) * (n + 1) > (size_t)sk::Slab<CB>::FLOATS ? (size_t)(m + 1) * (n + 1) : (size_t)sk::Slab<CB>::FLOATS; \
@@ -578,7 +596,7 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
         const int rpw = (m + 1 + SK_RS - 1) / SK_RS;                                                                                      \
         const size_t lds_dz = (size_t)SK_TC * (2 * rpw + 2 * (n + 1)) * sizeof(float);                                                    \
         hipLaunchKernelGGL((sinkhorn_bwd_dz_kernel<RA2, CB>), dim3(B * SK_RS), dim3(256), lds_dz, s, scores, alpha, m, n, iters, perm, dperm, dscores, \
-                           dalpha, tile_flags, vecs, rmaxs);                                                                              \
+                           dalpha, tile_flags, vecs, rmaxs, da_slab);                                                                     \
     } while (0)
     {
         const int M1 = m + 1, N1 = n + 1;      // RA2 = ceil(ceil(M1 / 8) / 16)
@@ -589,8 +607,10 @@ extern "C" int p3_sinkhorn_bwd(const float* scores, const float* alpha, int B, i
         else P3_SKB_LAUNCH(4, 16, 2);
     }
 #undef P3_SKB_LAUNCH
-    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags);
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(1024), lds, s, scores, alpha, m, n, iters, perm, uv_hist, dperm, dscores, dalpha, tile_flags,
+                       da_slab ? da_slab + (int64_t)B * SK_RS : nullptr);
     P3_LAUNCH_CHECK();
+    if (da_slab) return p3_det_reduce(da_slab, B * SK_RS + B, 1, dalpha, 1, 1, s);
     return P3_OK;
 }
 
@@ -598,8 +618,10 @@ extern "C" int p3_ce_loss_fwd(const float* logits, int ld, const int64_t* target
                               void* stream) {
     P3_CHECK(logits && targets && row_lse && acc && R > 0 && V > 0, P3_EINVAL, "p3_ce_loss_fwd: bad arguments");
     const int gr = (R + 3) / 4 < 512 ? (R + 3) / 4 : 512;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(gr), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, R, V, ignore_index, row_lse, acc);
+    float* slab = p3_det_scratch((int64_t)gr * 2, P3_F32);       // deterministic mode: (loss sum | valid rows) per workgroup, added in workgroup order
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(gr), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, R, V, ignore_index, row_lse, acc, slab);
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, gr, 2, acc, 2, 1, (hipStream_t)stream);
     return P3_OK;
 }
 
@@ -617,8 +639,11 @@ extern "C" int p3_ce_loss_bwd(const float* logits, int ld, const int64_t* target
 
 extern "C" int p3_bce_loss_fwd(const float* p, const float* y, int64_t n, float* acc, void* stream) {
     P3_CHECK(p && y && acc && n > 0, P3_EINVAL, "p3_bce_loss_fwd: bad arguments");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, y, n, acc);
+    const int gb = grid_for(n) > 512 ? 512 : grid_for(n);
+    float* slab = p3_det_scratch(gb, P3_F32);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(gb), dim3(256), 0, (hipStream_t)stream, p, y, n, acc, slab);
     P3_LAUNCH_CHECK();
+    if (slab) return p3_det_reduce(slab, gb, 1, acc, 1, 1, (hipStream_t)stream);
     return P3_OK;
 }
 

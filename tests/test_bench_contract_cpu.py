@@ -18,7 +18,7 @@ def _bench():
         sys.argv = argv
 
 
-def _line(name="r04_bench.json"):
+def _line(name="r05_bench.json"):
     with open(os.path.join(ROOT, "profiles", name)) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
@@ -38,31 +38,40 @@ def test_committed_bench_line_has_the_contract_keys_and_is_self_consistent():
         assert k in d, k
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "tiles/s"      # BASELINE names the N = 1/2/4/8 sweep and fwd ms/tile after it
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # the headline precision is the one that meets north_star's tolerance, and the line carries its own measured error against the oracle
+    assert d["precision"] == "fp32x3" and d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    e = d["fp32x3_vs_oracle"]
+    assert e["logits_rel"] < 1e-3 and e["perm_rel"] < 1e-3 and e["argmax_agree"] == 1.0 and e["argmax_positions"] >= 770
+    assert d["bf16_vs_oracle"]["logits_rel"] > 1e-3                                        # why bf16 is a sub-object and not `value`
     tiles = d["config"]["tiles_per_gpu"] * d["n_gpus"]
     assert abs(d["value"] - tiles / d["ms_per_step"] * 1e3) < 0.01 * d["value"]            # value = whole-job tiles / step time
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and (r["peak"] == 8000.0 or abs(r["peak"] - 2500.0 / 3.0) < 1.0)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # achieved = algorithmic bytes per launch / measured launch time: re-derive it from the line's own fields
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
+    # achieved = algorithmic bytes (or FLOP) per launch / measured launch time: re-derive it from the line's own fields
+    if r["bound"] == "hbm":
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
+    else:
+        assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 0.01 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]   # counter traffic cannot be below the algorithmic bytes
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
-    f = d["fp32_parity_mode"]
-    assert f["dtype"] == "f32" and f["value"] > 0 and abs(f["value"] - tiles / f["ms_per_step"] * 1e3) < 0.01 * f["value"]
+    for key, dt_ in (("fp32_exact_mode", "f32"), ("bf16_mode", "bf16")):
+        f = d[key]
+        assert f["dtype"] == dt_ and f["value"] > 0 and abs(f["value"] - tiles / f["ms_per_step"] * 1e3) < 0.01 * f["value"]
+    assert d["bf16_mode"]["value"] > d["value"] > d["fp32_exact_mode"]["value"]
     p = d["pcie_inclusive"]
     assert p["value"] <= d["value"] * 1.02 and len(p["ms_per_step_all"]) == p["repeats"] >= 3
 
 
 def test_pmc_table_feeds_the_roofline_traffic_fields():
     bench, _ = _bench()
-    table, src = bench.pmc_step_traffic()
-    assert table is not None and src == "profiles/r04_pmc_traffic.json"
+    table, src = bench.pmc_step_traffic("fp32x3")
+    assert table is not None and src == "profiles/r05_pmc_traffic_fp32x3.json"
     r = _line()["roofline"]
     per_launch = bench.kernel_traffic(table, r["kernel"])
     # hand computation of the same average: the PMC rows of that kernel (rocprofv3 spells bf16 "unsigned short"), launches-weighted
@@ -73,10 +82,11 @@ def test_pmc_table_feeds_the_roofline_traffic_fields():
             n += v["launches"]
     assert n > 0 and per_launch == round(tot / n)
     assert r["traffic_source"] == src and r["traffic"] == per_launch
-    assert 0.5e11 < table["_step_total_bytes"] < 2e11 and table["_steps"] >= 1
+    assert 0.5e11 < table["_step_total_bytes"] < 3e11 and table["_steps"] >= 1
     assert bench.kernel_traffic(None, r["kernel"]) is None
-    # the r01 / r02 label (every plain-A bf16 instantiation of gemm_kernel) still resolves
-    assert bench.kernel_traffic(table, "gemm_kernel<bf16,plain>") > 0
+    # the r01 / r02 label (every plain-A bf16 instantiation of gemm_kernel) still resolves on the bf16 table
+    tb, sb = bench.pmc_step_traffic("bf16")
+    assert tb is not None and bench.kernel_traffic(tb, "gemm_kernel<bf16,plain>") > 0
     for v in table.values():
         if isinstance(v, dict) and "fetch_bytes_raw" in v:                                   # gfx950 correction of the guide: FETCH_SIZE doubled
             assert abs(v["fetch_bytes_corrected"] - 2.0 * v["fetch_bytes_raw"]) <= 1e-6 * max(1.0, v["fetch_bytes_corrected"])
@@ -88,14 +98,14 @@ def test_rocprof_summary_agrees_with_the_live_kernel_timing():
     the line lists (tier brief, measurement section)."""
     import re
     r = _line()["roofline"]
-    txt = open(os.path.join(ROOT, "profiles", "r04_train_step_graph_summary.txt")).read()
+    txt = open(os.path.join(ROOT, "profiles", "r05_fp32x3_step_summary.txt")).read()
     avg = {}
     for m in re.finditer(r"n=\s*([0-9.]+)\s+avg=\s*([0-9.]+) us\s+(\S.*)$", txt, re.M):
         avg[m.group(3).replace(" ", "")] = (float(m.group(2)), float(m.group(1)))
     key = r["kernel"].replace(" ", "")
     assert key in avg, f"{r['kernel']} missing from the rocprof summary"
     assert abs(avg[key][0] - r["avg_launch_us"]) < 0.10 * r["avg_launch_us"]
-    assert abs(avg[key][1] * 2 - r["launches"]) <= 0.02 * r["launches"]          # 2 instrumented steps
+    assert abs(avg[key][1] * 2 - r["launches"]) <= 0.03 * r["launches"]          # 2 instrumented steps (the pillar stem's two internal p3_gemm launches per step are not bracketed by the host timer)
     for nk in r["next_kernels"][:3]:
         k2 = nk["kernel"].replace(" ", "")
         if k2 in avg:

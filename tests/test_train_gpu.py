@@ -140,3 +140,43 @@ def test_a_backward_pass_that_raises_does_not_poison_the_next_step():
     atomic = {"bin_score", "decoder.embedding.weight"}
     bad = [k for k in g_ok if k not in atomic and not torch.equal(g_fail[k], g_ok[k])]
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_parity_mode_train_step_is_bit_reproducible(precision):
+    """The reference seeds everything and sets cudnn.deterministic (misc/shared_utils.py:120-126).  Here, with P3_DETERMINISTIC >= 1 (the default), every kernel of
+    the fp32-family train step that would finish in fp32 atomics - BatchNorm sums of the pillar stem / fusion conv / ScoreNet, split-M weight gradients, bias and
+    LayerNorm parameter gradients, the embedding gradient, the loss scalars, the Sinkhorn dustbin gradient - adds its workgroup partials in a fixed order in float64
+    instead: two runs of the same early-fusion step from the same state give the same BITS in every output, every running statistic and every parameter gradient."""
+    from oracle import p3_oracle as O
+    from pixelspointspolygons_amd import hip, ops
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pix2poly import Pix2PolyModel, Tokenizer
+    from pixelspointspolygons_amd.training import FlatAdamW, pix2poly_loss
+    assert hip.DETERMINISTIC >= 1
+    sd = O.make_state_dict("fusion", seed=42)
+    inp = {k: v.to("cuda") for k, v in O.make_inputs(4, seed=5).items()}
+
+    def run():
+        ops.reset_process_state()
+        cfg = make_config("early_fusion_vit", precision=precision, device="cuda")
+        m = Pix2PolyModel(cfg, Tokenizer(cfg).vocab_size, 0)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        opt = FlatAdamW(m, compute_dtype=torch.float32)       # the bench's wiring: gradients accumulated in place in the flat arena; decoder dropout ON (counter-based masks)
+        ops.manual_seed(1234, "cuda")
+        opt.zero_grad()
+        ops.advance_rng("cuda")
+        logits, perm = m(inp["image"], (inp["lidar_values"], inp["lidar_offsets"]), inp["y"][:, :-1])
+        loss = pix2poly_loss(logits, perm, inp["y"][:, 1:], inp["y_perm"])[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {"loss": loss.detach().clone(), "logits": logits.detach().clone(), "perm": perm.detach().clone()}
+        out.update({"g:" + k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        out.update({"b:" + k: v.detach().clone() for k, v in m.named_buffers() if v.is_floating_point()})
+        opt.close()
+        return out
+    a, b = run(), run()
+    ops.reset_process_state()
+    bad = sorted(((float((a[k].float() - b[k].float()).abs().max() / a[k].float().abs().max().clamp_min(1e-30)), k) for k in a if not torch.equal(a[k], b[k])), reverse=True)
+    assert not bad, (len(bad), bad[:10])
