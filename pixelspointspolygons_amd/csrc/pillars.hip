@@ -1084,7 +1084,10 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
         hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
     P3_LAUNCH_CHECK();
     // dW2[C, 64] = dH2^T . X2
-    int rc = p3_gemm_tn_ex(w.H2, w.X2, dw2, (int)rows, C, K2, C, K2, K2, d->dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+    // deterministic mode: the split-M partial tiles go through the scratch and are added in split order (the host wrappers of p3_gemm_tn hand their own slabs in)
+    const int tn_slabs = 64;
+    float* tslab = p3_det_scratch((int64_t)tn_slabs * C * K2, kdt);
+    int rc = p3_gemm_tn_ex(w.H2, w.X2, dw2, (int)rows, C, K2, C, K2, K2, d->dtype, 0, nullptr, nullptr, nullptr, 0, nullptr, tslab, tslab ? tn_slabs : 0, stream);
     if (rc != P3_OK) return rc;
     // dX2[rows, 64] = dH2 . W2  (written over X2, which the weight-gradient GEMM above has finished with)
     p3_gemm_desc gd;
