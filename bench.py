@@ -329,7 +329,7 @@ def cpu_baseline(args, kind, probes=None):
     for B in (1, 8):
         inp, img, lidar = inputs(B)
         with torch.no_grad():
-            ts = run(lambda: O.pix2poly_forward(sd, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=False), 3 if B == 1 else 1, 10, 10.0, min_n=3)
+            ts = run(lambda: O.pix2poly_forward(sd, inp["y"][:, :-1], img, lidar, cfg=cfgv, training=False), 3 if B == 1 else 1, 10, 10.0 if B == 1 else 40.0, min_n=3)      # 10 timed iterations per leg (B = 8: ~2.5 s each)
         fwd[f"B{B}_ms_per_tile"] = _stats([t * 1e3 / B for t in ts])
     p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     params = [v for v in p.values() if v.is_floating_point() and v.requires_grad]

@@ -91,6 +91,16 @@ int p3_reduce_flush(void* stream);
 int p3_reduce_pending(void);
 int p3_reduce_drop(void);              /* forget the parked sets without adding them (after a backward pass that raised); returns how many */
 int p3_scratch_stream(void* stream);
+/* Deferred weight-gradient reduces (r05), the same idea for the split-M weight-gradient GEMMs (p3_gemm_tn / p3_gemm_tn_ex / p3_gemm_tn_x3) in the deterministic mode:
+ * between p3_tn_defer_enable(1) and (0) a launch that would store its partial tiles in the caller's `slabs` and add them to C with a reduce launch of its own
+ * (109 launches of ~16 us per fp32x3 train step) parks them in `arena` instead (p3_tn_defer: device memory, caller-owned; a full arena / table falls back to the
+ * immediate reduce); p3_tn_flush(stream) adds every parked set to its C - float64, split order: bit-identical gradients - in ceil(sets / 96) launches.  Only for
+ * C that stays valid and unread until the flush (views of the optimizer's gradient arena); call the flush after the backward pass. */
+int p3_tn_defer(float* arena, int64_t floats);
+int p3_tn_defer_enable(int on);
+int p3_tn_flush(void* stream);
+int p3_tn_pending(void);
+int p3_tn_drop(void);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[M,N] = act(A'[M,K] * W[N,K]^T + bias) + residual

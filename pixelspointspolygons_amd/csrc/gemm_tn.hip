@@ -461,6 +461,75 @@ void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, in
     int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, slabs, C, N, K, ldc, splits);
 }
+
+// ---- deferred weight-gradient reduces (r05) ------------------------------------------------------------------------------------------------------
+// In the deterministic mode every split-M weight gradient stores its partial tiles and a tn_reduce launch adds them to C at once: 109 launches of ~16 us per
+// fp32x3 train step.  When C is an accumulation target that stays valid and unread until the end of the backward pass (a view of the optimizer's gradient
+// arena), the partial tiles may instead be PARKED in a caller-provided arena (p3_tn_defer) and added by p3_tn_flush: the same float64 sum in split order per
+// element - bit-identical gradients - in ceil(n / 96) launches.  The host brackets exactly those launches with p3_tn_defer_enable(1 / 0).
+namespace {
+constexpr int TNP_MAX = 96;                 // entries per flush launch (kernel-argument table: 96 x 40 B)
+struct TnpEntry { const float* slab; float* C; int N, K, ldc, splits, first_block, pad; };
+struct TnpTable { TnpEntry e[TNP_MAX]; int n; };
+constexpr int TNP_CAP = 4 * TNP_MAX;
+TnpEntry g_tnp[TNP_CAP];
+int g_tnp_n = 0, g_tnp_on = 0;
+float* g_tnp_arena = nullptr;
+int64_t g_tnp_cap = 0, g_tnp_used = 0;
+
+__global__ __launch_bounds__(256) void tn_flush_kernel(TnpTable t) {
+    // block -> entry (the table is small: a linear walk), then 256 x 4 consecutive elements of that entry's tile
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.e[e + 1].first_block) ++e;
+    const TnpEntry en = t.e[e];
+    const int64_t total = (int64_t)en.N * en.K;
+    const int64_t i0 = ((int64_t)(blockIdx.x - en.first_block) * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < en.splits; ++s) {      // split order, float64 (tn_reduce_kernel's sum)
+        const float4 v = *reinterpret_cast<const float4*>(en.slab + (int64_t)s * total + i0);
+        a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+    }
+    const int n = (int)(i0 / en.K), k = (int)(i0 - (int64_t)n * en.K);       // K % 4 == 0: the four elements share a row
+    float* c = en.C + (int64_t)n * en.ldc + k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = (float)((double)c[q] + a[q]);
+}
+}  // namespace
+
+extern "C" int p3_tn_defer(float* arena, int64_t floats) { g_tnp_arena = arena; g_tnp_cap = arena ? floats : 0; g_tnp_used = 0; g_tnp_n = 0; return P3_OK; }
+extern "C" int p3_tn_defer_enable(int on) { const int was = g_tnp_on; g_tnp_on = on ? 1 : 0; return was; }
+extern "C" int p3_tn_pending(void) { return g_tnp_n; }
+extern "C" int p3_tn_drop(void) { const int n = g_tnp_n; g_tnp_n = 0; g_tnp_used = 0; return n; }
+
+// a slot of splits x N x K floats for this launch's partial tiles, with the reduce left to p3_tn_flush; NULL: the caller reduces at once
+float* p3_tn_park(float* C, int N, int K, int ldc, int splits) {
+    const int64_t floats = (int64_t)splits * N * K;
+    if (!g_tnp_on || !g_tnp_arena || g_tnp_n >= TNP_CAP || g_tnp_used + floats > g_tnp_cap || K % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C % 16) != 0) return nullptr;
+    float* slot = g_tnp_arena + g_tnp_used;
+    g_tnp_used += (floats + 63) / 64 * 64;
+    TnpEntry& en = g_tnp[g_tnp_n++];
+    en.slab = slot; en.C = C; en.N = N; en.K = K; en.ldc = ldc; en.splits = splits; en.first_block = 0; en.pad = 0;
+    return slot;
+}
+
+extern "C" int p3_tn_flush(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < g_tnp_n; base += TNP_MAX) {
+        TnpTable t;
+        t.n = g_tnp_n - base < TNP_MAX ? g_tnp_n - base : TNP_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.n; ++i) {
+            t.e[i] = g_tnp[base + i];
+            t.e[i].first_block = blocks;
+            blocks += p3_ceil_div((int64_t)t.e[i].N * t.e[i].K, 1024);
+        }
+        hipLaunchKernelGGL(tn_flush_kernel, dim3(blocks), dim3(256), 0, s, t);
+    }
+    g_tnp_n = 0; g_tnp_used = 0;
+    P3_LAUNCH_CHECK();
+    return P3_OK;
+}
 int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float* colsum, float* slabs, int max_slabs,
                        hipStream_t s);      // gemm_tn_dma.hip
 
@@ -525,6 +594,8 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     g.rows_per_split = p3_ceil_div(p3_ceil_div(M, splits), bm) * bm;
     splits = p3_ceil_div(M, g.rows_per_split);
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
+    bool parked = false;
+    if (g.slabs) { float* slot = p3_tn_park(C, N, K, ldc, splits); if (slot) { g.slabs = slot; parked = true; } }
     g.splits = splits;
     g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, dtype) : nullptr;
     dim3 grid(tiles * splits), block(256);
@@ -540,7 +611,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     else if (g.b_mode == P3_A_AFFINE_MASK2) P3_TN_LAUNCH(P3_A_AFFINE_MASK2);
     else P3_TN_LAUNCH(P3_A_PAIR_AFFINE_RELU);
 #undef P3_TN_LAUNCH
-    if (g.slabs) {
+    if (g.slabs && !parked) {
         int64_t gr = ((int64_t)N * K + 255) / 256; if (gr > 4096) gr = 4096;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
     }

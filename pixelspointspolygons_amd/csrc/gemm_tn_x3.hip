@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_x3_kernel(TdArgs g) {
 
 // C[n,k] += sum_s slabs[s][n][k] (float64, split order) - gemm_tn.hip
 void p3_tn_reduce_launch(const float* slabs, float* C, int N, int K, int ldc, int splits, hipStream_t s);
+float* p3_tn_park(float* C, int N, int K, int ldc, int splits);      // gemm_tn.hip: deferred reduce slot or NULL
 
 extern "C" int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, float* C, int ldc, int M, int N, int K,
                              float* colsum, float* slabs, int max_slabs, void* stream) {
@@ -248,6 +249,8 @@ extern "C" int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const 
     splits = p3_ceil_div(M, g.rows_per_split);
     g.splits = splits;
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
+    bool parked = false;                             // p3_tn_defer: the partial tiles wait in the caller's arena for p3_tn_flush instead of a reduce launch of their own
+    if (g.slabs) { float* slot = p3_tn_park(C, N, K, ldc, splits); if (slot) { g.slabs = slot; parked = true; } }
     g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, P3_F32) : nullptr;
     constexpr int NBUF = 4;
     const size_t lds = (size_t)NBUF * TD_STEP_BYTES;       // 4 x 32 KB (>= the 64 KB the fold needs)
@@ -260,7 +263,7 @@ extern "C" int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const 
     dim3 grid(tiles * splits), block(512);
     hipLaunchKernelGGL(gemm_tn_x3_kernel<NBUF>, grid, block, lds, s, g);
     if (p3_tracing()) p3_note_kernel("gemm_tn_x3_kernel<4>");
-    if (g.slabs) p3_tn_reduce_launch(g.slabs, C, N, K, ldc, splits, s);
+    if (g.slabs && !parked) p3_tn_reduce_launch(g.slabs, C, N, K, ldc, splits, s);
     P3_LAUNCH_CHECK();
     if (g.cs_slab) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
     return P3_OK;

@@ -500,11 +500,38 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict_
     }
 }
 
-// bf16, C % 8 == 0, C <= 512: a lane owns 8 consecutive channels (ONE 16-byte load per row instead of C / 64 two-byte loads), four rows in
-// flight; same outputs as pfn_l2_reduce_kernel.  (r02: 241 us in the column-group form, whose row loop was a chain of dependent loads.)
-__global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const bf16_t* __restrict__ H2, VoxTab t, int max_voxels, int max_points, int nslots,
+// eight consecutive channels of one row: ONE 16-byte access in bf16, two in fp32
+template <typename T> struct Row8;
+template <> struct Row8<bf16_t> {
+    uint4 raw;
+    __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    }
+};
+template <> struct Row8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void get(float (&v)[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+};
+
+// C % 8 == 0, C <= 512: a lane owns 8 consecutive channels (ONE 16-byte load per row in bf16, two in fp32, instead of C / 64 scalar loads), four rows in
+// flight; same outputs as pfn_l2_reduce_kernel.  (r02: 241 us in the column-group form, whose row loop was a chain of dependent loads; r05: the fp32 family
+// used to stay on that form - 2.05 ms at 40 k points per tile against this one's 0.50 in bf16 - and takes this kernel too.)
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const T* __restrict__ H2, VoxTab t, int max_voxels, int max_points, int nslots,
                                                              int C, float* __restrict__ hmax, float* __restrict__ hmin,
-                                                             float* __restrict__ sums /*[2C] or null*/) {
+                                                             float* __restrict__ sums /*[2C] or null*/, float* __restrict__ slab = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool act = lane * 8 < C;
     float s1[8], s2[8];
@@ -514,23 +541,24 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const bf16_t* __res
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         const int cnt = t.cnt[v];
         const int nrow = cnt + (cnt < max_points ? 1 : 0);
-        const bf16_t* base = H2 + (int64_t)t.row[v] * C + lane * 8;
+        const T* base = H2 + (int64_t)t.row[v] * C + lane * 8;
         float mx[8], mn[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { mx[k] = -INFINITY; mn[k] = INFINITY; }
         if (act) {
             for (int r0 = 0; r0 < nrow; r0 += 4) {
-                uint4 raw[4];
+                Row8<T> raw[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) raw[q] = r0 + q < nrow ? *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + q) * C) : make_uint4(0, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (r0 + q >= nrow) break;
                     const float wgt = r0 + q < cnt ? 1.f : (float)(max_points - cnt);
-                    const uint32_t wd[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+                    float vals[8];
+                    raw[q].get(vals);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const float val = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                        const float val = vals[k];
                         mx[k] = fmaxf(mx[k], val); mn[k] = fminf(mn[k], val);
                         s1[k] += wgt * val; s2[k] += wgt * val * val;
                     }
@@ -548,8 +576,8 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const bf16_t* __res
         for (int k = 0; k < 8; ++k) { red[wv][lane * 8 + k] = s1[k]; red[wv][512 + lane * 8 + k] = s2[k]; }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
-            atomicAdd(sums + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-            atomicAdd(sums + C + c, (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]));
+            p3_commit(sums, slab, 2 * C, c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+            p3_commit(sums, slab, 2 * C, C + c, (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]));
         }
     }
 }
@@ -712,8 +740,9 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows_kernel(VoxTab t, int max_
     }
 }
 
-// bf16, C % 8 == 0, C <= 512: a lane owns 8 channels (16-byte row accesses, the per-channel constants in registers for the whole walk)
-__global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max_voxels, int max_points, int nslots, int C, bf16_t* __restrict__ H2,
+// C % 8 == 0, C <= 512: a lane owns 8 channels (16-byte row accesses, the per-channel constants in registers for the whole walk); r05: fp32 too
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max_voxels, int max_points, int nslots, int C, T* __restrict__ H2,
                                                                const float* __restrict__ g, const float* __restrict__ hsel,
                                                                const float* __restrict__ gamma2, const float* __restrict__ mean2,
                                                                const float* __restrict__ rstd2, const float* __restrict__ dbeta,
@@ -731,7 +760,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max
         if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         const int cnt = t.cnt[v];
         const int nrow = cnt + (cnt < max_points ? 1 : 0);
-        bf16_t* base = H2 + (int64_t)t.row[v] * C + c0;
+        T* base = H2 + (int64_t)t.row[v] * C + c0;
         const float* gp = g + (int64_t)v * C + c0;
         const float* hp = hsel + (int64_t)v * C + c0;
         const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
@@ -739,23 +768,23 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max
         const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, hs[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         uint32_t found = 0;                              // bit k: the arg-max row of channel k has been credited
         for (int r0 = 0; r0 < nrow; r0 += 4) {
-            uint4 raw[4];
+            Row8<T> raw[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) raw[q] = r0 + q < nrow ? *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + q) * C) : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (r0 + q >= nrow) break;
                 const float wgt = r0 + q < cnt ? 1.f : (float)(max_points - cnt);
-                const uint32_t wd[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
-                float o[8];
+                float vals[8], o[8];
+                raw[q].get(vals);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float val = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
+                    const float val = vals[k];
                     float dv = -wgt * (a[k] + (val - mean[k]) * rstd[k] * bb[k]);
                     if (!((found >> k) & 1u) && val == hs[k]) { dv += gv[k]; found |= 1u << k; }
                     o[k] = gm[k] * dv;
                 }
-                *reinterpret_cast<uint4*>(base + (int64_t)(r0 + q) * C) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+                Row8<T>::store(base + (int64_t)(r0 + q) * C, o);
             }
         }
     }
@@ -989,9 +1018,14 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     int rc = p3_gemm(w.X2, w2, w.H2, &gd, stream);
     if (rc != P3_OK) return rc;
     float* sums2 = d->training ? w.sums2 : nullptr;
-    if (d->dtype == P3_BF16 && d->C % 8 == 0 && d->C <= 512)
-        hipLaunchKernelGGL(pfn_l2_reduce8_kernel, dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
-    else if (d->dtype == P3_BF16)
+    if (d->C % 8 == 0 && d->C <= 512) {
+        const int g2 = vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS;
+        float* slab2 = sums2 ? p3_det_scratch((int64_t)g2 * 2 * d->C, kdt) : nullptr;
+        if (d->dtype == P3_BF16) hipLaunchKernelGGL((pfn_l2_reduce8_kernel<bf16_t>), dim3(g2), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2, slab2);
+        else hipLaunchKernelGGL((pfn_l2_reduce8_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2, slab2);
+        P3_LAUNCH_CHECK();
+        if (slab2) { int rc2 = p3_det_reduce(slab2, g2, 2 * d->C, sums2, 2 * d->C, 1, s); if (rc2 != P3_OK) return rc2; }
+    } else if (d->dtype == P3_BF16)
         hipLaunchKernelGGL((pfn_l2_reduce_kernel<bf16_t>), dim3(vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS), dim3(256), 0, s, (const bf16_t*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2);
     else {
         const int g2 = vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS;
@@ -1076,9 +1110,10 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     P3_LAUNCH_CHECK();
     }
     if (phases & 2) {
-    if (bf && C % 8 == 0 && C <= 512)
-        hipLaunchKernelGGL(pfn_bwd_l2_rows8_kernel, dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
-    else if (bf)
+    if (C % 8 == 0 && C <= 512) {
+        if (bf) hipLaunchKernelGGL((pfn_bwd_l2_rows8_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
+        else hipLaunchKernelGGL((pfn_bwd_l2_rows8_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
+    } else if (bf)
         hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<bf16_t>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (bf16_t*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);
     else
         hipLaunchKernelGGL((pfn_bwd_l2_rows_kernel<float>), dim3(vgrid), dim3(256), 0, s, t, d->max_voxels, d->max_points, nslots, C, (float*)w.H2, w.hmax, w.hmin, bn2_gamma, w.m2, w.r2, s2_db, s2_dg, w.totals, d->training);

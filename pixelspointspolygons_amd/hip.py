@@ -352,16 +352,51 @@ def param_reduce_arena(mb=None):
     return True
 
 
+_tn_park = {"buf": None}
+
+
+def tn_defer_arena(mb=None):
+    """register (once per process) the arena the deterministic weight-gradient GEMMs park their split-M partial tiles in (p3_tn_defer); P3_TN_DEFER_MB, default 2560"""
+    if _tn_park["buf"] is None:
+        mb = int(_os0.environ.get("P3_TN_DEFER_MB", "2560")) if mb is None else mb
+        if mb <= 0:
+            _tn_park["buf"] = False
+            return False
+        _tn_park["buf"] = torch.empty(mb * (1 << 20) // 4, dtype=torch.float32, device="cuda")
+        check(lib().p3_tn_defer(ptr(_tn_park["buf"]), c_int64(_tn_park["buf"].numel())), "p3_tn_defer")
+    return _tn_park["buf"] is not False
+
+
+class tn_parking:
+    """`with hip.tn_parking(on):` weight-gradient launches inside may leave their split-M partial tiles parked for reduce_flush() (their outputs must be
+    accumulation targets that stay valid and unread until then: views of the optimizer's gradient arena)"""
+
+    def __init__(self, on):
+        self.on = bool(on) and DETERMINISTIC >= 1 and tn_defer_arena()
+
+    def __enter__(self):
+        if self.on:
+            lib().p3_tn_defer_enable(c_int(1))
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib().p3_tn_defer_enable(c_int(0))
+        return False
+
+
 def reduce_pending():
-    return int(lib().p3_reduce_pending())
+    return int(lib().p3_reduce_pending()) + int(lib().p3_tn_pending())
 
 
 def reduce_flush():
     check(lib().p3_reduce_flush(stream()), "p3_reduce_flush")
+    if lib().p3_tn_pending():
+        check(lib().p3_tn_flush(stream()), "p3_tn_flush")
 
 
 def reduce_drop():
-    return int(lib().p3_reduce_drop())
+    return int(lib().p3_reduce_drop()) + int(lib().p3_tn_drop())
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_dtype=None, dgamma=None, dbeta=None, dres=None, want_lo=False, lo_drop=None, park=False):

@@ -120,7 +120,12 @@ def side_join(*names):
 def _tn_side(a, b, **kw):
     """weight-gradient GEMM into the gradient arena: on the 'dw' side stream when switched on (the operands are kept from reuse until it ran)"""
     if not side_on("dw"):
-        return hip.gemm_tn(a, b, **kw)
+        # straight into the gradient arena (every caller passes out = a view of it): the split-M partial tiles of a deterministic launch may wait for the ONE
+        # flush at the end of the backward pass (hip.tn_parking) instead of a reduce launch per weight gradient
+        with hip.tn_parking(_park_ok()):
+            r = hip.gemm_tn(a, b, **kw)
+        _after_parking_launch()
+        return r
     with on_side("dw") as s:
         hip.gemm_tn(a, b, **kw)
     a.record_stream(s)
@@ -374,6 +379,7 @@ def reset_process_state():
     try:
         from ._lib import lib as _lib
         _lib().p3_reduce_drop()          # partials a failed backward pass left parked must not reach the next model's gradients
+        _lib().p3_tn_drop()
     except Exception:                    # noqa: BLE001 - no library in this process: nothing parked
         pass
     _BUMPS[0] = None

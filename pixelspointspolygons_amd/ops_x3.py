@@ -32,7 +32,9 @@ def block_params(blk):
 def _accum(weight, bias, dy, x, grads, iw, ib):
     """dW (+)= dy^T x, db (+)= colsum(dy): straight into the gradient arena under FlatAdamW(direct_grad), else into fresh tensors returned through autograd"""
     if ops.DIRECT_GRAD[0] and weight.grad is not None and bias.grad is not None:
-        hip.gemm_tn_x3(dy, x, out=weight.grad, colsum_out=bias.grad)
+        with hip.tn_parking(ops._park_ok()):            # the split-M partial tiles wait for the one flush at the end of the backward pass
+            hip.gemm_tn_x3(dy, x, out=weight.grad, colsum_out=bias.grad)
+        ops._after_parking_launch()
         ops._grad_ready(weight, bias)
         return
     db = torch.zeros_like(bias)
