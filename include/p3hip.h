@@ -508,6 +508,10 @@ int p3_pair_bwd_fused(const void* dH2, const void* W2t, const void* U, const voi
                       float* dU, float* dV, float* acc, int B, int N, void* workspace, void* stream);
 int p3_pair_stats_bwd(const void* U, const void* V, const float* a, const float* b, float* dU, float* dV, int B, int N, int C, int dtype,
                       void* stream);
+/* the same launch for P3_F32X3 (csrc/pair_bwd_x3.hip): everything fp32 in memory (dH2 [B N^2, 128], W2t [256, 128], U / V [B N, 256]), the products as
+ * three bf16 MFMA terms with fp32 accumulation; W2t's hi / lo split lives in registers.  Same outputs, same workspace size. */
+int p3_pair_bwd_fused_x3(const float* dH2, const float* W2t, const float* U, const float* V, const float* scale, const float* shift, const float* mean,
+                         float* dU, float* dV, float* acc, int B, int N, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FFL / *CNN encoder tails (models/fusion_layers/early_fusion_vit_cnn.py:87-104, models/vision_transformer/vit_cnn.py:45-57,

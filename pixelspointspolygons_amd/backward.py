@@ -6,7 +6,7 @@ import torch
 
 SUMS_FROM_G = [__import__("os").environ.get("P3_SUMS_FROM_G", "1") != "0"]    # BatchNorm-2 backward sums from the dual-operand weight-gradient GEMM (A/B switch)
 FUSED_BN2 = [__import__("os").environ.get("P3_BN2_FUSED", "1") != "0"]        # conv3 input gradient with the BatchNorm-2 / ReLU backward as its epilogue (needs SUMS_FROM_G)
-FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # bf16: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
+FUSED_PAIR = [__import__("os").environ.get("P3_PAIR_FUSED", "1") != "0"]      # bf16 / fp32x3: conv2 input gradient + pair backward in one launch (tests switch it off to compare with the two-launch form)
 
 
 def scorenet_backward(net, feats, keep, dout, transpose_acc):
@@ -70,7 +70,7 @@ def scorenet_backward_steps(net, feats, keep, dout, transpose_acc):
     db2 = ops.bias_grad_before_bn(dH2, training, net.conv2.bias)
     w2t = ops.shadow(net.conv2.weight, cd, key="2dT", fn=lambda t: t.reshape(t.shape[0], -1).t())          # [256, 128]
     acc1 = torch.zeros(2 * 256, **f32)
-    if cd == torch.bfloat16 and FUSED_PAIR[0]:
+    if (cd == torch.bfloat16 or (cd == torch.float32 and hip.split_now())) and FUSED_PAIR[0]:
         # dA2 = dH2 W2 ([R, 256]: 1.2 GB per net) is formed tile by tile inside the pair kernel and never stored (csrc/pair_bwd_mma.hip)
         dU, dV = hip.pair_bwd_fused(dH2, w2t, U, V, sc1, sh1, m1, B, N, acc1)
     else:

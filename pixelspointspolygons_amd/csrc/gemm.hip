@@ -768,6 +768,8 @@ int launch_mode(const GemmArgs& g, hipStream_t s) {
 // 9: 128 x 384 tile, 8 waves)
 int p3_rows_gemm_try(const void* A, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);   // rows_gemm.hip: 0x7fffffff = not one of its shapes
 int p3_pair_fwd_try(const void* U, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);    // pair_fwd_mma.hip: same convention
+int p3_pair_fwd_x3_try(const void* U, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s); // pair_fwd_x3.hip: the P3_F32X3 form
+int p3_rows_x3_try(const void* A, const void* W, void* C, const p3_gemm_desc* d, hipStream_t s);     // rows_x3.hip: conv3 forward, P3_F32X3
 int p3_gemm_dma_eligible(const p3_gemm_desc* d, const void* A, const void* W, const void* C);
 int p3_gemm_dma_launch(const void* A, const void* W, void* C, const p3_gemm_desc* d, int variant, hipStream_t s);
 static int gemm_dma_mode() { static int m = -1; if (m < 0) { const char* e = getenv("P3_GEMM_DMA"); m = (e && e[0] == '0') ? 0 : 1; } return m; }
@@ -827,6 +829,12 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
         if (rc != 0x7fffffff) return rc;
         rc = p3_pair_fwd_try(A, W, C, d, s);
         if (rc != 0x7fffffff) return rc;
+        if (split) {
+            rc = p3_pair_fwd_x3_try(A, W, C, d, s);
+            if (rc != 0x7fffffff) return rc;
+            rc = p3_rows_x3_try(A, W, C, d, s);
+            if (rc != 0x7fffffff) return rc;
+        }
     }
     if (gemm_dma_mode() > 0 && d->M >= 2048 && p3_gemm_dma_eligible(d, A, W, C)) {
         // P3_GEMM_DMA=0 switches the rule off (everything on the register-staged kernel).  The rule (r03, tools/mb_gemm_shapes.py + same-box A/B of the

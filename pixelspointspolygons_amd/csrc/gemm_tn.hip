@@ -538,6 +538,10 @@ int p3_pair_dw_try(const void* A, const void* U, float* C, int M, int N, int K, 
 
 int p3_mask2_dw_try(const void* A, const void* B, float* C, int M, int N, int Kb, int lda, int ldb, int ldc, const float* scale, const float* shift,
                     float* slabs, int max_slabs, hipStream_t s);      // mask2_dw_mma.hip
+int p3_mask2_dw_x3_try(const void* A, const void* B, float* C, int M, int N, int Kb, int lda, int ldb, int ldc, const float* scale, const float* shift,
+                       float* slabs, int max_slabs, hipStream_t s);      // mask2_dw_x3.hip: the P3_F32X3 form
+int p3_pair_dw_x3_try(const void* A, const void* U, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* scale, const float* shift,
+                      const void* pair_V, int pair_n, float* slabs, int max_slabs, hipStream_t s);   // pair_dw_x3.hip: the P3_F32X3 form
 
 extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype_in, int b_mode,
                              const float* b_scale, const float* b_shift, const void* pair_V, int pair_n, float* colsum, float* slabs, int max_slabs, void* stream) {
@@ -561,8 +565,16 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
         const int rc = p3_pair_dw_try(A, B, C, M, N, K, lda, ldb, ldc, b_scale, b_shift, pair_V, pair_n, slabs, max_slabs, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
+    if (split && b_mode == P3_A_PAIR_AFFINE_RELU && !colsum) {                     // the same launch with fp32 operands, products as bf16 x 3: pair_dw_x3.hip
+        const int rc = p3_pair_dw_x3_try(A, B, C, M, N, K, lda, ldb, ldc, b_scale, b_shift, pair_V, pair_n, slabs, max_slabs, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     if (dtype == P3_BF16 && b_mode == P3_A_AFFINE_MASK2 && !colsum) {             // conv3's dual-operand weight gradient: mask2_dw_mma.hip
         const int rc = p3_mask2_dw_try(A, B, C, M, N, K, lda, ldb, ldc, b_scale, b_shift, slabs, max_slabs, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
+    if (split && b_mode == P3_A_AFFINE_MASK2 && !colsum) {                        // fp32 operands, products as bf16 x 3: mask2_dw_x3.hip
+        const int rc = p3_mask2_dw_x3_try(A, B, C, M, N, K, lda, ldb, ldc, b_scale, b_shift, slabs, max_slabs, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
     TnArgs g; g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

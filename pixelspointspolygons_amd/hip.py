@@ -1095,14 +1095,21 @@ def pair_bwd(dA, U, V, scale, shift, mean, B, N, acc):
 
 
 def pair_bwd_fused(dH2, w2t, U, V, scale, shift, mean, B, N, acc):
-    """conv2's input gradient + pair_bwd in one launch (bf16): dA2 = dH2 @ w2t^T never touches memory.  -> (dU, dV) fp32 [B N, 256]"""
-    if dt(dH2) != BF16 or dt(U) != BF16 or w2t.shape != (256, 128) or not w2t.is_contiguous() or not dH2.is_contiguous():
-        raise P3Error("pair_bwd_fused: bf16, contiguous dH2 [B N N, 128] and w2t [256, 128]")
+    """conv2's input gradient + pair_bwd in one launch: dA2 = dH2 @ w2t^T never touches memory.  -> (dU, dV) fp32 [B N, 256].
+    bf16 operands (csrc/pair_bwd_mma.hip), or fp32 operands inside a gemm_split scope (fp32x3: csrc/pair_bwd_x3.hip)."""
+    x3 = dt(dH2) == F32 and split_now()
+    want = F32 if x3 else BF16
+    if any(dt(t) != want for t in (dH2, w2t, U, V)) or w2t.shape != (256, 128) or not all(t.is_contiguous() for t in (dH2, w2t, U, V)) or dH2.shape[1] != 128:
+        raise P3Error("pair_bwd_fused: bf16 (or fp32 under gemm_split), contiguous dH2 [B N N, 128], w2t [256, 128], U / V [B N, 256]")
     dU = torch.empty((B * N, 256), dtype=torch.float32, device=U.device)
     dV = torch.zeros((B * N, 256), dtype=torch.float32, device=U.device)
     L = lib()
     L.p3_pair_bwd_fused_workspace_bytes.restype = c_int64
     ws = workspace(L.p3_pair_bwd_fused_workspace_bytes(c_int(B), c_int(N)), U.device, "pair_bwd")
+    if x3:
+        check(L.p3_pair_bwd_fused_x3(ptr(dH2), ptr(w2t), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N),
+                                     ptr(ws), stream()), "p3_pair_bwd_fused_x3")
+        return dU, dV
     check(L.p3_pair_bwd_fused(ptr(dH2), ptr(w2t), ptr(U), ptr(V), ptr(scale), ptr(shift), ptr(mean), ptr(dU), ptr(dV), ptr(acc), c_int(B), c_int(N),
                               ptr(ws), stream()), "p3_pair_bwd_fused")
     return dU, dV

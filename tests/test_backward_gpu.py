@@ -86,6 +86,40 @@ def test_pair_weight_gradient_kernel_of_the_scorenet_conv2(Bn, n):
     assert rel_err(out.cpu() - 0.25, ref.float()) < 2e-4
 
 
+@pytest.mark.parametrize("Bn,n", [(3, 48), (1, 192), (40, 16)])
+def test_pair_weight_gradient_x3_kernel_of_the_scorenet_conv2(Bn, n):
+    """csrc/pair_dw_x3.hip (p3_gemm_tn_ex in pair mode, P3_F32X3, n % 16 == 0): dW2 += dH2^T relu(bn1(U_i + V_j)) from fp32 operands as three bf16 MFMA terms,
+    against float64 at a split product's accuracy, accumulated into a non-zero C; (40, 16): several units per workgroup; n = 24 stays on gemm_tn.hip and agrees;
+    with slabs (the deterministic weight-gradient path) two launches are bit-identical."""
+    h = _h()
+    g = torch.Generator().manual_seed(13)
+    R = Bn * n * n
+    dH = torch.randn(R, 128, generator=g) * 0.3
+    U, V = torch.randn(Bn * n, 256, generator=g) * 0.7, torch.randn(Bn * n, 256, generator=g) * 0.7
+    sc, sh = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+
+    def ref_of(dHh, Uh, Vh, nn):
+        a1 = torch.relu(torch.addcmul(torch.addcmul(sh, Uh.view(-1, nn, 1, 256), sc), Vh.view(-1, 1, nn, 256), sc)).reshape(-1, 256)   # fp32, the kernel's fma order
+        return dHh.double().t() @ a1.double()
+    with h.gemm_split(True):
+        h.lib().p3_trace_kernels(1)
+        outs = []
+        for _ in range(2):
+            out = torch.full((128, 256), 0.25, device=DEV)
+            h.gemm_tn_ex(dH.to(DEV), U.to(DEV), out, h.A_PAIR_AFFINE_RELU, sc.to(DEV), sh.to(DEV), pair_v=V.to(DEV), pair_n=n, M=R)
+            outs.append(out)
+        picked = h.lib().p3_last_kernel().decode()
+        h.lib().p3_trace_kernels(0); h.lib().p3_trace_kernels(1)      # clears the last name: gemm_tn.hip's tile kernel records none
+        out24 = torch.zeros((128, 256), device=DEV)
+        h.gemm_tn_ex(dH[:576].to(DEV), U[:24].to(DEV), out24, h.A_PAIR_AFFINE_RELU, sc.to(DEV), sh.to(DEV), pair_v=V[:24].to(DEV), pair_n=24, M=576)
+        picked24 = h.lib().p3_last_kernel().decode()
+        h.lib().p3_trace_kernels(0)
+    assert picked == "pair_dw_x3_kernel" and picked24 != "pair_dw_x3_kernel", (picked, picked24)
+    assert rel_err(outs[0].cpu() - 0.25, ref_of(dH, U, V, n).float()) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(out24.cpu(), ref_of(dH[:576], U[:24], V[:24], 24).float()) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(3000, 384, 384), (50 * 385, 256, 1024), (777, 132, 64)])
 def test_gemm_tn_fp32_operands_as_bf16x3(M, N, K):
     """p3_gemm_tn with dtype P3_F32X3 (hip.gemm_split scope): the fp32 weight gradient as a_lo b_hi + a_hi b_lo + a_hi b_hi from transposing reads of the split images; 1e-5 against
@@ -701,6 +735,38 @@ def test_dual_operand_weight_gradient_streaming_kernel(R):
     assert rel_err(G.cpu() - 0.5, ref.float()) < 1e-4
 
 
+@pytest.mark.parametrize("R", [64 * 256, 64 * 601])
+def test_dual_operand_weight_gradient_x3_kernel(R):
+    """csrc/mask2_dw_x3.hip (p3_gemm_tn_ex P3_A_AFFINE_MASK2, P3_F32X3, R % 64 == 0, R >= 16384): G = dH3^T [y > 0] (two bf16 terms: the mask is exact) and G2 = dH3^T
+    ([y > 0] H2) (three) from fp32 operands - against float64 with the kernel's own decisions, accumulating into a non-zero matrix; 601 steps over 256 workgroups:
+    ragged walk; two launches bit-identical (slabs); a shorter R stays on gemm_tn.hip and agrees."""
+    h = _h()
+    g = torch.Generator().manual_seed(17)
+    dH3, H2 = torch.randn(R, 64, generator=g) * 0.3, torch.randn(R, 128, generator=g)
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    on = torch.addcmul(sh, H2, sc) > 0
+    ref = torch.cat([dH3.double().t() @ on.double(), dH3.double().t() @ (on * H2).double()], 1)
+    with h.gemm_split(True):
+        h.lib().p3_trace_kernels(1)
+        Gs = []
+        for _ in range(2):
+            G = torch.full((64, 256), 0.5, device=DEV)
+            h.gemm_tn_ex(dH3.to(DEV), H2.to(DEV), G, h.A_AFFINE_MASK2, sc.to(DEV), sh.to(DEV))
+            Gs.append(G)
+        picked = h.lib().p3_last_kernel().decode()
+        h.lib().p3_trace_kernels(0); h.lib().p3_trace_kernels(1)      # clears the last name: gemm_tn.hip's tile kernel records none
+        Gt = torch.zeros((64, 256), device=DEV)
+        h.gemm_tn_ex(dH3[:4096].to(DEV), H2[:4096].to(DEV), Gt, h.A_AFFINE_MASK2, sc.to(DEV), sh.to(DEV))
+        picked_t = h.lib().p3_last_kernel().decode()
+        h.lib().p3_trace_kernels(0)
+    assert picked == "mask2_dw_x3_kernel" and picked_t != "mask2_dw_x3_kernel", (picked, picked_t)
+    assert torch.equal(Gs[0], Gs[1])
+    # a decision may differ from the host expression's where y rounds to +-0 (fma vs mul + add): 1e-4 as for the bf16 kernel, measured ~1e-6
+    assert rel_err(Gs[0].cpu() - 0.5, ref.float()) < 1e-4
+    ref_t = torch.cat([dH3[:4096].double().t() @ on[:4096].double(), dH3[:4096].double().t() @ (on * H2)[:4096].double()], 1)
+    assert rel_err(Gt.cpu(), ref_t.float()) < 1e-4
+
+
 @pytest.mark.parametrize("B,N", [(2, 192), (3, 60), (2, 24), (1, 13), (1, 16)])
 def test_pair_bwd_fused_vs_float64_and_the_two_launch_form(B, N):
     """csrc/pair_bwd_mma.hip: conv2's input gradient dA2 = dH2 W2 formed in the MFMA accumulators of the pair kernel (never stored) - dU, dV and the
@@ -732,6 +798,45 @@ def test_pair_bwd_fused_vs_float64_and_the_two_launch_form(B, N):
     acc3 = torch.zeros(512, device=DEV)
     dU3, dV3 = h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, acc3)
     assert torch.equal(dU, dU3) and torch.equal(dV, dV3)
+
+
+@pytest.mark.parametrize("B,N", [(2, 192), (3, 60), (2, 24), (1, 13), (1, 16)])
+def test_pair_bwd_fused_x3_vs_float64_and_the_two_launch_form(B, N):
+    """csrc/pair_bwd_x3.hip, the fp32x3 form of the launch above: fp32 operands, dA2 = dH2 W2 as three bf16 MFMA terms in the accumulators of the pair
+    kernel.  Against float64 at a split product's accuracy (2e-5; measured ~3e-6), against p3_gemm (P3_F32X3) + p3_pair_bwd, and bit-reproducible -
+    BatchNorm sums included (the fp32 family reduces in fixed order)."""
+    h = _h()
+    R = B * N * N
+    dH2, w2t = _rand(R, 128, seed=1) * 0.5, _rand(256, 128, seed=2) * 0.1
+    U, V = _rand(B * N, 256, seed=3), _rand(B * N, 256, seed=4)
+    sc, sh, mu = 0.5 + _rand(256, seed=5).abs(), _rand(256, seed=6) * 0.3, _rand(256, seed=7)
+    dA = (dH2.double() @ w2t.double().t()).view(B, N, N, 256)
+    Uv, Vv = U.view(B, N, 1, 256), V.view(B, 1, N, 256)
+    on = torch.addcmul(torch.addcmul(sh, Uv, sc), Vv, sc) > 0      # the kernel's decision: fma(V, scale, fma(U, scale, shift)) > 0 (addcmul rounds twice, an
+    pre = Uv.double() + Vv.double()                                 # fma once: a handful of elements within 1e-7 of the kink may differ - inside the bound)
+    dz = dA * on
+    acc_ref = torch.cat([(dz * (pre - mu.double())).sum((0, 1, 2)), dz.sum((0, 1, 2))])
+    dU_ref = (dz * sc.double()).sum(2).reshape(B * N, 256)
+    dV_ref = (dz * sc.double()).sum(1).reshape(B * N, 256)
+    d = lambda t: t.to(DEV)
+    with h.gemm_split(True):
+        acc = torch.zeros(512, device=DEV)
+        h.lib().p3_trace_kernels(1)
+        dU, dV = h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, acc)
+        picked = h.lib().p3_last_kernel().decode()
+        h.lib().p3_trace_kernels(0)
+        assert picked == "pair_bwd_x3_kernel", picked
+        errs = (l2_err(dU.cpu(), dU_ref), l2_err(dV.cpu(), dV_ref), l2_err(acc.cpu(), acc_ref))
+        assert max(errs) < 2e-5, errs
+        dA2 = h.gemm(d(dH2), d(w2t), out_dtype=torch.float32)
+        acc2 = torch.zeros(512, device=DEV)
+        dU2, dV2 = h.pair_bwd(dA2, d(U), d(V), d(sc), d(sh), d(mu), B, N, acc2)
+        assert l2_err(dU.cpu(), dU2.cpu()) < 2e-5 and l2_err(dV.cpu(), dV2.cpu()) < 2e-5 and l2_err(acc.cpu(), acc2.cpu()) < 2e-5
+        acc3 = torch.zeros(512, device=DEV)
+        dU3, dV3 = h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, acc3)
+        assert torch.equal(dU, dU3) and torch.equal(dV, dV3) and torch.equal(acc, acc3)
+    with pytest.raises(h.P3Error):                                  # fp32 operands outside a split scope: there is no exact-fp32 form of this launch
+        h.pair_bwd_fused(d(dH2), d(w2t), d(U), d(V), d(sc), d(sh), d(mu), B, N, torch.zeros(512, device=DEV))
 
 
 @pytest.mark.parametrize("transpose,train,N,B", [(False, True, 24, 3), (True, True, 24, 3), (False, False, 24, 3), (True, False, 24, 3),

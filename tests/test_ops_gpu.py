@@ -242,6 +242,50 @@ def test_pair_forward_kernel_of_the_scorenet_conv2(Bn, n):
     assert torch.equal(ye, y)                                       # eval form (no sums)
 
 
+@pytest.mark.parametrize("Bn,n", [(3, 64), (2, 40), (1, 192)])
+def test_pair_forward_x3_kernel_of_the_scorenet_conv2(Bn, n):
+    """csrc/pair_fwd_x3.hip (P3_F32X3 at the ScoreNet conv2 shape: fp32 operands, the generated operand and W2 split into hi / lo bf16, three MFMA terms):
+    relu(bn1(U_i + V_j)) W2^T + bias with the BatchNorm-2 column sums against float64 at a split product's accuracy, against the tile kernel (same mode,
+    n = 20: not a multiple of 8 stays there); bit-reproducible; n = 40: ragged last 16-column step; the eval form (no sums) gives the same output."""
+    hip = _h()
+    from pixelspointspolygons_amd._lib import lib
+    g = torch.Generator().manual_seed(7)
+    U, V = torch.randn(Bn * n, 256, generator=g) * 0.7, torch.randn(Bn * n, 256, generator=g) * 0.7
+    w = torch.randn(128, 256, generator=g) * 0.08
+    bias, sc, sh = torch.randn(128, generator=g), torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2
+    kw = dict(bias=bias.to(DEV), a_mode=hip.A_PAIR_AFFINE_RELU, M=Bn * n * n, pair_v=V.to(DEV), pair_n=n, a_scale=sc.to(DEV), a_shift=sh.to(DEV),
+              out_dtype=torch.float32)
+    hip.KTIMER.enable()
+    try:
+        with hip.gemm_split(True):
+            def run():
+                sums = torch.zeros(256, device=DEV)
+                y = hip.gemm(U.to(DEV), w.to(DEV), colsum=sums[:128], colsumsq=sums[128:], **kw)
+                return y, sums, lib().p3_last_kernel().decode()
+            y, sums, name = run()
+            y2, sums2, _ = run()
+            ye = hip.gemm(U.to(DEV), w.to(DEV), **kw)
+            U20, V20 = U[:20 * 1], V[:20 * 1]
+            kw20 = dict(kw, M=400, pair_v=V20.to(DEV), pair_n=20)
+            y20 = hip.gemm(U20.to(DEV), w.to(DEV), **kw20)
+            name20 = lib().p3_last_kernel().decode()
+    finally:
+        hip.KTIMER.disable()
+    assert name == "pair_fwd_x3_kernel", name
+    assert name20.startswith("gemm_kernel<float"), name20
+    assert torch.equal(y, y2) and torch.equal(sums, sums2) and torch.equal(ye, y)
+
+    def ref_of(Uh, Vh, nn):
+        pair = (Uh.view(-1, nn, 1, 256) + Vh.view(-1, 1, nn, 256)).reshape(-1, 256)
+        a_ref = torch.relu(torch.addcmul(torch.addcmul(sh, Uh.view(-1, nn, 1, 256), sc), Vh.view(-1, 1, nn, 256), sc)).reshape(-1, 256)   # fp32, the kernel's order
+        del pair
+        return a_ref.double() @ w.double().t() + bias.double()
+    ref = ref_of(U, V, n)
+    errs = (rel_err(y.cpu(), ref.float()), rel_err(sums[:128].cpu(), ref.sum(0).float()), rel_err(sums[128:].cpu(), (ref * ref).sum(0).float()))
+    assert max(errs) < 2e-5, errs
+    assert rel_err(y20.cpu(), ref_of(U20, V20, 20).float()) < 2e-5
+
+
 def test_rows_gemm_kernels_of_the_scorenet_conv3():
     """csrc/rows_gemm.hip (weight-stationary streaming kernels p3_gemm picks for bf16, M % 32 == 0, M >= 4096): conv3 forward (K = 128 -> N = 64 with the
     BatchNorm-2 / ReLU A operand, bias, BatchNorm-3 column sums) and its input gradient (K = 64 -> N = 128 with the P3_ACT_BN_RELU epilogue), against
@@ -285,6 +329,40 @@ def test_rows_gemm_kernels_of_the_scorenet_conv3():
         assert (~far).float().mean() < 2e-4                      # the excluded kink band is a handful of the 9.5 M elements
     finally:
         hip.KTIMER.disable()
+
+
+def test_rows_x3_kernel_of_the_scorenet_conv3():
+    """csrc/rows_x3.hip (P3_F32X3, conv3 forward K = 128 -> N = 64 with the BatchNorm-2 / ReLU A operand, bias, BatchNorm-3 column sums; M % 32 == 0, M >= 4096):
+    against float64 at a split product's accuracy; the kernel trace names it; output and sums bit-reproducible; a ragged M stays on the tile kernel and agrees."""
+    hip = _h()
+    M = 32 * 2311                        # 2311 row groups over 512 x 2 wave pairs: ragged walk
+    g = torch.Generator().manual_seed(5)
+    x, w = torch.randn(M, 128, generator=g) * 0.5, torch.randn(64, 128, generator=g) * 0.1
+    bias, sc, sh = torch.randn(64, generator=g), torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    from pixelspointspolygons_amd._lib import lib
+    last_kernel = lambda: lib().p3_last_kernel().decode()
+    kw = dict(bias=bias.to(DEV), a_mode=hip.A_AFFINE_RELU, a_scale=sc.to(DEV), a_shift=sh.to(DEV), out_dtype=torch.float32)
+    hip.KTIMER.enable()
+    try:
+        with hip.gemm_split(True):
+            def fwd():
+                sums = torch.zeros(128, device=DEV)
+                y = hip.gemm(x.to(DEV), w.to(DEV), colsum=sums[:64], colsumsq=sums[64:], **kw)
+                return y, sums, last_kernel()
+            y, sums, name = fwd()
+            y2, sums2, _ = fwd()
+            ye = hip.gemm(x.to(DEV), w.to(DEV), **kw)
+            name_e = last_kernel()
+            yr = hip.gemm(x[:5001].to(DEV), w.to(DEV), **kw)
+            name_r = last_kernel()
+    finally:
+        hip.KTIMER.disable()
+    assert name == "rows_x3_fwd_kernel" and name_e == "rows_x3_fwd_kernel" and name_r.startswith("gemm_kernel<float"), (name, name_e, name_r)
+    assert torch.equal(y, y2) and torch.equal(sums, sums2) and torch.equal(ye, y)
+    ref = torch.relu(torch.addcmul(sh, x, sc)).double() @ w.double().t() + bias.double()        # the operand in fp32 (fma), the product in float64
+    errs = (rel_err(y.cpu(), ref.float()), rel_err(sums[:64].cpu(), ref.sum(0).float()), rel_err(sums[64:].cpu(), (ref * ref).sum(0).float()))
+    assert max(errs) < 2e-5, errs
+    assert rel_err(yr.cpu(), ref[:5001].float()) < 2e-5
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 6e-3), (torch.float32, 2e-6)])
