@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512, 1) void mask2_dw_mma_kernel(MdArgs g) {
                      : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
     };
     const int64_t my_steps = (g.steps - (int64_t)blockIdx.x + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
-    // step q of this workgroup = rows [128 (blockIdx.x + q gridDim.x), +128): dH3 rows are 128 bytes (8 slots, slot ^ (row & 7)), H2 rows 256 bytes (16 slots, ^ (row & 15))
+    // step q of this workgroup = rows [128 (blockIdx.x + q gridDim.x), +128): dH3 rows are 128 bytes (8 slots, slot ^ (((row >> 1) & 1) << 2)), H2 rows 256 bytes (16 slots, ^ ((row & 3) << 2))
     auto stage = [&](int64_t q) __attribute__((always_inline)) {
         const int64_t row0 = ((int64_t)blockIdx.x + q * (int64_t)gridDim.x) * 128;
         const int buf = (int)(q & 1);
@@ -48,12 +48,12 @@ __global__ __launch_bounds__(512, 1) void mask2_dw_mma_kernel(MdArgs g) {
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             const int p = wave * 2 + p2, r = p * 8 + (lane >> 3), slot = lane & 7;
-            dma1(ab, da + (uint32_t)(p * 1024), (uint32_t)((r * 64 + ((slot ^ (r & 7)) * 8)) * 2));
+            dma1(ab, da + (uint32_t)(p * 1024), (uint32_t)((r * 64 + ((slot ^ (((r >> 1) & 1) << 2)) * 8)) * 2));
         }
 #pragma unroll
         for (int p4 = 0; p4 < 4; ++p4) {
             const int p = wave * 4 + p4, r = p * 4 + (lane >> 4), slot = lane & 15;
-            dma1(bb, db + (uint32_t)(p * 1024), (uint32_t)((r * 128 + ((slot ^ (r & 15)) * 8)) * 2));
+            dma1(bb, db + (uint32_t)(p * 1024), (uint32_t)((r * 128 + ((slot ^ ((r & 3) << 2)) * 8)) * 2));
         }
     };
     f32x16 acc[2];
@@ -68,8 +68,9 @@ __global__ __launch_bounds__(512, 1) void mask2_dw_mma_kernel(MdArgs g) {
     for (int hh = 0; hh < 2; ++hh) {
         const int row = (g4 >> 1) * 8 + hh * 4 + (li >> 2);
         const int sa = mi * 4 + (g4 & 1) * 2 + ((li & 3) >> 1), sb = nq * 4 + (g4 & 1) * 2 + ((li & 3) >> 1);
-        offa[hh] = (uint32_t)(row * 128 + ((sa ^ (row & 7)) * 16) + ((li & 3) & 1) * 8);
-        offb[hh] = (uint32_t)(MD_A_BYTES + row * 256 + ((sb ^ row) * 16) + ((li & 3) & 1) * 8);
+        // slot swizzles for transposing reads (r05; see pair_dw_mma.hip / mask2_dw_x3.hip): 256-byte rows chunk ^ ((row & 3) << 2), 128-byte rows chunk ^ (((row >> 1) & 1) << 2)
+        offa[hh] = (uint32_t)(row * 128 + ((sa ^ (((row >> 1) & 1) << 2)) * 16) + ((li & 3) & 1) * 8);
+        offb[hh] = (uint32_t)(MD_A_BYTES + row * 256 + ((sb ^ ((row & 3) << 2)) * 16) + ((li & 3) & 1) * 8);
     }
     const float s_ = g.sc[nq * 32 + l31], h_ = g.sh[nq * 32 + l31];
     if (my_steps > 0) stage(0);

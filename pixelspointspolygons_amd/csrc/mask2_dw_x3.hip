@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void mask2_dw_x3_kernel(MxArgs g) {
             const float x[8] = {pa[0].x, pa[0].y, pa[0].z, pa[0].w, pa[1].x, pa[1].y, pa[1].z, pa[1].w};
             u32x4_t h, l;
             mx_split8(x, h, l);
-            const uint32_t off = (uint32_t)(ar * 128 + ((ack ^ (ar & 7)) * 16));
+            const uint32_t off = (uint32_t)(ar * 128 + ((ack ^ (((ar >> 1) & 1) << 2)) * 16));
             *reinterpret_cast<u32x4_t*>(base + off) = h;
             *reinterpret_cast<u32x4_t*>(base + MX_OFF_AL + off) = l;
         }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void mask2_dw_x3_kernel(MxArgs g) {
             }
             u32x4_t h, l;
             mx_split8(m, h, l);
-            const uint32_t off = (uint32_t)(r * 256 + ((bck ^ (r & 15)) * 16));
+            const uint32_t off = (uint32_t)(r * 256 + ((bck ^ ((r & 3) << 2)) * 16));
             *reinterpret_cast<u32x4_t*>(base + MX_OFF_M1 + off) = m1;
             *reinterpret_cast<u32x4_t*>(base + MX_OFF_M2H + off) = h;
             *reinterpret_cast<u32x4_t*>(base + MX_OFF_M2L + off) = l;
@@ -103,8 +103,10 @@ __global__ __launch_bounds__(512, 2) void mask2_dw_x3_kernel(MxArgs g) {
     for (int hh = 0; hh < 2; ++hh) {
         const int row = (g4 >> 1) * 8 + hh * 4 + (li >> 2);
         const int sa = mi * 4 + (g4 & 1) * 2 + ((li & 3) >> 1), sb = nq * 4 + (g4 & 1) * 2 + ((li & 3) >> 1);
-        offa[hh] = (uint32_t)(row * 128 + ((sa ^ (row & 7)) * 16) + ((li & 3) & 1) * 8);
-        offb[hh] = (uint32_t)(row * 256 + ((sb ^ row) * 16) + ((li & 3) & 1) * 8);
+        // slot swizzles for TRANSPOSING reads (16 lanes take 32 bytes of each of 4 consecutive rows; see pair_dw_x3.hip): 256-byte rows - chunk ^ ((row & 3) << 2);
+        // 128-byte rows - rows r, r + 1 already sit in different bank halves, chunk ^ (((row >> 1) & 1) << 2) separates the pairs
+        offa[hh] = (uint32_t)(row * 128 + ((sa ^ (((row >> 1) & 1) << 2)) * 16) + ((li & 3) & 1) * 8);
+        offb[hh] = (uint32_t)(row * 256 + ((sb ^ ((row & 3) << 2)) * 16) + ((li & 3) & 1) * 8);
     }
     if (my_steps > 0) { fetch(0); commit(0); }
     for (int64_t q = 0; q < my_steps; ++q) {

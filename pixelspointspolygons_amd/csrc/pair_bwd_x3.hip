@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_x3_kernel(PxArgs g) {
         }
     };
     auto convert = [&](int st) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this lane's own pieces (and everything older)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this lane's own pieces and everything older (the builtin, not asm: the compiler's
+        asm volatile("" ::: "memory");                                // counter model then knows the V loads are complete too and inserts no waits of its own for them)
         unsigned char* base = lds + (st & 1) * PX_TILE + wave * 4 * 2048 + lane * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -132,11 +133,13 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_x3_kernel(PxArgs g) {
     for (int st = 0; st < nsteps; ++st) {
         __syncthreads();                                            // images of step st complete; reads of step st - 1 (buffer (st + 1) & 1) done
         const int j0 = st * PX_JT;
-        if (st + 1 < nsteps) park(st + 1);
+        // V loads FIRST: vmcnt retires in order - the epilogue's wait for them must not be a wait for the DMA pieces (HBM) issued behind them
         float v[16];
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) v[jj] = Vb[(int64_t)min(j0 + jj, N - 1) * 256];
         if (st > 0) store_dv(st - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < nsteps) park(st + 1);
         __builtin_amdgcn_sched_barrier(0);                          // the loads above stay above the products
         const unsigned char* Ah = lds + (st & 1) * PX_TILE + arow;
         auto rd = [&](int half, int kk, PxFrag& f) __attribute__((always_inline)) {
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void pair_bwd_x3_kernel(PxArgs g) {
                     }
                 }
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0) on every path (see convert)
         if (st + 1 < nsteps) convert(st + 1);
     }
     if (nsteps > 0) {

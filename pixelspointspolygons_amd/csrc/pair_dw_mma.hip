@@ -10,7 +10,9 @@
 //     j: the generated operand's fragment is relu(fma(V[j, c], scale[c], us[i][c])) for i = 0 .. 7 with us = U_i scale + shift held in 16 registers - it is
 //     built IN REGISTERS in the MFMA layout (8 fma + 8 max + 4 packs per fragment, one 2-byte LDS read for V): no LDS image, no staging set, no spill;
 //   * dH2^T fragments come from the row-major tile by transposing reads (ds_read_b64_tr_b16: 16 lanes read 4 rows x 32 bytes and receive 4 rows of their own
-//     column) at the tile's 16-byte-slot swizzle (slot ^ (row & 15), applied on the DMA source address like in pair_bwd_mma.hip);
+//     column) at the tile's 16-byte-slot swizzle, applied on the DMA source address like in pair_bwd_mma.hip - but slot ^ ((row & 3) << 2), not that kernel's
+//     slot ^ (row & 15): the 16 lanes of a transposing read take 32 bytes of each of 4 consecutive rows, and the row-fragment swizzle puts rows r, r + 1 into the same
+//     32-byte bank range (r05, SQ_LDS_BANK_CONFLICT of the fp32x3 twin pair_dw_x3.hip: 23 % of the wave cycles with the old swizzle, 0 with this one);
 //   * the 128 x 256 accumulator (64 registers per lane, 8 waves as 2 x 4) lives across ALL units of the workgroup (one workgroup per CU): 256 partial tiles
 //     per launch -> fp32 atomics (8.4 M) or, with slabs, stores + the float64 reduce of the weight-gradient path.
 // Shapes: bf16, N % 16 == 0 (no ragged group of rows / step of columns); everything else stays on gemm_tn.hip.
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(512, 1) void pair_dw_mma_kernel(PdArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = wave * 4 + q, r = p * 4 + (lane >> 4), slot = lane & 15;      // tile row r = jj * 8 + ii
-            dma1(dHb, da + (uint32_t)(p * 1024), (uint32_t)((((int64_t)(r & 7) * N + j0 + (r >> 3)) * 128 + ((slot ^ (r & 15)) * 8)) * 2));
+            dma1(dHb, da + (uint32_t)(p * 1024), (uint32_t)((((int64_t)(r & 7) * N + j0 + (r >> 3)) * 128 + ((slot ^ ((r & 3) << 2)) * 8)) * 2));
         }
         dma1(Vb, dv + (uint32_t)(wave * 1024), (uint32_t)(((j0 + wave * 2 + (lane >> 5)) * 256 + (lane & 31) * 8) * 2));
     };
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void pair_dw_mma_kernel(PdArgs g) {
         for (int hh = 0; hh < 2; ++hh) {
             const int row = (g4 >> 1) * 8 + hh * 4 + (li >> 2);                      // row & 15 of every 16-row block
             const int slot = (wr * 2 + ib) * 4 + (g4 & 1) * 2 + ((li & 3) >> 1);       // 16-byte slot of channels (64 wr + 32 ib) + 16 (g4 & 1) + 4 (li & 3)
-            troff[ib][hh] = (uint32_t)(row * 256 + ((slot ^ row) * 16) + ((li & 3) & 1) * 8);
+            troff[ib][hh] = (uint32_t)(row * 256 + ((slot ^ ((row & 3) << 2)) * 16) + ((li & 3) & 1) * 8);
         }
     float s_[2], us[2][8];
     if (total > 0) stage(0);

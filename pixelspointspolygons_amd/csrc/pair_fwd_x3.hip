@@ -8,7 +8,7 @@
 //   * a wave's slice of W2 (32 channels x 256 k), split into hi / lo ONCE, lives in 128 registers for the workgroup's life (hi + lo of the whole W2 would be
 //     128 KB of LDS);
 //   * the generated operand relu(fma(V_j, scale, U_i scale + shift)) is computed in fp32, split, and written as hi / lo bf16 images (2 x 16 KB, 128 rows x 64 k,
-//     chunk slot c ^ (r & 7)) for stage g + 1 WHILE stage g is multiplied out of the other pair of images - one split per element;
+//     chunk slot c ^ (r & 7) ^ ((r >> 3) & 1)) for stage g + 1 WHILE stage g is multiplied out of the other pair of images - one split per element;
 //   * (U_i scale + shift) of the group's 8 rows: an LDS table built once per group; the V rows of a step (16 KB) are fetched one step ahead through registers
 //     into a double-buffered LDS copy; scale: an LDS table;
 //   * ONE LDS-only barrier per stage (s_waitcnt lgkmcnt(0); s_barrier), as in the bf16 kernel; the epilogue needs no LDS: a lane holds one channel and 16 rows ->
@@ -32,6 +32,8 @@ constexpr int QX_LDS = QX_OFF_SC + 256 * 4;
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct QxFrag { u32x4_t ah[2], al[2]; };
 
 struct QxArgs {
     const float* U; const float* V; const float* W2; float* Y;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
     float s1 = 0.f, s2 = 0.f;
     const int nsteps = (N + QX_JT - 1) / QX_JT;
     const uint32_t arow = (uint32_t)((wr * 64 + l31) * 128);
-    const int sxa = l31 & 7;
+    const int sxa = (l31 & 7) ^ ((l31 >> 3) & 1);            // chunk swizzle of this lane's fragment rows: rows r and r + 8 of a 16-lane pass in different slots
 
     for (int grp = blockIdx.x; grp < g.ngroups; grp += gridDim.x) {
         const int i0 = grp * QX_IB;
@@ -99,14 +101,13 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
                 *reinterpret_cast<float4*>(lds + QX_OFF_V + buf * QX_V_BYTES + row * 1024 + c4 * 16) = vpre[q];
             }
         };
-        auto gen = [&](int s, unsigned char* img, int vbuf) __attribute__((always_inline)) {
+        auto gen = [&](int s, unsigned char* img, int vbuf, int q) __attribute__((always_inline)) {
             const int k0 = s * QX_KS + gc * 8;
             const float4 c0 = *reinterpret_cast<const float4*>(sct + k0), c1 = *reinterpret_cast<const float4*>(sct + k0 + 4);
             const float4 u0 = *reinterpret_cast<const float4*>(ust + gii * QX_US_STRIDE + k0), u1 = *reinterpret_cast<const float4*>(ust + gii * QX_US_STRIDE + k0 + 4);
             const float scv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             const float usv[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            {
                 const int r = rg + 64 * q, jj = gjb + 8 * q;
                 const float* vp = reinterpret_cast<const float*>(lds + QX_OFF_V + vbuf * QX_V_BYTES + jj * 1024) + k0;
                 const float4 v0 = *reinterpret_cast<const float4*>(vp), v1 = *reinterpret_cast<const float4*>(vp + 4);
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
                 for (int e = 0; e < 8; ++e) a[e] = fmaxf(fmaf(vv[e], scv[e], usv[e]), 0.f);
                 u32x4_t h, l;
                 qx_split8(a, h, l);
-                const uint32_t off = (uint32_t)(r * 128 + ((gc ^ (r & 7)) * 16));
+                const uint32_t off = (uint32_t)(r * 128 + ((gc ^ ((r & 7) ^ ((r >> 3) & 1))) * 16));
                 *reinterpret_cast<u32x4_t*>(img + off) = h;
                 *reinterpret_cast<u32x4_t*>(img + QX_IMG + off) = l;
             }
@@ -128,19 +129,45 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ib][r] = 0.f;
         };
-        auto mma = [&](int s, const unsigned char* img) __attribute__((always_inline)) {
+        auto rd = [&](const unsigned char* img, int kk, QxFrag& f) __attribute__((always_inline)) {
+            const uint32_t co = (uint32_t)(((2 * kk + hi) ^ sxa) * 16);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint32_t co = (uint32_t)(((2 * kk + hi) ^ sxa) * 16);
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib) {
-                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(img + arow + ib * 32 * 128 + co));
-                    const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(img + QX_IMG + arow + ib * 32 * 128 + co));
-                    acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[s * 4 + kk], acc[ib], 0, 0, 0);
-                    acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[s * 4 + kk], acc[ib], 0, 0, 0);
-                    acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[s * 4 + kk], acc[ib], 0, 0, 0);
-                }
+            for (int ib = 0; ib < 2; ++ib) {
+                f.ah[ib] = *reinterpret_cast<const u32x4_t*>(img + arow + ib * 32 * 128 + co);
+                f.al[ib] = *reinterpret_cast<const u32x4_t*>(img + QX_IMG + arow + ib * 32 * 128 + co);
             }
+        };
+        auto mma1 = [&](int ks, const QxFrag& f) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.al[ib]), wh[ks], acc[ib], 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.ah[ib]), wl[ks], acc[ib], 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.ah[ib]), wh[ks], acc[ib], 0, 0, 0);
+        };
+        // one 64-deep stage: the products of stage s out of `img`, with the next stage's operand (two row halves) generated into `gimg` in the gaps; fragments
+        // double-buffered per 16-deep block (the next block's four reads are in flight during the six MFMAs of this one)
+        auto stage = [&](int s, const unsigned char* img, bool dogen, int gs_, unsigned char* gimg, int gvb) __attribute__((always_inline)) {
+            QxFrag f0, f1;
+            rd(img, 0, f0);
+            if (dogen) gen(gs_, gimg, gvb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(img, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(s * 4 + 0, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dogen) gen(gs_, gimg, gvb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(img, 2, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(s * 4 + 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(img, 3, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(s * 4 + 2, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma1(s * 4 + 3, f1);
+            __builtin_amdgcn_sched_barrier(0);
         };
         unsigned char* A0 = lds;
         unsigned char* A1 = lds + QX_A_BYTES;
@@ -155,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
         fetch_v(0);
         put_v(0);
         qx_barrier();
-        gen(0, A0, 0);
+        gen(0, A0, 0, 0); gen(0, A0, 0, 1);
         zero_acc();
         for (int st = 0; st < nsteps; ++st) {
             const bool more = st + 1 < nsteps;
@@ -163,21 +190,17 @@ __global__ __launch_bounds__(512, 2) void pair_fwd_x3_kernel(QxArgs g) {
             // stage 0: multiply A0, generate stage 1 into A1; the next step's V rows start their way here
             qx_barrier();
             if (more) fetch_v(st + 1);
-            gen(1, A1, vb);
-            mma(0, A0);
+            stage(0, A0, true, 1, A1, vb);
             // stage 1: the next step's V rows land in the other copy (last read three barriers ago)
             qx_barrier();
             if (more) put_v(vb ^ 1);
-            gen(2, A0, vb);
-            mma(1, A1);
+            stage(1, A1, true, 2, A0, vb);
             // stage 2
             qx_barrier();
-            gen(3, A1, vb);
-            mma(2, A0);
+            stage(2, A0, true, 3, A1, vb);
             // stage 3: generate the next step's stage 0, multiply, epilogue
             qx_barrier();
-            if (more) gen(0, A0, vb ^ 1);
-            mma(3, A1);
+            stage(3, A1, more, 0, A0, vb ^ 1);
             {
                 // N % 8 == 0 (host check): every row i of the group exists; a column j beyond N (ragged last step) is a wave-uniform skip
                 const int j0 = st * QX_JT;
