@@ -301,6 +301,7 @@ typedef struct {
     float bn_eps, bn_momentum;
     int dtype;            /* dtype of w2, of the internal X2/H2 matrices and of `out` */
     int out_ld, out_col_off;
+    int no_backward;      /* != 0: no p3_pillar_stem_bwd will follow on this workspace - the layer-1 activation matrix need not be kept (C = 128 / 384, bf16 / P3_F32X3: never written) */
 } p3_pillar_desc;
 int64_t p3_pillar_stem_workspace_bytes(const p3_pillar_desc* d);
 int p3_pillar_stem(const float* values, const int64_t* offsets, const float* w1, const float* bn1_gamma,

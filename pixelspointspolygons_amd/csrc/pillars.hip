@@ -500,6 +500,9 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce_kernel(const T* __restrict_
     }
 }
 
+#ifndef P3_PFN_NR
+#define P3_PFN_NR 8       // rows of a pillar in flight per lane group in the rows8 kernels
+#endif
 // eight consecutive channels of one row: ONE 16-byte access in bf16, two in fp32
 template <typename T> struct Row8;
 template <> struct Row8<bf16_t> {
@@ -532,26 +535,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const T* __restrict__ H2, VoxTab t, int max_voxels, int max_points, int nslots,
                                                              int C, float* __restrict__ hmax, float* __restrict__ hmin,
                                                              float* __restrict__ sums /*[2C] or null*/, float* __restrict__ slab = nullptr) {
+    // a row takes C / 8 lanes: the wave walks G = 64 / (C / 8) pillars at once, one per lane group (C = 128: 4 groups of 16 lanes) - no cross-lane traffic, and G x
+    // the rows in flight (r05: with one pillar per wave 48 of the 64 lanes sat idle at C = 128 and the launch ran at 1.5 TB/s at 40 k points per tile)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool act = lane * 8 < C;
+    const int lpr = C >> 3, G = 64 / lpr, grp = lane / lpr, cl = lane - grp * lpr;
+    const bool act = grp < G;
     float s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    for (int v = blockIdx.x * 4 + wv; v < nslots; v += gridDim.x * 4) {
-        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+    for (int vb = (blockIdx.x * 4 + wv) * G; vb < nslots; vb += gridDim.x * 4 * G) {
+        const int v = vb + grp;
+        if (!act || v >= nslots || (v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         const int cnt = t.cnt[v];
         const int nrow = cnt + (cnt < max_points ? 1 : 0);
-        const T* base = H2 + (int64_t)t.row[v] * C + lane * 8;
+        const T* base = H2 + (int64_t)t.row[v] * C + cl * 8;
         float mx[8], mn[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { mx[k] = -INFINITY; mn[k] = INFINITY; }
-        if (act) {
-            for (int r0 = 0; r0 < nrow; r0 += 4) {
-                Row8<T> raw[4];
+        {
+            for (int r0 = 0; r0 < nrow; r0 += P3_PFN_NR) {
+                Row8<T> raw[P3_PFN_NR];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
+                for (int q = 0; q < P3_PFN_NR; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < P3_PFN_NR; ++q) {
                     if (r0 + q >= nrow) break;
                     const float wgt = r0 + q < cnt ? 1.f : (float)(max_points - cnt);
                     float vals[8];
@@ -564,20 +571,182 @@ __global__ __launch_bounds__(256) void pfn_l2_reduce8_kernel(const T* __restrict
                     }
                 }
             }
-            float* hx = hmax + (int64_t)v * C + lane * 8;
-            float* hn = hmin + (int64_t)v * C + lane * 8;
+            float* hx = hmax + (int64_t)v * C + cl * 8;
+            float* hn = hmin + (int64_t)v * C + cl * 8;
             *reinterpret_cast<float4*>(hx) = make_float4(mx[0], mx[1], mx[2], mx[3]); *reinterpret_cast<float4*>(hx + 4) = make_float4(mx[4], mx[5], mx[6], mx[7]);
             *reinterpret_cast<float4*>(hn) = make_float4(mn[0], mn[1], mn[2], mn[3]); *reinterpret_cast<float4*>(hn + 4) = make_float4(mn[4], mn[5], mn[6], mn[7]);
         }
     }
     if (sums) {
-        __shared__ float red[4][2 * 512];
+        __shared__ float red[4][2 * 512];               // [wave][lane group x C | the same for the squares]: lane * 8 = grp * C + cl * 8
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { red[wv][lane * 8 + k] = s1[k]; red[wv][512 + lane * 8 + k] = s2[k]; }
+        for (int k = 0; k < 8; ++k) { red[wv][lane * 8 + k] = act ? s1[k] : 0.f; red[wv][512 + lane * 8 + k] = act ? s2[k] : 0.f; }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
-            p3_commit(sums, slab, 2 * C, c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-            p3_commit(sums, slab, 2 * C, C + c, (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]));
+            float a1 = 0.f, a2 = 0.f;
+            for (int gg = 0; gg < G; ++gg) {               // fixed order: groups, then waves
+                a1 += (red[0][gg * C + c] + red[1][gg * C + c]) + (red[2][gg * C + c] + red[3][gg * C + c]);
+                a2 += (red[0][512 + gg * C + c] + red[1][512 + gg * C + c]) + (red[2][512 + gg * C + c] + red[3][512 + gg * C + c]);
+            }
+            p3_commit(sums, slab, 2 * C, c, a1);
+            p3_commit(sums, slab, 2 * C, C + c, a2);
+        }
+    }
+}
+
+// ---- PFN layer 1 in ONE launch for DENSE clouds (r05; C = 32 NBW WPP: 384 = 3 x 4 - the path's width - and 128 = 2 x 2; bf16 or fp32 rows with the products as
+// bf16 x 3): H2 = X2 W2^T, the per-pillar max / min over its rows and the weighted BatchNorm sums - what p3_gemm + pfn_l2_reduce8_kernel do in two passes over a
+// [rows, C] matrix (C = 384 at 40 k points per tile: 4 GB written, then read).  The weight-stationary streaming form of rows_x3.hip with the pillar as the unit: a
+// wave owns 32 NBW output channels (its slice of W2 as MFMA B fragments in registers: 32 NBW VGPRs for hi + lo) and one pillar at a time, 32 rows per MFMA group;
+// the WPP waves of a group take the same pillar (the later reads of its rows are L1 / L2 hits).  In the accumulator layout a lane holds one channel and 16 rows:
+// max / min / sums are per-lane operations, the two row halves meet in one exchange per pillar - no atomics.  STORE: also write H2 (the backward reads it); without
+// it (no backward follows) the matrix never exists.  bf16: the value is rounded to bf16 BEFORE the max, as the two-pass form took it from the stored matrix - the
+// backward finds the arg-max row by equality with the stored value.
+// Measured (40 k points per tile, ~51 rows per pillar, training): 1.46 ms + 0.26 ms (zeroing the rows of no pillar) against 1.51 + 0.92 ms for the two passes; at
+// 3 k points per tile (~4 rows per pillar) a pillar fills an eighth of an MFMA group and pays its own latency chain: 0.39 against 0.27 ms - the host therefore takes
+// this path from 16 points per pillar slot on.  (Also measured and dropped: walking 32-row groups of the whole row range with per-lane running (pillar, max, min)
+// handed over by atomic max / min - full MFMA groups at any density, but ~100 M atomic lane-operations per launch at 40 k: 2.46 ms.)
+template <typename T, bool STORE, int NBW, int WPP>
+__global__ __launch_bounds__(256, 2) void pfn_l2_fused_kernel(const T* __restrict__ X2, const T* __restrict__ W2, VoxTab t, int max_voxels, int max_points,
+                                                              int nslots, T* __restrict__ H2, float* __restrict__ hmax, float* __restrict__ hmin,
+                                                              float* __restrict__ sums /*[2 C] or null*/, float* __restrict__ slab) {
+    constexpr int C = 32 * NBW * WPP, NS = 4 / WPP;      // NS: pillars in flight per workgroup
+    constexpr bool X3 = sizeof(T) == 4;
+    constexpr int XR = X3 ? 8 : 4;                       // 16-byte registers of one lane's share of a 32 x 64 row group
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int cg = w % WPP, stream = w / WPP, ch0 = cg * 32 * NBW + l31;      // this lane's channels: ch0 + 32 nb
+    auto split8 = [](const float (&v)[8], u32x4_t& h, u32x4_t& l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t hw = pack_bf2(v[2 * k], v[2 * k + 1]);
+            h[k] = hw;
+            l[k] = pack_bf2(v[2 * k] - __uint_as_float(hw << 16), v[2 * k + 1] - __uint_as_float(hw & 0xffff0000u));
+        }
+    };
+    // W2 rows (channels) ch0 + 32 nb, k = 16 s + 8 hi .. + 8
+    bf16x8_t wh[NBW][4], wl[X3 ? NBW : 1][X3 ? 4 : 1];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) {
+            const T* wp = W2 + (int64_t)(ch0 + nb * 32) * K2 + 16 * sk + 8 * hi;
+            if constexpr (X3) {
+                const float4 x0 = *reinterpret_cast<const float4*>(wp), x1 = *reinterpret_cast<const float4*>(wp + 4);
+                const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                u32x4_t h, l;
+                split8(v, h, l);
+                wh[nb][sk] = __builtin_bit_cast(bf16x8_t, h); wl[nb][sk] = __builtin_bit_cast(bf16x8_t, l);
+            } else {
+                wh[nb][sk] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wp));
+            }
+        }
+    float s1[NBW], s2[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+    for (int v = blockIdx.x * NS + stream; v < nslots; v += gridDim.x * NS) {
+        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+        const int cnt = t.cnt[v];
+        const int nrow = cnt + (cnt < max_points ? 1 : 0);
+        const int64_t row0 = t.row[v];
+        const float padw = (float)(max_points - cnt);
+        float mx[NBW], mn[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { mx[nb] = -INFINITY; mn[nb] = INFINITY; }
+        u32x4_t xa[XR];
+        auto fetch = [&](int g0) __attribute__((always_inline)) {
+            const int rl = min(g0 + l31, nrow - 1);                       // rows beyond the pillar: a valid address, masked below
+            const T* ap = X2 + (row0 + rl) * K2 + 8 * hi;
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk) {
+                if constexpr (X3) { xa[2 * sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk); xa[2 * sk + 1] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk + 4); }
+                else xa[sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk);
+            }
+        };
+        fetch(0);
+        for (int g0 = 0; g0 < nrow; g0 += 32) {
+            f32x16 acc[NBW];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk) {
+                if constexpr (X3) {
+                    const float a[8] = {__uint_as_float(xa[2 * sk][0]), __uint_as_float(xa[2 * sk][1]), __uint_as_float(xa[2 * sk][2]), __uint_as_float(xa[2 * sk][3]),
+                                        __uint_as_float(xa[2 * sk + 1][0]), __uint_as_float(xa[2 * sk + 1][1]), __uint_as_float(xa[2 * sk + 1][2]), __uint_as_float(xa[2 * sk + 1][3])};
+                    u32x4_t ah_, al_;
+                    split8(a, ah_, al_);
+                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ah_), al = __builtin_bit_cast(bf16x8_t, al_);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[nb][sk], acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[nb][sk], acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[nb][sk], acc[nb], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, xa[sk]), wh[nb][sk], acc[nb], 0, 0, 0);
+                }
+            }
+            // the pillar's next group: issued here, in flight during the epilogue (one register set: the products above were its last readers)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g0 + 32 < nrow) fetch(g0 + 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = g0 + crow32(r, hi);
+                if (row < nrow) {
+                    const float wgt = row < cnt ? 1.f : padw;
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        float val = acc[nb][r];
+                        if constexpr (!X3) val = bf2f(f2bf(val));
+                        mx[nb] = fmaxf(mx[nb], val); mn[nb] = fminf(mn[nb], val);
+                        s1[nb] += wgt * val; s2[nb] += wgt * val * val;
+                        if constexpr (STORE) H2[(row0 + row) * C + ch0 + nb * 32] = Cvt<T>::from_f(val);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float a = fmaxf(mx[nb], __shfl_xor(mx[nb], 32, 64)), b = fminf(mn[nb], __shfl_xor(mn[nb], 32, 64));
+            if (hi == 0) { hmax[(int64_t)v * C + ch0 + nb * 32] = a; hmin[(int64_t)v * C + ch0 + nb * 32] = b; }
+        }
+    }
+    if (sums) {
+        // the two row halves of a lane pair, then the workgroup's pillar streams, in a fixed order
+        __shared__ float red[NS][2 * C];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float a1 = s1[nb] + __shfl_xor(s1[nb], 32, 64), a2 = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+            if (hi == 0) { red[stream][ch0 + nb * 32] = a1; red[stream][C + ch0 + nb * 32] = a2; }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            float a = red[0][i];
+#pragma unroll
+            for (int q = 1; q < NS; ++q) a += red[q][i];
+            p3_commit(sums, slab, 2 * C, i, a);
+        }
+    }
+}
+
+// rows of H2 that belong to no kept pillar (points beyond the per-pillar cap, outside the range, in pillars beyond max_voxels): the weight-gradient and input-gradient
+// products of the backward run over ALL rows, so they must hold zeros (the two-pass form's GEMM writes them as the product of zero rows)
+template <typename T>
+__global__ __launch_bounds__(256) void pfn_zero_unused_rows_kernel(T* __restrict__ H2, const int* __restrict__ row_vox, int64_t rows, int C) {
+    // a wave looks at 64 consecutive rows at once (one coalesced load of their owners) and zeroes the few that have none
+    const int lane = threadIdx.x & 63;
+    for (int64_t rb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; rb < rows; rb += (int64_t)gridDim.x * 4 * 64) {
+        const int64_t r = rb + lane;
+        unsigned long long m = __ballot(r < rows && row_vox[r] < 0);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            for (int c = lane; c < C; c += 64) H2[(rb + k) * C + c] = Cvt<T>::from_f(0.f);
         }
     }
 }
@@ -747,8 +916,9 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max
                                                                const float* __restrict__ gamma2, const float* __restrict__ mean2,
                                                                const float* __restrict__ rstd2, const float* __restrict__ dbeta,
                                                                const float* __restrict__ dgamma, const int* __restrict__ totals, int training) {
-    const int lane = threadIdx.x & 63, c0 = lane * 8;
-    if (c0 >= C) return;
+    // G = 64 / (C / 8) pillars per wave, one per lane group (see pfn_l2_reduce8_kernel)
+    const int lane = threadIdx.x & 63, lpr = C >> 3, G = 64 / lpr, grp = lane / lpr, c0 = (lane - grp * lpr) * 8;
+    if (grp >= G) return;
     const float inv_n = training ? 1.f / fmaxf((float)totals[0] * (float)max_points, 1.f) : 0.f;
     float mean[8], rstd[8], gm[8], a[8], bb[8];
 #pragma unroll
@@ -756,8 +926,9 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max
         mean[k] = mean2[c0 + k]; rstd[k] = rstd2[c0 + k]; gm[k] = gamma2[c0 + k] * rstd[k];
         a[k] = dbeta[c0 + k] * inv_n; bb[k] = dgamma[c0 + k] * inv_n;
     }
-    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nslots; v += gridDim.x * 4) {
-        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
+    for (int vb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G; vb < nslots; vb += gridDim.x * 4 * G) {
+        const int v = vb + grp;
+        if (v >= nslots || (v % max_voxels) >= t.nvox[v / max_voxels]) continue;
         const int cnt = t.cnt[v];
         const int nrow = cnt + (cnt < max_points ? 1 : 0);
         T* base = H2 + (int64_t)t.row[v] * C + c0;
@@ -767,12 +938,12 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_rows8_kernel(VoxTab t, int max
         const float4 h0 = *reinterpret_cast<const float4*>(hp), h1 = *reinterpret_cast<const float4*>(hp + 4);
         const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, hs[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         uint32_t found = 0;                              // bit k: the arg-max row of channel k has been credited
-        for (int r0 = 0; r0 < nrow; r0 += 4) {
-            Row8<T> raw[4];
+        for (int r0 = 0; r0 < nrow; r0 += P3_PFN_NR) {
+            Row8<T> raw[P3_PFN_NR];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
+            for (int q = 0; q < P3_PFN_NR; ++q) { if (r0 + q < nrow) raw[q].load(base + (int64_t)(r0 + q) * C); else raw[q].zero(); }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < P3_PFN_NR; ++q) {
                 if (r0 + q >= nrow) break;
                 const float wgt = r0 + q < cnt ? 1.f : (float)(max_points - cnt);
                 float vals[8], o[8];
@@ -812,16 +983,27 @@ __global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxel
         const int64_t row0 = t.row[v];
         float best = -INFINITY; int bi = 0x7fffffff;
         float dxm = 0.f;
-        for (int r = half; r < nrow; r += 2) {
-            dxm += Cvt<T>::to_f(dX2[(row0 + r) * K2 + C1 + c]);
-            if (r < cnt) {
-                const float4 f0 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8), f1 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4);
-                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                float h = 0.f;
+        // four rows per parity in flight (r05: one row per trip was a chain of dependent loads - 748 us at 40 k points per tile for ~0.8 GB)
+        for (int r0 = half; r0 < nrow; r0 += 8) {
+            float dxv[4]; float4 fa[4], fb[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
-                const float x = fmaxf(h * s + sh, 0.f);
-                if (x > best) { best = x; bi = r; }
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 2 * q;
+                dxv[q] = r < nrow ? Cvt<T>::to_f(dX2[(row0 + r) * K2 + C1 + c]) : 0.f;
+                if (r < cnt) { fa[q] = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8); fb[q] = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 2 * q;
+                dxm += dxv[q];
+                if (r < cnt) {
+                    const float f[8] = {fa[q].x, fa[q].y, fa[q].z, fa[q].w, fb[q].x, fb[q].y, fb[q].z, fb[q].w};
+                    float h = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
+                    const float x = fmaxf(h * s + sh, 0.f);
+                    if (x > best) { best = x; bi = r; }
+                }
             }
         }
         {
@@ -830,19 +1012,32 @@ __global__ __launch_bounds__(256) void pfn_bwd_l1_kernel(VoxTab t, int max_voxel
             dxm += __shfl_xor(dxm, 32, 64);
         }
         const bool pad_arg = has_pad && fmaxf(sh, 0.f) > best;
-        for (int r = half; r < cnt; r += 2) {
-            const float4 f0 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8), f1 = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4);
-            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-            float h = 0.f;
+        for (int r0 = half; r0 < cnt; r0 += 8) {
+            float dyv[4]; float4 fa[4], fb[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
-            const float y = h * s + sh;
-            float dy = Cvt<T>::to_f(dX2[(row0 + r) * K2 + c]) + ((r == bi && !pad_arg) ? dxm : 0.f);
-            dy = y > 0.f ? dy : 0.f;
-            const float xh = (h - m1) * r1;
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 2 * q;
+                if (r < cnt) {
+                    dyv[q] = Cvt<T>::to_f(dX2[(row0 + r) * K2 + c]);
+                    fa[q] = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8); fb[q] = *reinterpret_cast<const float4*>(F8 + (row0 + r) * 8 + 4);
+                }
+            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { a_dyf[k] += dy * f[k]; a_xf[k] += xh * f[k]; a_f[k] += f[k]; }
-            db += dy; dg += dy * xh;
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 2 * q;
+                if (r >= cnt) break;
+                const float f[8] = {fa[q].x, fa[q].y, fa[q].z, fa[q].w, fb[q].x, fb[q].y, fb[q].z, fb[q].w};
+                float h = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h += wr[k] * f[k];
+                const float y = h * s + sh;
+                float dy = dyv[q] + ((r == bi && !pad_arg) ? dxm : 0.f);
+                dy = y > 0.f ? dy : 0.f;
+                const float xh = (h - m1) * r1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a_dyf[k] += dy * f[k]; a_xf[k] += xh * f[k]; a_f[k] += f[k]; }
+                db += dy; dg += dy * xh;
+            }
         }
         if (has_pad && half == 0) {   // the padded slots: h = 0, y = shift; their summed gradient sits in the representative row
             float dp = Cvt<T>::to_f(dX2[(row0 + cnt) * K2 + c]) + (pad_arg ? dxm : 0.f);
@@ -1011,13 +1206,37 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     else { if (d->max_points > 64) P3_L1_APPLY(float, true); else P3_L1_APPLY(float, false); }
 #undef P3_L1_APPLY
     P3_LAUNCH_CHECK();
+    float* sums2 = d->training ? w.sums2 : nullptr;
+    // dense clouds only (>= 16 points per pillar slot on average; the bench's 3 k points per tile are 3.8, BASELINE's real tiles ~51): see pfn_l2_fused_kernel
+    const bool fused2 = (d->C == 128 || d->C == 384) && (d->dtype == P3_BF16 || d->dtype == P3_F32X3) && ((uintptr_t)w2 % 16) == 0 &&
+                        d->total_points >= 16 * (int64_t)nslots;
+    if (fused2) {
+        // layer 1 in one launch: product, per-pillar max / min, BatchNorm sums (pfn_l2_fused_kernel); H2 is written only when a backward pass will read it
+        const int ns = d->C == 128 ? 2 : 1;                          // pillars in flight per workgroup
+        const int gf = (nslots + ns - 1) / ns < 1024 ? (nslots + ns - 1) / ns : 1024;
+        float* slab2 = sums2 ? p3_det_scratch((int64_t)gf * 2 * d->C, kdt) : nullptr;
+        const bool keep = !d->no_backward;
+#define P3_L2_FUSED(T, ST) do { if (d->C == 128) hipLaunchKernelGGL((pfn_l2_fused_kernel<T, ST, 2, 2>), dim3(gf), dim3(256), 0, s, (const T*)w.X2, (const T*)w2, t, d->max_voxels, d->max_points, nslots, (T*)w.H2, w.hmax, w.hmin, sums2, slab2); \
+        else hipLaunchKernelGGL((pfn_l2_fused_kernel<T, ST, 3, 4>), dim3(gf), dim3(256), 0, s, (const T*)w.X2, (const T*)w2, t, d->max_voxels, d->max_points, nslots, (T*)w.H2, w.hmax, w.hmin, sums2, slab2); } while (0)
+        if (d->dtype == P3_BF16) { if (keep) P3_L2_FUSED(bf16_t, true); else P3_L2_FUSED(bf16_t, false); }
+        else { if (keep) P3_L2_FUSED(float, true); else P3_L2_FUSED(float, false); }
+#undef P3_L2_FUSED
+        P3_LAUNCH_CHECK();
+        if (p3_tracing()) p3_note_kernel(keep ? "pfn_l2_fused_kernel<store>" : "pfn_l2_fused_kernel");
+        if (keep) {
+            const int gz = (int)((rows + 255) / 256 < 1024 ? (rows + 255) / 256 : 1024);
+            if (d->dtype == P3_BF16) hipLaunchKernelGGL((pfn_zero_unused_rows_kernel<bf16_t>), dim3(gz), dim3(256), 0, s, (bf16_t*)w.H2, w.row_vox, (int64_t)rows, d->C);
+            else hipLaunchKernelGGL((pfn_zero_unused_rows_kernel<float>), dim3(gz), dim3(256), 0, s, (float*)w.H2, w.row_vox, (int64_t)rows, d->C);
+            P3_LAUNCH_CHECK();
+        }
+        if (slab2) { int rc2 = p3_det_reduce(slab2, gf, 2 * d->C, sums2, 2 * d->C, 1, s); if (rc2 != P3_OK) return rc2; }
+    } else {
     p3_gemm_desc gd;
     memset(&gd, 0, sizeof(gd));
     gd.M = (int)rows; gd.N = d->C; gd.K = K2; gd.lda = K2; gd.ldb = K2; gd.ldc = d->C;
     gd.dtype_in = d->dtype; gd.dtype_out = d->dtype == P3_F32X3 ? P3_F32 : d->dtype; gd.act = P3_ACT_NONE; gd.a_mode = P3_A_PLAIN;    // P3_F32X3: the PFN products as bf16 x 3, storage fp32
     int rc = p3_gemm(w.X2, w2, w.H2, &gd, stream);
     if (rc != P3_OK) return rc;
-    float* sums2 = d->training ? w.sums2 : nullptr;
     if (d->C % 8 == 0 && d->C <= 512) {
         const int g2 = vgrid < L2R_BLOCKS ? vgrid : L2R_BLOCKS;
         float* slab2 = sums2 ? p3_det_scratch((int64_t)g2 * 2 * d->C, kdt) : nullptr;
@@ -1033,6 +1252,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
         hipLaunchKernelGGL((pfn_l2_reduce_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)w.H2, t, d->max_voxels, d->max_points, nslots, d->C, w.hmax, w.hmin, sums2, slab2);
         P3_LAUNCH_CHECK();
         if (slab2) { int rc2 = p3_det_reduce(slab2, g2, 2 * d->C, sums2, 2 * d->C, 1, s); if (rc2 != P3_OK) return rc2; }
+    }
     }
     P3_LAUNCH_CHECK();
     }

@@ -477,7 +477,7 @@ class PillarDesc(Structure):
     _fields_ = [("B", c_int), ("total_points", c_int64), ("nx", c_int), ("ny", c_int), ("vx", c_float), ("vy", c_float),
                 ("vz", c_float), ("zmax", c_float), ("max_points", c_int), ("max_voxels", c_int), ("C", c_int),
                 ("training", c_int), ("bn_eps", c_float), ("bn_momentum", c_float), ("dtype", c_int), ("out_ld", c_int),
-                ("out_col_off", c_int)]
+                ("out_col_off", c_int), ("no_backward", c_int)]
 
 
 _ws_cache = {}
@@ -518,6 +518,7 @@ def pillar_stem(values, offsets, w1, bn1, w2, bn2, out, *, B, grid, voxel, zmax,
     d.max_points, d.max_voxels, d.C = max_points, max_voxels, w2.shape[0]
     d.training, d.bn_eps, d.bn_momentum = int(training), 1e-3, 0.01
     d.dtype, d.out_ld, d.out_col_off = dt_mm(out), out.stride(-2), col_off
+    d.no_backward = int(not keep_workspace)      # a workspace nobody keeps cannot feed p3_pillar_stem_bwd
     if w2.dtype != out.dtype:
         raise P3Error("pillar_stem: w2 dtype must equal the canvas dtype")
     L = lib()

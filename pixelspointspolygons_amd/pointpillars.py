@@ -66,8 +66,9 @@ class PointPillarsEncoder(nn.Module):
         """Run the stem and write the [B, ny*nx, C] features into canvas[..., col_off:col_off+C] (token-major)."""
         values, offsets, B = jagged_parts(x_lidar)
         l0, l1 = self.voxel_encoder.pfn_layers
+        # grad mode is read HERE: inside Function.forward it is always off, and needs_input_grad stays true for the parameters under torch.no_grad()
         return _PillarStem.apply(values.contiguous().float(), offsets.to(torch.int64), l0.linear.weight, l0.norm.weight, l0.norm.bias,
-                                 l1.linear.weight, l1.norm.weight, l1.norm.bias, canvas, self, B, col_off)
+                                 l1.linear.weight, l1.norm.weight, l1.norm.bias, canvas, self, B, col_off, torch.is_grad_enabled())
 
     @torch.no_grad()
     def voxelize(self, x_lidar):
@@ -122,11 +123,11 @@ class PointPillarsEncoder(nn.Module):
 @hip.precision_scoped
 class _PillarStem(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, values, offsets, w1, g1, b1, w2, g2, b2, canvas, mod, B, col_off):
+    def forward(ctx, values, offsets, w1, g1, b1, w2, g2, b2, canvas, mod, B, col_off, grad_on=True):
         l0, l1 = mod.voxel_encoder.pfn_layers
         training = mod.training
         w2c = ops.shadow(w2, mod.cd)
-        need = any(ctx.needs_input_grad)
+        need = grad_on and any(ctx.needs_input_grad)
         r = hip.pillar_stem(values, offsets, w1.detach(), (g1.detach(), b1.detach(), l0.norm.running_mean, l0.norm.running_var), w2c,
                             (g2.detach(), b2.detach(), l1.norm.running_mean, l1.norm.running_var), canvas, B=B, grid=(mod.nx, mod.ny),
                             voxel=mod.voxel, zmax=mod.zmax, max_points=mod.max_points,
@@ -152,7 +153,7 @@ class _PillarStem(torch.autograd.Function):
         dw1, dg1, db1, dw2, dg2, db2 = hip.pillar_stem_bwd(dc, w1.detach(), g1.detach(), w2t, g2.detach(), ctx.ws, ctx.desc,
                                                            sync=ops.sync_stats if ops.sync_active() else None)
         ctx.ws = None
-        return None, None, dw1, dg1, db1, dw2, dg2, db2, dcanvas, None, None, None
+        return None, None, dw1, dg1, db1, dw2, dg2, db2, dcanvas, None, None, None, None
 
 
 class PointPillarsViT(nn.Module):

@@ -927,6 +927,61 @@ def test_pillar_stem_backward_native_vs_oracle_autograd(train, max_points, n_poi
         assert err < 3e-3, (k, err)       # (cap 16 at 15 points per pillar: 2.6e-3 on the layer-0 BatchNorm scale - the max over slots sits next to ties)
 
 
+@pytest.mark.parametrize("precision,tol_out,tol_grad", [("fp32x3", 2e-5, 4e-3), ("bf16", 2e-2, 0.15)])
+@pytest.mark.parametrize("train", [True, False])
+def test_pillar_stem_layer1_in_one_launch_vs_the_two_pass_exact_path(precision, tol_out, tol_grad, train):
+    """csrc/pillars.hip pfn_l2_fused_kernel (C = 384, bf16 / fp32x3): PFN layer 1's product, per-pillar max / min and BatchNorm sums in one launch.  Against the
+    exact-fp32 stem of the same module (p3_gemm + pfn_l2_reduce8, held to the oracle by the test above): canvas and all six parameter gradients; the trace names
+    the kernel; without a backward (no_grad) the activation matrix is not written and the canvas is the autograd run's."""
+    from pixelspointspolygons_amd import hip
+    from pixelspointspolygons_amd.config import make_config
+    from pixelspointspolygons_amd.pointpillars import PointPillarsEncoder
+    B, n_points = 3, 20000                  # >= 16 points per pillar slot: the density from which the stem takes the one-launch layer (3 x 784 slots)
+    sd = O.make_state_dict("lidar", seed=13)
+    pre = "encoder.vit.patch_embed."
+    inp = O.make_inputs(B, seed=77, n_points=n_points, jitter=n_points // 10)
+    lid = (inp["lidar_values"].to(DEV), inp["lidar_offsets"].to(DEV))
+    g = _rand(B, 784, 384, seed=8)
+
+    def run(prec, grad=True):
+        cfg = make_config("pointpillars_vit", precision=prec, device=DEV)
+        enc = PointPillarsEncoder(cfg).to(DEV)
+        enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+        enc.train(train)
+        hip.lib().p3_trace_kernels(1)
+        if not grad:
+            with torch.no_grad():
+                out = enc(lid)
+            name = hip.lib().p3_last_kernel().decode()
+            hip.lib().p3_trace_kernels(0)
+            return out, None, name, enc.C
+        out = enc(lid)
+        name = hip.lib().p3_last_kernel().decode()
+        hip.lib().p3_trace_kernels(0)
+        out.float().backward(g.to(DEV)[..., :out.shape[-1]].to(out.dtype).float())
+        return out.detach(), {k: p_.grad.float().cpu() for k, p_ in enc.named_parameters()}, name, enc.C
+    ref_out, ref_g, ref_name, C = run("fp32")
+    out, gr, name, _ = run(precision)
+    assert C in (128, 384)
+    assert "pfn_l2_fused" not in ref_name and name == "pfn_l2_fused_kernel<store>", (ref_name, name)
+    assert rel_err(out.float().cpu(), ref_out.float().cpu()) < tol_out
+    gnorm = max(float(v.norm()) for v in ref_g.values())
+    for k in ref_g:
+        err = l2_err(gr[k], ref_g[k], floor=1e-3 * gnorm)
+        assert err < tol_grad, (k, err)
+    out_ng, _, name_ng, _ = run(precision, grad=False)
+    # the same arithmetic in another template instantiation (the compiler contracts the sums' multiply-adds its own way in each): the last bit of a BatchNorm statistic
+    assert name_ng == "pfn_l2_fused_kernel" and rel_err(out_ng.float().cpu(), out.float().cpu()) < (1e-6 if precision == "fp32x3" else 1e-2)
+    # a sparse cloud stays on the two-pass form
+    sparse = O.make_inputs(B, seed=78, n_points=3000, jitter=300)
+    enc = PointPillarsEncoder(make_config("pointpillars_vit", precision=precision, device=DEV)).to(DEV).train(train)
+    hip.lib().p3_trace_kernels(1)
+    enc((sparse["lidar_values"].to(DEV), sparse["lidar_offsets"].to(DEV)))
+    name_sp = hip.lib().p3_last_kernel().decode()
+    hip.lib().p3_trace_kernels(0)
+    assert "pfn_l2_fused" not in name_sp, name_sp
+
+
 def _mask_provider(seed_value, probs):
     """Reads the product's own counter-based masks back (p3_dropout_apply on ones) so the oracle can replay them."""
     from pixelspointspolygons_amd import hip

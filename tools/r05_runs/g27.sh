@@ -1,0 +1,13 @@
+# r05: rows8 pillar kernels with G pillars per wave (one per lane group): tests, 40 k-point profile, 3 k step
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+timeout 1200 python -m pytest tests/test_pillar_membership_gpu.py tests/test_backward_gpu.py tests/test_model_gpu.py tests/test_train_gpu.py -x -q -k "pillar or canvas or bit_reproducible or lidar or stem" 2>&1 | tail -3
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_d40 -o st -- python bench.py --lean --points 40000 --steps 6 --warmup 2 > gpurun_out/r05/g27_run.log 2>&1
+find /tmp/pf_d40 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05/g27_dense40k_fp32x3_kernel_stats.csv \;
+python tools/kstats.py gpurun_out/r05/g27_dense40k_fp32x3_kernel_stats.csv 9 70 > gpurun_out/r05/g27_dense40k_fp32x3_summary.txt
+grep -E "total|pfn|pillar" gpurun_out/r05/g27_dense40k_fp32x3_summary.txt
+grep '"metric"' gpurun_out/r05/g27_run.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32x3 40k ms/step', d['ms_per_step'])"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_3k -o st -- python bench.py --lean --steps 10 --warmup 3 > gpurun_out/r05/g27_run3k.log 2>&1
+find /tmp/pf_3k -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05/g27_3k_kernel_stats.csv \;
+python tools/kstats.py gpurun_out/r05/g27_3k_kernel_stats.csv 13 80 | grep -E "total|pfn|pillar"
+grep '"metric"' gpurun_out/r05/g27_run3k.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32x3 3k ms/step', d['ms_per_step'])"
