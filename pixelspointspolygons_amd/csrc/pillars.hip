@@ -154,6 +154,138 @@ __global__ __launch_bounds__(SORT_THREADS) void pillar_sort_kernel(const float* 
     }
 }
 
+// ---- the same sort for DENSE clouds, a tile's points over SORT_SPLIT workgroups (r05: one workgroup per tile = 64 of 256 CUs was 0.54 ms at 40 k points per tile) --
+// count: workgroup (k, b) histograms chunk k of tile b;  tables: one workgroup per tile scans the chunk histograms and writes the pillar tables exactly as
+// pillar_sort_kernel does;  fill: workgroup (k, b) walks its chunk again in order.  Chunks are contiguous point ranges in ascending order and a chunk's waves take
+// contiguous sub-ranges, so "ascending point index inside a pillar" (the <= max_points lowest indices survive) holds as in the one-workgroup form.
+constexpr int SORT_SPLIT = 4;
+
+__device__ __forceinline__ void sort_chunk_range(int n, int k, int w, int& beg, int& end) {
+    int cw = (n + SORT_SPLIT - 1) / SORT_SPLIT;
+    cw = (cw + SORT_THREADS - 1) / SORT_THREADS * SORT_THREADS;          // per-wave sub-ranges stay multiples of 64
+    const int kb = min(n, k * cw), ke = min(n, kb + cw);
+    int sub = (ke - kb + SORT_WAVES - 1) / SORT_WAVES;
+    sub = (sub + 63) / 64 * 64;
+    beg = min(ke, kb + w * sub); end = min(ke, beg + sub);
+}
+
+// per-wave histograms of the workgroup's chunk into hist[16][nc] (LDS), as step 1 of pillar_sort_kernel
+__device__ __forceinline__ void sort_wave_hist(const float* __restrict__ pts, int64_t p0, const PillarGeom& g, unsigned* hist, int beg, int end) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nc = g.nc;
+    for (int i = tid; i < SORT_WAVES * nc; i += SORT_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int i = beg + lane; i < end; i += 64) {
+        const float* p = pts + 3 * (p0 + i);
+        const int c = cell_of(g, p[0], p[1], p[2]);
+        if (c >= 0) atomicAdd(&hist[w * nc + c], 1u);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void pillar_sort_count_kernel(const float* __restrict__ pts, const int64_t* __restrict__ offs, PillarGeom g,
+                                                                         unsigned* __restrict__ ghist /*[B][SORT_SPLIT][nc]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    const int nc = g.nc, k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int64_t p0 = offs[b];
+    const int n = (int)(offs[b + 1] - p0);
+    int beg, end;
+    sort_chunk_range(n, k, tid >> 6, beg, end);
+    sort_wave_hist(pts, p0, g, sm, beg, end);
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        unsigned run = 0;
+        for (int q = 0; q < SORT_WAVES; ++q) run += sm[q * nc + c];
+        ghist[((int64_t)b * SORT_SPLIT + k) * nc + c] = run;
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void pillar_sort_tables_kernel(const int64_t* __restrict__ offs, PillarGeom g, int max_points, int max_voxels, SortOut o,
+                                                                          unsigned* __restrict__ ghist /* in: chunk counts, out: chunk bases */,
+                                                                          unsigned* __restrict__ gstart /*[B][nc]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    const int nc = g.nc;
+    unsigned* tot = sm;                       // [nc] points per cell
+    unsigned* start = tot + nc;               // [nc] first position in the sorted list
+    unsigned* kept = start + nc;              // [nc] 1 if the pillar is emitted
+    unsigned* slot = kept + nc;               // [nc] output slot of a kept pillar
+    unsigned* rows = slot + nc;               // [nc] first X2 row (sample local)
+    unsigned* tmp = rows + nc;                // [32]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t p0 = offs[b];
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        unsigned run = 0;
+        for (int k = 0; k < SORT_SPLIT; ++k) { unsigned* h = ghist + ((int64_t)b * SORT_SPLIT + k) * nc + c; const unsigned t = *h; *h = run; run += t; }
+        tot[c] = run; start[c] = run; slot[c] = run > 0 ? 1u : 0u;
+    }
+    __syncthreads();
+    block_scan_excl(start, nc, tmp);
+    block_scan_excl(slot, nc, tmp);   // rank among non-empty cells in hash order: max_voxels counts BEFORE the bounds filter
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy;
+        kept[c] = (tot[c] > 0 && slot[c] < (unsigned)max_voxels && cx < g.nx && cy < g.ny) ? 1u : 0u;
+        gstart[(int64_t)b * nc + c] = start[c];
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        slot[c] = kept[c];
+        const unsigned cnt = min(tot[c], (unsigned)max_points);
+        rows[c] = kept[c] ? cnt + (cnt < (unsigned)max_points ? 1u : 0u) : 0u;
+    }
+    __syncthreads();
+    const unsigned nkept = block_scan_excl(slot, nc, tmp);
+    block_scan_excl(rows, nc, tmp);
+    const int plane = g.ncx * g.ncy;
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        if (kept[c]) {
+            const int cx = c % g.ncx, cy = (c / g.ncx) % g.ncy, cz = c / plane;
+            const bool overwritten = (cz == 0) && kept[c + plane];      // see pillar_sort_kernel
+            const int idx = b * max_voxels + (int)slot[c];
+            o.vox_xy[idx] = (cy * g.nx + cx) | (overwritten ? (1 << 30) : 0);
+            o.vox_start[idx] = (int)(p0 + start[c]);
+            o.vox_cnt[idx] = (int)min(tot[c], (unsigned)max_points);
+            o.vox_row[idx] = (int)(p0 + (int64_t)b * max_voxels + rows[c]);
+        }
+    }
+    if (tid == 0) { o.nvox[b] = (int)nkept; atomicAdd(o.totals, (int)nkept); }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void pillar_sort_fill_kernel(const float* __restrict__ pts, const int64_t* __restrict__ offs, PillarGeom g,
+                                                                        const unsigned* __restrict__ gbase /*[B][SORT_SPLIT][nc]*/,
+                                                                        const unsigned* __restrict__ gstart /*[B][nc]*/, int* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned sm[];
+    const int nc = g.nc, k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned* hist = sm;                      // [16][nc] per-wave histograms -> positions of the wave's next point of a cell
+    const int64_t p0 = offs[b];
+    const int n = (int)(offs[b + 1] - p0);
+    int beg, end;
+    sort_chunk_range(n, k, w, beg, end);
+    sort_wave_hist(pts, p0, g, hist, beg, end);
+    for (int c = tid; c < nc; c += SORT_THREADS) {
+        unsigned run = gstart[(int64_t)b * nc + c] + gbase[((int64_t)b * SORT_SPLIT + k) * nc + c];
+        for (int q = 0; q < SORT_WAVES; ++q) { const unsigned t = hist[q * nc + c]; hist[q * nc + c] = run; run += t; }
+    }
+    __syncthreads();
+    // in-order fill: every wave walks its range again; rank inside a 64-point chunk by a match loop (as pillar_sort_kernel)
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        int c = -1;
+        if (i < end) { const float* p = pts + 3 * (p0 + i); c = cell_of(g, p[0], p[1], p[2]); }
+        unsigned long long active = __ballot(c >= 0);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int lc = __shfl(c, leader, 64);
+            const unsigned long long m = __ballot(c == lc);
+            if (c == lc) {
+                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                sorted[p0 + hist[w * nc + lc] + rank] = (int)(p0 + i);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) hist[w * nc + lc] += (unsigned)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            active &= ~m;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PFN layer 0
 // ------------------------------------------------------------------------------------------------
@@ -1085,6 +1217,7 @@ struct Ws {
     float* m1; float* r1; float* m2; float* r2;   // saved BatchNorm mean / rstd (backward)
     float* acc1;                                  // backward accumulators of PFN layer 0 (ACC1_FLOATS)
     void* X2; void* H2; float* F8; int* row_vox; float* row_w;
+    unsigned* sort_tmp;
     size_t bytes;
 };
 
@@ -1110,6 +1243,7 @@ Ws carve(void* base, const p3_pillar_desc* d) {
     w.F8 = (float*)take(rows * 8 * 4); w.row_w = (float*)take(rows * 4); w.row_vox = (int*)take(rows * 4);
     w.X2 = take(rows * K2 * es);
     w.H2 = take(rows * (size_t)d->C * es);
+    w.sort_tmp = (unsigned*)take((size_t)d->B * (SORT_SPLIT + 1) * (size_t)(d->nx + 1) * (d->ny + 1) * 2 * 4);   // the split sort's chunk histograms + cell starts
     w.bytes = off;
     (void)zero_end;
     return w;
@@ -1158,8 +1292,14 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     if (phases & 1) {
     e = hipMemsetAsync(w.totals, 0, (char*)w.sc1 - (char*)w.totals, s);
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
-    e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
-    if (e == hipSuccess) e = hipMemsetAsync(w.F8, 0, (char*)w.row_vox - (char*)w.F8, s);
+    // the one-launch layer 1 without a backward reads the rows of kept pillars only: the rows of no pillar need no defined content then (0.67 GB of memset at 40 k
+    // points per tile); every other path multiplies ALL rows (the GEMM, the backward's products) and needs them finite / zero
+    const bool lean_rows = d->no_backward && (d->C == 128 || d->C == 384) && (d->dtype == P3_BF16 || d->dtype == P3_F32X3) && ((uintptr_t)w2 % 16) == 0 &&
+                           d->total_points >= 16 * (int64_t)nslots;
+    if (!lean_rows) {
+        e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
+        if (e == hipSuccess) e = hipMemsetAsync(w.F8, 0, (char*)w.row_vox - (char*)w.F8, s);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(w.row_vox, 0xFF, rows * 4, s);   // -1 = unused row
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     // zero canvas columns [col_off, col_off + C) of every token row (empty pillars stay exactly 0)
@@ -1185,8 +1325,27 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
         (void)hipFuncSetAttribute((const void*)pillar_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
-    P3_LAUNCH_CHECK();
+    if (d->total_points >= 16 * (int64_t)nslots) {
+        // dense clouds: a tile's points over SORT_SPLIT workgroups (count / tables / fill)
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)pillar_sort_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pillar_sort_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        unsigned* ghist = w.sort_tmp;
+        unsigned* gstart = w.sort_tmp + (size_t)d->B * SORT_SPLIT * g.nc;
+        const size_t lds_h = (size_t)SORT_WAVES * g.nc * 4, lds_t = (size_t)5 * g.nc * 4 + 32 * 4;
+        hipLaunchKernelGGL(pillar_sort_count_kernel, dim3(SORT_SPLIT, d->B), dim3(SORT_THREADS), lds_h, s, values, offsets, g, ghist);
+        P3_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pillar_sort_tables_kernel, dim3(d->B), dim3(SORT_THREADS), lds_t, s, offsets, g, d->max_points, d->max_voxels, so, ghist, gstart);
+        P3_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pillar_sort_fill_kernel, dim3(SORT_SPLIT, d->B), dim3(SORT_THREADS), lds_h, s, values, offsets, g, ghist, gstart, w.sorted);
+        P3_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(pillar_sort_kernel, dim3(d->B), dim3(SORT_THREADS), lds, s, values, offsets, g, d->max_points, d->max_voxels, so);
+        P3_LAUNCH_CHECK();
+    }
     if (d->training) {
         // deterministic mode (p3_set_deterministic covers this dtype): the workgroups' partial sums go to the scratch and are added in workgroup order in float64
         const int g1 = vgrid < 512 ? vgrid : 512;

@@ -92,6 +92,30 @@ def test_pillar_membership_bit_exact_real_density():
     _check(vals, torch.tensor([0, 40000, 80000]))
 
 
+@pytest.mark.parametrize("max_points", [4, 64, 512])
+def test_pillar_membership_bit_exact_split_sort(max_points):
+    """clouds of >= 16 points per pillar slot take the sort that spreads a tile's points over several workgroups (csrc/pillars.hip: pillar_sort_count / tables / fill):
+    a capped dense corner (ascending point index inside a pillar must survive the chunking), a 5-point tile, an empty tile and a full tile in one batch"""
+    g = torch.Generator().manual_seed(21)
+    dense = torch.rand(45000, 3, generator=g) * torch.tensor([60.0, 60.0, 99.0])
+    full = torch.rand(40001, 3, generator=g) * torch.tensor([223.99, 223.99, 99.99])
+    full[::777, 2] = 100.0
+    tiny = torch.rand(5, 3, generator=g) * torch.tensor([223.0, 223.0, 99.0])
+    vals = torch.cat([dense, tiny, full])
+    offs = torch.tensor([0, 45000, 45005, 45005, 85006])               # tiles: dense corner, 5 points, empty, full
+    assert vals.shape[0] >= 16 * 4 * 784
+    _check(vals, offs, max_points=max_points)
+
+
+def test_pillar_membership_bit_exact_split_sort_max_voxels():
+    """the split sort with max_num_voxels below the number of non-empty cells (the cap counts BEFORE the bounds filter)"""
+    g = torch.Generator().manual_seed(23)
+    vals = torch.rand(30000, 3, generator=g) * torch.tensor([224.0, 224.0, 100.0])
+    vals[::5, 0] = 224.0
+    assert vals.shape[0] >= 16 * 2 * 300
+    _check(vals, torch.tensor([0, 15000, 30000]), max_voxels=300)
+
+
 def test_pillar_membership_bit_exact_boundaries_and_empty_sample():
     """x == 224 / y == 224 (out-of-grid cell, filtered but counted), z == 100 (top-z pillar), out-of-range points, an empty sample"""
     g = torch.Generator().manual_seed(5)

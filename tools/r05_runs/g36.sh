@@ -1,0 +1,12 @@
+# r05: split counting sort for dense clouds + lean no-backward memsets: membership / pillar / model tests, dense leg, 40 k profile
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+timeout 1500 python -m pytest tests/test_pillar_membership_gpu.py tests/test_backward_gpu.py tests/test_model_gpu.py tests/test_train_gpu.py -x -q -k "pillar or canvas or lidar or stem or bit_reproducible" > gpurun_out/r05/g36_tests.txt 2>&1
+tail -3 gpurun_out/r05/g36_tests.txt | cut -c1-250
+python bench.py --no-cpu-baseline --no-fp32-leg --no-predict --no-host-feed --no-ffl --no-kernel-timing 2>&1 | grep '"metric"' | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', d['ms_per_step']); print(json.dumps(d.get('dense_lidar'))[200:900])"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_d40 -o st -- python bench.py --lean --points 40000 --steps 6 --warmup 2 > gpurun_out/r05/g36_run.log 2>&1
+find /tmp/pf_d40 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05/g36_dense40k_fp32x3_kernel_stats.csv \;
+python tools/kstats.py gpurun_out/r05/g36_dense40k_fp32x3_kernel_stats.csv 9 70 > gpurun_out/r05/g36_dense40k_fp32x3_summary.txt
+grep -E "total|pfn|pillar" gpurun_out/r05/g36_dense40k_fp32x3_summary.txt
+grep '"metric"' gpurun_out/r05/g36_run.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32x3 40k ms/step', d['ms_per_step'])"
