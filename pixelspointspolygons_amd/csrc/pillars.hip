@@ -62,6 +62,19 @@ __device__ unsigned block_scan_excl(unsigned* arr, int n, unsigned* tmp) {
     return total;
 }
 
+// rank of this lane among the lanes of the wave that hold the same cell (earlier lanes only) and the number of such lanes: 64 scalar broadcasts + compares, no LDS
+// (r05: the match loop this replaces - leader, shuffle, ballot, LDS update per DISTINCT cell of the chunk - ran ~60 dependent rounds per chunk on a dense cloud)
+__device__ __forceinline__ void sort_rank_in_wave(int c, int lane, unsigned& rank, unsigned& same) {
+    rank = 0; same = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const int cj = __builtin_amdgcn_readlane(c, j);
+        const unsigned eq = (cj == c) ? 1u : 0u;
+        same += eq;
+        rank += (j < lane) ? eq : 0u;
+    }
+}
+
 struct SortOut {
     int* sorted;      // [total_points] global point index, grouped by pillar hash, ascending index inside a pillar
     int* vox_xy;      // [B*MV] cy*nx+cx of kept pillar, bit 30 = "skip in scatter" (overwritten by the top-z pillar)
@@ -132,25 +145,20 @@ __global__ __launch_bounds__(SORT_THREADS) void pillar_sort_kernel(const float* 
         }
     }
     if (tid == 0) { o.nvox[b] = (int)nkept; atomicAdd(o.totals, (int)nkept); }
-    // ---- in-order fill: every wave walks its range again; rank inside a 64-point chunk by a match loop ----
+    // ---- in-order fill: every wave walks its range again; rank inside a 64-point chunk = the earlier lanes of the chunk in the same cell ----
     for (int i0 = beg; i0 < end; i0 += 64) {
         const int i = i0 + lane;
         int c = -1;
         if (i < end) { const float* p = pts + 3 * (p0 + i); c = cell_of(g, p[0], p[1], p[2]); }
-        unsigned long long active = __ballot(c >= 0);
-        while (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const int lc = __shfl(c, leader, 64);
-            const unsigned long long m = __ballot(c == lc);
-            if (c == lc) {
-                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                o.sorted[p0 + start[lc] + hist[w * nc + lc] + rank] = (int)(p0 + i);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == leader) hist[w * nc + lc] += (unsigned)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            active &= ~m;
+        unsigned rank, same;
+        sort_rank_in_wave(c, lane, rank, same);
+        const unsigned base = c >= 0 ? hist[w * nc + c] : 0u;
+        __builtin_amdgcn_wave_barrier();                       // every lane has read its cell's position before a cell's first lane moves it on
+        if (c >= 0) {
+            o.sorted[p0 + start[c] + base + rank] = (int)(p0 + i);
+            if (rank == 0) hist[w * nc + c] = base + same;     // one lane per distinct cell of the chunk
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -264,25 +272,20 @@ __global__ __launch_bounds__(SORT_THREADS) void pillar_sort_fill_kernel(const fl
         for (int q = 0; q < SORT_WAVES; ++q) { const unsigned t = hist[q * nc + c]; hist[q * nc + c] = run; run += t; }
     }
     __syncthreads();
-    // in-order fill: every wave walks its range again; rank inside a 64-point chunk by a match loop (as pillar_sort_kernel)
+    // in-order fill: every wave walks its range again (as pillar_sort_kernel)
     for (int i0 = beg; i0 < end; i0 += 64) {
         const int i = i0 + lane;
         int c = -1;
         if (i < end) { const float* p = pts + 3 * (p0 + i); c = cell_of(g, p[0], p[1], p[2]); }
-        unsigned long long active = __ballot(c >= 0);
-        while (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const int lc = __shfl(c, leader, 64);
-            const unsigned long long m = __ballot(c == lc);
-            if (c == lc) {
-                const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                sorted[p0 + hist[w * nc + lc] + rank] = (int)(p0 + i);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == leader) hist[w * nc + lc] += (unsigned)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            active &= ~m;
+        unsigned rank, same;
+        sort_rank_in_wave(c, lane, rank, same);
+        const unsigned base = c >= 0 ? hist[w * nc + c] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (c >= 0) {
+            sorted[p0 + base + rank] = (int)(p0 + i);
+            if (rank == 0) hist[w * nc + c] = base + same;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -777,26 +780,35 @@ __global__ __launch_bounds__(256, 2) void pfn_l2_fused_kernel(const T* __restric
     float s1[NBW], s2[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
-    for (int v = blockIdx.x * NS + stream; v < nslots; v += gridDim.x * NS) {
-        if ((v % max_voxels) >= t.nvox[v / max_voxels]) continue;
-        const int cnt = t.cnt[v];
+    // pillars of this stream: v, v + vstride, ... (slots beyond a tile's kept pillars are skipped).  The NEXT pillar's table entries are loaded while this one is
+    // multiplied, and its first row group is fetched between the last group's products and epilogue: no pillar starts with an exposed chain of dependent loads
+    const int vstride = gridDim.x * NS;
+    auto next_valid = [&](int v) __attribute__((always_inline)) {
+        while (v < nslots && (v % max_voxels) >= t.nvox[v / max_voxels]) v += vstride;
+        return v;
+    };
+    u32x4_t xa[XR];
+    auto fetch = [&](int64_t row0, int nrow, int g0) __attribute__((always_inline)) {
+        const int rl = min(g0 + l31, nrow - 1);                       // rows beyond the pillar: a valid address, masked in the epilogue
+        const T* ap = X2 + (row0 + rl) * K2 + 8 * hi;
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) {
+            if constexpr (X3) { xa[2 * sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk); xa[2 * sk + 1] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk + 4); }
+            else xa[sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk);
+        }
+    };
+    int v = next_valid(blockIdx.x * NS + stream);
+    int cnt = 0; int64_t row0 = 0;
+    if (v < nslots) { cnt = t.cnt[v]; row0 = t.row[v]; fetch(row0, cnt + (cnt < max_points ? 1 : 0), 0); }
+    while (v < nslots) {
         const int nrow = cnt + (cnt < max_points ? 1 : 0);
-        const int64_t row0 = t.row[v];
         const float padw = (float)(max_points - cnt);
+        const int vn = next_valid(v + vstride);
+        int cntn = 0; int64_t row0n = 0;
+        if (vn < nslots) { cntn = t.cnt[vn]; row0n = t.row[vn]; }
         float mx[NBW], mn[NBW];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) { mx[nb] = -INFINITY; mn[nb] = INFINITY; }
-        u32x4_t xa[XR];
-        auto fetch = [&](int g0) __attribute__((always_inline)) {
-            const int rl = min(g0 + l31, nrow - 1);                       // rows beyond the pillar: a valid address, masked below
-            const T* ap = X2 + (row0 + rl) * K2 + 8 * hi;
-#pragma unroll
-            for (int sk = 0; sk < 4; ++sk) {
-                if constexpr (X3) { xa[2 * sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk); xa[2 * sk + 1] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk + 4); }
-                else xa[sk] = *reinterpret_cast<const u32x4_t*>(ap + 16 * sk);
-            }
-        };
-        fetch(0);
         for (int g0 = 0; g0 < nrow; g0 += 32) {
             f32x16 acc[NBW];
 #pragma unroll
@@ -822,9 +834,11 @@ __global__ __launch_bounds__(256, 2) void pfn_l2_fused_kernel(const T* __restric
                     for (int nb = 0; nb < NBW; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, xa[sk]), wh[nb][sk], acc[nb], 0, 0, 0);
                 }
             }
-            // the pillar's next group: issued here, in flight during the epilogue (one register set: the products above were its last readers)
+            // the next row group - of this pillar, or the first one of the next pillar: issued here, in flight during the epilogue (one register set: the products
+            // above were its last readers)
             __builtin_amdgcn_sched_barrier(0);
-            if (g0 + 32 < nrow) fetch(g0 + 32);
+            if (g0 + 32 < nrow) fetch(row0, nrow, g0 + 32);
+            else if (vn < nslots) fetch(row0n, cntn + (cntn < max_points ? 1 : 0), 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -847,6 +861,7 @@ __global__ __launch_bounds__(256, 2) void pfn_l2_fused_kernel(const T* __restric
             const float a = fmaxf(mx[nb], __shfl_xor(mx[nb], 32, 64)), b = fminf(mn[nb], __shfl_xor(mn[nb], 32, 64));
             if (hi == 0) { hmax[(int64_t)v * C + ch0 + nb * 32] = a; hmin[(int64_t)v * C + ch0 + nb * 32] = b; }
         }
+        v = vn; cnt = cntn; row0 = row0n;
     }
     if (sums) {
         // the two row halves of a lane pair, then the workgroup's pillar streams, in a fixed order
