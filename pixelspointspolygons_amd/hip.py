@@ -1305,6 +1305,10 @@ class GemmX3Desc(Structure):
                 ("ln_hi", c_void_p), ("ln_lo", c_void_p), ("ldln", c_int), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
 
 
+X3_CUS = 256                                                                 # CUs of the chip: the 128 x 384 tile runs one workgroup per CU
+X3_RAGGED_SPLIT = [_os0.environ.get("P3_X3_RAGGED", "1") != "0"]               # A/B switch of the ragged-round rule below
+
+
 def gemm_x3(a, w, *, bias=None, act=ACT_NONE, residual=None, aux=None, mul=None, out=None, out_planes=False, ln=None):
     """C = epilogue((a_hi + a_lo) (w_hi + w_lo)^T).  a: Planes [M, K]; w: (hi, lo) bf16 [N, K] tensors (or Planes); out: fp32 [M, N] tensor or Planes
     (out_planes=True allocates one).  ln = (gamma, beta, eps, Planes out, mean, rstd): LayerNorm of the output row fused into the epilogue (N == 384)."""
@@ -1338,12 +1342,44 @@ def gemm_x3(a, w, *, bias=None, act=ACT_NONE, residual=None, aux=None, mul=None,
         d.ln_gamma, d.ln_beta, d.ln_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
         d.ln_hi, d.ln_lo, d.ldln = lnout.hi.data_ptr(), lnout.lo.data_ptr(), lnout.ld
         d.ln_mean, d.ln_rstd = (mean.data_ptr() if mean is not None else None), (rstd.data_ptr() if rstd is not None else None)
-    ev = KTIMER.begin()
-    check(lib().p3_gemm_x3(byref(d), stream()), "p3_gemm_x3")
-    if ev is not None:
-        nbytes = 4.0 * (M * K + N * K + M * N) + (4.0 * M * N if residual is not None else 0) + (4.0 * M * N if aux is not None else 0) + (4.0 * M * N if mul is not None else 0) \
-            + (4.0 * M * N if ln is not None else 0)
-        KTIMER.end(ev, lib().p3_last_kernel().decode() or "gemm_x3_kernel", 2.0 * M * N * K, nbytes)
+    def launch(dd, rows):
+        ev = KTIMER.begin()
+        check(lib().p3_gemm_x3(byref(dd), stream()), "p3_gemm_x3")
+        if ev is not None:
+            nbytes = 4.0 * (rows * K + N * K + rows * N) + (4.0 * rows * N if residual is not None else 0) + (4.0 * rows * N if aux is not None else 0) \
+                + (4.0 * rows * N if mul is not None else 0) + (4.0 * rows * N if ln is not None else 0)
+            KTIMER.end(ev, lib().p3_last_kernel().decode() or "gemm_x3_kernel", 2.0 * rows * N * K, nbytes)
+
+    # A ragged last round of the 128 x 384 tile (csrc/gemm_x3.hip picks it for N > 256, K >= 1024; one workgroup per CU): M = 50 240 is 393 row tiles = a full round
+    # of 256 and a round of 137 with 119 CUs idle - two round times for 1.5 rounds of work.  Whole rounds go to the big tile, the remainder to the 128 x 128 tile
+    # (two workgroups per CU: 137 x 3 = 411 small tiles are ONE round of 512 slots at a third of the work each), back to back on the same stream.
+    tm = (M + 127) // 128
+    rem = tm % X3_CUS
+    if X3_RAGGED_SPLIT[0] and ln is None and 256 < N <= 384 and K >= 1024 and tm > X3_CUS and 0 < rem <= (3 * X3_CUS) // 4:
+        head = (tm - rem) * 128
+        d2 = GemmX3Desc()
+        ctypes.memmove(byref(d2), byref(d), ctypes.sizeof(d))
+        d.M, d2.M = head, M - head
+        d2.a_hi, d2.a_lo = d.a_hi + head * d.lda * 2, d.a_lo + head * d.lda * 2
+        esz = 2 if isinstance(out, Planes) else 4
+        d2.c = d.c + head * d.ldc * esz
+        if isinstance(out, Planes):
+            d2.c_lo = d.c_lo + head * d.ldc * esz
+        if residual is not None:
+            d2.residual = d.residual + head * d.ldr * 4
+        if aux is not None:
+            d2.aux = d.aux + head * d.ldaux * 4
+        if mul is not None:
+            d2.mul = d.mul + head * d.ldmul * 4
+        was = lib().p3_gemm_x3_tile(c_int(2))
+        try:
+            launch(d, head)
+            lib().p3_gemm_x3_tile(c_int(1))
+            launch(d2, M - head)
+        finally:
+            lib().p3_gemm_x3_tile(c_int(was))
+        return out
+    launch(d, M)
     return out
 
 
@@ -1359,7 +1395,7 @@ def gemm_tn_x3(a, b, out=None, colsum_out=None):
     check(lib().p3_gemm_tn_x3(ptr(a.hi), ptr(a.lo), c_int(a.ld), ptr(b.hi), ptr(b.lo), c_int(b.ld), ptr(out), c_int(out.stride(0)), c_int(M), c_int(N), c_int(K),
                               ptr(colsum_out), ptr(slabs), c_int(ns), stream()), "p3_gemm_tn_x3")
     if ev is not None:
-        KTIMER.end(ev, "gemm_tn_x3_kernel<2>", 2.0 * a.rows * N * K, float(4 * a.rows * (N + K) + N * K * 4))
+        KTIMER.end(ev, lib().p3_last_kernel().decode() or "gemm_tn_x3_kernel<4>", 2.0 * a.rows * N * K, float(4 * a.rows * (N + K) + N * K * 4))
     return out
 
 

@@ -55,6 +55,40 @@ def test_gemm_x3_plain_and_epilogues(M, N, K):
     assert rel_err(hip.from_planes(dp).cpu(), (ref * mul.double()).float()) < 2e-5
 
 
+def test_gemm_x3_ragged_last_round_goes_to_the_small_tile():
+    """hip.gemm_x3 at M = 40 000, N = 384, K = 1024: 313 row tiles of the 128 x 384 kernel = one full round of 256 workgroups and 57 in a second one - the binding
+    launches the 256 whole-round tiles on the big tile and the remaining rows on the 128 x 128 tile (profiles: the ViT's 393-tile products).  Both halves
+    against float64 with every epilogue operand (bias, residual, multiplier, planes output), equal to the unsplit launch to a rounding, and the kernel
+    timer sees two launches."""
+    hip = _h()
+    M, N, K = 40000, 384, 1024
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1)
+    bias, res, mul = _rand(N, seed=3), _rand(M, N, seed=4), _rand(M, N, seed=5)
+    ap, wp = hip.to_planes(a.to(DEV)), hip.to_planes(w.to(DEV), pad=1)
+    ref = a.double() @ w.double().t()
+
+    def run():
+        y = hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV))
+        yp = hip.gemm_x3(ap, wp, mul=mul.to(DEV), out_planes=True)
+        return y, hip.from_planes(yp)
+    hip.KTIMER.enable()
+    try:
+        y, g = run()
+        names = dict(hip.KTIMER.summary())
+    finally:
+        hip.KTIMER.disable()
+    assert "gemm_x3_n384_kernel<false>" in names and any(k.startswith("gemm_x3_kernel<") for k in names), names
+    assert rel_err(y.cpu(), (ref + bias.double() + res.double()).float()) < 1e-5
+    assert rel_err(g.cpu(), (ref * mul.double()).float()) < 2e-5
+    hip.X3_RAGGED_SPLIT[0] = False
+    try:
+        y1, g1 = run()
+    finally:
+        hip.X3_RAGGED_SPLIT[0] = True
+    assert rel_err(y.cpu(), y1.cpu()) < 1e-6 and rel_err(g.cpu(), g1.cpu()) < 1e-6
+    assert torch.equal(y[:32768], y1[:32768])                      # the whole-round rows run the same kernel on the same tiles
+
+
 @pytest.mark.parametrize("M,K", [(1570, 384), (1000, 1536), (128, 384)])
 def test_gemm_x3_fused_layernorm_of_the_output_row(M, K):
     """proj / fc2 of timm's Block with the following LayerNorm in the epilogue (N == 384): C, LN(C) as planes, mean and rstd"""
