@@ -506,6 +506,16 @@ extern "C" int p3_tn_drop(void) { const int n = g_tnp_n; g_tnp_n = 0; g_tnp_used
 float* p3_tn_park(float* C, int N, int K, int ldc, int splits) {
     const int64_t floats = (int64_t)splits * N * K;
     if (!g_tnp_on || !g_tnp_arena || g_tnp_n >= TNP_CAP || g_tnp_used + floats > g_tnp_cap || K % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C % 16) != 0) return nullptr;
+    // a target that overlaps an already parked one (a shared weight, a second gradient into the same rows) is reduced at once: two entries of one flush would read-modify-write
+    // the same addresses from different workgroups (the parked one keeps its place; both sums end up in C, in launch order)
+    {
+        const uintptr_t lo = (uintptr_t)C, hi = (uintptr_t)(C + (int64_t)(N - 1) * ldc + K);
+        for (int i = 0; i < g_tnp_n; ++i) {
+            const TnpEntry& o = g_tnp[i];
+            const uintptr_t olo = (uintptr_t)o.C, ohi = (uintptr_t)(o.C + (int64_t)(o.N - 1) * o.ldc + o.K);
+            if (lo < ohi && olo < hi) return nullptr;
+        }
+    }
     float* slot = g_tnp_arena + g_tnp_used;
     g_tnp_used += (floats + 63) / 64 * 64;
     TnpEntry& en = g_tnp[g_tnp_n++];

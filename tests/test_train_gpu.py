@@ -181,3 +181,29 @@ def test_parity_mode_train_step_is_bit_reproducible(precision):
     ops.reset_process_state()
     bad = sorted(((float((a[k].float() - b[k].float()).abs().max() / a[k].float().abs().max().clamp_min(1e-30)), k) for k in a if not torch.equal(a[k], b[k])), reverse=True)
     assert not bad, (len(bad), bad[:10])
+
+
+def test_parked_weight_gradients_that_share_a_target_are_not_flushed_side_by_side():
+    """csrc/gemm_tn.hip p3_tn_park: the ONE flush launch adds every parked set with plain read-modify-writes from different workgroups, so a second product into an
+    overlapping target (a shared weight, a second gradient into the same rows) must not be parked beside the first - it is reduced at once.  Both sums end up in the target."""
+    import pixelspointspolygons_amd.hip as h
+    if not h.tn_defer_arena():
+        pytest.skip("weight-gradient parking is switched off (P3_TN_DEFER_MB=0)")
+    g = torch.Generator().manual_seed(3)
+    a1, b1 = torch.randn(4096, 256, generator=g).to(DEV), torch.randn(4096, 128, generator=g).to(DEV)
+    a2, b2 = torch.randn(4096, 256, generator=g).to(DEV), torch.randn(4096, 128, generator=g).to(DEV)
+    out, other = torch.zeros(256, 128, device=DEV), torch.zeros(256, 128, device=DEV)
+    h.reduce_drop()
+    with h.tn_parking(True):
+        h.gemm_tn(a1, b1, out=out)
+        n1 = h.reduce_pending()
+        h.gemm_tn(a2, b2, out=out)                     # same target: reduced at once
+        n2 = h.reduce_pending()
+        h.gemm_tn(a2, b2, out=other)                   # another target: parked
+        n3 = h.reduce_pending()
+    assert (n1, n2, n3) == (1, 1, 2), (n1, n2, n3)
+    h.reduce_flush()
+    assert h.reduce_pending() == 0
+    ref = a1.double().t() @ b1.double() + a2.double().t() @ b2.double()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float((other.double() - a2.double().t() @ b2.double()).abs().max() / ref.abs().max()) < 2e-6
