@@ -1274,6 +1274,13 @@ __global__ __launch_bounds__(256) void zero_cols16_kernel(char* __restrict__ bas
     }
 }
 
+// does PFN layer 1 run as one launch (pfn_l2_fused_kernel)?  Dense clouds only - >= 16 points per pillar slot on average (the bench's 3 k points per tile are 3.8,
+// BASELINE's real tiles ~51): below that a pillar fills a fraction of a 32-row MFMA group and the two-pass form is faster - at the widths the kernel is built for
+static bool pfn_layer1_fused(const p3_pillar_desc* d, const void* w2) {
+    return (d->C == 128 || d->C == 384) && (d->dtype == P3_BF16 || d->dtype == P3_F32X3) && ((uintptr_t)w2 % 16) == 0 &&
+           d->total_points >= 16 * (int64_t)d->B * d->max_voxels;
+}
+
 extern "C" int64_t p3_pillar_stem_workspace_bytes(const p3_pillar_desc* d) {
     if (!d) return -1;
     return (int64_t)carve(nullptr, d).bytes;
@@ -1309,8 +1316,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
     if (e != hipSuccess) { p3_set_error(hipGetErrorString(e)); return (int)e; }
     // the one-launch layer 1 without a backward reads the rows of kept pillars only: the rows of no pillar need no defined content then (0.67 GB of memset at 40 k
     // points per tile); every other path multiplies ALL rows (the GEMM, the backward's products) and needs them finite / zero
-    const bool lean_rows = d->no_backward && (d->C == 128 || d->C == 384) && (d->dtype == P3_BF16 || d->dtype == P3_F32X3) && ((uintptr_t)w2 % 16) == 0 &&
-                           d->total_points >= 16 * (int64_t)nslots;
+    const bool lean_rows = d->no_backward && pfn_layer1_fused(d, w2);
     if (!lean_rows) {
         e = hipMemsetAsync(w.X2, 0, rows * K2 * es, s);   // unused rows must be finite for the GEMM
         if (e == hipSuccess) e = hipMemsetAsync(w.F8, 0, (char*)w.row_vox - (char*)w.F8, s);
@@ -1381,9 +1387,7 @@ extern "C" int p3_pillar_stem_phased(const float* values, const int64_t* offsets
 #undef P3_L1_APPLY
     P3_LAUNCH_CHECK();
     float* sums2 = d->training ? w.sums2 : nullptr;
-    // dense clouds only (>= 16 points per pillar slot on average; the bench's 3 k points per tile are 3.8, BASELINE's real tiles ~51): see pfn_l2_fused_kernel
-    const bool fused2 = (d->C == 128 || d->C == 384) && (d->dtype == P3_BF16 || d->dtype == P3_F32X3) && ((uintptr_t)w2 % 16) == 0 &&
-                        d->total_points >= 16 * (int64_t)nslots;
+    const bool fused2 = pfn_layer1_fused(d, w2);
     if (fused2) {
         // layer 1 in one launch: product, per-pillar max / min, BatchNorm sums (pfn_l2_fused_kernel); H2 is written only when a backward pass will read it
         const int ns = d->C == 128 ? 2 : 1;                          // pillars in flight per workgroup
@@ -1464,6 +1468,7 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     P3_CHECK(dcanvas && w1 && bn1_gamma && w2t && bn2_gamma && workspace && d && dw1 && dg1 && db1 && dw2 && dg2 && db2, P3_EINVAL,
              "p3_pillar_stem_bwd: null pointer");
     P3_CHECK(d->C % 64 == 0 && d->C <= 768 && d->max_points > 0 && d->max_points <= 4096, P3_ESHAPE, "p3_pillar_stem_bwd: shape");
+    P3_CHECK(!d->no_backward, P3_EINVAL, "p3_pillar_stem_bwd: the forward ran with no_backward set - its workspace holds no layer-1 activations");
     hipStream_t s = (hipStream_t)stream;
     const int kdt = d->dtype == P3_BF16 ? P3_BF16 : P3_F32;       // the dtype p3_det_scratch decides by (P3_F32X3 is fp32 storage)
     Ws w = carve(workspace, d);
