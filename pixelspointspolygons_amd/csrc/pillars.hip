@@ -976,11 +976,15 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats_kernel(VoxTab t, int max
 
 // bf16 canvas gradient, C % 8 == 0, C <= 512, 16-byte aligned rows: a lane owns 8 channels - the four per-channel BatchNorm vectors live in
 // registers for the whole walk (the column-group form re-read them for every pillar), one 16-byte / two 16-byte accesses per tensor
+// (r05: templated on the canvas gradient's type - the fp32 family used to stay on the column-group form: 207 us at 3 k points per tile against 70 for bf16 -
+// and, with a slab, its workgroup partials go to the fixed-order reduce instead of atomics)
+template <typename T>
 __global__ __launch_bounds__(256) void pfn_bwd_l2_stats8_kernel(VoxTab t, int max_voxels, int nslots, int C, int ncell,
-                                                                const bf16_t* __restrict__ dcanvas, int dld, const float* __restrict__ sc2,
+                                                                const T* __restrict__ dcanvas, int dld, const float* __restrict__ sc2,
                                                                 const float* __restrict__ sh2, const float* __restrict__ mean2,
                                                                 const float* __restrict__ rstd2, float* __restrict__ hmax,
-                                                                float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                                float* __restrict__ hmin, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                float* __restrict__ slab = nullptr /* [gridDim.x][dbeta(C) | dgamma(C)] */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = lane * 8;
     const bool act = c0 < C;
     float sc[8], sh[8], mu[8], rs[8], s1[8], s2[8];
@@ -995,20 +999,21 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats8_kernel(VoxTab t, int ma
         if (!act) continue;
         const int xyf = t.xy[v];
         const bool live = (xyf & (1 << 30)) == 0;
-        const uint4 raw = *reinterpret_cast<const uint4*>(dcanvas + ((int64_t)b * ncell + (xyf & 0xffffff)) * dld + c0);
+        Row8<T> raw;
+        raw.load(dcanvas + ((int64_t)b * ncell + (xyf & 0xffffff)) * dld + c0);
+        float gin[8];
+        raw.get(gin);
         float* hx = hmax + (int64_t)v * C + c0;
         float* hn = hmin + (int64_t)v * C + c0;
         const float4 x0 = *reinterpret_cast<const float4*>(hx), x1 = *reinterpret_cast<const float4*>(hx + 4);
         const float4 n0 = *reinterpret_cast<const float4*>(hn), n1 = *reinterpret_cast<const float4*>(hn + 4);
         const float hxv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, hnv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-        const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
         float gv[8], hs[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             hs[k] = sc[k] > 0.f ? hxv[k] : hnv[k];
             const float y = sc[k] * hs[k] + sh[k];
-            const float g = (k & 1) ? __uint_as_float(wd[k >> 1] & 0xffff0000u) : __uint_as_float(wd[k >> 1] << 16);
-            gv[k] = (live && y > 0.f) ? g : 0.f;
+            gv[k] = (live && y > 0.f) ? gin[k] : 0.f;
             s1[k] += gv[k]; s2[k] += gv[k] * (hs[k] - mu[k]) * rs[k];
         }
         *reinterpret_cast<float4*>(hx) = make_float4(gv[0], gv[1], gv[2], gv[3]); *reinterpret_cast<float4*>(hx + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
@@ -1019,8 +1024,10 @@ __global__ __launch_bounds__(256) void pfn_bwd_l2_stats8_kernel(VoxTab t, int ma
     for (int k = 0; k < 8; ++k) { red[wv][c0 + k] = s1[k]; red[wv][512 + c0 + k] = s2[k]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(dbeta + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-        atomicAdd(dgamma + c, (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]));
+        const float vb = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        const float vg = (red[0][512 + c] + red[1][512 + c]) + (red[2][512 + c] + red[3][512 + c]);
+        if (slab) { slab[(int64_t)blockIdx.x * 2 * C + c] = vb; slab[(int64_t)blockIdx.x * 2 * C + C + c] = vg; }
+        else { atomicAdd(dbeta + c, vb); atomicAdd(dgamma + c, vg); }
     }
 }
 
@@ -1492,12 +1499,15 @@ extern "C" int p3_pillar_stem_bwd_phased(const void* dcanvas, int dcanvas_ld, co
     if (phases & 1) {
     if (bf)
         if (C % 8 == 0 && C <= 512 && d->out_col_off % 8 == 0 && dcanvas_ld % 8 == 0 && ((uintptr_t)dcanvas % 16) == 0)
-            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel, dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
+            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel<bf16_t>, dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2, (float*)nullptr);
         else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<bf16_t>), dim3(vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const bf16_t*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2);
     else {
         const int g3 = vgrid < L2S_BLOCKS ? vgrid : L2S_BLOCKS;
         float* slab3 = p3_det_scratch((int64_t)g3 * 2 * C, kdt);
+        if (C % 8 == 0 && C <= 512 && d->out_col_off % 4 == 0 && dcanvas_ld % 4 == 0 && ((uintptr_t)dcanvas % 16) == 0)
+            hipLaunchKernelGGL(pfn_bwd_l2_stats8_kernel<float>, dim3(g3), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2, slab3);
+        else
         hipLaunchKernelGGL((pfn_bwd_l2_stats_kernel<float>), dim3(g3), dim3(256), 0, s, t, d->max_voxels, nslots, C, ncell, (const float*)dcanvas + d->out_col_off, dcanvas_ld, w.sc2, w.sh2, w.m2, w.r2, w.hmax, w.hmin, db2, dg2, slab3);
         P3_LAUNCH_CHECK();
         if (slab3) {
