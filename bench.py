@@ -21,7 +21,7 @@ Extra objects in the JSON line (N = 1): `roofline` (dominant kernel, HIP events 
 committed PMC passes), `encoder_fwd` (the fused ViT + LiDAR encoder forward alone: the quantity the north star's MFMA fraction is defined on),
 `fp32_exact_mode` (the same step on the exact fp32 MFMA path) and `bf16_mode` (bf16 storage - faster, outside the tolerance),
 `bf16_vs_oracle` / `fp32_vs_oracle` / `fp32x3_vs_oracle` (MEASURED error of each bench model on two tiles of the
-bench batch against the oracle on the host), `dense_lidar` (the LiDAR stem at 3 k and 40 k points per tile), `ffl` (BASELINE configs[4], 5 captured steps),
+bench batch against the oracle on the host), `dense_lidar` (the LiDAR stem at 3 k and 40 k points per tile), `ffl` (BASELINE configs[4], 5 captured steps), `image_b16` (BASELINE configs[1]: the ViT-B/16 image-only step at bs 64 in bf16 and fp32x3),
 `predict` (BASELINE configs[0]: image-only model, batch 1, 385-step greedy decode of the demo tile), `pcie_inclusive` (host-fed step, never `value`),
 `cpu_baseline` (the oracle on this box's host cores), `rank_ms_per_step` (min / max over the ranks).
 """
@@ -71,13 +71,14 @@ def parse():
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency legs (profiling runs)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the timed legs of the other two precisions (bf16_mode, fp32_exact_mode)")
     ap.add_argument("--no-ffl", action="store_true", help="skip the short FFL (configs[4]) sub-run of the default line")
+    ap.add_argument("--no-b16", action="store_true", help="skip the ViT-B/16 image-only (configs[1]) sub-run of the default line")
     ap.add_argument("--no-predict", action="store_true", help="skip the configs[0] predict leg (image-only, batch 1, 385-step decode)")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive leg (host uint8 tiles + point lists through the device input pipeline)")
     ap.add_argument("--lean", action="store_true", help="timed loop only (= all --no-* switches; profiling / A-B runs)")
     a = ap.parse_args()
     if a.lean:
-        a.no_cpu_baseline = a.no_kernel_timing = a.no_fwd = a.no_fp32_leg = a.no_predict = a.no_host_feed = a.no_ffl = True
+        a.no_cpu_baseline = a.no_kernel_timing = a.no_fwd = a.no_fp32_leg = a.no_predict = a.no_host_feed = a.no_ffl = a.no_b16 = True
     return a
 
 
@@ -301,12 +302,17 @@ def cpu_baseline(args, kind, probes=None):
     vs = {}
     for name, pr in (probes or {}).items():
         with torch.no_grad():
-            rl, rp = O.pix2poly_forward({k: v.clone() for k, v in pr["sd"].items()}, pr["y"], pr["image"], pr["lidar"], cfg=cfgv, training=False)
+            rl, rp = O.pix2poly_forward({k: v.clone() for k, v in pr["sd"].items()}, pr["y"], pr["image"], pr["lidar"],
+                                        cfg=O.VIT_B16 if name.startswith("image_b16_") else cfgv, training=False)
         rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+        # element-wise: every value against ITS OWN size, floored at 1 % of the largest reference value (the norm-wise figure alone hides small entries)
+        erel = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-2 * float(b.double().abs().max()))).max())
         am = (pr["logits"].argmax(-1) == rl.argmax(-1))
         vs[name] = {"tiles": int(pr["y"].shape[0]), "logits_rel": float(f"{rel(pr['logits'], rl):.3e}"), "perm_rel": float(f"{rel(pr['perm'], rp):.3e}"),
+                    "logits_rel_elementwise": float(f"{erel(pr['logits'], rl):.3e}"), "perm_rel_elementwise": float(f"{erel(pr['perm'], rp):.3e}"),
                     "argmax_agree": round(float(am.float().mean()), 6), "argmax_positions": int(am.numel()),
-                    "what": "eval-mode forward of the bench model on tiles 0..n-1 of the bench batch vs oracle.pix2poly_forward on the host; max-abs error / max-abs reference"}
+                    "what": "eval-mode forward of the bench model on tiles 0..n-1 of the bench batch vs oracle.pix2poly_forward on the host; *_rel = max-abs error / max-abs "
+                            "reference, *_rel_elementwise = max over elements of |a - b| / max(|b|, 1e-2 max|b|)"}
     sd = O.make_state_dict(okind, cfgv, seed=42)
 
     def inputs(B):
@@ -576,6 +582,29 @@ def ffl_leg(args, dev, local, S, rank, world):
     return out
 
 
+def image_b16_leg(args, dev, local, S, rank, world, with_oracle):
+    """BASELINE configs[1] driver-timed: image-only Pix2Poly with the ViT-B/16 shape (197 tokens x 768, depth 12), bs 64 - the train step in `bf16` (the
+    precision configs[1] names) and in `fp32x3` (the one that meets north_star's tolerance), each with its own measured error against the oracle."""
+    import argparse as _ap
+    a2 = _ap.Namespace(**vars(args))
+    a2.workload = "image_b16"
+    out = {"workload": f"pix2poly_image_b16_bs{args.batch}x1", "step": "fwd+CE+10*BCE+bwd+AdamW", "gflop_fwd_per_tile_executed": GFLOP_FWD["image_b16"]}
+    probes = {}
+    for prec in ("bf16", "fp32x3"):
+        _, model, opt, reducer, pool, st = build(a2, dev, local, prec, S, rank, world, False)
+        n = max(3, min(args.steps, 10))
+        dt, loss = timed_steps(st, pool, n, 3, 1, dev)
+        out[prec] = {"value": round(args.batch * n / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n, "warmup": 3, "dtype": DTYPE_NAME[prec],
+                     "hip_graph": st.graph is not None, "mfma_peak_tflops": round(PEAK_TF[prec], 1),
+                     "step_mfma_frac": round(3 * GFLOP_FWD["image_b16"] * args.batch / (dt / n) / 1e3 / PEAK_TF[prec], 4), "final_loss": round(loss, 4)}
+        if with_oracle:
+            probes[f"image_b16_{prec}_vs_oracle"] = parity_probe(model, pool, "image")
+        opt.close()
+        del st, reducer, opt, model, pool
+        torch.cuda.empty_cache()
+    return out, probes
+
+
 def build(args, dev, local, precision, S, rank, world, sync_bn):
     """model + optimizer + reducer + synthetic pool + stepper for one precision"""
     from pixelspointspolygons_amd.training import FlatAdamW, GradBucketReducer
@@ -774,6 +803,17 @@ def main():
             torch.cuda.empty_cache()
         ffl = ffl_leg(args, dev, local, S, rank, world)
 
+    b16 = None
+    if single and rank == 0 and pix and not args.no_b16 and args.workload == "fusion_s8":
+        if main_alive:
+            main_alive = False
+            del st, reducer
+            opt.close()
+            del opt, model
+            torch.cuda.empty_cache()
+        b16, b16_probes = image_b16_leg(args, dev, local, S, rank, world, not args.no_cpu_baseline)
+        probes.update(b16_probes)
+
     predict = None
     if single and rank == 0 and not args.no_predict and args.workload != "ffl_fusion":
         try:
@@ -817,6 +857,8 @@ def main():
             line[{"bf16": "bf16_mode", "fp32": "fp32_exact_mode", "fp32x3": "fp32x3_mode"}[prec]] = leg
         if ffl is not None:
             line["ffl"] = ffl
+        if b16 is not None:
+            line["image_b16"] = b16
         if predict is not None:
             line["predict"] = predict
         if feed is not None:

@@ -181,7 +181,9 @@ int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, in
  *   that GELU);  residual != NULL: v += residual[m, n] (fp32, ldr);  then C <- v as fp32 (c, ldc; c_lo == NULL) or as planes (c = hi, c_lo = lo, ldc).
  *   Fused LayerNorm of the OUTPUT row (ln_gamma != NULL; needs N == 384 == the tile width, fp32 C): besides C the kernel writes LN(C) as planes (ln_hi, ln_lo,
  *   ldln) and the row statistics (ln_mean, ln_rstd) - the norm2 / next block's norm1 of timm's Block, whose separate pass re-read the 77 MB stream.
- * Shapes: K % 32 == 0, N % 8 == 0, 16-byte aligned rows.  Tiles: 128 x 128 (4 waves) or, for N == 384, 128 x 384 (8 waves).
+ * Shapes: K % 32 == 0, N % 8 == 0, 16-byte aligned rows.  Kernels: K = 256 / 384 with N % 32 == 0 and M >= 1024 - the A-stationary persistent kernel
+ * (gemm_x3_as.hip: the A rows of a wave live in registers, the weights stream through LDS, one workgroup per CU walks (row block, column block) units);
+ * otherwise tiles of 128 x 128 (4 waves) or, for N == 384 and K >= 1024, 128 x 384 (8 waves).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int M, N, K;
@@ -198,8 +200,12 @@ typedef struct {
     float* ln_mean; float* ln_rstd;
 } p3_gemm_x3_desc;
 int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream);
-/* measurement hook (tools/mb_x3.py): 0 = the library's tile rule, 1 = every product on the 128 x 128 tile, 2 = on the 128 x 384 tile; returns the previous mode */
+/* measurement hook (tools/mb_x3.py, tools/mb_as.py): 0 = the library's rule, 1 = every product on the 128 x 128 tile, 2 = on the 128 x 384 tile, 3 = on the
+ * A-stationary persistent kernel (csrc/gemm_x3_as.hip; P3_EUNSUP unless K = 256 / 384, N % 32 == 0, M >= 1024); returns the previous mode */
 int p3_gemm_x3_tile(int mode);
+/* measurement hook: device buffer [256][8][8] of 64-bit cycle sums written by the instrumented variants of the A-stationary kernel (environment P3_AS_VAR & 64);
+ * NULL switches it off */
+int p3_gemm_x3_as_debug(void* buf);
 /* weight gradient from planes:  C[N, K] (+)= (a_hi + a_lo)[M, N]^T (b_hi + b_lo)[M, K]  (fp32 C, split over M: fp32 atomics, or - `slabs` given - partial
  * tiles + a fixed-order reduce like p3_gemm_tn_ex); colsum (optional, [N]) += column sums of A (the bias gradient).  M % 64 == 0, N % 128 == 0, K % 128 == 0. */
 int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, float* C, int ldc, int M, int N, int K,

@@ -116,19 +116,35 @@ def precision_scoped(cls):
     return cls
 
 
+class _ScopedMethod:
+    """Instance attribute that shadows a method of a scoped module: calls the CLASS's function on the module under the product precision `split`.  The module
+    is held WEAKLY and `__wrapped__` is the unbound function, so module -> attribute -> module is not a reference cycle: `del model` frees the module and the
+    arenas its parameters view at once, not at the next cyclic collection.  A deep copy re-binds to the copied module."""
+
+    def __init__(self, module, name, split):
+        import functools
+        import weakref
+        self._ref, self._name, self._split = weakref.ref(module), name, bool(split)
+        functools.update_wrapper(self, getattr(type(module), name))
+
+    def __call__(self, *a, **k):
+        m = self._ref()
+        if m is None:
+            raise ReferenceError(f"the module of scoped method {self._name!r} is gone")
+        with gemm_split(self._split):
+            return getattr(type(m), self._name)(m, *a, **k)
+
+    def __deepcopy__(self, memo):
+        m = self._ref()
+        twin = memo.get(id(m)) if m is not None else None
+        return _ScopedMethod(twin if twin is not None else m, self._name, self._split)
+
+
 def scope_module(module, split, methods=()):
     """every forward of `module` (and whatever it calls) - and every call of the named methods - runs with the product precision `split`; scopes nest"""
     stack = []
-    import functools
-
     for name in methods:
-        fn = getattr(module, name)
-
-        def wrapped(*a, __fn=fn, **k):
-            with gemm_split(split):
-                return __fn(*a, **k)
-
-        setattr(module, name, functools.wraps(fn)(wrapped))
+        setattr(module, name, _ScopedMethod(module, name, split))
 
     def pre(_m, _a):
         stack.append(_SPLIT[0])

@@ -45,11 +45,14 @@ def _accum(weight, bias, dy, x, grads, iw, ib):
 @hip.precision_scoped
 class _ViTStackX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, heads, eps, fuse_ln, *params):
+    def forward(ctx, x, heads, eps, fuse_ln, grad_on, *params):
         B, L, D = x.shape
         M = B * L
         nblk = len(params) // PER_BLOCK
-        need = any(ctx.needs_input_grad)                  # (grad mode is off inside forward: is_grad_enabled() says nothing here)
+        # grad_on = torch.is_grad_enabled() read by the CALLER (inside forward the grad mode is always off, and needs_input_grad is True under no_grad() whenever
+        # the parameters require grad): an eval / predict pass must not run the training variant - attention with the LSE, fc1 writing the 300 MB GELU' tensor,
+        # 1.2 GB of activations per block parked until forward returns
+        need = grad_on and any(ctx.needs_input_grad)
         dev = x.device
         xs = x.reshape(M, D)
         if not xs.is_contiguous():
@@ -102,6 +105,8 @@ class _ViTStackX3(torch.autograd.Function):
     def backward(ctx, g):
         B, L, D, heads, scale, nblk = ctx.cfg
         params, saved = ctx.params, ctx.saved
+        if saved is None:
+            raise RuntimeError("_ViTStackX3: backward called a second time - the block activations are freed by the first pass (retain_graph is not supported here)")
         ctx.saved = None
         M = B * L
         g = g.reshape(M, D)
@@ -135,7 +140,7 @@ class _ViTStackX3(torch.autograd.Function):
             del dqp, h1
             g, gp = _ln_bwd(dh1, xs, n1w, n1b, m1, r1, g1, grads, k0 + 0, k0 + 1, direct)
             del dh1, g1, g1p
-        return (g.view(B, L, D), None, None, None) + tuple(grads)
+        return (g.view(B, L, D), None, None, None, None) + tuple(grads)
 
 
 def _ln_bwd(dy, x, gamma, beta, mean, rstd, dres, grads, ig, ib, direct):
@@ -161,4 +166,4 @@ def vit_stack(x, blocks, heads, eps):
     params = []
     for blk in blocks:
         params.extend(block_params(blk))
-    return _ViTStackX3.apply(x, heads, eps, FUSE_LN[0], *params)
+    return _ViTStackX3.apply(x, heads, eps, FUSE_LN[0], torch.is_grad_enabled(), *params)

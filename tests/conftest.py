@@ -14,10 +14,11 @@ def pytest_configure(config):
 
 # Order of the GPU suite (the driver runs it with -x): the BASELINE-config parity and bit-exact evidence first - whole-model forward parity
 # (configs #2 S/8 and B/16, #3 incl. the bs-64 batch, pillar membership, greedy tokens), configs[0] on the demo tile, FFL (config #5),
-# decode / assignment / post-processing (integer outputs) - then training-step and multi-rank tests, micro-op and backward-kernel tests last.
+# decode / assignment / post-processing (integer outputs) - then training-step and multi-rank tests, the HiSup heads, micro-op (incl. the planes kernels) and
+# backward-kernel tests last.
 _ORDER = ["test_model_gpu", "test_pillar_membership_gpu", "test_predict_demo_gpu", "test_ffl_gpu", "test_decode_layer_gpu", "test_assignment_gpu", "test_postprocess_gpu",
           "test_input_pipeline_gpu", "test_ffl_loss_gpu", "test_afm_gpu", "test_train_gpu", "test_syncbn_gpu", "test_rccl_single_rank_gpu",
-          "test_ops_gpu", "test_backward_gpu"]
+          "test_hisup_gpu", "test_ops_gpu", "test_x3_gpu", "test_backward_gpu"]
 
 
 def _rank(item):

@@ -309,3 +309,38 @@ def test_only_checkers_import_the_oracle():
     hits = [m.start() for m in pat.finditer(src)]
     body = src[src.index("def cpu_baseline("):src.index("def pmc_step_traffic(")]
     assert len(hits) == 1 and pat.search(body)
+
+
+def test_scoped_module_is_freed_without_the_cyclic_collector_and_deepcopies_bind_to_the_copy():
+    """hip.scope_module: the method wrapper holds its module weakly - `del model` frees it (and the arenas its parameters view) at once - and a
+    deep copy of a scoped module calls ITS OWN methods, not the original's."""
+    import copy
+    import gc
+    import weakref
+    from pixelspointspolygons_amd import hip
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+            self.seen = []
+
+        def forward(self, x):
+            return x
+
+        def probe(self, tag):
+            self.seen.append((tag, hip._SPLIT[0]))
+            return self
+
+    gc.disable()
+    try:
+        m = hip.scope_module(M(), True, ("probe",))
+        assert m.probe("a") is m and m.seen == [("a", True)] and hip._SPLIT[0] is False          # the scope closes behind the call
+        twin = copy.deepcopy(m)
+        assert twin.probe("b") is twin and twin.seen == [("a", True), ("b", True)] and m.seen == [("a", True)]
+        ref = weakref.ref(m)
+        del m
+        assert ref() is None, "a scoped module must not sit in a reference cycle"
+        assert twin.probe("c") is twin                                                          # the copy does not depend on the original
+    finally:
+        gc.enable()

@@ -90,7 +90,7 @@ def test_prefetcher_reuses_its_staging_sets_without_allocating():
     acc = torch.zeros(20, 3, dtype=torch.float64, device=DEV)
     mem = []
     import gc
-    gc.collect()                          # garbage of earlier tests (reference cycles holding device tensors) must not be freed in the middle of the measurement
+    gc.collect()                          # start from a collected heap (scoped modules no longer form cycles - hip._ScopedMethod - but autograd graphs of other tests may)
     torch.cuda.synchronize()
     for i, d in enumerate(DevicePrefetcher(iter(host), DEV, max_points=B * 1500)):
         if static is None:
@@ -101,8 +101,7 @@ def test_prefetcher_reuses_its_staging_sets_without_allocating():
             acc[i, j] = static[k].sum(dtype=torch.float64)
         mem.append(torch.cuda.memory_allocated())
     torch.cuda.synchronize()
-    # no staging-sized GROWTH (a set is ~7 MB here); a drop is somebody else's garbage being collected (process-wide counter: seen once in a full-suite run, -222 MB)
-    assert len(mem) == 20 and max(mem[6:]) - mem[6] < (1 << 16), (mem[6], max(mem[6:]))
+    assert len(mem) == 20 and max(mem[6:]) - min(mem[6:]) < (1 << 16), (min(mem[6:]), max(mem[6:]))     # flat: no staging-sized growth (a set is ~7 MB here), no drop
     for h, (a, b, c) in zip(host, acc.cpu().tolist()):
         assert abs(float(a) - float(h["image"].double().sum()) / 255.0) < 1e-6 * float(a)      # Normalize(mean 0, std 1, max 255)
         assert abs(float(b) - float(np.concatenate(h["lidar"]).astype(np.float64).sum())) < 1e-6 * float(b)

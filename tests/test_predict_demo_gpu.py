@@ -37,10 +37,16 @@ def test_demo_tile_predict_matches_the_oracle(graphs, precision):
         low = np.nonzero(margins < (1e-4 if precision == "fp32" else 5e-4))[0]         # fp32x3: 2e-5 relative on the logits instead of 1e-6
         upto = int(low[0]) + 1 if len(low) else want.shape[1]
         assert torch.equal(tokens[0, :upto], want[0, :upto]), (upto, int((tokens[0] != want[0]).nonzero()[0]))
-        if torch.equal(tokens, want):                      # same sequence -> same decoder features -> same assignment -> same polygons
-            flat = np.concatenate([p.numpy() for p in polys]) if polys else np.zeros((0, 2), np.float32)
+        # unconditional: the vertices are the tokens up to the EOS (asserted bit-exact above), whatever the free-running tail does - the polygons cover exactly
+        # the fixture's vertex multiset
+        flat = np.concatenate([p.numpy() for p in polys]) if polys else np.zeros((0, 2), np.float32)
+        assert flat.shape == fx["poly_flat"].shape
+        assert np.array_equal(flat[np.lexsort(flat.T)], fx["poly_flat"][np.lexsort(fx["poly_flat"].T)])
+        if torch.equal(tokens, want):                      # same sequence -> same decoder features -> same assignment -> same polygons, vertex for vertex
             assert [len(p) for p in polys] == fx["poly_len"].tolist()
             assert np.array_equal(flat, fx["poly_flat"])
+        else:                                              # a tail that left the oracle's sequence below the margin: say so instead of passing silently
+            print(f"[demo {precision} graphs={graphs} rep={rep}] free-running tail differs from the oracle's from position {int((tokens[0] != want[0]).nonzero()[0])}")
     assert len(fx["poly_len"]) > 0
 
 

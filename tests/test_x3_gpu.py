@@ -55,6 +55,51 @@ def test_gemm_x3_plain_and_epilogues(M, N, K):
     assert rel_err(hip.from_planes(dp).cpu(), (ref * mul.double()).float()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(1570, 1536, 384), (4100, 1152, 384), (2500, 768, 256), (1111, 64, 384), (20000, 384, 384), (1030, 2048, 256)])
+def test_gemm_x3_a_stationary_kernel(M, N, K):
+    """csrc/gemm_x3_as.hip (K = 256 / 384, N % 32 == 0, M >= 1024: the library's default for those shapes): the A rows of a wave in registers, the weights
+    streamed through LDS, one persistent workgroup per CU walking (row block, column block) units.  Against float64 with every epilogue it builds (plain, bias +
+    GELU + GELU' -> planes, bias + residual -> fp32, x multiplier -> planes), ragged M (row blocks of 256, row tiles of 16), workgroups that cross row blocks
+    (4100 x 1152: 612 units over 256 workgroups), the launch the kernel timer names, bit-identical repeats, and the tile kernel's result beside it."""
+    hip = _h()
+    from pixelspointspolygons_amd._lib import lib
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1)
+    bias, res, mul = _rand(N, seed=3), _rand(M, N, seed=4), _rand(M, N, seed=5)
+    ap, wp = hip.to_planes(a.to(DEV)), hip.to_planes(w.to(DEV), pad=1)
+    ref = hip.from_planes(ap)[:M].double().cpu() @ hip.from_planes(wp)[:N].double().cpu().t()          # the planes' own values: what the kernels multiply
+    was = lib().p3_gemm_x3_tile(3)
+    try:
+        hip.KTIMER.enable()
+        try:
+            out = hip.gemm_x3(ap, wp)
+            names = dict(hip.KTIMER.summary())
+        finally:
+            hip.KTIMER.disable()
+        assert any(k.startswith("gemm_x3_as_kernel") for k in names), names
+        assert rel_err(out.cpu(), ref.float()) < 1e-5
+        aux = torch.full((M, N), float("nan"), device=DEV)
+        hp = hip.gemm_x3(ap, (wp.hi, wp.lo), bias=bias.to(DEV), act=hip.ACT_GELU, aux=aux, out_planes=True)
+        pre = (ref + bias.double()).requires_grad_(True)
+        g = F.gelu(pre)
+        g.sum().backward()
+        assert rel_err(hip.from_planes(hp)[:M].cpu(), g.detach().float()) < 2e-5
+        assert rel_err(aux.cpu(), pre.grad.float()) < 1e-4
+        assert hp.buf.shape[0] == M or float(hp.buf[M:].float().abs().max()) == 0.0                     # the zero tail of the output planes stays untouched
+        o2 = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV), out=o2)
+        assert rel_err(o2.cpu(), (ref + bias.double() + res.double()).float()) < 1e-5
+        o3 = torch.empty_like(o2)
+        hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV), out=o3)
+        assert torch.equal(o2, o3)                                                                        # no atomics, no order dependence: the same bits
+        dp = hip.gemm_x3(ap, wp, mul=mul.to(DEV), out_planes=True)
+        assert rel_err(hip.from_planes(dp)[:M].cpu(), (ref * mul.double()).float()) < 2e-5
+        lib().p3_gemm_x3_tile(1)
+        t1 = hip.gemm_x3(ap, wp, bias=bias.to(DEV), residual=res.to(DEV))
+        assert rel_err(o2.cpu(), t1.cpu()) < 2e-6                                                          # same products, another summation order
+    finally:
+        lib().p3_gemm_x3_tile(was)
+
+
 def test_gemm_x3_ragged_last_round_goes_to_the_small_tile():
     """hip.gemm_x3 at M = 40 000, N = 384, K = 1024: 313 row tiles of the 128 x 384 kernel = one full round of 256 workgroups and 57 in a second one - the binding
     launches the 256 whole-round tiles on the big tile and the remaining rows on the 128 x 128 tile (profiles: the ViT's 393-tile products).  Both halves

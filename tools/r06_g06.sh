@@ -1,0 +1,10 @@
+#!/bin/bash
+# r06 g06: A-stationary kernel v4 (finisher at raised priority, epilogue at the end of its tick, no pending loads at joins): check, timing, stage sums
+mkdir -p gpurun_out
+O=gpurun_out/mb_as_6.txt
+: > $O
+timeout 300 python tools/mb_as.py check >> $O 2>&1
+timeout 300 python tools/mb_as.py time >> $O 2>&1
+P3_AS_VAR=2 timeout 200 python tools/mb_as.py as >> $O 2>&1
+echo "== P3_AS_VAR=1" >> $O; P3_AS_VAR=1 timeout 200 python tools/mb_as.py dbg >> $O 2>&1
+grep -v amdgpu.ids $O | tail -80
