@@ -181,7 +181,7 @@ int p3_gemm_dma(const void* A, const void* W, void* C, const p3_gemm_desc* d, in
  *   that GELU);  residual != NULL: v += residual[m, n] (fp32, ldr);  then C <- v as fp32 (c, ldc; c_lo == NULL) or as planes (c = hi, c_lo = lo, ldc).
  *   Fused LayerNorm of the OUTPUT row (ln_gamma != NULL; needs N == 384 == the tile width, fp32 C): besides C the kernel writes LN(C) as planes (ln_hi, ln_lo,
  *   ldln) and the row statistics (ln_mean, ln_rstd) - the norm2 / next block's norm1 of timm's Block, whose separate pass re-read the 77 MB stream.
- * Shapes: K % 32 == 0, N % 8 == 0, 16-byte aligned rows.  Kernels: K = 256 / 384 with N % 32 == 0 and M >= 1024 - the A-stationary persistent kernel
+ * Shapes: K % 32 == 0, N % 8 == 0, 16-byte aligned rows.  Kernels: K = 256 / 384 with 1024 <= N <= 4096, N % 32 == 0 - the A-stationary persistent kernel
  * (gemm_x3_as.hip: the A rows of a wave live in registers, the weights stream through LDS, one workgroup per CU walks (row block, column block) units);
  * otherwise tiles of 128 x 128 (4 waves) or, for N == 384 and K >= 1024, 128 x 384 (8 waves).
  * ------------------------------------------------------------------------------------------ */
@@ -201,7 +201,7 @@ typedef struct {
 } p3_gemm_x3_desc;
 int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream);
 /* measurement hook (tools/mb_x3.py, tools/mb_as.py): 0 = the library's rule, 1 = every product on the 128 x 128 tile, 2 = on the 128 x 384 tile, 3 = on the
- * A-stationary persistent kernel (csrc/gemm_x3_as.hip; P3_EUNSUP unless K = 256 / 384, N % 32 == 0, M >= 1024); returns the previous mode */
+ * A-stationary persistent kernel (csrc/gemm_x3_as.hip; P3_EUNSUP unless K = 256 / 384, N % 32 == 0, N <= 4096); returns the previous mode */
 int p3_gemm_x3_tile(int mode);
 /* measurement hook: device buffer [256][8][8] of 64-bit cycle sums written by the instrumented variants of the A-stationary kernel (environment P3_AS_VAR & 64);
  * NULL switches it off */

@@ -53,6 +53,18 @@ __device__ __forceinline__ void as_dma1(const bf16_t* base, uint32_t dst, uint32
         : "=&s"(keep) : "v"(v0), "s"(base), "s"(dst) : "memory");
 }
 
+// 16- / 8-byte stores at wave-uniform base + 32-bit byte offset; SC1: write-through (the line is not kept in this XCD's L2, where the weight stream lives)
+typedef float as_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t as_u32x2 __attribute__((ext_vector_type(2)));
+template <bool SC1> __device__ __forceinline__ void as_store16(void* base, uint32_t off, as_f32x4 v) {
+    if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(off), "v"(v), "s"(base) : "memory");
+    else *reinterpret_cast<as_f32x4*>(reinterpret_cast<char*>(base) + (size_t)off) = v;
+}
+template <bool SC1> __device__ __forceinline__ void as_store8(void* base, uint32_t off, as_u32x2 v) {
+    if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(off), "v"(v), "s"(base) : "memory");
+    else *reinterpret_cast<as_u32x2*>(reinterpret_cast<char*>(base) + (size_t)off) = v;
+}
+
 // The lane id again, opaque to the optimiser: what the epilogue and the A reload derive from it (row, column chunk, pointers) is computed where it is used
 // instead of living in ~16 VGPRs across the MFMA loop - at K = 384 the A slice (192) + accumulator (16) + two fragment sets (16) leave 32 registers in all.
 __device__ __forceinline__ int as_lane() {
@@ -62,8 +74,10 @@ __device__ __forceinline__ int as_lane() {
 }
 
 constexpr int AS_PLANES = 1, AS_GELU = 2, AS_MUL = 4, AS_RES = 8;      // EPI bits (bias and aux stay run-time switches: wave-uniform, cheap)
-constexpr int AS_NOEPI = 16;                                          // measurement: no epilogue (tools/mb_as.py)
-constexpr int AS_SLOTS = 6;                                           // half blocks in the LDS ring
+constexpr int AS_NOEPI = 16, AS_NODMA = 32, AS_FOLD = 64;             // measurement: no epilogue / no weight stream / every row block's epilogue traffic folded
+                                                                      // onto rows 0..255 (cache-resident) - tools/mb_as.py; wrong results, timing only
+constexpr int AS_SC1 = 128;                                           // measurement: write-through (sc1) epilogue stores - they do not stay in the XCD's L2
+constexpr int AS_SLOTS = 5;                                           // half blocks in the LDS ring (120 KB at K = 384; + bias, junk, 18 KB of epilogue images)
 
 // KS = K / 16 (24: K = 384, 16: K = 256); EPI: which epilogue streams exist (compile-time: the register budget has no room for the union of their operands)
 template <int KS, int EPI, bool DBG>
@@ -101,17 +115,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_as_kernel(AsArgs g) {
     const uint32_t dst_w = lds_addr + (uint32_t)(rg * 1024);
     // the DMA stream walks half blocks hb = 0, 1, 2, ...: (column block, half) kept incrementally
     int d_hb = 0, d_cb = cb0, d_slot = 0;
-    auto dma_next = [&]() __attribute__((always_inline)) {
-        const int64_t so = (int64_t)d_cb * 32 * d.ldb + (d_hb & 1) * (GH * 64);
-        const uint32_t dst = dst_w + (uint32_t)(d_slot * HALF_B);
-#pragma unroll
-        for (int p = 0; p < GH; ++p) {
-            as_dma1(Wh_ + so + p * 64, dst + (uint32_t)(p * 4096), voffW);
-            as_dma1(Wl_ + so + p * 64, dst + (uint32_t)((GH + p) * 4096), voffW);
-        }
+    // piece x of the next half block: x < GH: w_hi, 64-deep group x; else w_lo, group x - GH
+    auto dma_piece = [&](int x) __attribute__((always_inline)) {
+        const int64_t so = (int64_t)d_cb * 32 * d.ldb + (d_hb & 1) * (GH * 64) + (x % GH) * 64;
+        as_dma1((x < GH ? Wh_ : Wl_) + so, dst_w + (uint32_t)(d_slot * HALF_B + x * 4096), voffW);
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
         if (d_hb & 1) { if (++d_cb == CB) d_cb = 0; }
         ++d_hb;
         if (++d_slot == AS_SLOTS) d_slot = 0;
+    };
+    auto dma_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < 2 * GH; ++x) dma_piece(x);
+        dma_advance();
     };
     // Prefetch without registers: a 4-byte LDS-DMA per lane into a junk corner of LDS pulls the line the lane points at into this XCD's L2 -
     //   * the multiplier / residual row segment of a unit (32 columns x 4 B = one 128-byte line per lane), issued when the unit's first half starts: two ticks
@@ -197,137 +214,132 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_as_kernel(AsArgs g) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) { acc[ct][rt][0] = bv.x; acc[ct][rt][1] = bv.y; acc[ct][rt][2] = bv.z; acc[ct][rt][3] = bv.w; }
         }
+        // four separate register tuples from here on (hipcc would keep ONE copy of the bias per column tile as the srcC of both row tiles' first MFMA, write
+        // their results elsewhere - and spill an A fragment for the eight extra registers)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
     };
-    // the MFMAs of a half block: per 32-deep step four fragment reads (w_hi, w_lo x two column tiles) and twelve MFMAs; the reads of step j + 1 are in flight
-    // while the MFMAs of step j issue (two fragment sets; the order is pinned: left alone under this register pressure hipcc reads one fragment, waits, multiplies)
-    auto half_mma = [&](int half, uint32_t sbase) __attribute__((always_inline)) {        // `half` is a compile-time constant at every call site
+    // the MFMAs of a half block: per 32-deep step four fragment reads (w_hi, w_lo x two column tiles) and twelve MFMAs - w_hi a_lo, w_lo a_hi (the small terms
+    // first), w_hi a_hi; the order is pinned: left alone under this register pressure hipcc reads one fragment, waits, multiplies
+    // `dma`: this wave also issues the 2 GH pieces of half block tt + 3, behind the MFMAs (queued, they keep the pipe busy while the pieces issue)
+    auto half_mma = [&](int half, uint32_t sbase, bool dma) __attribute__((always_inline)) {        // `half` is a compile-time constant at every call site
         const unsigned char* sb = lds + sbase;
-        as_u32x4 wf[2][2][2];                   // [set][image][ct]
-        auto rd = [&](int j) __attribute__((always_inline)) {
+        // w_hi feeds two of the three terms: two fragment sets, the reads of step j + 1 in flight under the MFMAs of step j.  w_lo feeds one term (the middle
+        // four MFMAs): ONE set, re-read for step j + 1 right behind them - eight MFMAs ahead of its use.  24 fragment registers instead of 32.
+        as_u32x4 whf[2][2], wlf[2];             // [set][ct], [ct]
+        auto rd = [&](int j, int im) __attribute__((always_inline)) {
             uint32_t fo;
             asm volatile("v_xor_b32 %0, %2, %1" : "=v"(fo) : "v"(foff0), "n"((j & 1) * 64));      // volatile: not hoisted into live registers
-            const unsigned char* gp = sb + (j >> 1) * 4096 + fo;
+            const unsigned char* gp = sb + (j >> 1) * 4096 + fo + im * (GH * 4096);
 #pragma unroll
-            for (int im = 0; im < 2; ++im)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) wf[j & 1][im][ct] = *reinterpret_cast<const as_u32x4*>(gp + im * (GH * 4096) + ct * 2048);
+            for (int ct = 0; ct < 2; ++ct) {
+                const as_u32x4 t = *reinterpret_cast<const as_u32x4*>(gp + ct * 2048);
+                if (im == 0) whf[j & 1][ct] = t; else wlf[ct] = t;
+            }
         };
-        rd(0);
+        auto mma4 = [&](const as_u32x4 (&w)[2], bool alo, int kj) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const as_u32x4 av = alo ? Al[rt][kj] : Ah[rt][kj];
+                    acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[ct]), __builtin_bit_cast(bf16x8_t, av), acc[ct][rt], 0, 0, 0);
+                }
+        };
+        rd(0, 0);
+        rd(0, 1);
 #pragma unroll
         for (int j = 0; j < NJH; ++j) {
-            if (j + 1 < NJH) rd(j + 1);
+            if (j + 1 < NJH) rd(j + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const int kj = half * NJH + j, f = j & 1;
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {               // w_lo a_hi, w_hi a_lo, w_hi a_hi: small terms first
-                const int wim = term == 0 ? 1 : 0;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
-                        const as_u32x4 av = term == 1 ? Al[rt][kj] : Ah[rt][kj];
-                        acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[f][wim][ct]), __builtin_bit_cast(bf16x8_t, av), acc[ct][rt], 0, 0, 0);
-                    }
-            }
+            const int kj = half * NJH + j;
+            mma4(whf[j & 1], true, kj);            // w_hi a_lo
+            mma4(wlf, false, kj);                  // w_lo a_hi
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < NJH) rd(j + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4(whf[j & 1], false, kj);           // w_hi a_hi
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the pieces of half block tt + 3 ride behind this half's MFMAs (interleaving one piece per step measured the same time and cost ~12 registers)
+        if (dma) dma_next();
     };
 
-    // ---- epilogue of unit (rb, cb).  acc[ct][rt] register r = column 16 ct + 4 q + r of row 16 rt + m.  v_permlane16_swap of (acc[0][rt], acc[1][rt]) trades the
-    // column-tile-1 registers of the even 16-lane rows for the column-tile-0 registers of the odd ones: a lane then holds 8 CONSECUTIVE columns
-    // (q = 0, 1, 2, 3 -> columns 0, 16, 8, 24 .. + 7) of its two rows m and 16 + m (chunk pr = row tile).
-    // The bias is already in: the accumulators of a unit START from it.  The multiplier / residual loads (4 x 16 bytes) are issued before the first store, and
-    // no store is waited for here.  Addresses are wave-uniform base + 32-bit byte offset: one VGPR per stream instead of a 64-bit pointer pair.
-    auto epilogue = [&](int rb, int cb) __attribute__((always_inline)) {
+    // ---- epilogue of unit (rb, cb), IN TWO HALVES (chunk pr = row tile pr of the wave: rows 16 pr + m): acc[ct][rt] register r = column 16 ct + 4 q + r of
+    // row 16 rt + m.  v_permlane16_swap of (acc[0][rt], acc[1][rt]) trades the column-tile-1 registers of the even 16-lane rows for the column-tile-0 registers
+    // of the odd ones: a lane then holds 8 CONSECUTIVE columns (q = 0, 1, 2, 3 -> columns 0, 16, 8, 24 .. + 7) of its rows m (chunk 0) and 16 + m (chunk 1).
+    //   epi_half(0): at the END of the finisher's tick - row tile 0's swap and epilogue;
+    //   epi_half(1): at the START of the next tick (the wave is the starter then: the partner has the matrix pipe anyway) - row tile 1, whose accumulators
+    //   simply stay where they are until then: init_acc comes after it, no parking registers.
+    // So every wave runs HALF an epilogue per tick, always beside the other wave's MFMAs: starter [epilogue half | MFMAs], finisher [MFMAs | epilogue half].
+    // (One whole epilogue per unit - 3700 cycles with GELU + GELU' - was longer than the partner's MFMA phase: r06, fc1 272 us against 150 without epilogue.)
+    // The bias is already in (the accumulators start from it).  The multiplier / residual loads of a half (2 x 16 bytes, L2 hits after prefetch_x) are issued
+    // before its stores, and no store is waited for.  Addresses are wave-uniform base + 32-bit byte offset: one VGPR per stream instead of a pointer pair.
+    // The half goes through a private LDS image of the wave ([16 rows][36 floats]: written as the lane holds it, read back ROW-MAJOR - lane -> (row l / 8 + 8
+    // pass, columns 4 (l % 8) .. + 3)), because of what the memory pipeline does with a store (or load) instruction: it merges ADJACENT lanes into 64-byte requests.
+    // Out of the registers adjacent lanes are different ROWS (6 KB apart): 64 requests of 16 bytes per instruction, and the store path of a CU saturates at
+    // ~7 - 10 B / clk in that form (r06: every epilogue cost its bytes at ~5 TB/s ON TOP of the MFMA time, whatever was overlapped with what: fc1 150 -> 277 us).
+    // Row-major, 8 lanes cover 128 contiguous bytes of a row.
+    float* stage = reinterpret_cast<float*>(lds + AS_SLOTS * HALF_B + d.N * 4 + 8 * 256) + wave * (16 * 36);
+    auto epi_half = [&](int pr, int rb, int cb) __attribute__((always_inline)) {      // pr is a compile-time constant at both call sites
         if constexpr ((EPI & AS_NOEPI) != 0) {
-            asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+            asm volatile("" :: "v"(acc[0][pr]), "v"(acc[1][pr]));
             return;
         }
-        const int ln = as_lane(), eq = ln >> 4;
-        const uint32_t urow0 = (uint32_t)(rb * 256 + wave * 32 + (ln & 15));
-        // rows beyond M (the last row block) take no part at all: a load issued for them and never consumed would leave hipcc a pending register at the join,
-        // i.e. an `s_waitcnt vmcnt(0)` in front of the next unit's first LDS read - which waits for every store and DMA piece this wave has in flight
-        if (urow0 >= (uint32_t)d.M) return;
-        const bool live1 = urow0 + 16u < (uint32_t)d.M;               // the lane's second row (row tile 1)
-        const uint32_t ecol = (uint32_t)(cb * 32 + ((eq & 1) ? 12 + 4 * eq : 4 * eq));      // this lane's 8 columns
-        float4 xq[4];
+        const int ln = as_lane();
+        {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][pr][i]), __float_as_uint(acc[1][pr][i]), false, false);
+                v[i] = __uint_as_float(sw[0]); v[4 + i] = __uint_as_float(sw[1]);
+            }
+            const int eq = ln >> 4;
+            float* wp = stage + (ln & 15) * 36 + ((eq & 1) ? 12 + 4 * eq : 4 * eq);
+            *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        const uint32_t col = (uint32_t)(cb * 32 + (ln & 7) * 4);
+        const uint32_t urow0 = (uint32_t)(((EPI & AS_FOLD) ? 0 : rb * 256) + wave * 32 + 16 * pr + (ln >> 3));       // pass p: row urow0 + 8 p
+        // rows beyond M take no part at all: a load issued for them and never consumed would leave hipcc a pending register at the join, i.e. an
+        // `s_waitcnt vmcnt(0)` in front of the next LDS read - which waits for every store and DMA piece this wave has in flight
+        float4 xq[2];
         if constexpr ((EPI & (AS_MUL | AS_RES)) != 0) {
             const float* xs = (EPI & AS_MUL) ? d.mul : d.residual;
             const uint32_t ldx = (uint32_t)((EPI & AS_MUL) ? d.ldmul : d.ldr);
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const uint32_t rr = (pr == 1 && !live1) ? urow0 : urow0 + 16u * pr;
-                const char* xp = reinterpret_cast<const char*>(xs) + (size_t)((rr * ldx + ecol) * 4u);
-                xq[2 * pr] = *reinterpret_cast<const float4*>(xp);
-                xq[2 * pr + 1] = *reinterpret_cast<const float4*>(xp + 16);
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t rr = min(urow0 + 8u * p, (uint32_t)d.M - 1u);
+                xq[p] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs) + (size_t)((rr * ldx + col) * 4u));
             }
         }
-        float v[2][8];
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][pr][i]), __float_as_uint(acc[1][pr][i]), false, false);
-                v[pr][i] = __uint_as_float(sw[0]); v[pr][4 + i] = __uint_as_float(sw[1]);
-            }
-        if constexpr ((EPI & (AS_MUL | AS_RES)) != 0) {
-            // all four loads are out and waited for HERE, in one round trip (left alone hipcc sinks the second chunk's pair to its use: a second round trip)
-            typedef float as_f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                as_f32x4 t = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
-                asm volatile("" : "+v"(t));
-                xq[k] = make_float4(t[0], t[1], t[2], t[3]);
-            }
-        }
-        float gd[8];
-        auto math = [&](int pr) __attribute__((always_inline)) {
+        for (int p = 0; p < 2; ++p) {
+            const float4 w = *reinterpret_cast<const float4*>(stage + ((ln >> 3) + 8 * p) * 36 + (ln & 7) * 4);
+            float v[4] = {w.x, w.y, w.z, w.w};
+            const uint32_t urow = urow0 + 8u * p;
+            if constexpr ((EPI & AS_MUL) != 0) { v[0] *= xq[p].x; v[1] *= xq[p].y; v[2] *= xq[p].z; v[3] *= xq[p].w; }
+            if constexpr ((EPI & AS_RES) != 0) { v[0] += xq[p].x; v[1] += xq[p].y; v[2] += xq[p].z; v[3] += xq[p].w; }
+            const bool live = urow < (uint32_t)d.M;
             if constexpr ((EPI & AS_GELU) != 0) {
+                float gd[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    gelu_and_grad(v[pr][k], v[pr][k], gd[k]);
-                    if (k == 3) __builtin_amdgcn_sched_barrier(0);        // four values at a time: eight interleaved chains need ~50 temporaries
-                }
+                for (int k = 0; k < 4; ++k) gelu_and_grad(v[k], v[k], gd[k]);
+                if (d.aux && live) as_store16<(EPI & AS_SC1) != 0>(d.aux, (urow * (uint32_t)d.ldaux + col) * 4u, as_f32x4{gd[0], gd[1], gd[2], gd[3]});
             }
-            if constexpr ((EPI & (AS_MUL | AS_RES)) != 0) {
-                const float4 x0 = xq[2 * pr], x1 = xq[2 * pr + 1];
-                if constexpr ((EPI & AS_MUL) != 0) {
-                    v[pr][0] *= x0.x; v[pr][1] *= x0.y; v[pr][2] *= x0.z; v[pr][3] *= x0.w; v[pr][4] *= x1.x; v[pr][5] *= x1.y; v[pr][6] *= x1.z; v[pr][7] *= x1.w;
+            if (live) {
+                if constexpr (PLANES) {
+                    const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+                    const uint32_t l0 = pack_bf2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                    const uint32_t l1 = pack_bf2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                    const uint32_t co = (urow * (uint32_t)d.ldc + col) * 2u;
+                    as_store8<(EPI & AS_SC1) != 0>(d.c, co, as_u32x2{h0, h1});
+                    as_store8<(EPI & AS_SC1) != 0>(d.c_lo, co, as_u32x2{l0, l1});
                 } else {
-                    v[pr][0] += x0.x; v[pr][1] += x0.y; v[pr][2] += x0.z; v[pr][3] += x0.w; v[pr][4] += x1.x; v[pr][5] += x1.y; v[pr][6] += x1.z; v[pr][7] += x1.w;
+                    as_store16<(EPI & AS_SC1) != 0>(d.c, (urow * (uint32_t)d.ldc + col) * 4u, as_f32x4{v[0], v[1], v[2], v[3]});
                 }
             }
-        };
-        auto stores = [&](int pr) __attribute__((always_inline)) {
-            if (pr == 1 && !live1) return;
-            const uint32_t col = ecol, urow = urow0 + 16u * pr;
-            if constexpr ((EPI & AS_GELU) != 0) {
-                if (d.aux) {
-                    char* a = reinterpret_cast<char*>(d.aux) + (size_t)((urow * (uint32_t)d.ldaux + col) * 4u);
-                    *reinterpret_cast<float4*>(a) = make_float4(gd[0], gd[1], gd[2], gd[3]);
-                    *reinterpret_cast<float4*>(a + 16) = make_float4(gd[4], gd[5], gd[6], gd[7]);
-                }
-            }
-            if constexpr (PLANES) {
-                uint4 h, l;
-                x3_split8(v[pr], h, l);
-                const size_t co = (size_t)((urow * (uint32_t)d.ldc + col) * 2u);
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(d.c) + co) = h;
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(d.c_lo) + co) = l;
-            } else {
-                char* c = reinterpret_cast<char*>(d.c) + (size_t)((urow * (uint32_t)d.ldc + col) * 4u);
-                *reinterpret_cast<float4*>(c) = make_float4(v[pr][0], v[pr][1], v[pr][2], v[pr][3]);
-                *reinterpret_cast<float4*>(c + 16) = make_float4(v[pr][4], v[pr][5], v[pr][6], v[pr][7]);
-            }
-        };
-        // (the fences keep hipcc from interleaving the two chunks: it would need both chunks' temporaries at once, and there are ~40 free registers in all)
-        math(0);
-        __builtin_amdgcn_sched_barrier(0);
-        stores(0);
-        __builtin_amdgcn_sched_barrier(0);
-        math(1);
-        __builtin_amdgcn_sched_barrier(0);
-        stores(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -339,59 +351,94 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_as_kernel(AsArgs g) {
 
     // ---- prologue: the first four half blocks on their way
     const int nhb = 2 * nU;
-    if (grp == 0) {
+    if (grp == 0 && (EPI & AS_NODMA) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 3; ++k)
             if (k < nhb) dma_next();
     }
     int c_rb = rb0, c_cb = cb0, c_left = nU;       // the unit this wave multiplies; units left including it
+    int e_rb = rb0, e_cb = cb0;                    // the unit whose second epilogue half is still in the accumulators
     int cur_rb = -1;
-    const int nticks = nhb + 1;                    // group 1 runs one tick behind group 0
+    // vmcnt bookkeeping of waves 0..3: S1 / S2 / S3 = store instructions this wave issued one / two / three ticks back, F1.. = it was the finisher then (a
+    // finisher's stores FOLLOW its DMA batch, a starter's precede it).  Behind the batch of tick tt - 3 came: S3 if F3, S2 + a batch, S1 + a batch.
+    int S1 = 0, S2 = 0, S3 = 0;
+    bool F1 = false, F2 = false, F3 = false;
+    // store instructions of one epilogue half of a wave whose 16 rows are ALL live (counted only then: an under-count merely waits a little longer)
+    const int s_half = (EPI & AS_NOEPI) ? 0 : (PLANES ? 4 : 2) + (((EPI & AS_GELU) != 0 && d.aux) ? 2 : 0);
+    const int nticks = nhb + 2;                    // group 1 runs one tick behind group 0; a wave's last epilogue half is the tick after its last MFMAs
     for (int tt = 0; tt < nticks; ++tt) {
         const unsigned long long t0 = now();
-        // Opening of tick tt.  Waves 0..3 (the DMA issuers): half block tt's pieces were issued four ticks ago and three batches (>= 12 pieces) since - with at
-        // most 12 operations in flight they have landed, while the newest pieces and the epilogue's stores stay in flight across the barrier; once the stream
-        // has run out (tt + 3 >= nhb) everything is waited for.  Waves 4..7 issue no pieces: nothing of theirs has to land before the barrier.  After the
-        // barrier half block tt is readable by group 0, tt - 1 by group 1, and the slot of half block tt - 2 (last read in tick tt - 1) is free for tt + 4.
+        // Opening of tick tt.  Waves 0..3 (the DMA issuers): half block tt's pieces were issued three ticks ago and two batches (4 GH pieces) since - with at
+        // most that many operations in flight they have landed, while the newest pieces and the epilogue's stores stay in flight across the barrier; once the
+        // stream has run out (tt + 2 >= nhb) everything is waited for.  Waves 4..7 issue no pieces: nothing of theirs has to land before the barrier.  After the
+        // barrier half block tt is readable by group 0, tt - 1 by group 1, and the slot of half block tt - 2 (last read in tick tt - 1) is free for tt + 3.
         if (grp == 0) {
-            if (tt + 3 < nhb) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (tt + 2 < nhb) {
+                // in flight at most: the two newest batches (4 GH pieces) + every store issued behind the batch of tick tt - 3 (vmcnt retires in order: counting
+                // the stores in keeps them in flight for ~3 ticks instead of ~1.5 - the HBM write stream needs that window; r06: fc1 150 us without epilogue,
+                // 210 with its stores folded onto cache-resident rows, 279 real)
+                const int extra = S1 + S2 + (F3 ? S3 : 0);
+                switch (extra >> 1) {
+                    case 0: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+                    case 1: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+                    case 2: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+                    case 3: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+                    case 4: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+                    case 5: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); break;
+                    case 6: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
+                    case 7: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory"); break;
+                    case 8: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); break;
+                    default: if constexpr (GH == 3) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)" ::: "memory"); break;
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        S3 = S2; F3 = F2; S2 = S1; F2 = F1; S1 = 0; F1 = false;          // tick tt's own counts are filled in below
         __builtin_amdgcn_s_barrier();
         const unsigned long long t1 = now();
         tsum[0] += t1 - t0; tsum[7] += 1;
         const int lt = tt - grp;                   // this wave's own half-block counter
-        if (lt < 0 || lt >= nhb) continue;
-        const uint32_t sbase = (uint32_t)((lt % AS_SLOTS) * HALF_B);
-        const bool dma = grp == 0 && tt + 4 < nhb;
+        // (one home for the accumulators per tick: without this pin hipcc splits their live ranges over the two role branches - MFMAs with vdst != srcC, copies,
+        // and a spilled A fragment to pay for them)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        if (lt < 0 || lt > nhb) continue;
+        const bool dma = (EPI & AS_NODMA) == 0 && grp == 0 && tt + 3 < nhb;
         if ((lt & 1) == 0) {
-            // STARTER of this tick: first half of a unit at normal priority - the partner wave of the SIMD is finishing its unit
+            // STARTER of this tick: the parked epilogue half of the unit it finished last tick FIRST (the partner wave of the SIMD, at raised priority, has the
+            // matrix pipe), then the first half of the next unit
+            if (lt > 0) {
+                epi_half(1, e_rb, e_cb);
+                if (e_rb * 256 + wave * 32 + 32 <= d.M) S1 += s_half;
+            }
+            const unsigned long long t2 = now();
+            tsum[1] += t2 - t1;
+            if (lt == nhb) continue;               // that was this wave's last unit
             prefetch_x(c_rb, c_cb);
             if (c_cb == CB - 1 && c_left > 1) prefetch_a(c_rb + 1);
             if (c_rb != cur_rb) { load_a(c_rb); cur_rb = c_rb; }
             init_acc(c_cb);
             const unsigned long long t4 = now();
-            half_mma(0, sbase);
+            half_mma(0, (uint32_t)((lt % AS_SLOTS) * HALF_B), dma);
             const unsigned long long t5 = now();
-            if (dma) dma_next();
-            tsum[3] += t4 - t1; tsum[4] += t5 - t4;
-            if constexpr (DBG) tsum[2] += now() - t5;
+            tsum[3] += t4 - t2; tsum[4] += t5 - t4;
         } else {
-            // FINISHER: second half at RAISED priority (its MFMAs go first: ~1500 cycles instead of ~2300 behind the partner's), then the pieces of half block
-            // tt + 4, then the epilogue - loads, arithmetic and stores under the rest of the partner's MFMAs.  The stores stay in flight across the barrier.
+            // FINISHER: second half at RAISED priority (its MFMAs go first), then the unit's first epilogue half under the rest of the partner's MFMAs; the
+            // second half waits in the accumulators for the next tick.  The stores stay in flight across the barrier.
             __builtin_amdgcn_s_setprio(1);
-            half_mma(1, sbase);
+            half_mma(1, (uint32_t)((lt % AS_SLOTS) * HALF_B), dma);
             __builtin_amdgcn_s_setprio(0);
             const unsigned long long t5 = now();
-            if (dma) dma_next();
-            const unsigned long long t6 = now();
-            epilogue(c_rb, c_cb);
+            epi_half(0, c_rb, c_cb);
+            if (c_rb * 256 + wave * 32 + 16 <= d.M) S1 += s_half;
+            F1 = true;
+            e_rb = c_rb; e_cb = c_cb;
             if (++c_cb == CB) { c_cb = 0; ++c_rb; }
             --c_left;
-            tsum[5] += t5 - t1; tsum[2] += t6 - t5;
-            if constexpr (DBG) tsum[1] += now() - t6;
+            tsum[5] += t5 - t1;
+            if constexpr (DBG) tsum[2] += now() - t5;
         }
     }
     if constexpr (DBG) {
@@ -405,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_as_kernel(AsArgs g) {
 
 template <int KS, int EPI, bool DBG>
 int as_launch1(const AsArgs& g, int nwg, hipStream_t s) {
-    const size_t LDS = AS_SLOTS * ((KS / 8) * 2 * 4096) + (size_t)g.d.N * 4 + 8 * 256;
+    const size_t LDS = AS_SLOTS * ((KS / 8) * 2 * 4096) + (size_t)g.d.N * 4 + 8 * 256 + 8 * 16 * 36 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_as_kernel<KS, EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -417,11 +464,14 @@ int as_launch1(const AsArgs& g, int nwg, hipStream_t s) {
     return P3_OK;
 }
 
-// var: 0 the kernel, 1 its instrumented twin (s_memtime sums), 2 without epilogue (measurement)
+// var: 0 the kernel, 1 its instrumented twin (s_memtime sums), 2 without epilogue, 3 without epilogue and weight stream (measurement)
 template <int KS, int EPI>
 int as_launch(const AsArgs& g, int var, int nwg, hipStream_t s) {
     if (var == 1) return as_launch1<KS, EPI, true>(g, nwg, s);
     if (var == 2) return as_launch1<KS, EPI | AS_NOEPI, false>(g, nwg, s);
+    if (var == 3) return as_launch1<KS, EPI | AS_NOEPI | AS_NODMA, false>(g, nwg, s);
+    if (var == 4) return as_launch1<KS, EPI | AS_FOLD, false>(g, nwg, s);
+    if (var == 5) return as_launch1<KS, EPI | AS_SC1, false>(g, nwg, s);
     return as_launch1<KS, EPI, false>(g, nwg, s);
 }
 
@@ -450,9 +500,10 @@ int as_dispatch(const AsArgs& g, int epi, int var, int nwg, hipStream_t s) {
 
 }  // namespace
 
-// eligibility of the A-stationary kernel (the caller, p3_gemm_x3, has done the alignment checks)
+// eligibility of the A-stationary kernel (the caller, p3_gemm_x3, has done the alignment checks).  No condition on M: the kernel choice must not depend on the
+// batch (a tile run alone gives the bits it gives inside a batch of 64 - tests/test_model_gpu.py::test_full_bench_batch_is_batch_independent...)
 bool p3_gemm_x3_as_ok(const p3_gemm_x3_desc* d) {
-    return (d->K == 384 || d->K == 256) && d->N % 32 == 0 && d->N <= 4096 && d->M >= 1024 && !d->ln_gamma && as_epi_built(as_epi_of(d)) &&
+    return (d->K == 384 || d->K == 256) && d->N % 32 == 0 && d->N <= 4096 && !d->ln_gamma && as_epi_built(as_epi_of(d)) &&
            (int64_t)d->N * d->ldb * 2 < (1ll << 31) && (!d->bias || (uintptr_t)d->bias % 16 == 0) &&
            (int64_t)d->M * d->ldc * 4 < (1ll << 32) && (!d->aux || (int64_t)d->M * d->ldaux * 4 < (1ll << 32)) &&
            (!d->mul || (int64_t)d->M * d->ldmul * 4 < (1ll << 32)) && (!d->residual || (int64_t)d->M * d->ldr * 4 < (1ll << 32));

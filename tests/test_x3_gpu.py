@@ -55,9 +55,9 @@ def test_gemm_x3_plain_and_epilogues(M, N, K):
     assert rel_err(hip.from_planes(dp).cpu(), (ref * mul.double()).float()) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(1570, 1536, 384), (4100, 1152, 384), (2500, 768, 256), (1111, 64, 384), (20000, 384, 384), (1030, 2048, 256)])
+@pytest.mark.parametrize("M,N,K", [(1570, 1536, 384), (4100, 1152, 384), (2500, 768, 256), (1111, 64, 384), (20000, 384, 384), (1030, 2048, 256), (785, 1152, 384), (100, 1536, 384)])
 def test_gemm_x3_a_stationary_kernel(M, N, K):
-    """csrc/gemm_x3_as.hip (K = 256 / 384, N % 32 == 0, M >= 1024: the library's default for those shapes): the A rows of a wave in registers, the weights
+    """csrc/gemm_x3_as.hip (K = 256 / 384, N % 32 == 0; the library's default from N = 1024 on, at EVERY M - the choice must not depend on the batch): the A rows of a wave in registers, the weights
     streamed through LDS, one persistent workgroup per CU walking (row block, column block) units.  Against float64 with every epilogue it builds (plain, bias +
     GELU + GELU' -> planes, bias + residual -> fp32, x multiplier -> planes), ragged M (row blocks of 256, row tiles of 16), workgroups that cross row blocks
     (4100 x 1152: 612 units over 256 workgroups), the launch the kernel timer names, bit-identical repeats, and the tile kernel's result beside it."""
