@@ -47,7 +47,7 @@ GFLOP_FWD = {k: (v if k == "ffl_fusion" else round(v - _SCORENET_SKIPPED, 2)) fo
 GFLOP_ENC = {"fusion_s8": 49.1, "image_s8": 2 * 22.405, "image_b16": 35.13, "lidar_s8": 2 * (22.347 + 0.0745)}
 # algorithmic HBM bytes of one train step at 64 tiles: 1.14 MB/tile of inputs + outputs, AdamW 16 B per parameter
 STEP_ALGO_BYTES = {"fusion_s8": 64 * 1.14e6 + 16 * 34.6e6}
-PMC_FILES = {"fp32x3": ("r05_pmc_traffic_fp32x3.json",), "bf16": ("r05_pmc_traffic_bf16.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"), "fp32": ()}
+PMC_FILES = {"fp32x3": ("r06_pmc_traffic_fp32x3.json", "r05_pmc_traffic_fp32x3.json"), "bf16": ("r05_pmc_traffic_bf16.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"), "fp32": ()}
 # MFMA peak a mode is priced against: bf16 dense 2.5 PF; 'fp32x3' issues three bf16 MFMAs per algorithmic product -> 2.5 PF / 3; exact fp32 MFMA 157.3 TF
 PEAK_TF = {"bf16": 2500.0, "fp32x3": 2500.0 / 3.0, "fp32": 157.3}
 DTYPE_NAME = {"bf16": "bf16", "fp32x3": "f32 (products as bf16x3 on the bf16 MFMA, fp32 accumulate)", "fp32": "f32"}

@@ -210,6 +210,8 @@ int p3_gemm_x3_as_debug(void* buf);
  * tiles + a fixed-order reduce like p3_gemm_tn_ex); colsum (optional, [N]) += column sums of A (the bias gradient).  M % 64 == 0, N % 128 == 0, K % 128 == 0. */
 int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const void* b_hi, const void* b_lo, int ldb, float* C, int ldc, int M, int N, int K,
                   float* colsum, float* slabs, int max_slabs, void* stream);
+/* measurement hook: 0 keeps every weight gradient on the 128 x 128 tile (the 128 x 384 tile is the default where K % 384 == 0 and it has >= 8 tiles); returns the previous setting */
+int p3_gemm_tn_x3_wide(int on);
 /* fp32 [rows, cols] (ld_src) -> planes (hi, lo; ld_dst), and back (x = hi + lo): the seams of the planes region (attention outputs, tests) */
 int p3_to_planes(const float* src, int ld_src, void* hi, void* lo, int ld_dst, int64_t rows, int cols, void* stream);
 int p3_from_planes(const void* hi, const void* lo, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream);

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const bf16_t* __restri
 
 // gemm_x3_as.hip: the A-stationary persistent kernel for K = 256 / 384
 bool p3_gemm_x3_as_ok(const p3_gemm_x3_desc* d);
+bool p3_gemm_x3_as_default(const p3_gemm_x3_desc* d);
 int p3_gemm_x3_as(const p3_gemm_x3_desc* d, hipStream_t s);
 
 static int g_x3_tile = 0;
@@ -528,7 +529,7 @@ extern "C" int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream) {
     // workgroup walks >= 28 units per A slice; the 384- / 256- / 768-wide ones stay on the tile kernels (their 9 - 12 units per workgroup do not pay the slice load)
     static int as_on = -1;                            // P3_X3_AS=0: same-box A/B of the step without the A-stationary kernel (bench.py --lean)
     if (as_on < 0) { const char* e = getenv("P3_X3_AS"); as_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (((g_x3_tile == 0 && d->N >= 1024 && as_on) || g_x3_tile == 3) && p3_gemm_x3_as_ok(d)) return p3_gemm_x3_as(d, s);
+    if (((g_x3_tile == 0 && as_on && p3_gemm_x3_as_default(d)) || g_x3_tile == 3) && p3_gemm_x3_as_ok(d)) return p3_gemm_x3_as(d, s);
     P3_CHECK(g_x3_tile != 3, P3_EUNSUP, "p3_gemm_x3: the A-stationary kernel needs K = 256 / 384, N % 32 == 0, N <= 4096, an epilogue it builds, no fused LayerNorm");
     // tile choice: p3_gemm_x3_tile(1) forces the 128 x 128 kernel, (2) the 128 x 384 kernel, (0) the measured rule (tools/mb_x3.py, profiles/r05_mb_x3.txt)
     const bool big = g_x3_tile == 2 ? d->N > 128 : (g_x3_tile == 1 ? false : x3_big_tile(d));

@@ -76,7 +76,8 @@ __device__ __forceinline__ int as_lane() {
 constexpr int AS_PLANES = 1, AS_GELU = 2, AS_MUL = 4, AS_RES = 8;      // EPI bits (bias and aux stay run-time switches: wave-uniform, cheap)
 constexpr int AS_NOEPI = 16, AS_NODMA = 32, AS_FOLD = 64;             // measurement: no epilogue / no weight stream / every row block's epilogue traffic folded
                                                                       // onto rows 0..255 (cache-resident) - tools/mb_as.py; wrong results, timing only
-constexpr int AS_SC1 = 128;                                           // measurement: write-through (sc1) epilogue stores - they do not stay in the XCD's L2
+constexpr int AS_SC1 = 128;                                           // write-through (sc1) epilogue stores: the output lines do not stay in the XCD's L2, where the weight
+                                                                      // stream lives (r06 same-box A/B, profiles/r06_mb_as.txt: qkv 161 -> 151 us, fc1 279 -> 271); var 5 = plain
 constexpr int AS_SLOTS = 5;                                           // half blocks in the LDS ring (120 KB at K = 384; + bias, junk, 18 KB of epilogue images)
 
 // KS = K / 16 (24: K = 384, 16: K = 256); EPI: which epilogue streams exist (compile-time: the register budget has no room for the union of their operands)
@@ -467,12 +468,12 @@ int as_launch1(const AsArgs& g, int nwg, hipStream_t s) {
 // var: 0 the kernel, 1 its instrumented twin (s_memtime sums), 2 without epilogue, 3 without epilogue and weight stream (measurement)
 template <int KS, int EPI>
 int as_launch(const AsArgs& g, int var, int nwg, hipStream_t s) {
-    if (var == 1) return as_launch1<KS, EPI, true>(g, nwg, s);
+    if (var == 1) return as_launch1<KS, EPI | AS_SC1, true>(g, nwg, s);
     if (var == 2) return as_launch1<KS, EPI | AS_NOEPI, false>(g, nwg, s);
     if (var == 3) return as_launch1<KS, EPI | AS_NOEPI | AS_NODMA, false>(g, nwg, s);
     if (var == 4) return as_launch1<KS, EPI | AS_FOLD, false>(g, nwg, s);
-    if (var == 5) return as_launch1<KS, EPI | AS_SC1, false>(g, nwg, s);
-    return as_launch1<KS, EPI, false>(g, nwg, s);
+    if (var == 5) return as_launch1<KS, EPI, false>(g, nwg, s);
+    return as_launch1<KS, EPI | AS_SC1, false>(g, nwg, s);
 }
 
 int as_epi_of(const p3_gemm_x3_desc* d) {
@@ -502,6 +503,10 @@ int as_dispatch(const AsArgs& g, int epi, int var, int nwg, hipStream_t s) {
 
 // eligibility of the A-stationary kernel (the caller, p3_gemm_x3, has done the alignment checks).  No condition on M: the kernel choice must not depend on the
 // batch (a tile run alone gives the bits it gives inside a batch of 64 - tests/test_model_gpu.py::test_full_bench_batch_is_batch_independent...)
+// the default rule leaves the planes + multiplier epilogue (dX of fc2) on the tile kernels: its epilogue LOADS 309 MB, every load wait drains the wave's stores
+// (vmcnt retires in order), and in the step it measured 291 us against the tile kernel's 281 (profiles/r06_fp32x3_step_summary_mid.txt)
+bool p3_gemm_x3_as_default(const p3_gemm_x3_desc* d) { return d->N >= 1024 && !(d->mul && d->c_lo); }
+
 bool p3_gemm_x3_as_ok(const p3_gemm_x3_desc* d) {
     return (d->K == 384 || d->K == 256) && d->N % 32 == 0 && d->N <= 4096 && !d->ln_gamma && as_epi_built(as_epi_of(d)) &&
            (int64_t)d->N * d->ldb * 2 < (1ll << 31) && (!d->bias || (uintptr_t)d->bias % 16 == 0) &&
@@ -528,8 +533,12 @@ int p3_gemm_x3_as(const p3_gemm_x3_desc* d, hipStream_t s) {
     g.dbg = g_as_dbg;
     const int nwg = g.units < n_cu ? g.units : n_cu;
     const int epi = as_epi_of(d);
-    if (p3_tracing()) p3_note_kernel((epi & AS_PLANES) ? "gemm_x3_as_kernel<planes>" : "gemm_x3_as_kernel<f32>");
     static int var = -1;
     if (var < 0) { const char* e = getenv("P3_AS_VAR"); var = e ? atoi(e) : 0; }
+    if (p3_tracing()) {                               // the instantiation as rocprofv3 spells it (bench.py matches its PMC table by this name)
+        char nm[64];
+        snprintf(nm, sizeof(nm), "gemm_x3_as_kernel<%d, %d, false>", d->K / 16, epi | (var == 0 ? AS_SC1 : 0));
+        p3_note_kernel(nm);
+    }
     return d->K == 384 ? as_dispatch<24>(g, epi, var, nwg, s) : as_dispatch<16>(g, epi, var, nwg, s);
 }

@@ -372,9 +372,9 @@ _tn_park = {"buf": None}
 
 
 def tn_defer_arena(mb=None):
-    """register (once per process) the arena the deterministic weight-gradient GEMMs park their split-M partial tiles in (p3_tn_defer); P3_TN_DEFER_MB, default 2560"""
+    """register (once per process) the arena the deterministic weight-gradient GEMMs park their split-M partial tiles in (p3_tn_defer); P3_TN_DEFER_MB, default 4096 (r06: the 128 x 384 weight-gradient tile runs 21 - 28 splits per launch: 2 GB of partial tiles per backward pass of the 12 blocks)"""
     if _tn_park["buf"] is None:
-        mb = int(_os0.environ.get("P3_TN_DEFER_MB", "2560")) if mb is None else mb
+        mb = int(_os0.environ.get("P3_TN_DEFER_MB", "4096")) if mb is None else mb
         if mb <= 0:
             _tn_park["buf"] = False
             return False

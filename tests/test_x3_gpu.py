@@ -158,18 +158,36 @@ def test_gemm_x3_fused_layernorm_of_the_output_row(M, K):
     assert rel_err(hip.from_planes(h2).cpu(), hip.from_planes(h).cpu()) < 1e-5 and rel_err(m2.cpu(), mean.cpu()) < 1e-5 and rel_err(r2.cpu(), rstd.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(1570, 384, 384), (1570, 1536, 384), (1570, 384, 1536), (3200, 1152, 384), (130, 768, 768)])
-def test_gemm_tn_x3_weight_gradient(M, N, K):
+@pytest.mark.parametrize("wide", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(1570, 384, 384), (1570, 1536, 384), (1570, 384, 1536), (3200, 1152, 384), (130, 768, 768), (50240, 1536, 384)])
+def test_gemm_tn_x3_weight_gradient(M, N, K, wide):
+    """p3_gemm_tn_x3 on both tiles: the 128 x 384 one (r06: every wave on all rows of a 16-row step; the default where K % 384 == 0 and it has >= 8 tiles - the
+    kernel timer names it) and the 128 x 128 one (two wave groups on half the rows each) - against float64, accumulating, with the bias column sums,
+    bit-identical on a second launch (deterministic partial tiles)."""
     hip = _h()
+    from pixelspointspolygons_amd._lib import lib
     dy, x = _rand(M, N, seed=21), _rand(M, K, seed=22)
     dyp, xp = hip.to_planes(dy.to(DEV)), hip.to_planes(x.to(DEV))
     ref = dy.double().t() @ x.double()
-    cs = torch.zeros(N, device=DEV)
-    out = hip.gemm_tn_x3(dyp, xp, colsum_out=cs)
-    assert rel_err(out.cpu(), ref.float()) < 1e-5
-    assert rel_err(cs.cpu(), dy.double().sum(0).float()) < 1e-5
-    hip.gemm_tn_x3(dyp, xp, out=out, colsum_out=cs)                 # accumulates (gradient arena semantics)
-    assert rel_err(out.cpu(), (2 * ref).float()) < 1e-5 and rel_err(cs.cpu(), (2 * dy.double().sum(0)).float()) < 1e-5
+    was = lib().p3_gemm_tn_x3_wide(wide)
+    try:
+        cs = torch.zeros(N, device=DEV)
+        hip.KTIMER.enable()
+        try:
+            out = hip.gemm_tn_x3(dyp, xp, colsum_out=cs)
+            names = dict(hip.KTIMER.summary())
+        finally:
+            hip.KTIMER.disable()
+        expect_wide = bool(wide) and K % 384 == 0 and (N // 128) * (K // 384) >= 8
+        assert any(k.startswith("gemm_tn_x3_wide_kernel") for k in names) == expect_wide, names
+        assert rel_err(out.cpu(), ref.float()) < 1e-5
+        assert rel_err(cs.cpu(), dy.double().sum(0).float()) < 1e-5
+        again = hip.gemm_tn_x3(dyp, xp)
+        assert torch.equal(again, out)
+        hip.gemm_tn_x3(dyp, xp, out=out, colsum_out=cs)                 # accumulates (gradient arena semantics)
+        assert rel_err(out.cpu(), (2 * ref).float()) < 1e-5 and rel_err(cs.cpu(), (2 * dy.double().sum(0)).float()) < 1e-5
+    finally:
+        lib().p3_gemm_tn_x3_wide(was)
 
 
 def test_layernorm_planes_forward_backward():
