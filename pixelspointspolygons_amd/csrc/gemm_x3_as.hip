@@ -78,6 +78,7 @@ constexpr int AS_NOEPI = 16, AS_NODMA = 32, AS_FOLD = 64;             // measure
                                                                       // onto rows 0..255 (cache-resident) - tools/mb_as.py; wrong results, timing only
 constexpr int AS_SC1 = 128;                                           // write-through (sc1) epilogue stores: the output lines do not stay in the XCD's L2, where the weight
                                                                       // stream lives (r06 same-box A/B, profiles/r06_mb_as.txt: qkv 161 -> 151 us, fc1 279 -> 271); var 5 = plain
+constexpr int AS_NOPRIO = 256;                                        // measurement: the finisher's MFMAs at normal priority
 constexpr int AS_SLOTS = 5;                                           // half blocks in the LDS ring (120 KB at K = 384; + bias, junk, 18 KB of epilogue images)
 
 // KS = K / 16 (24: K = 384, 16: K = 256); EPI: which epilogue streams exist (compile-time: the register budget has no room for the union of their operands)
@@ -428,9 +429,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_as_kernel(AsArgs g) {
         } else {
             // FINISHER: second half at RAISED priority (its MFMAs go first), then the unit's first epilogue half under the rest of the partner's MFMAs; the
             // second half waits in the accumulators for the next tick.  The stores stay in flight across the barrier.
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr ((EPI & AS_NOPRIO) == 0) __builtin_amdgcn_s_setprio(1);
             half_mma(1, (uint32_t)((lt % AS_SLOTS) * HALF_B), dma);
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr ((EPI & AS_NOPRIO) == 0) __builtin_amdgcn_s_setprio(0);
             const unsigned long long t5 = now();
             epi_half(0, c_rb, c_cb);
             if (c_rb * 256 + wave * 32 + 16 <= d.M) S1 += s_half;
@@ -473,6 +474,7 @@ int as_launch(const AsArgs& g, int var, int nwg, hipStream_t s) {
     if (var == 3) return as_launch1<KS, EPI | AS_NOEPI | AS_NODMA, false>(g, nwg, s);
     if (var == 4) return as_launch1<KS, EPI | AS_FOLD, false>(g, nwg, s);
     if (var == 5) return as_launch1<KS, EPI, false>(g, nwg, s);
+    if (var == 6) return as_launch1<KS, EPI | AS_SC1 | AS_NOPRIO, false>(g, nwg, s);
     return as_launch1<KS, EPI | AS_SC1, false>(g, nwg, s);
 }
 
