@@ -90,14 +90,15 @@ template <int D> struct TrAddr {
     }
 };
 
-// split 8 fp32 values (two float4) into the hi / lo bf16 fragments
+// split 8 fp32 values (two float4) into the hi / lo bf16 fragments: one v_cvt_pk_bf16_f32 per PAIR for hi, the two halves of that word back as fp32 by a shift / a
+// mask, two subtractions, one more pack for lo - 3 VALU ops per value (r06: the form that rounded every value separately and then packed the rounded floats
+// again cost 4; the bits are the same)
 __device__ __forceinline__ void split8(const float (&x)[8], s16x8& h, s16x8& l) {
     uint32_t hw[4], lw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float h0 = bf2f(f2bf(x[2 * i])), h1 = bf2f(f2bf(x[2 * i + 1]));
-        hw[i] = pack_bf2(h0, h1);
-        lw[i] = pack_bf2(x[2 * i] - h0, x[2 * i + 1] - h1);
+        hw[i] = pack_bf2(x[2 * i], x[2 * i + 1]);
+        lw[i] = pack_bf2(x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u));
     }
     h = __builtin_bit_cast(s16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
     l = __builtin_bit_cast(s16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
@@ -124,12 +125,13 @@ template <int D, int R> struct SplitStage {
         for (int i = 0; i < N; ++i) {
             const int item = tid + 256 * i;
             if (ITEMS % 256 == 0 || item < ITEMS) {
-                float h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float x = __uint_as_float(v[i][e]); h[e] = bf2f(f2bf(x)); l[e] = x - h[e]; }
+                const float x0 = __uint_as_float(v[i][0]), x1 = __uint_as_float(v[i][1]), x2 = __uint_as_float(v[i][2]), x3 = __uint_as_float(v[i][3]);
+                const uint32_t h0 = pack_bf2(x0, x1), h1 = pack_bf2(x2, x3);              // 3 VALU ops per value (see split8)
+                const uint32_t l0 = pack_bf2(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = pack_bf2(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
                 bf16_t* p = img + base + i * (256 / VPR) * D;
-                *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
-                *reinterpret_cast<uint2*>(p + R * D) = make_uint2(pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3]));
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + R * D) = make_uint2(l0, l1);
             }
         }
     }

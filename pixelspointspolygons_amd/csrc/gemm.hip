@@ -167,12 +167,14 @@ __device__ __forceinline__ void lds_put(T* buf, int row, int kq, const uint4& v)
 // split form: 4 consecutive k of one row -> 8 bytes into the hi image and 8 into the lo image
 __device__ __forceinline__ void lds_put_split(float* buf, int row, int kq, const uint4& v) {
     const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-    float h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { h[e] = bf2f(f2bf(x[e])); l[e] = x[e] - h[e]; }
+    // hi by one v_cvt_pk_bf16_f32 per PAIR, its halves back as fp32 by a shift / a mask, lo = pack(x - hi): 3 VALU ops per value (r06; the form that rounded every
+    // value on its own and packed the rounded floats again cost 4 - the same bits)
+    const uint32_t h0 = pack_bf2(x[0], x[1]), h1 = pack_bf2(x[2], x[3]);
+    const uint32_t l0 = pack_bf2(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
+    const uint32_t l1 = pack_bf2(x[2] - __uint_as_float(h1 << 16), x[3] - __uint_as_float(h1 & 0xffff0000u));
     unsigned char* b = reinterpret_cast<unsigned char*>(buf) + row * SPLIT_PITCH_B + kq * 2;
-    *reinterpret_cast<uint2*>(b) = make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
-    *reinterpret_cast<uint2*>(b + SPLIT_IMG_B) = make_uint2(pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3]));
+    *reinterpret_cast<uint2*>(b) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(b + SPLIT_IMG_B) = make_uint2(l0, l1);
 }
 
 // STATS = true (BatchNorm column sums requested): persistent workgroups walk the tiles vb, vb + gridDim.x, ... of ONE tile column

@@ -214,12 +214,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
             }
         } else if constexpr (SPLIT) {
             auto put = [&](T* img, int row, const u32x4& v) __attribute__((always_inline)) {
-                float h[4], l[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const float x = __uint_as_float(v[q]); h[q] = bf2f(f2bf(x)); l[q] = x - h[q]; }
+                const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);
+                const uint32_t h0 = pack_bf2(x0, x1), h1 = pack_bf2(x2, x3);              // 3 VALU ops per value (gemm.hip lds_put_split)
+                const uint32_t l0 = pack_bf2(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = pack_bf2(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
                 unsigned char* b = reinterpret_cast<unsigned char*>(img) + (row * TS_PITCH + cv) * 2;
-                *reinterpret_cast<u32x2*>(b) = u32x2{pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-                *reinterpret_cast<u32x2*>(b + TS_IMG_B) = u32x2{pack_bf2(l[0], l[1]), pack_bf2(l[2], l[3])};
+                *reinterpret_cast<u32x2*>(b) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(b + TS_IMG_B) = u32x2{l0, l1};
             };
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) { put(as, rt + 8 * i, ra[i]); put(bs, rt + 8 * i, rb[i]); }
