@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
             for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if defined(P3_ATTN_ABL) && (P3_ATTN_ABL & 4)
+                    const float p = fmaf(sacc[h2][r], c, -m_use);          // timing ablation: the exponentials - wrong numbers
+#else
                     const float p = __builtin_amdgcn_exp2f(fmaf(sacc[h2][r], c, -m_use));
+#endif
                     sacc[h2][r] = p;
                     psum += p;
                 }

@@ -98,7 +98,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], s16x8& h, s16x8& l) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         hw[i] = pack_bf2(x[2 * i], x[2 * i + 1]);
+#if defined(P3_ATTN_ABL) && (P3_ATTN_ABL & 2)
+        lw[i] = hw[i];                        // timing ablation (tools/r06_g25.sh): what the split of P costs - wrong numbers
+#else
         lw[i] = pack_bf2(x[2 * i] - __uint_as_float(hw[i] << 16), x[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u));
+#endif
     }
     h = __builtin_bit_cast(s16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
     l = __builtin_bit_cast(s16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
@@ -127,8 +131,12 @@ template <int D, int R> struct SplitStage {
             if (ITEMS % 256 == 0 || item < ITEMS) {
                 const float x0 = __uint_as_float(v[i][0]), x1 = __uint_as_float(v[i][1]), x2 = __uint_as_float(v[i][2]), x3 = __uint_as_float(v[i][3]);
                 const uint32_t h0 = pack_bf2(x0, x1), h1 = pack_bf2(x2, x3);              // 3 VALU ops per value (see split8)
+#if defined(P3_ATTN_ABL) && (P3_ATTN_ABL & 1)
+                const uint32_t l0 = h0, l1 = h1;      // timing ablation: what the split of the staged rows costs - wrong numbers
+#else
                 const uint32_t l0 = pack_bf2(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
                 const uint32_t l1 = pack_bf2(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
+#endif
                 bf16_t* p = img + base + i * (256 / VPR) * D;
                 *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(p + R * D) = make_uint2(l0, l1);

@@ -514,7 +514,18 @@ float* p3_tn_park(float* C, int N, int K, int ldc, int splits) {
         for (int i = 0; i < g_tnp_n; ++i) {
             const TnpEntry& o = g_tnp[i];
             const uintptr_t olo = (uintptr_t)o.C, ohi = (uintptr_t)(o.C + (int64_t)(o.N - 1) * o.ldc + o.K);
-            if (lo < ohi && olo < hi) return nullptr;
+            if (lo < ohi && olo < hi) {
+                // address ranges interleave - but two COLUMN SLICES of one matrix (the nine shifted products of a 3 x 3 convolution's weight gradient, each into its
+                // own [Co, Ci] slice of the [Co, 9 Ci] weight) share no element: same row stride, column intervals disjoint inside a row
+                if (o.ldc == ldc) {
+                    const bool fwd = C >= o.C;
+                    const int64_t dist = fwd ? C - o.C : o.C - C;
+                    const int64_t cs = dist % ldc;                           // the later slice's first column, counted from the earlier one's
+                    const int k_first = fwd ? o.K : K, k_second = fwd ? K : o.K;
+                    if (cs >= k_first && cs + k_second <= ldc) continue;
+                }
+                return nullptr;
+            }
         }
     }
     float* slot = g_tnp_arena + g_tnp_used;

@@ -139,10 +139,13 @@ def _conv3x3_bwd(dY, Xpad, ldx, cin, w, cd, B, H, ci_dx, key, residual=None):
     dYpad = hip.pad_nhwc(dY, Co, None, None, 0, Co, Co, B, H, H)
     dp2, cp2 = dYpad.view(Rp, Co), Xpad.view(Rp, ldx)[:, :cin]
     dW2 = torch.zeros((Co, 9 * cin), dtype=torch.float32, device=dY.device)
-    for t in range(9):      # dW[co, tap, ci] = sum_rows dY[r, co] * X[r + shift(tap), ci] in the zero-bordered row space
-        s = (t // 3 - 1) * P + (t % 3 - 1)
-        r0, r1 = max(0, -s), Rp - max(0, s)
-        hip.gemm_tn(dp2[r0:r1], cp2[r0 + s:r1 + s], out=dW2[:, t * cin:(t + 1) * cin])
+    with hip.tn_parking(hip.CONV_PARK) as parking:      # partial tiles of the nine products parked side by side, one flush (fusion_layers._FusionConvBN.backward)
+        for t in range(9):      # dW[co, tap, ci] = sum_rows dY[r, co] * X[r + shift(tap), ci] in the zero-bordered row space
+            s = (t // 3 - 1) * P + (t % 3 - 1)
+            r0, r1 = max(0, -s), Rp - max(0, s)
+            hip.gemm_tn(dp2[r0:r1], cp2[r0 + s:r1 + s], out=dW2[:, t * cin:(t + 1) * cin])
+    if parking.on and hip.reduce_pending():
+        hip.reduce_flush()
     del dYpad
     # input gradient: correlation with the flipped kernel, weight laid out [ci, (ky', kx', co)]
     wf = ops.shadow(w, cd, key=key, fn=lambda t_: t_[:, :ci_dx].flip(2, 3).permute(1, 2, 3, 0).reshape(ci_dx, -1))

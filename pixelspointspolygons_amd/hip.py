@@ -383,6 +383,9 @@ def tn_defer_arena(mb=None):
     return _tn_park["buf"] is not False
 
 
+CONV_PARK = _os0.environ.get("P3_CONV_PARK", "1") != "0"     # the nine shifted weight-gradient products of a 3 x 3 convolution park their partial tiles, one flush (A/B switch)
+
+
 class tn_parking:
     """`with hip.tn_parking(on):` weight-gradient launches inside may leave their split-M partial tiles parked for reduce_flush() (their outputs must be
     accumulation targets that stay valid and unread until then: views of the optimizer's gradient arena)"""

@@ -18,7 +18,7 @@ def _bench():
         sys.argv = argv
 
 
-def _line(name="r05_bench.json"):
+def _line(name="r06_bench.json"):
     with open(os.path.join(ROOT, "profiles", name)) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
@@ -71,7 +71,7 @@ def test_committed_bench_line_has_the_contract_keys_and_is_self_consistent():
 def test_pmc_table_feeds_the_roofline_traffic_fields():
     bench, _ = _bench()
     table, src = bench.pmc_step_traffic("fp32x3")
-    assert table is not None and src == "profiles/r05_pmc_traffic_fp32x3.json"
+    assert table is not None and src == "profiles/r06_pmc_traffic_fp32x3.json"
     r = _line()["roofline"]
     per_launch = bench.kernel_traffic(table, r["kernel"])
     # hand computation of the same average: the PMC rows of that kernel (rocprofv3 spells bf16 "unsigned short"), launches-weighted
@@ -98,7 +98,7 @@ def test_rocprof_summary_agrees_with_the_live_kernel_timing():
     the line lists (tier brief, measurement section)."""
     import re
     r = _line()["roofline"]
-    txt = open(os.path.join(ROOT, "profiles", "r05_fp32x3_step_summary.txt")).read()
+    txt = open(os.path.join(ROOT, "profiles", "r06_fp32x3_step_summary.txt")).read()
     avg = {}
     for m in re.finditer(r"n=\s*([0-9.]+)\s+avg=\s*([0-9.]+) us\s+(\S.*)$", txt, re.M):
         avg[m.group(3).replace(" ", "")] = (float(m.group(2)), float(m.group(1)))
