@@ -134,6 +134,37 @@ __device__ __forceinline__ f32x16 score_mma(const T* rowimg, int sub, const s16x
     return acc;
 }
 
+// fp32x3: the two score-like products of a sub-tile (S from one image with one set of row fragments, dP from the other) as two interleaved accumulator chains, the
+// fragments of k-step ks + 1 read while the six MFMAs of step ks run (score_mma above compiles to read -> s_waitcnt lgkmcnt(0) -> three MFMAs on one chain, eight
+// times per product).  -DP3_ATTN_PAIR=0: the two separate calls (A/B)
+#ifndef P3_ATTN_PAIR
+#define P3_ATTN_PAIR 1
+#endif
+template <typename T, int D, int R>
+__device__ __forceinline__ void score_mma_pair(const T* img1, const T* img2, int sub, const s16x8 (&y1b)[D / 16], const s16x8 (&y1l)[D / 16], const s16x8 (&y2b)[D / 16],
+                                               const s16x8 (&y2l)[D / 16], const FragAddr<T, D>& fa, f32x16& a1, f32x16& a2) {
+    const bf16_t* h1 = reinterpret_cast<const bf16_t*>(img1);
+    const bf16_t* h2 = reinterpret_cast<const bf16_t*>(img2);
+    s16x8 f[2][4];
+    auto rd = [&](int bsel, int ks) __attribute__((always_inline)) {
+        f[bsel][0] = fa.s.frag(h1, sub, ks); f[bsel][1] = fa.s.frag(h1 + R * D, sub, ks);
+        f[bsel][2] = fa.s.frag(h2, sub, ks); f[bsel][3] = fa.s.frag(h2 + R * D, sub, ks);
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
+    rd(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        const int bsel = ks & 1;
+        if (ks + 1 < D / 16) rd(bsel ^ 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = p3attn::mfma_bf16(f[bsel][1], y1b[ks], a1); a2 = p3attn::mfma_bf16(f[bsel][3], y2b[ks], a2);      // small terms first
+        a1 = p3attn::mfma_bf16(f[bsel][0], y1l[ks], a1); a2 = p3attn::mfma_bf16(f[bsel][2], y2l[ks], a2);
+        a1 = p3attn::mfma_bf16(f[bsel][0], y1b[ks], a1); a2 = p3attn::mfma_bf16(f[bsel][2], y2b[ks], a2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // accumulate product: out[dj][d32 x cols32] += X^T[d, rows(sub)] . W[rows(sub), cols]   with W lane-local (f32x16 of sub-tile `sub`)
 template <typename T, int D, int R>
 __device__ __forceinline__ void accum_mma(const T* rowimg, int sub, const f32x16& w, f32x16 (&out)[D / 32], const FragAddr<T, D>& fa, int l31, int hi) {
@@ -302,14 +333,29 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? 3 : 2)) void attn_b
     DropKey dkey; uint32_t drop_rk = 0;
     if constexpr (DROP) { dkey = drop_key(d.drop); drop_rk = drop_rowkey(dkey, (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq + (uint64_t)qc); }
     Stage<T, D, KT> kreg, vreg;
+    // fp32x3: K / V rows by LDS-DMA into raw fp32 images (dynamic LDS), split at the tile switch (attn_tile.h SplitDma) - no staging registers across the tile
+    using SD = p3attn::SplitDma<X3 ? D : 64, 64>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_raw[];
+    const uint32_t raw_lds = X3 ? (uint32_t)(uintptr_t)attn_raw : 0u;
     FragAddr<T, D> fa; fa.init(lane, l31, hi);
-    if (ntiles > 0) { kreg.load(Kp, 0, d.Lk, d.k_rs, tid); vreg.load(Vp, 0, d.Lk, d.v_rs, tid); }
+    float kbreg = 0.f;                               // the next tile's key bias rides with its prefetch (see attention.hip)
+    auto load_tile = [&](int row0) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            SD::issue(reinterpret_cast<const float*>(Kp), row0, d.Lk, d.k_rs, raw_lds, wave, lane);
+            SD::issue(reinterpret_cast<const float*>(Vp), row0, d.Lk, d.v_rs, raw_lds + SD::RAW_B, wave, lane);
+        } else {
+            kreg.load(Kp, row0, d.Lk, d.k_rs, tid); vreg.load(Vp, row0, d.Lk, d.v_rs, tid);
+        }
+        if (kbias && tid < KT) { const int kvb = row0 + tid; kbreg = kbias[kvb < d.Lk ? kvb : d.Lk - 1]; }
+    };
+    if (ntiles > 0) load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
+        if constexpr (X3) p3attn::wait_vm0();
         __syncthreads();
-        kreg.store(Krow, tid);
-        vreg.store(Vrow, tid);
-        if (kbias && tid < KT) { const int kvb = kv0 + tid; Kb[tid] = kbias[kvb < d.Lk ? kvb : d.Lk - 1] * LOG2E; }   // see attention.hip
+        if constexpr (X3) { SD::split_store(attn_raw, reinterpret_cast<bf16_t*>(Krow), tid); SD::split_store(attn_raw + SD::RAW_B, reinterpret_cast<bf16_t*>(Vrow), tid); }
+        else { kreg.store(Krow, tid); vreg.store(Vrow, tid); }
+        if (kbias && tid < KT) Kb[tid] = kbreg * LOG2E;
         __syncthreads();
         // keep-bit words of this tile's 32-key halves: loaded BEFORE the next tile's prefetch is issued - vmcnt retires in order, so a
         // small load issued after the prefetch would make its consumer wait for the whole prefetch (the ISA showed vmcnt(0) there)
@@ -322,15 +368,20 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? 3 : 2)) void attn_b
                 if (kw < nkw) dwords[sub] = d.drop_rows[(((int64_t)b * d.H + h) * nkw + kw) * d.Lq + qc];
             }
         }
-        if (t + 1 < ntiles) { kreg.load(Kp, kv0 + KT, d.Lk, d.k_rs, tid); vreg.load(Vp, kv0 + KT, d.Lk, d.v_rs, tid); }
+        if (t + 1 < ntiles) load_tile(kv0 + KT);
         if (qblk + wave * 32 >= d.Lq) continue;      // tail q-block: this wave has no live query, it only stages
         int vis_end = kv_end;                        // keys this wave's queries can see (causal: up to its last query)
         if (d.causal) { const int wl = qblk + wave * 32 + 32; if (wl < vis_end) vis_end = wl; }
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             if (kv0 + sub * 32 >= vis_end) continue;                          // 32-key half with no visible key: dS == 0
-            f32x16 s = score_mma<T, D, KT>(Krow, sub, qb, ql, qf, fa, l31, hi);   // S^T[kv, q]
-            f32x16 dp = score_mma<T, D, KT>(Vrow, sub, gb, gl, gf, fa, l31, hi);  // dP^T[kv, q]
+            f32x16 s, dp;                                                         // S^T[kv, q], dP^T[kv, q]
+            if constexpr (X3 && P3_ATTN_PAIR) {
+                score_mma_pair<T, D, KT>(Krow, Vrow, sub, qb, ql, gb, gl, fa, s, dp);
+            } else {
+                s = score_mma<T, D, KT>(Krow, sub, qb, ql, qf, fa, l31, hi);
+                dp = score_mma<T, D, KT>(Vrow, sub, gb, gl, gf, fa, l31, hi);
+            }
             // tile entirely inside [0, Lk), below the causal diagonal of this wave's first query, no key bias: no per-element masks
             const bool full = (kv0 + sub * 32 + 32 <= d.Lk) && (!d.causal || kv0 + sub * 32 + 31 <= qblk + wave * 32) && !kbias;
             const uint32_t dword = dwords[sub];
@@ -410,18 +461,47 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)
     if constexpr (DROP != 0) { dkey = drop_key(d.drop); drop_ck = drop_colkey(dkey, (uint32_t)kvc); drop_bh = (uint64_t)((int64_t)b * d.H + h) * (uint64_t)d.Lq; }
     const int64_t stat_base = ((int64_t)b * d.H + h) * d.Lq;
     Stage<T, D, QT> qreg, greg;
-    FragAddr<T, D> fa; fa.init(lane, l31, hi);
-    if (q_begin < d.Lq) { qreg.load(Qp, q_begin, d.Lq, d.q_rs, tid); greg.load(dOp, q_begin, d.Lq, d.o_rs, tid); }
-    const int64_t word_row = (((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq;
-    for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
-        __syncthreads();
-        qreg.store(Qrow, tid);
-        greg.store(Grow, tid);
-        if (tid < QT) {
-            const int qq = q0 + tid < d.Lq ? q0 + tid : d.Lq - 1;
-            Ls[tid] = a.lse[stat_base + qq] * 1.4426950408889634f; Ds[tid] = a.delta[stat_base + qq];   // lse in log2 units
+    constexpr bool X3 = Kind<T>::X3;
+    using SD = p3attn::SplitDma<X3 ? D : 64, 64>;       // fp32x3: Q / dO rows by LDS-DMA into raw images, split at the tile switch (see the dQ kernel)
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_raw[];
+    const uint32_t raw_lds = X3 ? (uint32_t)(uintptr_t)attn_raw : 0u;
+    auto load_tile = [&](int row0) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            SD::issue(reinterpret_cast<const float*>(Qp), row0, d.Lq, d.q_rs, raw_lds, wave, lane);
+            SD::issue(reinterpret_cast<const float*>(dOp), row0, d.Lq, d.o_rs, raw_lds + SD::RAW_B, wave, lane);
+        } else {
+            qreg.load(Qp, row0, d.Lq, d.q_rs, tid); greg.load(dOp, row0, d.Lq, d.o_rs, tid);
         }
+    };
+    FragAddr<T, D> fa; fa.init(lane, l31, hi);
+    // the tile's log-sum-exp / delta rows ride with the prefetch (registers of the first QT threads): loaded inside the staging phase they were a global-load latency
+    // in front of barrier 2 in every tile - 20 % of this kernel's loop time (profiles/r06_attn_phases.txt)
+    float lreg = 0.f, dreg = 0.f;
+    auto load_stats = [&](int qrow0) __attribute__((always_inline)) {
+        if (tid < QT) { const int qq = qrow0 + tid < d.Lq ? qrow0 + tid : d.Lq - 1; lreg = a.lse[stat_base + qq]; dreg = a.delta[stat_base + qq]; }
+    };
+    if (q_begin < d.Lq) { load_tile(q_begin); load_stats(q_begin); }
+    const int64_t word_row = (((int64_t)b * d.H + h) * ((d.Lk + 31) >> 5) + ((kblk + wave * 32) >> 5)) * d.Lq;
+    // -DP3_ATTN_TIMING (diagnostic build, tools/mb_attn_phases.py, as in attention.hip): [0] barrier 1, [1] split + LDS stores, [2] barrier 2, [3] next tile's loads
+    // issued, [4] S and dP, [5] element-wise, [6] dV / dK products + loop tail, [7] 32-query halves counted
+#ifdef P3_ATTN_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define TM(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[k] += n_ - tprev; tprev = n_; } while (0)
+#else
+#define TM(k) do { } while (0)
+#endif
+    for (int q0 = q_begin; q0 < d.Lq; q0 += QT) {
+        TM(6);
+        if constexpr (X3) p3attn::wait_vm0();
         __syncthreads();
+        TM(0);
+        if constexpr (X3) { SD::split_store(attn_raw, reinterpret_cast<bf16_t*>(Qrow), tid); SD::split_store(attn_raw + SD::RAW_B, reinterpret_cast<bf16_t*>(Grow), tid); }
+        else { qreg.store(Qrow, tid); greg.store(Grow, tid); }
+        if (tid < QT) { Ls[tid] = lreg * 1.4426950408889634f; Ds[tid] = dreg; }   // lse in log2 units
+        TM(1);
+        __syncthreads();
+        TM(2);
         // DROP == 2: lane L loads the keep-bit word of query row q0 + sub*32 + (L & 31) for this wave's 32-key block, for both halves of
         // the tile and BEFORE the next tile's prefetch (vmcnt retires in order: a load issued after the prefetch waits for all of it)
         uint32_t mywords[QT / 32];
@@ -433,14 +513,24 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)
                 if (kblk + wave * 32 < d.Lk) mywords[sub] = d.drop_rows[word_row + (qr < d.Lq ? qr : d.Lq - 1)];
             }
         }
-        if (q0 + QT < d.Lq) { qreg.load(Qp, q0 + QT, d.Lq, d.q_rs, tid); greg.load(dOp, q0 + QT, d.Lq, d.o_rs, tid); }
+        if (q0 + QT < d.Lq) { load_tile(q0 + QT); load_stats(q0 + QT); }
+        TM(3);
         if (kblk + wave * 32 >= d.Lk) continue;      // tail k-block: this wave has no live key, it only stages
 #pragma unroll
         for (int sub = 0; sub < QT / 32; ++sub) {
             // 32-query half beyond Lq, or (causal) entirely before this wave's first key: P == dS == 0
             if (q0 + sub * 32 >= d.Lq || (d.causal && q0 + sub * 32 + 31 < kblk + wave * 32)) continue;
-            f32x16 s = score_mma<T, D, QT>(Qrow, sub, kb, kl, kf, fa, l31, hi);   // S[q, kv]
-            f32x16 dp = score_mma<T, D, QT>(Grow, sub, vb, vl, vf, fa, l31, hi);  // dP[q, kv]
+            f32x16 s, dp;                                                         // S[q, kv], dP[q, kv]
+            if constexpr (X3 && P3_ATTN_PAIR) {
+                score_mma_pair<T, D, QT>(Qrow, Grow, sub, kb, kl, vb, vl, fa, s, dp);
+            } else {
+                s = score_mma<T, D, QT>(Qrow, sub, kb, kl, kf, fa, l31, hi);
+                dp = score_mma<T, D, QT>(Grow, sub, vb, vl, vf, fa, l31, hi);
+            }
+            TM(4);
+#ifdef P3_ATTN_TIMING
+            tacc[7] += 1;
+#endif
             f32x16 ds;
             // all 32 queries of the sub-tile and all 32 keys of the wave valid, non-causal: no per-element masks
             const bool full = (q0 + sub * 32 + 32 <= d.Lq) && (kblk + wave * 32 + 32 <= d.Lk) && !d.causal;
@@ -472,10 +562,17 @@ __global__ __launch_bounds__(256, (D == 32 && !Kind<T>::X3 ? P3_DKV32_WAVES : 2)
                 }
             };
             if (__builtin_amdgcn_readfirstlane((int)full)) elements(std::true_type{}); else elements(std::false_type{});
+            TM(5);
             accum_mma<T, D, QT>(Grow, sub, s, dv, fa, l31, hi);               // dV^T[d, kv] += dO^T . P
             accum_mma<T, D, QT>(Qrow, sub, ds, dk, fa, l31, hi);              // dK^T[d, kv] += Q^T . dS
+            TM(6);
         }
     }
+#ifdef P3_ATTN_TIMING
+    if (lane == 0 && d.drop_rows && kblk + wave * 32 < d.Lk)
+        for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(d.drop_rows) + 8 + k, tacc[k]);
+#endif
+#undef TM
     if (kv < d.Lk) {
         if (gpl) {
             store_T_acc<T, D>(reinterpret_cast<T*>(reinterpret_cast<bf16_t*>(dKp) + (int64_t)kv * d.g_rs), dk, d.scale, hi, d.g_lo);
@@ -494,17 +591,31 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
     int g = (int)((rows + 3) / 4); if (g > 4096) g = 4096;
     (void)g;   // delta is produced by the dQ kernel (attn_delta_kernel kept for reference / standalone use)
     const dim3 gq(p3_ceil_div(d.Lq, 128) * d.H * d.B), gk(p3_ceil_div(d.Lk, 128) * d.H * d.B), blk(256);
+    // fp32x3: the raw fp32 images of the two staged operands in dynamic LDS (with the 32 KB of bf16 images above the 64 KB a kernel gets without asking for D = 64)
+    const size_t dyn = Kind<T>::X3 ? (size_t)2 * 64 * D * 4 : 0;
+    if constexpr (Kind<T>::X3 && D == 64) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            attr_set = true;
+        }
+    }
     if (d.drop.seed != nullptr && d.drop.p > 0.f) {
         if (d.drop_rows) {
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 2>), gq, blk, 0, s, a);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 2>), gk, blk, 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 2>), gq, blk, dyn, s, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 2>), gk, blk, dyn, s, a);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 1>), gq, blk, 0, s, a);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 1>), gk, blk, 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 1>), gq, blk, dyn, s, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 1>), gk, blk, dyn, s, a);
         }
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 0>), gq, blk, 0, s, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 0>), gk, blk, 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, 0>), gq, blk, dyn, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, 0>), gk, blk, dyn, s, a);
     }
     P3_LAUNCH_CHECK();
     return P3_OK;

@@ -145,6 +145,51 @@ template <int D, int R> struct SplitStage {
     }
 };
 
+// fp32x3, r06: the fp32 rows of a tile go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers held across the tile's MFMAs, no s_waitcnt vmcnt in
+// front of anything but the tile switch) into a RAW image - R rows x D fp32, linear, 1 KB pieces of 1024 / (4 D) rows, wave w of the four issues pieces w, w + 4, ... -
+// and are split into the hi / lo bf16 images LDS -> registers -> LDS at the tile switch.  The register-staged form (SplitStage) kept 32 registers per thread in flight
+// across the whole tile: the dK / dV kernel spilled, and every reload of a spilled register (scratch_load + s_waitcnt vmcnt(0)) drained the prefetch it was issued behind.
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t lds_dst, uint32_t voff) {      // 64 lanes x 16 B -> LDS [lds_dst, lds_dst + 1 KB), lane order
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int D, int R> struct SplitDma {
+    static constexpr int VPR = D / 4, ITEMS = R * VPR, N = ITEMS / 256, RPP = 1024 / (D * 4), PIECES = R / RPP, PW = PIECES / 4, RAW_B = R * D * 4;
+    static_assert(ITEMS % 256 == 0 && PIECES % 4 == 0, "whole pieces per wave");
+    // src: the (batch, head) base of the operand (wave-uniform); rows row0 .. row0 + R - 1, clamped to nvalid - 1
+    __device__ __forceinline__ static void issue(const float* __restrict__ src, int row0, int nvalid, int row_stride, uint32_t raw_lds, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int piece = wave + 4 * i;
+            int r = row0 + piece * RPP + lane / VPR; if (r >= nvalid) r = nvalid - 1;
+            lds_dma16(src, raw_lds + piece * 1024, (uint32_t)(r * row_stride + (lane % VPR) * 4) * 4u);
+        }
+    }
+    // raw image -> the two swizzled bf16 images (hi at img, lo at img + R * D): the item -> (row, chunk) map of SplitStage::store
+    __device__ __forceinline__ static void split_store(const unsigned char* raw, bf16_t* img, int tid) {
+        const int base = img_off<D>(tid / VPR, (tid % VPR) >> 1) + ((tid % VPR) & 1) * 4;
+        u32x4 v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = *reinterpret_cast<const u32x4*>(raw + (tid + 256 * i) * 16);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float x0 = __uint_as_float(v[i][0]), x1 = __uint_as_float(v[i][1]), x2 = __uint_as_float(v[i][2]), x3 = __uint_as_float(v[i][3]);
+            const uint32_t h0 = pack_bf2(x0, x1), h1 = pack_bf2(x2, x3);
+            const uint32_t l0 = pack_bf2(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
+            const uint32_t l1 = pack_bf2(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
+            bf16_t* p = img + base + i * (256 / VPR) * D;
+            *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(p + R * D) = make_uint2(l0, l1);
+        }
+    }
+};
+
 __device__ __forceinline__ f32x16 mfma_bf16(const s16x8& a, const s16x8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), a),
                                                    __builtin_bit_cast(__bf16 __attribute__((ext_vector_type(8))), b), c, 0, 0, 0);
