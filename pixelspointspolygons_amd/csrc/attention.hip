@@ -36,11 +36,8 @@ template <int D> struct ATr<bf16_t, D> {
     static constexpr int KT = 64, PK = D, PV = D;           // K [KT][D] ; V [KT][D], both swizzled (attn_tile.h)
     static constexpr int K_ELEMS = KT * D, V_ELEMS = KT * D;
 };
-#ifndef P3_ATTN_X3_KT64
-#define P3_ATTN_X3_KT64 64          // keys per tile of the fp32x3 forward kernel at head dim 64 (32: half the LDS and the score registers, twice the tile switches)
-#endif
 template <int D> struct ATr<f32s, D> {                        // fp32x3 mode: two swizzled bf16 images (hi | lo) per tile, in units of 4-byte elements
-    static constexpr int KT = D == 64 ? P3_ATTN_X3_KT64 : 64, PK = D, PV = D;
+    static constexpr int KT = 64, PK = D, PV = D;
     static constexpr int K_ELEMS = KT * D, V_ELEMS = KT * D;
 };
 template <int D> struct ATr<float, D> {
@@ -175,22 +172,29 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
     constexpr int KV16 = KT * D * (int)sizeof(T) / 16;      // 16-byte vectors per K tile
     constexpr int KPT = (KV16 + 255) / 256;                 // per thread
     constexpr int VPT = KPT;
+    // LDS-DMA staging for head dim 32 only (decoder: 91 -> 84 us same-box); at head dim 64 the forward kernel has the registers for the rows in flight and the raw
+    // image's extra LDS round trip made it slower (ViT: 288 -> 302 us, profiles/r06_attn_dma_ab.txt) - there the rows stay register-staged
+    constexpr bool DMA = X3 && D == 32;
     u32x4 kreg[X3 ? 1 : KPT];
     u32x4 vreg[X3 ? 1 : VPT];
+    p3attn::SplitStage<IMG ? D : 64, 64> ksp, vsp;  // fp32x3 without DMA: fp32 rows in flight, split into the hi / lo images at store time
     // fp32x3: the fp32 rows travel global -> LDS by LDS-DMA into raw images (dynamic LDS: K | V) and are split into the hi / lo images at the tile switch (attn_tile.h
     // SplitDma) - no staging registers live across the tile
     using SD = p3attn::SplitDma<IMG ? D : 64, X3 ? KT : 64>;
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_raw[];
-    const uint32_t raw_lds = X3 ? (uint32_t)(uintptr_t)attn_raw : 0u;
+    const uint32_t raw_lds = DMA ? (uint32_t)(uintptr_t)attn_raw : 0u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     p3attn::ScoreAddr<IMG ? D : 16> sadr;         // bf16 / fp32x3: lane-constant offsets into the swizzled K / V images
     p3attn::TrAddr<IMG ? D : 32> tadr;
     if constexpr (IMG) { sadr.init(l31, hi); tadr.init(lane); }
     float kbreg = 0.f;                            // the next tile's key bias (first KT threads), loaded with the tile: see below
     auto load_tile = [&](int t) __attribute__((always_inline)) {
-        if constexpr (X3) {
+        if constexpr (DMA) {
             SD::issue(reinterpret_cast<const float*>(Kp), t * KT, d.Lk, d.k_rs, raw_lds, wave_u, lane);
             SD::issue(reinterpret_cast<const float*>(Vp), t * KT, d.Lk, d.v_rs, raw_lds + SD::RAW_B, wave_u, lane);
+        } else if constexpr (X3) {
+            ksp.load(reinterpret_cast<const float*>(Kp), t * KT, d.Lk, d.k_rs, tid);
+            vsp.load(reinterpret_cast<const float*>(Vp), t * KT, d.Lk, d.v_rs, tid);
         } else {
             attn_load_tile<T, D, KPT, VPT>(t, tid, d, Kp, Vp, kreg, vreg);
         }
@@ -199,9 +203,10 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
 
     if (ntiles > 0) load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
-        if constexpr (X3) p3attn::wait_vm0();         // this wave's DMA pieces of the tile have landed
-        __syncthreads();  // previous tile's LDS reads are done (fp32x3: and every wave's pieces are in LDS)
-        if constexpr (X3) { SD::split_store(attn_raw, reinterpret_cast<bf16_t*>(Ks), tid); SD::split_store(attn_raw + SD::RAW_B, reinterpret_cast<bf16_t*>(Vs), tid); }
+        if constexpr (DMA) p3attn::wait_vm0();        // this wave's DMA pieces of the tile have landed
+        __syncthreads();  // previous tile's LDS reads are done (DMA: and every wave's pieces are in LDS)
+        if constexpr (DMA) { SD::split_store(attn_raw, reinterpret_cast<bf16_t*>(Ks), tid); SD::split_store(attn_raw + SD::RAW_B, reinterpret_cast<bf16_t*>(Vs), tid); }
+        else if constexpr (X3) { ksp.store(reinterpret_cast<bf16_t*>(Ks), tid); vsp.store(reinterpret_cast<bf16_t*>(Vs), tid); }
         else attn_store_tile<T, D, KPT, VPT>(tid, Ks, Vs, kreg, vreg);
         // the tile's key bias goes through LDS (log2 units): read per element from global memory it was 32 dependent loads per tile, each
         // followed by s_waitcnt vmcnt(0) - which also drained the next tile's prefetch (decoder self-attention: every tile has a bias).
@@ -520,7 +525,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
         return P3_OK;
     }
     // fp32x3: raw fp32 images of the K and V tile in dynamic LDS (static 32 KB of bf16 images + 32 KB: above the 64 KB a kernel gets without asking)
-    size_t dyn = d->dtype == P3_F32X3 ? (size_t)2 * (d->head_dim == 64 ? ATr<f32s, 64>::KT : ATr<f32s, 32>::KT) * d->head_dim * 4 : 0;
+    size_t dyn = d->dtype == P3_F32X3 && d->head_dim == 32 ? (size_t)2 * ATr<f32s, 32>::KT * 32 * 4 : 0;
     static int pad_lds = -1;              // P3_ATTN_PAD_LDS=<bytes> (diagnostic): extra dynamic LDS per workgroup of the fp32x3 kernels - 40000 leaves ONE workgroup per CU
     if (pad_lds < 0) { const char* e = getenv("P3_ATTN_PAD_LDS"); pad_lds = e ? atoi(e) : 0; }
     if (d->dtype == P3_F32X3) dyn += (size_t)pad_lds;
