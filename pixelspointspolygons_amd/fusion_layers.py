@@ -82,7 +82,7 @@ class _FusionConvBN(torch.autograd.Function):
         w2 = ops.shadow(w, cd, key="khwc", fn=lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))
         sums = torch.zeros(2 * D, dtype=torch.float32, device=canvas.device) if training else None
         pre = hip.gemm(canvas.view(B * g * g, 2 * D), w2, bias=b.detach(), a_mode=hip.A_CONV3X3, conv=(B, g, g, 2 * D), lda=2 * D,
-                       out_dtype=cd, colsum=sums[:D] if training else None, colsumsq=sums[D:] if training else None)
+                       out_dtype=cd, colsum=sums[:D] if training else None, colsumsq=sums[D:] if training else None, w_planes=ops.wpl(w2))
         world = ops.sync_stats(sums) if training else 1
         scale, shift, mean, rstd = hip.bn_finalize(sums, float(B * g * g * world), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
                                                    bn.eps, bn.momentum, training, save=True)
@@ -126,5 +126,5 @@ class _FusionConvBN(torch.autograd.Function):
         dw = dW2.view(D, 3, 3, 2 * D).permute(0, 3, 1, 2).contiguous()
         # input gradient: correlation with the flipped kernel, [Ci, (ky', kx', co)]
         wf = ops.shadow(w, cd, key="flipT", fn=lambda t_: t_.flip(2, 3).permute(1, 2, 3, 0).reshape(t_.shape[1], -1))
-        dcanvas = hip.gemm(dpre, wf, a_mode=hip.A_CONV3X3, conv=(B, g, g, D), lda=D, out_dtype=cd).view(B, g * g, 2 * D)
+        dcanvas = hip.gemm(dpre, wf, a_mode=hip.A_CONV3X3, conv=(B, g, g, D), lda=D, out_dtype=cd, w_planes=ops.wpl(wf)).view(B, g * g, 2 * D)
         return dcanvas, dw, db, dg, dbt, None, None

@@ -239,6 +239,9 @@ def _drop(spec):
     return d
 
 
+W_PLANES = [_os0.environ.get("P3_W_PLANES", "1") != "0"]      # fp32x3: the register-staged GEMM takes the weight as planes when the caller has them (A/B switch)
+
+
 class GemmDesc(Structure):
     _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
                 ("dtype_in", c_int), ("dtype_out", c_int), ("act", c_int), ("a_mode", c_int),
@@ -247,16 +250,23 @@ class GemmDesc(Structure):
                 ("a_scale", c_void_p), ("a_shift", c_void_p), ("pair_V", c_void_p), ("pair_n", c_int),
                 ("colsum", c_void_p), ("colsumsq", c_void_p), ("drop", Dropout),
                 ("bwd_saved", c_void_p), ("bwd_act", c_int), ("bwd_scale", c_float), ("aux_mode", c_int), ("conv_pad", c_int),
-                ("bwd_bn", c_void_p)]
+                ("bwd_bn", c_void_p), ("w_lo", c_void_p)]
 
 
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
-         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, variant=None):
+         lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, variant=None, w_planes=None):
     """C[M,N] = drop(act(A'[M,K] @ W[N,K]^T + bias)) + residual.  a: [..., K] (2-D view), w: [N, K].  drop = (seed, site, p).
-    variant = 4 | 6 | 9: call that LDS-DMA kernel (p3_gemm_dma, csrc/gemm_dma.hip) directly instead of p3_gemm's own choice (A/B tools, tests)."""
+    variant = 4 | 6 | 9: call that LDS-DMA kernel (p3_gemm_dma, csrc/gemm_dma.hip) directly instead of p3_gemm's own choice (A/B tools, tests).
+    w_planes = (hi, lo) bf16 [N, K] views of w's split (fp32x3 scope, plain or 3x3-gathered A): the kernel copies them instead of splitting w per tile."""
     _dev(a)
     N, K = w.shape
+    wpl = None
+    if w_planes is not None and W_PLANES[0] and dt_mm(a) == F32X3 and a_mode in (A_PLAIN, A_CONV3X3, A_CONV3X3_AFFINE_RELU) and K % 32 == 0:
+        wh, wl = w_planes
+        if (tuple(wh.shape) == (N, K) and wh.dtype == torch.bfloat16 and wl.dtype == torch.bfloat16 and wh.stride() == wl.stride() and wh.stride(1) == 1
+                and wh.stride(0) % 4 == 0 and wh.data_ptr() % 8 == 0 and wl.data_ptr() % 8 == 0):
+            wpl = (wh, wl)
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
         B, H, W_, C = conv
         M_ = B * H * W_
@@ -277,6 +287,8 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     d.dtype_in, d.dtype_out, d.act, d.a_mode = dt_mm(a), dt(out), act, a_mode
     if w.dtype != a.dtype:
         raise P3Error("gemm: A and W dtypes differ")
+    if wpl is not None:
+        d.ldb, d.w_lo = wpl[0].stride(0), wpl[1].data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     if residual is not None:
         d.residual, d.ldr, d.dtype_res = residual.data_ptr(), residual.stride(-2), dt(residual)
@@ -308,7 +320,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     if variant is not None:
         check(lib().p3_gemm_dma(ptr(a), ptr(w), ptr(out), byref(d), c_int(int(variant)), stream()), "p3_gemm_dma")
     else:
-        check(lib().p3_gemm(ptr(a), ptr(w), ptr(out), byref(d), stream()), "p3_gemm")
+        check(lib().p3_gemm(ptr(a), ptr(wpl[0] if wpl is not None else w), ptr(out), byref(d), stream()), "p3_gemm")
     if ev is not None:
         # algorithmic HBM bytes of this launch: A read once (generated A: its sources), W once, C written once, residual / aux /
         # saved-activation streams once each
@@ -381,6 +393,16 @@ def tn_defer_arena(mb=None):
         _tn_park["buf"] = torch.empty(mb * (1 << 20) // 4, dtype=torch.float32, device="cuda")
         check(lib().p3_tn_defer(ptr(_tn_park["buf"]), c_int64(_tn_park["buf"].numel())), "p3_tn_defer")
     return _tn_park["buf"] is not False
+
+
+def tn_defer_release():
+    """unregister and free the parking arena of the weight-gradient GEMMs (FlatAdamW.close(), ops.reset_process_state()): partial tiles still parked are dropped;
+    the next optimizer - or the first parking launch - registers a new one"""
+    buf = _tn_park["buf"]
+    if buf is not None and buf is not False:
+        lib().p3_tn_drop()
+        check(lib().p3_tn_defer(ptr(None), c_int64(0)), "p3_tn_defer")
+    _tn_park["buf"] = None
 
 
 CONV_PARK = _os0.environ.get("P3_CONV_PARK", "1") != "0"     # the nine shifted weight-gradient products of a 3 x 3 convolution park their partial tiles, one flush (A/B switch)

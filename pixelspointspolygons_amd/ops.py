@@ -348,6 +348,15 @@ def weight_planes(p, transpose=False):
     return pl.hi, pl.lo
 
 
+def wpl(p, transpose=False):
+    """(hi, lo) of weight / derived weight tensor `p` for hip.gemm(w_planes=...) - the register-staged fp32x3 GEMM then copies the weight's planes instead of
+    splitting the fp32 weight in every tile - or None outside an fp32x3 scope / for a non-fp32 or non-2-D tensor.  Callers slice the pair the way they slice the
+    weight; hip.gemm checks shape / alignment and falls back to the fp32 weight when they do not fit."""
+    if not hip.W_PLANES[0] or not hip.split_now() or p.dtype != torch.float32 or p.dim() != 2:
+        return None
+    return weight_planes(p, transpose)
+
+
 def unregister(params):
     """optimizer teardown: forget the arena views (and the cached copies derived from them) of these parameters."""
     ids = {id(p) for p in params}
@@ -380,6 +389,7 @@ def reset_process_state():
         from ._lib import lib as _lib
         _lib().p3_reduce_drop()          # partials a failed backward pass left parked must not reach the next model's gradients
         _lib().p3_tn_drop()
+        hip.tn_defer_release()
     except Exception:                    # noqa: BLE001 - no library in this process: nothing parked
         pass
     _BUMPS[0] = None
@@ -626,9 +636,11 @@ class _Linear(torch.autograd.Function):
         if ctx.gin is not None:
             gin.armed = True
         ctx.gout_res = gout_res if (gout_res is not None and gout_res.armed and residual is not None) else None
+        wp = wpl(weight) if cd == torch.float32 else None
         if rows is not None:
             w = w[rows[0]:rows[1]]
             bias = bias[rows[0]:rows[1]] if bias is not None else None
+            wp = (wp[0][rows[0]:rows[1]], wp[1][rows[0]:rows[1]]) if wp is not None else None
         ctx.rows = rows
         x2 = x.reshape(-1, x.shape[-1])
         need = any(ctx.needs_input_grad)
@@ -636,7 +648,7 @@ class _Linear(torch.autograd.Function):
         if need and act == hip.ACT_GELU:
             aux = torch.empty((x2.shape[0], w.shape[0]), dtype=out_dtype, device=x.device)
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
-        y = hip.gemm(x2, w, bias=bias, act=act, residual=res2, out_dtype=out_dtype, aux=aux, drop=drop)
+        y = hip.gemm(x2, w, bias=bias, act=act, residual=res2, out_dtype=out_dtype, aux=aux, drop=drop, w_planes=wp)
         ctx.drop = drop if (drop is not None and drop[2] > 0.0) else None
         if ctx.drop is not None and act == hip.ACT_GELU:
             raise NotImplementedError("dropout after GELU is not on the reference path")
@@ -676,8 +688,11 @@ class _Linear(torch.autograd.Function):
             nfull = (weight.shape[0] + 63) // 64 * 64
             wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
             wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
+            wtp = wpl(weight, transpose=True) if cd == torch.float32 else None          # [K, N] planes of W^T (unpadded: a padded N falls back inside hip.gemm)
+            if wtp is not None and rows is not None:
+                wtp = (wtp[0][:, rows[0]:rows[1]], wtp[1][:, rows[0]:rows[1]])
             gother = ctx.gin.take() if ctx.gin is not None else None
-            dx = hip.gemm(dpre, wt, out_dtype=cd, residual=gother.reshape(-1, gother.shape[-1]) if gother is not None else None).view(ctx.xshape)
+            dx = hip.gemm(dpre, wt, out_dtype=cd, residual=gother.reshape(-1, gother.shape[-1]) if gother is not None else None, w_planes=wtp).view(ctx.xshape)
             if ctx.gout_x is not None:
                 ctx.gout_x.g, dx = dx, None
         direct = DIRECT_GRAD[0] and weight.grad is not None and dpre.shape[1] == n_true
@@ -759,9 +774,10 @@ class _Mlp(torch.autograd.Function):
         if drop1 is not None and act != hip.ACT_RELU:
             raise NotImplementedError("dropout after GELU is not on the reference path")
         aux = torch.empty((x2.shape[0], w1.shape[0]), dtype=cd, device=x.device) if (need and act == hip.ACT_GELU) else None
-        h = hip.gemm(x2, w1c, bias=b1, act=act, out_dtype=cd, aux=aux, aux_grad=True, drop=drop1)   # aux <- GELU'(pre), not pre
+        wp1, wp2 = (wpl(w1), wpl(w2)) if cd == torch.float32 else (None, None)
+        h = hip.gemm(x2, w1c, bias=b1, act=act, out_dtype=cd, aux=aux, aux_grad=True, drop=drop1, w_planes=wp1)   # aux <- GELU'(pre), not pre
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
-        y = hip.gemm(h, w2c, bias=b2, residual=res2, out_dtype=out_dtype, drop=drop2)
+        y = hip.gemm(h, w2c, bias=b2, residual=res2, out_dtype=out_dtype, drop=drop2, w_planes=wp2)
         ctx.cfg = (act, cd, residual is not None, drop1, drop2, x.shape)
         ctx.b1, ctx.b2 = b1, b2
         if need:
@@ -782,12 +798,13 @@ class _Mlp(torch.autograd.Function):
         w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                       # [hidden, out]
         scale = 1.0 / (1.0 - drop1[2]) if drop1 is not None else 1.0
         bwd = (aux, hip.ACT_MUL, 1.0) if act == hip.ACT_GELU else (h, act, scale)            # GELU' was stored by the forward epilogue
-        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=bwd)                                  # dH * act'(.) in the epilogue
+        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=bwd, w_planes=wpl(w2, transpose=True) if cd == torch.float32 else None)   # dH * act'(.) in the epilogue
         dw1, db1 = _weight_grads(dpre1, x2, w1, ctx.b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
             w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())                   # [in, hidden]
-            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None).view(xshape)
+            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None,
+                          w_planes=wpl(w1, transpose=True) if cd == torch.float32 else None).view(xshape)
             if ctx.res_is_x:
                 dres = None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None, None

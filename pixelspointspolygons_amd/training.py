@@ -91,6 +91,8 @@ class FlatAdamW:
         self._index = {id(p): i for i, p in enumerate(params)}
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         ops.DIRECT_GRAD[0] = bool(direct_grad)   # kernels accumulate parameter gradients in place in the arena
+        if direct_grad and hip.DETERMINISTIC >= 1 and dev.type == "cuda":
+            hip.tn_defer_arena()                 # the parking arena of the weight-gradient GEMMs: registered HERE, not by the first parking launch (which may sit inside a hipGraph capture)
         # Step counter, schedule and bias corrections live on the device (p3_adamw_schedule runs right before the update kernel, inside
         # a captured graph as well): the host may run any number of steps ahead.  A custom Python lr_lambda switches to host-fed
         # scalars through a ring of pinned slots, each guarded by an event.
@@ -142,6 +144,7 @@ class FlatAdamW:
         """teardown: drop this optimizer's entries from the process-wide registries (they hold strong references to the arenas)."""
         ops.unregister(self.params)
         ops.DIRECT_GRAD[0] = False
+        hip.tn_defer_release()               # the parking arena of the weight-gradient GEMMs (4 GB by default) goes with the optimizer whose gradients it served
 
     def _build_transposes(self, params, offs, dev):
         """bf16 W^T copies ([in, out]) of every 2-D weight whose dX GEMM reads the plain transpose (out % 64 == 0): one arena, one

@@ -274,3 +274,45 @@ def test_flat_adamw_keeps_the_weight_planes_fresh():
     check()
     opt.close()
     ops.reset_process_state()
+
+
+@pytest.mark.parametrize("M,N,K", [(1570, 256, 256), (2000, 2048, 256), (1000, 256, 2048), (777, 768, 256)])
+def test_register_staged_gemm_with_the_weight_as_planes_gives_the_bits_of_the_fp32_weight(M, N, K):
+    """p3_gemm_desc.w_lo (r06): the fp32x3 form of the register-staged GEMM copies the weight's hi / lo planes instead of splitting the fp32 weight in every tile -
+    the same two bf16 images reach LDS, so the result is bit-identical; epilogues, a row slice of the planes (in_proj_weight's q / kv rows), the transposed planes."""
+    hip = _h()
+    a, w = _rand(M, K, seed=1).to(DEV), _rand(N, K, seed=2, scale=0.1).to(DEV)
+    bias, res = _rand(N, seed=3).to(DEV), _rand(M, N, seed=4).to(DEV)
+    wp = hip.to_planes(w, pad=1)
+    with hip.gemm_split(True):
+        ref = hip.gemm(a, w, bias=bias, residual=res)
+        hip.lib().p3_trace_kernels(1)
+        out = hip.gemm(a, w, bias=bias, residual=res, w_planes=(wp.hi, wp.lo))
+        name = hip.lib().p3_last_kernel().decode()
+        hip.lib().p3_trace_kernels(0)
+        assert name == "gemm_kernel<float, float, 0, 18, false>", name
+        assert torch.equal(out, ref)
+        assert rel_err(out.cpu(), (a.double() @ w.double().t() + bias.double() + res.double()).float().cpu()) < 1e-5
+        # ReLU + the saved-activation backward epilogue, rows [64, N) of the weight
+        r0 = 64
+        ref = hip.gemm(a, w[r0:], bias=bias[r0:], act=hip.ACT_RELU)
+        out = hip.gemm(a, w[r0:], bias=bias[r0:], act=hip.ACT_RELU, w_planes=(wp.hi[r0:], wp.lo[r0:]))
+        assert torch.equal(out, ref)
+        # planes that do not fit (wrong shape) are ignored, not misread
+        out = hip.gemm(a, w[r0:], bias=bias[r0:], act=hip.ACT_RELU, w_planes=(wp.hi, wp.lo))
+        assert torch.equal(out, ref)
+    # outside an fp32x3 scope the planes are ignored (exact fp32 products)
+    exact = hip.gemm(a, w, w_planes=(wp.hi, wp.lo))
+    assert torch.equal(exact, hip.gemm(a, w))
+
+
+def test_conv3x3_gather_with_the_weight_as_planes():
+    hip = _h()
+    B, H, W_, C, Co = 2, 28, 28, 64, 128
+    x = _rand(B * H * W_, C, seed=5).to(DEV)
+    w = _rand(Co, 9 * C, seed=6, scale=0.05).to(DEV)
+    wp = hip.to_planes(w, pad=1)
+    with hip.gemm_split(True):
+        ref = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C)
+        out = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C, w_planes=(wp.hi, wp.lo))
+    assert torch.equal(out, ref)
