@@ -160,8 +160,8 @@ typedef struct {
                            * without bounds checks; conv_H / conv_W stay the OUTPUT size */
     const float* bwd_bn;  /* bwd_act = P3_ACT_BN_RELU: [4, N] floats (scale | shift | a | b) */
     const void* w_lo;     /* dtype_in = P3_F32X3 with a plain / 3x3-gathered A only: non-NULL = the weight comes as PLANES - W addresses hi = bf16(w) [N, K], w_lo the
-                           * matching lo = bf16(w - hi), both with row stride ldb (bf16 elements, % 4 == 0, 8-byte aligned) - what the optimizer keeps fresh for every
-                           * 2-D master (training.FlatAdamW).  The kernel then stages W with plain copies instead of splitting it in every tile (r06: MFMA and VALU
+                           * matching lo = bf16(w - hi), both with row stride ldb (bf16 elements, % 8 == 0, 16-byte aligned) - what the optimizer keeps fresh for every
+                           * 2-D master (training.FlatAdamW).  The kernel then stages W with plain 16-byte copies instead of splitting it in every tile (r06: MFMA and VALU
                            * work do not overlap on a SIMD - tools/probe/coissue_probe.hip - so the split of an operand that never changes was pure added time);
                            * the bits of the result are those of the fp32 weight's split */
 } p3_gemm_desc;

@@ -133,9 +133,11 @@ __global__ __launch_bounds__(64 * NQ) void det_reduce_kernel(const float* __rest
 // partials in a caller-provided arena instead of reducing them at once; p3_reduce_flush adds all parked sets in ONE launch (grid.y = set), the same
 // 16-lane fixed-order float64 sum per value as det_reduce_kernel<16>: bit-identical results.
 namespace {
-constexpr int DEF_MAX = 48;
+constexpr int DEF_MAX = 48;                 // sets per flush launch (kernel-argument table: 48 x 36 B)
+constexpr int DEF_CAP = 6 * DEF_MAX;        // sets parked at once (r06: the bias-gradient column sums of the weight-gradient GEMMs park here too: ~140 per train step)
 struct DefTable { const float* parts[DEF_MAX]; float* out[DEF_MAX]; float* out2[DEF_MAX]; int nparts[DEF_MAX]; int nvals[DEF_MAX]; int split[DEF_MAX]; };
-DefTable g_def;
+struct DefAll { const float* parts[DEF_CAP]; float* out[DEF_CAP]; float* out2[DEF_CAP]; int nparts[DEF_CAP]; int nvals[DEF_CAP]; int split[DEF_CAP]; };
+DefAll g_def;
 float* g_def_arena = nullptr;
 int64_t g_def_cap = 0, g_def_used = 0;
 int g_def_n = 0, g_def_maxvals = 0, g_def_on = 0;
@@ -184,7 +186,7 @@ extern "C" int p3_reduce_defer_enable(int on) { const int was = g_def_on; g_def_
 
 // a slot of `floats` for the partials of one set (nparts x nvals, stride nvals; values [0, split) += out, the rest += out2), or NULL: the caller reduces now
 float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* out, float* out2) {
-    if (!g_def_on || !g_def_arena || g_def_n >= DEF_MAX || g_def_used + floats > g_def_cap || nparts > 16 * 128) return nullptr;
+    if (!g_def_on || !g_def_arena || g_def_n >= DEF_CAP || g_def_used + floats > g_def_cap || nparts > 16 * 128) return nullptr;
     // the flush adds every parked set from its own block row without atomics: two sets with a common target (a LayerNorm module applied twice in one forward,
     // a second backward before the flush) would race there - the later one reduces immediately instead (stream order serialises it behind... the flush adds
     // to whatever it finds, so the order of the two additions does not matter, only that they are not concurrent)
@@ -198,9 +200,27 @@ float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* o
     return slot;
 }
 
+// [splits][N] partial column sums of a weight-gradient GEMM's bias gradient: parked for p3_reduce_flush when parking is on (the target is a parameter gradient that stays
+// unread until then: FlatAdamW(direct_grad)) - *parked = 1, the caller launches no reduce - else the deterministic scratch and a p3_det_reduce right behind the launch
+float* p3_colsum_parts(int splits, int N, float* colsum, int dtype, int* parked) {
+    float* slot = p3_reduce_park((int64_t)splits * N, splits, N, N, colsum, nullptr);
+    *parked = slot ? 1 : 0;
+    return slot ? slot : p3_det_scratch((int64_t)splits * N, dtype);
+}
+
 extern "C" int p3_reduce_flush(void* stream) {
     if (g_def_n == 0) return P3_OK;
-    hipLaunchKernelGGL(det_reduce_many_kernel, dim3((g_def_maxvals + 63) / 64, g_def_n), dim3(1024), 0, (hipStream_t)stream, g_def);
+    for (int base = 0; base < g_def_n; base += DEF_MAX) {
+        DefTable t;
+        const int n = g_def_n - base < DEF_MAX ? g_def_n - base : DEF_MAX;
+        int maxvals = 0;
+        for (int i = 0; i < n; ++i) {
+            t.parts[i] = g_def.parts[base + i]; t.out[i] = g_def.out[base + i]; t.out2[i] = g_def.out2[base + i];
+            t.nparts[i] = g_def.nparts[base + i]; t.nvals[i] = g_def.nvals[base + i]; t.split[i] = g_def.split[base + i];
+            if (t.nvals[i] > maxvals) maxvals = t.nvals[i];
+        }
+        hipLaunchKernelGGL(det_reduce_many_kernel, dim3((maxvals + 63) / 64, n), dim3(1024), 0, (hipStream_t)stream, t);
+    }
     g_def_n = 0; g_def_used = 0; g_def_maxvals = 0;
     P3_LAUNCH_CHECK();
     return P3_OK;

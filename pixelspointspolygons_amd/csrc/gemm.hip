@@ -42,8 +42,8 @@ template <int BKSEL> struct Tr<float, BKSEL> { static constexpr int BK = 16, PIT
 // a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 MFMA (2^-17 relative per product; the dropped a_lo b_lo term is 2^-18) - 16 x the fp32 MFMA rate for 3 x the issues.
 constexpr int BK_SPLIT = 17, SPLIT_BK = 32, SPLIT_PITCH_B = (SPLIT_BK + 8) * 2, SPLIT_IMG_B = 128 * SPLIT_PITCH_B;      // 80-byte rows: 8 consecutive rows cover all 32 banks
 template <> struct Tr<float, BK_SPLIT> { static constexpr int BK = SPLIT_BK, PITCH = SPLIT_BK + 8, VEC = 4, LDS_ELEMS = 2 * SPLIT_IMG_B / 4; };
-// BKSEL == BK_SPLIT_WPL: the split form with the WEIGHT given as planes (p3_gemm_desc.w_lo): a thread's 4 k-values of a W row are 8 bytes of the hi plane and 8 of the
-// lo plane, copied into the two images as they are - half of the loop's split arithmetic (3 VALU ops per staged value) gone
+// BKSEL == BK_SPLIT_WPL: the split form with the WEIGHT given as planes (p3_gemm_desc.w_lo): the W slice's hi / lo images are copied as they are (16-byte loads,
+// ds_write_b128; see ld_w / put_w) - half of the loop's split arithmetic (3 VALU ops per staged value) gone
 constexpr int BK_SPLIT_WPL = 18;
 template <> struct Tr<float, BK_SPLIT_WPL> : Tr<float, BK_SPLIT> {};
 template <typename T> struct VecOf { static constexpr int VEC = 16 / (int)sizeof(T); };
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
     for (int p = 0; p < NPASS; ++p) {
         arow[p] = make_row<AMODE>(d, tm * BM + r0 + p * ROWS_PER_PASS);
         int gn = tn * BN + r0 + p * ROWS_PER_PASS;
+        if constexpr (sizeof(T) == 4 && BKSEL == BK_SPLIT_WPL) gn = tn * BN + (tid >> 2) + 64 * (p & 1);      // weight planes: see ld_w
         wrow[p] = (int64_t)(gn < d.N ? gn : d.N - 1) * d.ldb;
     }
 
@@ -262,20 +263,16 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
         if constexpr (SPLIT) lds_put_split(reinterpret_cast<float*>(buf), row, kq, v);
         else lds_put<T, PITCH>(buf, row, kq, v);
     };
-    // W: planes (WPL) - v = (hi pair, hi pair, lo pair, lo pair) as loaded, copied into the two images
-    auto put_w = [&](T* buf, int row, const uint4& v) __attribute__((always_inline)) {
-        if constexpr (WPL) {
-            unsigned char* b = reinterpret_cast<unsigned char*>(buf) + row * SPLIT_PITCH_B + kq * 2;
-            *reinterpret_cast<uint2*>(b) = make_uint2(v.x, v.y);
-            *reinterpret_cast<uint2*>(b + SPLIT_IMG_B) = make_uint2(v.z, v.w);
-        } else put(buf, row, v);
+    // W as planes (WPL): the slice of a plane is 128 rows x 64 B = 512 sixteen-byte items, 1024 for both planes = the thread's four staged vectors: vector p is
+    // 8 k-values of row tid / 4 + 64 (p & 1) of plane p >> 1, loaded with ONE 16-byte load and stored with one ds_write_b128 - as many load instructions as the fp32
+    // weight needs (two 8-byte loads per vector, the first form of this, doubled the W side's address-path work and LOST 0.55 ms of the step: r06_g33) and no VALU
+    auto put_w = [&](T* buf, int p, const uint4& v) __attribute__((always_inline)) {
+        if constexpr (WPL) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(buf) + (p >> 1) * SPLIT_IMG_B + ((tid >> 2) + 64 * (p & 1)) * SPLIT_PITCH_B + (tid & 3) * 16) = v;
+        else put(buf, r0 + p * ROWS_PER_PASS, v);
     };
-    auto ld_w = [&](int64_t rowoff, int k) __attribute__((always_inline)) {
-        if constexpr (WPL) {
-            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.W) + rowoff + k);
-            const uint2 l = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(d.w_lo) + rowoff + k);
-            return make_uint4(h.x, h.y, l.x, l.y);
-        } else return load_w<T>(W, rowoff, k);
+    auto ld_w = [&](int p, int kslice) __attribute__((always_inline)) {
+        if constexpr (WPL) return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>((p >> 1) ? d.w_lo : g.W) + wrow[p & 1] + kslice + (tid & 3) * 8);
+        else return load_w<T>(W, wrow[p], kslice + kq);
     };
     auto put_a = [&](T* buf, int set, int p, int k) __attribute__((always_inline)) {
         if constexpr (XF) put(buf, r0 + p * ROWS_PER_PASS, xform_a<T, AMODE>(ra[set][p], rv[PAIRA ? set : 0][PAIRA ? p : 0], xsc, xsh, k));
@@ -284,18 +281,18 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
     const int nk = d.K / BK;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-        ra[0][p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[0][p] = ld_w(wrow[p], kq);
+        ra[0][p] = load_a<T, AMODE>(d, A, arow[p], kq); rb[0][p] = ld_w(p, 0);
         if constexpr (PAIRA) rv[0][p] = load_v(p, kq);
     }
     if (nk > 1) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            ra[1][p] = load_a<T, AMODE>(d, A, arow[p], BK + kq); rb[1][p] = ld_w(wrow[p], BK + kq);
+            ra[1][p] = load_a<T, AMODE>(d, A, arow[p], BK + kq); rb[1][p] = ld_w(p, BK);
             if constexpr (PAIRA) rv[1][p] = load_v(p, BK + kq);
         }
     }
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) { put_a(lds, 0, p, kq); put_w(lds + 2 * LDSE, r0 + p * ROWS_PER_PASS, rb[0][p]); }
+    for (int p = 0; p < NPASS; ++p) { put_a(lds, 0, p, kq); put_w(lds + 2 * LDSE, p, rb[0][p]); }
     __syncthreads();
 
     // FULL = steady state (slices t+1 and t+2 exist): no conditions around the loads / LDS stores.  With the conditions inside the loop the
@@ -310,7 +307,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
             const int k = (t + 2) * BK + kq;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = ld_w(wrow[p], k);
+                ra[s0][p] = load_a<T, AMODE>(d, A, arow[p], k); rb[s0][p] = ld_w(p, (t + 2) * BK);
                 if constexpr (PAIRA) rv[s0][p] = load_v(p, k);
             }
         }
@@ -374,7 +371,7 @@ __global__ __launch_bounds__(256, (BKSEL == 32 && !STATS && AMODE != P3_A_PAIR_A
             T* an = lds + (cur ^ 1) * LDSE;
             T* bn = lds + (2 + (cur ^ 1)) * LDSE;
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p) { put_a(an, s0 ^ 1, p, (t + 1) * BK + kq); put_w(bn, r0 + p * ROWS_PER_PASS, rb[s0 ^ 1][p]); }
+            for (int p = 0; p < NPASS; ++p) { put_a(an, s0 ^ 1, p, (t + 1) * BK + kq); put_w(bn, p, rb[s0 ^ 1][p]); }
         }
         __syncthreads();
     };
@@ -820,11 +817,11 @@ extern "C" int p3_gemm(const void* A, const void* W, void* C, const p3_gemm_desc
     P3_CHECK(d->dtype_out == P3_BF16 || d->dtype_out == P3_F32, P3_EUNSUP, "p3_gemm: dtype_out");
     P3_CHECK(d->K % bk == 0, P3_ESHAPE, "p3_gemm: K must be a multiple of 32 (bf16) / 16 (f32)");
     P3_CHECK(d->lda % vec == 0 && d->ldb % vec == 0, P3_EALIGN, "p3_gemm: lda/ldb must keep 16-byte row alignment");
-    P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % (d->w_lo ? 8 : 16)) == 0, P3_EALIGN, "p3_gemm: A/W must be 16-byte aligned");
+    P3_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, P3_EALIGN, "p3_gemm: A/W must be 16-byte aligned");
     if (d->w_lo) {
         P3_CHECK(split && (d->a_mode == P3_A_PLAIN || d->a_mode == P3_A_CONV3X3 || d->a_mode == P3_A_CONV3X3_AFFINE_RELU), P3_EUNSUP,
                  "p3_gemm: w_lo (weight planes) goes with P3_F32X3 and a plain or 3x3-gathered A");
-        P3_CHECK(((uintptr_t)d->w_lo % 8) == 0, P3_EALIGN, "p3_gemm: w_lo must be 8-byte aligned");
+        P3_CHECK(((uintptr_t)d->w_lo % 16) == 0 && d->ldb % 8 == 0, P3_EALIGN, "p3_gemm: weight planes: 16-byte aligned, ldb % 8 == 0");
     }
     if (d->a_mode == P3_A_CONV3X3 || d->a_mode == P3_A_CONV3X3_AFFINE_RELU) {
         P3_CHECK(d->conv_C > 0 && d->conv_C % bk == 0 && d->K == 9 * d->conv_C, P3_ESHAPE, "p3_gemm: conv3x3 needs K == 9*C, C % BK == 0");

@@ -487,7 +487,16 @@ __global__ __launch_bounds__(256) void tn_flush_kernel(TnpTable t) {
     const int64_t i0 = ((int64_t)(blockIdx.x - en.first_block) * 256 + threadIdx.x) * 4;
     if (i0 >= total) return;
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int s = 0; s < en.splits; ++s) {      // split order, float64 (tn_reduce_kernel's sum)
+    // split order, float64 (tn_reduce_kernel's sum); eight loads in flight per thread (r06: one at a time the launch ran at ~3 TB/s over the 2 - 4 GB of parked tiles)
+    int s = 0;
+    for (; s + 8 <= en.splits; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(en.slab + (int64_t)(s + u) * total + i0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w; }
+    }
+    for (; s < en.splits; ++s) {
         const float4 v = *reinterpret_cast<const float4*>(en.slab + (int64_t)s * total + i0);
         a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
     }
@@ -631,7 +640,8 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
     bool parked = false;
     if (g.slabs) { float* slot = p3_tn_park(C, N, K, ldc, splits); if (slot) { g.slabs = slot; parked = true; } }
     g.splits = splits;
-    g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, dtype) : nullptr;
+    int cs_parked = 0;
+    g.cs_slab = colsum ? p3_colsum_parts(splits, N, colsum, dtype, &cs_parked) : nullptr;
     dim3 grid(tiles * splits), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define P3_TN_LAUNCH(MODE)                                                                            \
@@ -650,7 +660,7 @@ extern "C" int p3_gemm_tn_ex(const void* A, const void* B, float* C, int M, int 
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)gr), dim3(256), 0, s, g.slabs, C, N, K, ldc, splits);
     }
     P3_LAUNCH_CHECK();
-    if (g.cs_slab) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
+    if (g.cs_slab && !cs_parked) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
     return P3_OK;
 }
 

@@ -252,7 +252,8 @@ int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int
     g.slabs = (slabs && splits > 1) ? slabs : nullptr;
     bool parked = false;                             // p3_tn_defer: the partial tiles wait in the caller's arena for p3_tn_flush instead of a reduce launch of their own
     if (g.slabs) { float* slot = p3_tn_park(C, N, K, ldc, splits); if (slot) { g.slabs = slot; parked = true; } }
-    g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, P3_BF16) : nullptr;
+    int cs_parked = 0;
+    g.cs_slab = colsum ? p3_colsum_parts(splits, N, colsum, P3_BF16, &cs_parked) : nullptr;
     constexpr int NBUF = 4;                          // three steps in flight (NBUF = 3 measured 2 % slower, profiles/r04_mb_tn.txt)
     const size_t lds = (size_t)NBUF * TD_STEP_BYTES;       // >= the 64 KB the fold needs
     static bool attr_set = false;
@@ -266,6 +267,6 @@ int p3_gemm_tn_dma_try(const void* A, const void* B, float* C, int M, int N, int
     if (p3_tracing()) p3_note_kernel("gemm_tn_dma_kernel<4>");
     if (g.slabs && !parked) p3_tn_reduce_launch(g.slabs, C, N, K, ldc, splits, s);
     P3_LAUNCH_CHECK();
-    if (g.cs_slab) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
+    if (g.cs_slab && !cs_parked) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
     return P3_OK;
 }

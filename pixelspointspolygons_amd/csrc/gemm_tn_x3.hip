@@ -438,7 +438,8 @@ extern "C" int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const 
     bool parked = false;                             // p3_tn_defer: the partial tiles wait in the caller's arena for p3_tn_flush instead of a reduce launch of their own
     if (g.slabs) { float* slot = p3_tn_park(C, N, K, ldc, splits); if (slot) { g.slabs = slot; parked = true; } }
     (void)step_rows;
-    g.cs_slab = colsum ? p3_det_scratch((int64_t)splits * N, P3_F32) : nullptr;
+    int cs_parked = 0;
+    g.cs_slab = colsum ? p3_colsum_parts(splits, N, colsum, P3_F32, &cs_parked) : nullptr;
     constexpr int NBUF = 4;
     const size_t lds = (size_t)NBUF * TD_STEP_BYTES;       // 4 x 32 KB (>= the 64 KB the fold needs); the wide kernel's steps are 32 KB too
     static bool attr_set = false;
@@ -454,6 +455,6 @@ extern "C" int p3_gemm_tn_x3(const void* a_hi, const void* a_lo, int lda, const 
     if (p3_tracing()) p3_note_kernel(wide ? "gemm_tn_x3_wide_kernel<4>" : "gemm_tn_x3_kernel<4>");
     if (g.slabs && !parked) p3_tn_reduce_launch(g.slabs, C, N, K, ldc, splits, s);
     P3_LAUNCH_CHECK();
-    if (g.cs_slab) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
+    if (g.cs_slab && !cs_parked) return p3_det_reduce(g.cs_slab, splits, N, colsum, N, 1, s);
     return P3_OK;
 }

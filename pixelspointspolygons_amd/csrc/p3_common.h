@@ -137,7 +137,9 @@ void p3_note_kernel(const char* name);
 float* p3_det_scratch(int64_t floats, int dtype);
 int p3_det_reduce(const float* parts, int nparts, int64_t stride, float* out, int nvals, int accumulate, hipStream_t s);
 float* p3_reduce_scratch(int64_t floats);     // the registered scratch for any dtype (per-tile partials), NULL if none / too small
-float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* out, float* out2);   // deferred parameter-gradient reduce (det_reduce.hip): slot or NULL
+float* p3_reduce_park(int64_t floats, int nparts, int nvals, int split, float* out, float* out2);
+float* p3_colsum_parts(int splits, int N, float* colsum, int dtype, int* parked);   // bias-gradient partial column sums: a parked slot (*parked = 1) or the deterministic scratch
+   // deferred parameter-gradient reduce (det_reduce.hip): slot or NULL
 int p3_det_reduce2(const float* parts, int nparts, int64_t stride, float* tmp, float* out, float* out2, int split, int nvals, int accumulate, hipStream_t s);
 #define P3_CHECK(cond, code, msg) \
     do {                          \

@@ -67,7 +67,7 @@ class _CNNTailMixin:
         w2 = ops.shadow(conv.weight, cd, key="khwc", fn=_khwc)
         sums = torch.zeros(512, dtype=torch.float32, device=tokens.device) if training else None
         hip.gemm(up.view(-1, D), w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, W, D), lda=D, out=buf,
-                 colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
+                 colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None, w_planes=ops.wpl(w2))
         if keep is not None:
             sc, sh, mean, rstd = _bn_affine(sums, float(B * H * W), bn, training, save=True)
             keep.update(up=up, bnP=(sc, sh, mean, rstd))
@@ -149,7 +149,7 @@ def _conv3x3_bwd(dY, Xpad, ldx, cin, w, cd, B, H, ci_dx, key, residual=None):
     del dYpad
     # input gradient: correlation with the flipped kernel, weight laid out [ci, (ky', kx', co)]
     wf = ops.shadow(w, cd, key=key, fn=lambda t_: t_[:, :ci_dx].flip(2, 3).permute(1, 2, 3, 0).reshape(ci_dx, -1))
-    dX = hip.gemm(dY, wf, a_mode=hip.A_CONV3X3, conv=(B, H, H, Co), lda=Co, out_dtype=cd, residual=residual)
+    dX = hip.gemm(dY, wf, a_mode=hip.A_CONV3X3, conv=(B, H, H, Co), lda=Co, out_dtype=cd, residual=residual, w_planes=ops.wpl(wf))
     return dW2.view(Co, 3, 3, cin), dX
 
 
@@ -293,7 +293,7 @@ class EncoderDecoder(nn.Module):
             w2 = ops.shadow(conv.weight, cd, key="khwc", fn=_khwc)
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
             s1 = hip.gemm(xpad, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, H, 256), lda=LDF, conv_pad=True, M=B * HW,
-                          out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
+                          out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None, w_planes=ops.wpl(w2))
             bnS = _bn_affine(sums, cnt, bn, training, save=save)
             seg = hip.head1x1(s1, 256, bnS[0], bnS[1], head.weight.detach().reshape(1, 256).contiguous(), head.bias.detach(), 0, 1.0, B, HW)
             xpad[:, 1:H + 1, 1:H + 1, 256] = seg.view(B, H, H)             # seg.clone().detach() -> channel 256 (torch.cat, model_ffl.py:87-89)
@@ -305,7 +305,7 @@ class EncoderDecoder(nn.Module):
             w2 = ops.shadow(conv.weight, cd, key="khwc320", fn=lambda t: _khwc(t, LDF))
             sums = torch.zeros(512, dtype=torch.float32, device=dev) if training else None
             c1 = hip.gemm(xpad, w2, bias=conv.bias.detach(), a_mode=hip.A_CONV3X3, conv=(B, H, H, LDF), lda=LDF, conv_pad=True, M=B * HW,
-                          out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None)
+                          out_dtype=cd, colsum=sums[:256] if training else None, colsumsq=sums[256:] if training else None, w_planes=ops.wpl(w2))
             bnC = _bn_affine(sums, cnt, bn, training, save=save)
             cf = hip.head1x1(c1, 256, bnC[0], bnC[1], head.weight.detach().reshape(4, 256).contiguous(), head.bias.detach(), 1, 2.0, B, HW)
             outputs["crossfield"] = cf.view(B, 4, H, H)

@@ -239,7 +239,7 @@ def _drop(spec):
     return d
 
 
-W_PLANES = [_os0.environ.get("P3_W_PLANES", "1") != "0"]      # fp32x3: the register-staged GEMM takes the weight as planes when the caller has them (A/B switch)
+W_PLANES = [_os0.environ.get("P3_W_PLANES", "0") == "1"]      # fp32x3: the register-staged GEMM takes the weight as planes when the caller has them.  OFF: measured no gain (r06, profiles/r06_w_planes_colsum_park_ab.txt: 65.55 vs 65.65 ms same-box) - the option and its test stay
 
 
 class GemmDesc(Structure):
@@ -265,7 +265,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     if w_planes is not None and W_PLANES[0] and dt_mm(a) == F32X3 and a_mode in (A_PLAIN, A_CONV3X3, A_CONV3X3_AFFINE_RELU) and K % 32 == 0:
         wh, wl = w_planes
         if (tuple(wh.shape) == (N, K) and wh.dtype == torch.bfloat16 and wl.dtype == torch.bfloat16 and wh.stride() == wl.stride() and wh.stride(1) == 1
-                and wh.stride(0) % 4 == 0 and wh.data_ptr() % 8 == 0 and wl.data_ptr() % 8 == 0):
+                and wh.stride(0) % 8 == 0 and wh.data_ptr() % 16 == 0 and wl.data_ptr() % 16 == 0):
             wpl = (wh, wl)
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
         B, H, W_, C = conv
@@ -405,6 +405,7 @@ def tn_defer_release():
     _tn_park["buf"] = None
 
 
+COLSUM_PARK = _os0.environ.get("P3_COLSUM_PARK", "1") != "0"   # bias-gradient column sums of the weight-gradient GEMMs park with the deferred reduces (A/B switch)
 CONV_PARK = _os0.environ.get("P3_CONV_PARK", "1") != "0"     # the nine shifted weight-gradient products of a 3 x 3 convolution park their partial tiles, one flush (A/B switch)
 
 
@@ -414,15 +415,22 @@ class tn_parking:
 
     def __init__(self, on):
         self.on = bool(on) and DETERMINISTIC >= 1 and tn_defer_arena()
+        # r06: the launch's bias-gradient column sums (colsum_out = a view of the gradient arena) park with the deferred parameter reduces (p3_reduce_park) - one
+        # det_reduce launch of ~6 us less per Linear and train step
+        self.on_colsum = self.on and COLSUM_PARK and param_reduce_arena()
 
     def __enter__(self):
         if self.on:
             lib().p3_tn_defer_enable(c_int(1))
+        if self.on_colsum:
+            lib().p3_reduce_defer_enable(c_int(1))
         return self
 
     def __exit__(self, *exc):
         if self.on:
             lib().p3_tn_defer_enable(c_int(0))
+        if self.on_colsum:
+            lib().p3_reduce_defer_enable(c_int(0))
         return False
 
 

@@ -354,6 +354,8 @@ def wpl(p, transpose=False):
     weight; hip.gemm checks shape / alignment and falls back to the fp32 weight when they do not fit."""
     if not hip.W_PLANES[0] or not hip.split_now() or p.dtype != torch.float32 or p.dim() != 2:
         return None
+    if p.shape[0 if transpose else 1] % 8 != 0:          # p3_to_planes: 16-byte rows (the 227-row vocabulary layer's transpose stays an fp32 operand)
+        return None
     return weight_planes(p, transpose)
 
 

@@ -68,8 +68,8 @@ class _PatchGemm(torch.autograd.Function):
         ctx.wshape, ctx.D = weight.shape, D
         ctx.chain = canvas is not None and canvas.requires_grad      # the pillar stem wrote into this canvas first: hand its gradient on
         if canvas is None:
-            return hip.gemm(patches, w2, bias=bias, out_dtype=cd)
-        hip.gemm(patches, w2, bias=bias, out=canvas[..., :D])
+            return hip.gemm(patches, w2, bias=bias, out_dtype=cd, w_planes=ops.wpl(w2))
+        hip.gemm(patches, w2, bias=bias, out=canvas[..., :D], w_planes=ops.wpl(w2))
         ctx.mark_dirty(canvas)
         return canvas
 

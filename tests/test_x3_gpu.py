@@ -284,6 +284,14 @@ def test_register_staged_gemm_with_the_weight_as_planes_gives_the_bits_of_the_fp
     a, w = _rand(M, K, seed=1).to(DEV), _rand(N, K, seed=2, scale=0.1).to(DEV)
     bias, res = _rand(N, seed=3).to(DEV), _rand(M, N, seed=4).to(DEV)
     wp = hip.to_planes(w, pad=1)
+    was, hip.W_PLANES[0] = hip.W_PLANES[0], True              # the option is off by default (no measured gain): switched on for the test
+    try:
+        _weight_planes_checks(hip, a, w, bias, res, wp)
+    finally:
+        hip.W_PLANES[0] = was
+
+
+def _weight_planes_checks(hip, a, w, bias, res, wp):
     with hip.gemm_split(True):
         ref = hip.gemm(a, w, bias=bias, residual=res)
         hip.lib().p3_trace_kernels(1)
@@ -312,7 +320,15 @@ def test_conv3x3_gather_with_the_weight_as_planes():
     x = _rand(B * H * W_, C, seed=5).to(DEV)
     w = _rand(Co, 9 * C, seed=6, scale=0.05).to(DEV)
     wp = hip.to_planes(w, pad=1)
-    with hip.gemm_split(True):
-        ref = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C)
-        out = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C, w_planes=(wp.hi, wp.lo))
+    was, hip.W_PLANES[0] = hip.W_PLANES[0], True
+    try:
+        with hip.gemm_split(True):
+            ref = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C)
+            hip.lib().p3_trace_kernels(1)
+            out = hip.gemm(x, w, a_mode=hip.A_CONV3X3, conv=(B, H, W_, C), lda=C, w_planes=(wp.hi, wp.lo))
+            name = hip.lib().p3_last_kernel().decode()
+            hip.lib().p3_trace_kernels(0)
+    finally:
+        hip.W_PLANES[0] = was
+    assert name == "gemm_kernel<float, float, 1, 18, false>", name
     assert torch.equal(out, ref)

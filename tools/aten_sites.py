@@ -1,11 +1,12 @@
 """Which python lines launch the ATen kernels of one train step (eager): torch.profiler with stacks, grouped by (op, innermost repo frame)."""
 import sys, collections, torch
 sys.path.insert(0, ".")
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32x3"          # python tools/aten_sites.py [bf16 | fp32x3]
 sys.argv = ["bench.py", "--lean", "--graph", "0"]
 import bench
 args = bench.parse()
 from pixelspointspolygons_amd import synthetic as S
-cfg, model, opt, reducer, pool, st = bench.build(args, "cuda:0", 0, "bf16", S, 0, 1, False)
+cfg, model, opt, reducer, pool, st = bench.build(args, "cuda:0", 0, PREC, S, 0, 1, False)
 for i in range(3):
     st.step(pool[i % len(pool)])
 torch.cuda.synchronize()

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 O=gpurun_out/r06_g33.txt
 : > $O
-timeout 1500 python -m pytest tests/test_x3_gpu.py tests/test_ops_gpu.py tests/test_backward_gpu.py tests/test_train_gpu.py tests/test_model_gpu.py -q -m gpu -x 2>&1 | tail -4 | tee -a $O
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_train_gpu.py tests/test_ffl_gpu.py tests/test_predict_demo_gpu.py -q -m gpu -x 2>&1 | tail -12 | tee -a $O
 for i in 1 2 3; do
   for P in 0 1; do
     echo -n "w_planes=$P " >> $O
