@@ -203,6 +203,9 @@ typedef struct {
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     void* ln_hi; void* ln_lo; int ldln;
     float* ln_mean; float* ln_rstd;
+    int tile;             /* 0: the library picks the kernel (measured rule); 1: the 128 x 128 tile kernel, 2: the 128 x 384 tile kernel, 3: the A-stationary kernel -
+                           * for THIS call (the host splits a launch with a ragged last round of 128 x 384 tiles into a head on tile 2 and a remainder on tile 1);
+                           * the process-wide p3_gemm_x3_tile hook is for measurement tools only and loses against this field */
 } p3_gemm_x3_desc;
 int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream);
 /* measurement hook (tools/mb_x3.py, tools/mb_as.py): 0 = the library's rule, 1 = every product on the 128 x 128 tile, 2 = on the 128 x 384 tile, 3 = on the

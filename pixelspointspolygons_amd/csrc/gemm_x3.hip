@@ -529,10 +529,14 @@ extern "C" int p3_gemm_x3(const p3_gemm_x3_desc* d, void* stream) {
     // workgroup walks >= 28 units per A slice; the 384- / 256- / 768-wide ones stay on the tile kernels (their 9 - 12 units per workgroup do not pay the slice load)
     static int as_on = -1;                            // P3_X3_AS=0: same-box A/B of the step without the A-stationary kernel (bench.py --lean)
     if (as_on < 0) { const char* e = getenv("P3_X3_AS"); as_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (((g_x3_tile == 0 && as_on && p3_gemm_x3_as_default(d)) || g_x3_tile == 3) && p3_gemm_x3_as_ok(d)) return p3_gemm_x3_as(d, s);
-    P3_CHECK(g_x3_tile != 3, P3_EUNSUP, "p3_gemm_x3: the A-stationary kernel needs K = 256 / 384, N % 32 == 0, N <= 4096, an epilogue it builds, no fused LayerNorm");
-    // tile choice: p3_gemm_x3_tile(1) forces the 128 x 128 kernel, (2) the 128 x 384 kernel, (0) the measured rule (tools/mb_x3.py, profiles/r05_mb_x3.txt)
-    const bool big = g_x3_tile == 2 ? d->N > 128 : (g_x3_tile == 1 ? false : x3_big_tile(d));
+    // the kernel of THIS call: p3_gemm_x3_desc.tile (1 / 2 / 3; the host's ragged-round split uses it) before the process-wide measurement hook p3_gemm_x3_tile before
+    // the measured rule
+    P3_CHECK(d->tile >= 0 && d->tile <= 3, P3_EINVAL, "p3_gemm_x3: tile must be 0 (the library's choice), 1 (128 x 128), 2 (128 x 384) or 3 (A-stationary)");
+    const int tile = d->tile ? d->tile : g_x3_tile;
+    if (((tile == 0 && as_on && p3_gemm_x3_as_default(d)) || tile == 3) && p3_gemm_x3_as_ok(d)) return p3_gemm_x3_as(d, s);
+    P3_CHECK(tile != 3, P3_EUNSUP, "p3_gemm_x3: the A-stationary kernel needs K = 256 / 384, N % 32 == 0, N <= 4096, an epilogue it builds, no fused LayerNorm");
+    // tile choice: 1 forces the 128 x 128 kernel, 2 the 128 x 384 kernel, 0 the measured rule (tools/mb_x3.py, profiles/r05_mb_x3.txt)
+    const bool big = tile == 2 ? d->N > 128 : (tile == 1 ? false : x3_big_tile(d));
     if (ln || big) {
         g.tiles_n = p3_ceil_div(d->N, 384);
         constexpr size_t LDS = 2 * (2 * 128 * 4 + 2 * 384 * 4) * 16;          // 2 slices x 64 KB

@@ -1351,10 +1351,21 @@ class GemmX3Desc(Structure):
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("act", c_int),
                 ("aux", c_void_p), ("ldaux", c_int), ("mul", c_void_p), ("ldmul", c_int),
                 ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
-                ("ln_hi", c_void_p), ("ln_lo", c_void_p), ("ldln", c_int), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
+                ("ln_hi", c_void_p), ("ln_lo", c_void_p), ("ldln", c_int), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("tile", c_int)]
 
 
-X3_CUS = 256                                                                 # CUs of the chip: the 128 x 384 tile runs one workgroup per CU
+_x3_cus = {}
+
+
+def x3_cus(device):
+    """CUs of the device the launch goes to (the 128 x 384 tile runs one workgroup per CU): queried once per device, 256 on MI355X"""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _x3_cus:
+        _x3_cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _x3_cus[idx]
+
+
 X3_RAGGED_SPLIT = [_os0.environ.get("P3_X3_RAGGED", "1") != "0"]               # A/B switch of the ragged-round rule below
 
 
@@ -1403,8 +1414,9 @@ def gemm_x3(a, w, *, bias=None, act=ACT_NONE, residual=None, aux=None, mul=None,
     # of 256 and a round of 137 with 119 CUs idle - two round times for 1.5 rounds of work.  Whole rounds go to the big tile, the remainder to the 128 x 128 tile
     # (two workgroups per CU: 137 x 3 = 411 small tiles are ONE round of 512 slots at a third of the work each), back to back on the same stream.
     tm = (M + 127) // 128
-    rem = tm % X3_CUS
-    if X3_RAGGED_SPLIT[0] and ln is None and 256 < N <= 384 and K >= 1024 and tm > X3_CUS and 0 < rem <= (3 * X3_CUS) // 4:
+    cus = x3_cus(a.buf.device)
+    rem = tm % cus
+    if X3_RAGGED_SPLIT[0] and ln is None and 256 < N <= 384 and K >= 1024 and tm > cus and 0 < rem <= (3 * cus) // 4:
         head = (tm - rem) * 128
         d2 = GemmX3Desc()
         ctypes.memmove(byref(d2), byref(d), ctypes.sizeof(d))
@@ -1420,13 +1432,9 @@ def gemm_x3(a, w, *, bias=None, act=ACT_NONE, residual=None, aux=None, mul=None,
             d2.aux = d.aux + head * d.ldaux * 4
         if mul is not None:
             d2.mul = d.mul + head * d.ldmul * 4
-        was = lib().p3_gemm_x3_tile(c_int(2))
-        try:
-            launch(d, head)
-            lib().p3_gemm_x3_tile(c_int(1))
-            launch(d2, M - head)
-        finally:
-            lib().p3_gemm_x3_tile(c_int(was))
+        d.tile, d2.tile = 2, 1               # per call (p3_gemm_x3_desc.tile): no process-wide state is touched
+        launch(d, head)
+        launch(d2, M - head)
         return out
     launch(d, M)
     return out
