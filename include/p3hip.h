@@ -288,6 +288,11 @@ typedef struct {
                              * leaves as the operand of the projection's dX / dW GEMMs, no fp32 tensor and no conversion pass.  0: dtype / strides of Q, K, V */
     int g_rs;
     int64_t g_bs, g_lo;
+    void* o_planes;         /* p3_attention with dtype P3_F32X3 only, optional: the output ALSO as planes - the bf16 hi plane of O at o_planes + b*op_bs + t*op_rs + h*head_dim
+                             * (bf16 elements), the lo plane op_lo elements behind it: the operand of the output projection's planes GEMM, written from the registers that
+                             * hold the fp32 row (r06: replaces a p3_to_planes pass over O per ViT block).  O itself is written as before (the backward reads it) */
+    int op_rs;
+    int64_t op_bs, op_lo;
 } p3_attn_desc;
 int p3_attention(const void* Q, const void* K, const void* V, void* O, const p3_attn_desc* d, void* stream);
 

@@ -413,6 +413,17 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
                 } else {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                 }
+                if constexpr (X3) {
+                    if (d.o_planes) {          // the same four values as planes: the output projection's operand (p3_attn_desc.o_planes)
+                        bf16_t* ph = reinterpret_cast<bf16_t*>(d.o_planes) + (int64_t)b * d.op_bs + (int64_t)q * d.op_rs + h * D + dd;
+                        uint2 hh, ll;
+                        hh.x = pack_bf2(o[0], o[1]); hh.y = pack_bf2(o[2], o[3]);
+                        ll.x = pack_bf2(o[0] - __uint_as_float(hh.x << 16), o[1] - __uint_as_float(hh.x & 0xffff0000u));
+                        ll.y = pack_bf2(o[2] - __uint_as_float(hh.y << 16), o[3] - __uint_as_float(hh.y & 0xffff0000u));
+                        *reinterpret_cast<uint2*>(ph) = hh;
+                        *reinterpret_cast<uint2*>(ph + d.op_lo) = ll;
+                    }
+                }
             }
         if (d.lse && hi == 0) d.lse[((int64_t)b * d.H + h) * d.Lq + q] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
     }
@@ -511,6 +522,8 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
     P3_CHECK(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->o_rs % 4 == 0, P3_EALIGN, "p3_attention: row strides");
     P3_CHECK(d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0 && d->o_bs % 4 == 0, P3_EALIGN, "p3_attention: batch strides");
     P3_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, P3_EALIGN, "p3_attention: 16-byte base alignment");
+    P3_CHECK(!d->o_planes || (d->dtype == P3_F32X3 && d->op_lo != 0 && d->op_rs % 4 == 0 && d->op_bs % 4 == 0 && d->op_lo % 4 == 0 && ((uintptr_t)d->o_planes % 8) == 0), P3_EINVAL,
+             "p3_attention: o_planes goes with P3_F32X3 and needs op_bs / op_rs / op_lo (multiples of 4 bf16 elements)");
     AttnArgs a; a.Q = Q; a.K = K; a.V = V; a.O = O; a.d = *d; a.order = p3_attn_order();
     dim3 grid(p3_ceil_div(d->Lq, 128) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;

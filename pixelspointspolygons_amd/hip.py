@@ -487,7 +487,8 @@ class AttnDesc(Structure):
                 ("q_bs", c_int64), ("k_bs", c_int64), ("v_bs", c_int64), ("o_bs", c_int64),
                 ("q_rs", c_int), ("k_rs", c_int), ("v_rs", c_int), ("o_rs", c_int),
                 ("scale", c_float), ("causal", c_int), ("key_bias", c_void_p), ("dtype", c_int), ("lse", c_void_p),
-                ("drop", Dropout), ("drop_rows", c_void_p), ("grad_planes", c_int), ("g_rs", c_int), ("g_bs", c_int64), ("g_lo", c_int64)]
+                ("drop", Dropout), ("drop_rows", c_void_p), ("grad_planes", c_int), ("g_rs", c_int), ("g_bs", c_int64), ("g_lo", c_int64),
+                ("o_planes", c_void_p), ("op_rs", c_int), ("op_bs", c_int64), ("op_lo", c_int64)]
 
 
 def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None, drop_rows=None):
@@ -505,8 +506,9 @@ def _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop=None, drop_
     return d
 
 
-def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False, drop=None, drop_rows=None):
-    """q [B,Lq,H*D], k/v [B,Lk,H*D] (arbitrary batch/row strides, unit inner stride) -> o [B,Lq,H*D]."""
+def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False, drop=None, drop_rows=None, out_planes=None):
+    """q [B,Lq,H*D], k/v [B,Lk,H*D] (arbitrary batch/row strides, unit inner stride) -> o [B,Lq,H*D].
+    out_planes (fp32x3 scope): a Planes [B * Lq, H*D] that receives the output as planes too (the output projection's operand), written by the same launch."""
     _dev(q)
     for t in (q, k, v):
         if t.stride(2) != 1:
@@ -514,6 +516,11 @@ def attention(q, k, v, heads, scale, causal=False, key_bias=None, need_lse=False
     o = torch.empty((q.shape[0], q.shape[1], q.shape[2]), dtype=q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if need_lse else None
     d = _attn_desc(q, k, v, o, heads, scale, causal, key_bias, lse, drop, drop_rows)
+    if out_planes is not None:
+        op = out_planes
+        if op.rows != q.shape[0] * q.shape[1] or op.cols != q.shape[2] or not split_now():
+            raise P3Error("attention: out_planes must be [B * Lq, H * D] and the call must run in an fp32x3 scope")
+        d.o_planes, d.op_rs, d.op_bs, d.op_lo = op.hi.data_ptr(), op.ld, q.shape[1] * op.ld, op.cols
     ev = KTIMER.begin()
     check(lib().p3_attention(ptr(q), ptr(k), ptr(v), ptr(o), byref(d), stream()), "p3_attention")
     KTIMER.end(ev, f"attn_fwd_kernel<{'bf16' if d.dtype == BF16 else 'f32'},{d.head_dim}>",

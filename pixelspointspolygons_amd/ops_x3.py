@@ -65,11 +65,11 @@ class _ViTStackX3(torch.autograd.Function):
                 h1, m1, r1 = hip.layernorm_planes(xs, n1w, n1b, eps)
             qkv = hip.gemm_x3(h1, ops.weight_planes(wqkv), bias=bqkv).view(B, L, 3 * D)
             q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+            o = hip.Planes.empty(M, D, dev)             # the attention launch writes its output as planes too (p3_attn_desc.o_planes): no conversion pass
             if need:
-                o32, lse = hip.attention(q, k, v, heads, scale, need_lse=True)
+                o32, lse = hip.attention(q, k, v, heads, scale, need_lse=True, out_planes=o)
             else:
-                o32, lse = hip.attention(q, k, v, heads, scale), None
-            o = hip.to_planes(o32.view(M, D))
+                o32, lse = hip.attention(q, k, v, heads, scale, out_planes=o), None
             x1 = torch.empty((M, D), dtype=torch.float32, device=dev)
             if fuse_ln and D == 384:
                 h2 = hip.Planes.empty(M, D, dev)

@@ -332,3 +332,20 @@ def test_conv3x3_gather_with_the_weight_as_planes():
         hip.W_PLANES[0] = was
     assert name == "gemm_kernel<float, float, 1, 18, false>", name
     assert torch.equal(out, ref)
+
+
+def test_attention_forward_writes_its_output_as_planes_too():
+    """p3_attn_desc.o_planes (r06): the fp32x3 attention forward stores the planes of O from the registers that hold the fp32 row - the same bits p3_to_planes gives."""
+    hip = _h()
+    B, L, H, D = 3, 785, 6, 64
+    qkv = (_rand(B, L, 3 * H * D, seed=7) * 0.5).to(DEV)
+    q, k, v = qkv[..., :H * D], qkv[..., H * D:2 * H * D], qkv[..., 2 * H * D:]
+    with hip.gemm_split(True):
+        o_ref, lse_ref = hip.attention(q, k, v, H, D ** -0.5, need_lse=True)
+        op = hip.Planes.empty(B * L, H * D, DEV)
+        o, lse = hip.attention(q, k, v, H, D ** -0.5, need_lse=True, out_planes=op)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    ref = hip.to_planes(o_ref.view(B * L, H * D))
+    assert torch.equal(op.hi[:B * L], ref.hi[:B * L]) and torch.equal(op.lo[:B * L], ref.lo[:B * L])
+    with pytest.raises(hip.P3Error):
+        hip.attention(q, k, v, H, D ** -0.5, out_planes=op)               # outside an fp32x3 scope
