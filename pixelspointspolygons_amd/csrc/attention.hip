@@ -405,7 +405,10 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
                 const int dd = j * 32 + 8 * rg + 4 * hi;
                 float o[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = oacc[j][4 * rg + i] * inv;
+                for (int i = 0; i < 4; ++i) {
+#pragma clang fp contract(off)          // a rounded product: the planes copy below must split the STORED value (no fma of this multiply with the split's subtraction)
+                    o[i] = oacc[j][4 * rg + i] * inv;
+                }
                 T* dst = Op + (int64_t)q * d.o_rs + dd;
                 if constexpr (BF) {
                     uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
@@ -418,8 +421,11 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
                         bf16_t* ph = reinterpret_cast<bf16_t*>(d.o_planes) + (int64_t)b * d.op_bs + (int64_t)q * d.op_rs + h * D + dd;
                         uint2 hh, ll;
                         hh.x = pack_bf2(o[0], o[1]); hh.y = pack_bf2(o[2], o[3]);
-                        ll.x = pack_bf2(o[0] - __uint_as_float(hh.x << 16), o[1] - __uint_as_float(hh.x & 0xffff0000u));
-                        ll.y = pack_bf2(o[2] - __uint_as_float(hh.y << 16), o[3] - __uint_as_float(hh.y & 0xffff0000u));
+                        {
+#pragma clang fp contract(off)
+                            ll.x = pack_bf2(o[0] - __uint_as_float(hh.x << 16), o[1] - __uint_as_float(hh.x & 0xffff0000u));
+                            ll.y = pack_bf2(o[2] - __uint_as_float(hh.y << 16), o[3] - __uint_as_float(hh.y & 0xffff0000u));
+                        }
                         *reinterpret_cast<uint2*>(ph) = hh;
                         *reinterpret_cast<uint2*>(ph + d.op_lo) = ll;
                     }

@@ -11,6 +11,8 @@ Per block, forward:   h1 = LN1(x) | qkv = h1 Wqkv^T + b | o = SDPA(qkv) | x1 = x
 backward (reverse):   dW2 / db2 = g^T hid | dU = (g W2) * aux | dW1 / db1 = dU^T h2 | dh2 = dU W1 | g1 = g + LN2'(dh2) | dWp / dbp = g1^T o | do = g1 Wp
                       | dqkv = SDPA'(do) | dWqkv / dbqkv = dqkv^T h1 | dh1 = dqkv Wqkv | g0 = g1 + LN1'(dh1)
 """
+import os
+
 import torch
 
 from . import hip, ops
@@ -65,11 +67,13 @@ class _ViTStackX3(torch.autograd.Function):
                 h1, m1, r1 = hip.layernorm_planes(xs, n1w, n1b, eps)
             qkv = hip.gemm_x3(h1, ops.weight_planes(wqkv), bias=bqkv).view(B, L, 3 * D)
             q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-            o = hip.Planes.empty(M, D, dev)             # the attention launch writes its output as planes too (p3_attn_desc.o_planes): no conversion pass
+            o = hip.Planes.empty(M, D, dev) if ATTN_OUT_PLANES[0] else None     # the attention launch writes its output as planes too (p3_attn_desc.o_planes): no conversion pass
             if need:
                 o32, lse = hip.attention(q, k, v, heads, scale, need_lse=True, out_planes=o)
             else:
                 o32, lse = hip.attention(q, k, v, heads, scale, out_planes=o), None
+            if o is None:
+                o = hip.to_planes(o32.view(M, D))
             x1 = torch.empty((M, D), dtype=torch.float32, device=dev)
             if fuse_ln and D == 384:
                 h2 = hip.Planes.empty(M, D, dev)
@@ -159,6 +163,7 @@ def _ln_bwd(dy, x, gamma, beta, mean, rstd, dres, grads, ig, ib, direct):
 # against 27 us for the separate LayerNorm launch it replaces - the three-pass epilogue (store + mean, variance, normalise) runs with the matrix pipe idle
 # (one workgroup per CU: nothing overlaps it).  Kept as a tested option, OFF.
 FUSE_LN = [False]
+ATTN_OUT_PLANES = [os.environ.get("P3_ATTN_OPLANES", "1") != "0"]      # A/B switch: 0 = a p3_to_planes pass over the attention output instead of planes written by the attention launch
 
 
 def vit_stack(x, blocks, heads, eps):
