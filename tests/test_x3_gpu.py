@@ -349,3 +349,29 @@ def test_attention_forward_writes_its_output_as_planes_too():
     assert torch.equal(op.hi[:B * L], ref.hi[:B * L]) and torch.equal(op.lo[:B * L], ref.lo[:B * L])
     with pytest.raises(hip.P3Error):
         hip.attention(q, k, v, H, D ** -0.5, out_planes=op)               # outside an fp32x3 scope
+
+
+@pytest.mark.parametrize("M,N,K", [(24640, 256, 256), (12288, 768, 256)])
+def test_parked_partial_tiles_and_column_sums_equal_the_immediate_reduces(M, N, K):
+    """hip.tn_parking (r04 / r06): the split-M partial tiles of a weight-gradient GEMM and - new - the [splits][N] partial column sums of its bias gradient wait for
+    reduce_flush() instead of a reduce launch each: the same float64 sums in split order, bit for bit; two column slices of one matrix park side by side."""
+    hip = _h()
+    a, b = _rand(M, N, seed=1).to(DEV), _rand(M, K, seed=2).to(DEV)
+
+    def run(park):
+        W, c = torch.zeros(N, 2 * K, device=DEV), torch.zeros(N, device=DEV)
+        with hip.gemm_split(True):
+            with hip.tn_parking(park) as pk:
+                hip.gemm_tn(a, b, out=W[:, :K], colsum_out=c)
+                hip.gemm_tn(a, b, out=W[:, K:])                       # a second column slice of the same matrix
+            if park:
+                assert pk.on and pk.on_colsum and hip.reduce_pending() == 3, hip.reduce_pending()
+                hip.reduce_flush()
+                assert hip.reduce_pending() == 0
+        return W, c
+    W0, c0 = run(False)
+    W1, c1 = run(True)
+    assert torch.equal(W0, W1) and torch.equal(c0, c1)
+    assert torch.equal(W1[:, :K], W1[:, K:])
+    assert rel_err(c1.cpu(), a.double().sum(0).float().cpu()) < 1e-5
+    assert rel_err(W1[:, :K].cpu(), (a.double().t() @ b.double()).float().cpu()) < 1e-5
