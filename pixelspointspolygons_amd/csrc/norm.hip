@@ -277,6 +277,59 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_half_kernel(const TDY* __restri
 
 }  // namespace
 
+// Forward, half-wave-per-row form for cols = CPL x 128 (256 / 384 / 768), planes output (r06): the one-wave-per-row kernel above keeps ONE row per wave in flight and
+// leaves half its lanes without a second chunk at 384 columns (4.5 TB/s on the ViT's 50 240 x 384 rows); here a half-wave owns a row (32 lanes x CPL float4 chunks cover it
+// exactly), every half-wave walks rows r, r + 8, ... of its block TWO at a time (2 x CPL loads in flight before the first reduction), gamma / beta stay in registers.
+// Same arithmetic per element; the row sums are taken over 32 lanes x CPL x 4 values instead of 64 lanes - equal to the rounding of an fp32 sum.
+template <int CPL>
+__global__ __launch_bounds__(256) void ln_fwd_half_planes_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, int64_t rows, int ldx, int ldy, float eps,
+                                                                 float* __restrict__ smean, float* __restrict__ srstd, int rows_per_block) {
+    constexpr int cols = CPL * 128;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hw = (threadIdx.x >> 6) * 2 + (lane >> 5);      // half-wave 0..7 of the block
+    float g[CPL][4], b[CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { load4<float>(gamma + (l31 + 32 * c) * 4, g[c]); load4<float>(beta + (l31 + 32 * c) * 4, b[c]); }
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    int64_t rend = rbeg + rows_per_block;
+    if (rend > rows) rend = rows;
+    for (int64_t r0 = rbeg + hw; r0 < rend; r0 += 16) {
+        float v[2][CPL][4];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t row = r0 + 8 * u;
+            ok[u] = row < rend;
+            const int64_t rr = ok[u] ? row : rend - 1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) load4<float>(x + rr * ldx + (l31 + 32 * c) * 4, v[u][c]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) s += (v[u][c][0] + v[u][c][1]) + (v[u][c][2] + v[u][c][3]);
+            const float mean = ln_half_sum(s) * (1.f / (float)cols);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float dlt = v[u][c][i] - mean; q += dlt * dlt; }
+            const float rstd = rsqrtf(ln_half_sum(q) * (1.f / (float)cols) + eps);
+            if (!ok[u]) continue;
+            const int64_t row = r0 + 8 * u;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (v[u][c][i] - mean) * rstd * g[c][i] + b[c][i];
+                store4_planes(y_hi + row * ldy + (l31 + 32 * c) * 4, y_lo + row * ldy + (l31 + 32 * c) * 4, o);
+            }
+            if (l31 == 0 && smean) { smean[row] = mean; srstd[row] = rstd; }
+        }
+    }
+}
+
 extern "C" int p3_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int cols, int ldx,
                             int ldy, float eps, int dtype_in, int dtype_out, float* save_mean, float* save_rstd, void* stream) {
     P3_CHECK(x && gamma && beta && y, P3_EINVAL, "p3_layernorm: null pointer");
@@ -337,6 +390,17 @@ extern "C" int p3_layernorm_planes(const float* x, const float* gamma, const flo
     P3_CHECK(cols > 0 && cols <= 1024 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, P3_ESHAPE, "p3_layernorm_planes: cols must be <=1024 and %4");
     P3_CHECK((save_mean == nullptr) == (save_rstd == nullptr), P3_EINVAL, "p3_layernorm_planes: save_mean / save_rstd go together");
     if (rows <= 0) return P3_OK;
+    static int half_on = -1;                // P3_LN_HALF=0: the one-wave-per-row kernel for every width (A/B switch)
+    if (half_on < 0) { const char* e = getenv("P3_LN_HALF"); half_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (half_on && (cols == 256 || cols == 384 || cols == 768)) {          // at EVERY row count: a tile alone must give the bits it gives in a batch
+        constexpr int RPB = 32;             // rows per block: four rows per half-wave, two at a time
+        const dim3 grid(p3_ceil_div(rows, RPB)), block(256);
+#define LNH(CPL) hipLaunchKernelGGL((ln_fwd_half_planes_kernel<CPL>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_hi, (bf16_t*)y_lo, rows, ldx, ldy, eps, save_mean, save_rstd, RPB)
+        if (cols == 256) LNH(2); else if (cols == 384) LNH(3); else LNH(6);
+#undef LNH
+        P3_LAUNCH_CHECK();
+        return P3_OK;
+    }
     hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t>), dim3(p3_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_hi, rows, cols, ldx, ldy, eps,
                        save_mean, save_rstd, (bf16_t*)y_lo);
     P3_LAUNCH_CHECK();
