@@ -253,6 +253,13 @@ class GemmDesc(Structure):
                 ("bwd_bn", c_void_p), ("w_lo", c_void_p)]
 
 
+def w_planes_fit(wp, K):
+    """can the register-staged fp32x3 GEMM take the weight as these (hi, lo) planes ([N, K] bf16, one row stride % 8, 16-byte aligned, K % 32 == 0)?"""
+    wh, wl = wp
+    return (wh.dim() == 2 and wh.shape[1] == K and K % 32 == 0 and wh.dtype == torch.bfloat16 and wl.dtype == torch.bfloat16 and wh.shape == wl.shape
+            and wh.stride() == wl.stride() and wh.stride(1) == 1 and wh.stride(0) % 8 == 0 and wh.data_ptr() % 16 == 0 and wl.data_ptr() % 16 == 0)
+
+
 def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=None, aux=None, M=None,
          a_mode=A_PLAIN, conv=None, a_scale=None, a_shift=None, pair_v=None, pair_n=0, colsum=None, colsumsq=None,
          lda=None, ldc=None, drop=None, bwd=None, aux_grad=False, conv_pad=False, variant=None, w_planes=None):
@@ -260,13 +267,17 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
     variant = 4 | 6 | 9: call that LDS-DMA kernel (p3_gemm_dma, csrc/gemm_dma.hip) directly instead of p3_gemm's own choice (A/B tools, tests).
     w_planes = (hi, lo) bf16 [N, K] views of w's split (fp32x3 scope, plain or 3x3-gathered A): the kernel copies them instead of splitting w per tile."""
     _dev(a)
-    N, K = w.shape
     wpl = None
-    if w_planes is not None and W_PLANES[0] and dt_mm(a) == F32X3 and a_mode in (A_PLAIN, A_CONV3X3, A_CONV3X3_AFFINE_RELU) and K % 32 == 0:
-        wh, wl = w_planes
-        if (tuple(wh.shape) == (N, K) and wh.dtype == torch.bfloat16 and wl.dtype == torch.bfloat16 and wh.stride() == wl.stride() and wh.stride(1) == 1
-                and wh.stride(0) % 8 == 0 and wh.data_ptr() % 16 == 0 and wl.data_ptr() % 16 == 0):
-            wpl = (wh, wl)
+    if w is None:                                   # the weight exists as planes only (ops.wpl_T_registered): the caller checked w_planes_fit
+        if w_planes is None or not w_planes_fit(w_planes, a.shape[-1]) or dt_mm(a) != F32X3 or a_mode != A_PLAIN:
+            raise P3Error("gemm: w = None needs fitting weight planes, a plain A and an fp32x3 scope")
+        wpl = w_planes
+        N, K = wpl[0].shape
+    else:
+        N, K = w.shape
+        if w_planes is not None and W_PLANES[0] and dt_mm(a) == F32X3 and a_mode in (A_PLAIN, A_CONV3X3, A_CONV3X3_AFFINE_RELU) and tuple(w_planes[0].shape) == (N, K) \
+                and w_planes_fit(w_planes, K):
+            wpl = w_planes
     if a_mode in (A_CONV3X3, A_CONV3X3_AFFINE_RELU):
         B, H, W_, C = conv
         M_ = B * H * W_
@@ -283,9 +294,9 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         out = torch.empty((M_, N), dtype=odt, device=a.device)
     d = GemmDesc()
     d.M, d.N, d.K = M_, N, K
-    d.lda, d.ldb, d.ldc = lda_, w.stride(0), (out.stride(-2) if ldc is None else ldc)
+    d.lda, d.ldb, d.ldc = lda_, (w.stride(0) if w is not None else wpl[0].stride(0)), (out.stride(-2) if ldc is None else ldc)
     d.dtype_in, d.dtype_out, d.act, d.a_mode = dt_mm(a), dt(out), act, a_mode
-    if w.dtype != a.dtype:
+    if w is not None and w.dtype != a.dtype:
         raise P3Error("gemm: A and W dtypes differ")
     if wpl is not None:
         d.ldb, d.w_lo = wpl[0].stride(0), wpl[1].data_ptr()

@@ -359,6 +359,23 @@ def wpl(p, transpose=False):
     return weight_planes(p, transpose)
 
 
+WT_PLANES = [os.environ.get("P3_WT_PLANES", "1") != "0"]      # A/B switch of wpl_T_registered below
+
+
+def wpl_T_registered(p):
+    """(hi_T, lo_T) [K, N] of a weight whose transposed planes the OPTIMIZER keeps fresh (training.FlatAdamW, fp32x3 models), else None.  The dX GEMMs of the per-operator
+    fp32x3 path (decoder) take them through hip.gemm(None, w_planes=...): the fp32 transposed copy they used to derive per weight and step - 36 strided copy launches
+    in the decoder's backward - is not made at all (r06)."""
+    if not WT_PLANES[0] or not hip.split_now() or p.dtype != torch.float32 or p.dim() != 2:
+        return None
+    reg = _registered_planes.get(id(p))
+    if reg is None or reg[0] is not p or reg[2] is None:
+        return None
+    if reg[3] is not None:
+        reg[3].check_fresh(p)
+    return reg[2]
+
+
 def unregister(params):
     """optimizer teardown: forget the arena views (and the cached copies derived from them) of these parameters."""
     ids = {id(p) for p in params}
@@ -687,14 +704,21 @@ class _Linear(torch.autograd.Function):
             dpad[:, :n_true] = dpre
             dpre = dpad
         if ctx.needs_input_grad[0]:
-            nfull = (weight.shape[0] + 63) // 64 * 64
-            wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
-            wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
-            wtp = wpl(weight, transpose=True) if cd == torch.float32 else None          # [K, N] planes of W^T (unpadded: a padded N falls back inside hip.gemm)
-            if wtp is not None and rows is not None:
-                wtp = (wtp[0][:, rows[0]:rows[1]], wtp[1][:, rows[0]:rows[1]])
             gother = ctx.gin.take() if ctx.gin is not None else None
-            dx = hip.gemm(dpre, wt, out_dtype=cd, residual=gother.reshape(-1, gother.shape[-1]) if gother is not None else None, w_planes=wtp).view(ctx.xshape)
+            res_g = gother.reshape(-1, gother.shape[-1]) if gother is not None else None
+            wtr = wpl_T_registered(weight) if (cd == torch.float32 and dpre.shape[1] == n_true) else None      # the optimizer's planes of W^T: no fp32 transpose is derived
+            if wtr is not None and rows is not None:
+                wtr = (wtr[0][:, rows[0]:rows[1]], wtr[1][:, rows[0]:rows[1]])
+            if wtr is not None and hip.w_planes_fit(wtr, dpre.shape[1]):
+                dx = hip.gemm(dpre, None, out_dtype=cd, residual=res_g, w_planes=wtr).view(ctx.xshape)
+            else:
+                nfull = (weight.shape[0] + 63) // 64 * 64
+                wt = shadow(weight, cd, key="T", fn=lambda t: _pad_cols(t.t(), nfull))         # [K, N_full (zero padded to %64)]
+                wt = wt[:, rows[0]:rows[1]] if rows is not None else wt[:, :dpre.shape[1]]
+                wtp = wpl(weight, transpose=True) if cd == torch.float32 else None          # [K, N] planes of W^T (unpadded: a padded N falls back inside hip.gemm)
+                if wtp is not None and rows is not None:
+                    wtp = (wtp[0][:, rows[0]:rows[1]], wtp[1][:, rows[0]:rows[1]])
+                dx = hip.gemm(dpre, wt, out_dtype=cd, residual=res_g, w_planes=wtp).view(ctx.xshape)
             if ctx.gout_x is not None:
                 ctx.gout_x.g, dx = dx, None
         direct = DIRECT_GRAD[0] and weight.grad is not None and dpre.shape[1] == n_true
@@ -797,16 +821,24 @@ class _Mlp(torch.autograd.Function):
         else:
             dpre2 = _to_cd(dy2, cd)
         dw2, db2 = _weight_grads(dpre2, h, w2, ctx.b2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
-        w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                       # [hidden, out]
         scale = 1.0 / (1.0 - drop1[2]) if drop1 is not None else 1.0
         bwd = (aux, hip.ACT_MUL, 1.0) if act == hip.ACT_GELU else (h, act, scale)            # GELU' was stored by the forward epilogue
-        dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=bwd, w_planes=wpl(w2, transpose=True) if cd == torch.float32 else None)   # dH * act'(.) in the epilogue
+        w2r = wpl_T_registered(w2) if cd == torch.float32 else None                          # the optimizer's planes of W2^T: no fp32 transpose is derived
+        if w2r is not None and hip.w_planes_fit(w2r, dpre2.shape[1]):
+            dpre1 = hip.gemm(dpre2, None, out_dtype=cd, bwd=bwd, w_planes=w2r)               # dH * act'(.) in the epilogue
+        else:
+            w2t = shadow(w2, cd, key="T", fn=lambda t: t.t().contiguous())                   # [hidden, out]
+            dpre1 = hip.gemm(dpre2, w2t, out_dtype=cd, bwd=bwd, w_planes=wpl(w2, transpose=True) if cd == torch.float32 else None)
         dw1, db1 = _weight_grads(dpre1, x2, w1, ctx.b1, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         dx = None
         if ctx.needs_input_grad[0]:
-            w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())                   # [in, hidden]
-            dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None,
-                          w_planes=wpl(w1, transpose=True) if cd == torch.float32 else None).view(xshape)
+            w1r = wpl_T_registered(w1) if cd == torch.float32 else None
+            if w1r is not None and hip.w_planes_fit(w1r, dpre1.shape[1]):
+                dx = hip.gemm(dpre1, None, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None, w_planes=w1r).view(xshape)
+            else:
+                w1t = shadow(w1, cd, key="T", fn=lambda t: t.t().contiguous())               # [in, hidden]
+                dx = hip.gemm(dpre1, w1t, out_dtype=cd, residual=_materialize(dy2) if ctx.res_is_x else None,
+                              w_planes=wpl(w1, transpose=True) if cd == torch.float32 else None).view(xshape)
             if ctx.res_is_x:
                 dres = None
         return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None, None
