@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, (Kind<T>::X3 ? 2 : 3)) void attn_fwd_kernel(At
     u32x4 kreg[X3 ? 1 : KPT];
     u32x4 vreg[X3 ? 1 : VPT];
     p3attn::SplitStage<IMG ? D : 64, 64> ksp, vsp;  // fp32x3 without DMA: fp32 rows in flight, split into the hi / lo images at store time
-    // fp32x3: the fp32 rows travel global -> LDS by LDS-DMA into raw images (dynamic LDS: K | V) and are split into the hi / lo images at the tile switch (attn_tile.h
+    // DMA: the fp32 rows travel global -> LDS by LDS-DMA into raw images (dynamic LDS: K | V) and are split into the hi / lo images at the tile switch (attn_tile.h
     // SplitDma) - no staging registers live across the tile
     using SD = p3attn::SplitDma<IMG ? D : 64, X3 ? KT : 64>;
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_raw[];
@@ -543,7 +543,7 @@ extern "C" int p3_attention(const void* Q, const void* K, const void* V, void* O
         P3_LAUNCH_CHECK();
         return P3_OK;
     }
-    // fp32x3: raw fp32 images of the K and V tile in dynamic LDS (static 32 KB of bf16 images + 32 KB: above the 64 KB a kernel gets without asking)
+    // fp32x3 at head dim 32: raw fp32 images of the K and V tile in dynamic LDS (2 x 8 KB; the attribute below also covers the diagnostic padding)
     size_t dyn = d->dtype == P3_F32X3 && d->head_dim == 32 ? (size_t)2 * ATr<f32s, 32>::KT * 32 * 4 : 0;
     static int pad_lds = -1;              // P3_ATTN_PAD_LDS=<bytes> (diagnostic): extra dynamic LDS per workgroup of the fp32x3 kernels - 40000 leaves ONE workgroup per CU
     if (pad_lds < 0) { const char* e = getenv("P3_ATTN_PAD_LDS"); pad_lds = e ? atoi(e) : 0; }
