@@ -344,3 +344,38 @@ def test_scoped_module_is_freed_without_the_cyclic_collector_and_deepcopies_bind
         assert twin.probe("c") is twin                                                          # the copy does not depend on the original
     finally:
         gc.enable()
+
+
+def test_weight_planes_rules_of_the_host_side():
+    """r06 host logic around p3_gemm_desc.w_lo (no GPU): which (hi, lo) pairs the register-staged fp32x3 GEMM may take as its weight (hip.w_planes_fit), and that the
+    optimizer's transposed planes are handed out only inside an fp32x3 scope, only for the registered parameter object, and not after unregister()."""
+    import torch
+    from pixelspointspolygons_amd import hip, ops
+    N, K = 128, 64
+    buf = torch.zeros(N, 2 * K, dtype=torch.bfloat16)
+    planes = (buf[:, :K], buf[:, K:])
+    assert hip.w_planes_fit(planes, K)
+    assert not hip.w_planes_fit(planes, 2 * K)                                           # the planes' K is not the product's
+    assert not hip.w_planes_fit((buf[:, :40], buf[:, K:K + 40]), 40)                     # K % 32
+    odd = torch.zeros(N, 2 * K + 4, dtype=torch.bfloat16)
+    assert not hip.w_planes_fit((odd[:, :K], odd[:, K:2 * K]), K)                        # row stride % 8 (16-byte rows)
+    assert not hip.w_planes_fit((buf[:, :K].float(), buf[:, K:].float()), K)             # bf16 only
+    assert not hip.w_planes_fit((buf[:, :K], buf[:64, K:]), K)                           # one shape
+    w = torch.nn.Parameter(torch.zeros(N, K))
+    t = (torch.zeros(K, N, dtype=torch.bfloat16), torch.zeros(K, N, dtype=torch.bfloat16))
+    ops.register_planes(w, None, t, None)
+    try:
+        assert ops.wpl_T_registered(w) is None                                           # outside an fp32x3 scope: exact fp32 products, no planes
+        with hip.gemm_split(True):
+            assert ops.wpl_T_registered(w) is t
+            assert ops.wpl_T_registered(torch.nn.Parameter(torch.zeros(N, K))) is None   # another object: not registered
+            assert ops.wpl(torch.zeros(N, K, dtype=torch.bfloat16)) is None              # a bf16 weight has no planes
+            was, ops.WT_PLANES[0] = ops.WT_PLANES[0], False
+            try:
+                assert ops.wpl_T_registered(w) is None                                   # the A/B switch
+            finally:
+                ops.WT_PLANES[0] = was
+    finally:
+        ops.unregister([w])
+    with hip.gemm_split(True):
+        assert ops.wpl_T_registered(w) is None
