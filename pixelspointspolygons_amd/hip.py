@@ -275,7 +275,7 @@ def gemm(a, w, *, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=No
         N, K = wpl[0].shape
     else:
         N, K = w.shape
-        # (the callers gate on their switches - ops.wpl: W_PLANES, ops.wpl_conv: CONV_W_PLANES; planes that are handed in and fit are used)
+        # (the callers gate on their switches - ops.wpl: W_PLANES; planes that are handed in and fit are used)
         if w_planes is not None and dt_mm(a) == F32X3 and a_mode in (A_PLAIN, A_CONV3X3, A_CONV3X3_AFFINE_RELU) and tuple(w_planes[0].shape) == (N, K) \
                 and w_planes_fit(w_planes, K):
             wpl = w_planes
